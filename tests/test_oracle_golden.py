@@ -1,0 +1,53 @@
+"""Pins the CPU oracle against vectors produced by the reference's own code
+(tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_g1_normalize_vec(oracle, golden_dir):
+    g = _load(golden_dir, "g1_rownorm.npz")
+    got = oracle.normalize_vec(g["x"])
+    np.testing.assert_allclose(got, g["normalize_vec"], rtol=1e-6, atol=1e-7)
+    assert np.all(got[7] == 0)                      # zero row stays zero (eps clamp)
+    assert np.all(np.isfinite(got))
+
+
+def test_g1_standardize_vec(oracle, golden_dir):
+    g = _load(golden_dir, "g1_rownorm.npz")
+    got = oracle.standardize_vec(g["x"])
+    np.testing.assert_allclose(got, g["standardize_vec"], rtol=2e-5, atol=2e-6)
+    assert np.all(got[7] == 0) and np.all(got[13] == 0)   # 0/(0+1e-12) = 0
+
+
+def test_g1_l2_normalize_matches_on_nonzero_rows(oracle, golden_dir):
+    # ovr/misc.py:l2_normalize differs from F.normalize only for ||x|| < eps
+    g = _load(golden_dir, "g1_rownorm.npz")
+    got = oracle.normalize_vec(g["x"])
+    rows = [i for i in range(g["x"].shape[0]) if i not in (7, 11)]
+    np.testing.assert_allclose(got[rows], g["l2_normalize"][rows], rtol=1e-6, atol=1e-7)
+
+
+def test_g2_dot_similarity(oracle, golden_dir):
+    g = _load(golden_dir, "g2_dot_similarity.npz")
+    np.testing.assert_allclose(oracle.linear(g["emb"], g["bank81"], None), g["sim81"], atol=1e-5)
+    np.testing.assert_allclose(oracle.linear(g["emb96"], g["bank1204"], None), g["sim1204"], atol=1e-5)
+    assert np.all(g["sim81"][:, -1] == 0)            # zero background row -> zero logit
+
+
+def test_g3_box_predictor(oracle, golden_dir):
+    g = _load(golden_dir, "g3_box_predictor.npz")
+    for tag, norm, std in (("dot", False, False), ("norm", True, False), ("std", False, True)):
+        cls_w, cls_b, k = oracle.set_class_embeddings(g["bank"], norm, std)
+        assert k == 80
+        np.testing.assert_allclose(cls_w, g[f"cls_w_{tag}"], rtol=2e-5, atol=2e-6)
+        assert np.all(g[f"cls_b_{tag}"] == 0)
+        scores, deltas, _ = oracle.box_predictor_forward(
+            g["feats"], g["emb_w"], g["emb_b"], g["bbox_w"], g["bbox_b"], cls_w, cls_b, norm, std)
+        np.testing.assert_allclose(deltas, g[f"deltas_{tag}"], atol=1e-6)
+        np.testing.assert_allclose(scores, g[f"scores_{tag}"], atol=1e-4, rtol=1e-5)
+        assert np.all(scores[:, -1] == 0)

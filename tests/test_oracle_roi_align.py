@@ -1,0 +1,175 @@
+"""Analytic pins for the ROIAlign / level-assignment restatement (SURVEY.md section 7
+"hard parts": no torchvision here, so the oracle is checked against closed forms and an
+independent pure-numpy evaluation)."""
+import math
+
+import numpy as np
+import torch
+
+
+def _ramp(N, C, H, W, ax, ay, c0):
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    f = np.zeros((N, C, H, W), np.float32)
+    for n in range(N):
+        for c in range(C):
+            f[n, c] = ax * xs + ay * ys + c0 + c + 10 * n
+    return f
+
+
+def test_constant_map(oracle):
+    f = np.full((1, 3, 20, 30), 2.5, np.float32)
+    rois = np.array([[0, 16, 16, 200, 150], [0, 0, 0, 16, 16], [0, 100.3, 20.7, 411.9, 300.1]], np.float32)
+    out = oracle.roi_align(f, rois, (7, 7), 1 / 16, 0, True)
+    np.testing.assert_allclose(out, 2.5, rtol=1e-6)
+
+
+def test_linear_ramp_gives_bin_centre_value(oracle):
+    # bilinear interpolation reproduces a linear map exactly -> the average over a regular
+    # sampling grid equals the value at the bin centre (box fully inside the map).
+    H, W = 40, 50
+    ax, ay, c0 = 0.25, -0.5, 3.0
+    f = _ramp(2, 2, H, W, ax, ay, c0)
+    rois = np.array([[0, 40, 48, 360, 400], [1, 100, 80, 164, 112], [1, 33.3, 47.1, 517.9, 333.3]], np.float32)
+    P, s = 14, 1 / 16
+    out = oracle.roi_align(f, rois, (P, P), s, 0, True)
+    for r, roi in enumerate(rois):
+        b = int(roi[0])
+        x0, y0, x1, y1 = (roi[1:] * s - 0.5).astype(np.float64)
+        bw, bh = (x1 - x0) / P, (y1 - y0) / P
+        for c in range(2):
+            cx = x0 + (np.arange(P) + 0.5) * bw
+            cy = y0 + (np.arange(P) + 0.5) * bh
+            want = ax * cx[None, :] + ay * cy[:, None] + c0 + c + 10 * b
+            np.testing.assert_allclose(out[r, c], want, atol=2e-4)
+
+
+def test_box_outside_map_is_zero(oracle):
+    f = np.ones((1, 2, 10, 10), np.float32)
+    rois = np.array([[0, 400, 400, 500, 500], [0, -900, -900, -700, -700]], np.float32)
+    out = oracle.roi_align(f, rois, (7, 7), 1 / 16, 0, True)
+    assert np.all(out == 0)
+
+
+def test_aligned_half_pixel_shift(oracle):
+    # aligned=True on box b  ==  aligned=False on the same box shifted by -0.5 px in feature space
+    # (when the legacy >=1 clamp does not bite, i.e. box larger than 1 feature pixel)
+    rng = np.random.default_rng(0)
+    f = rng.standard_normal((1, 4, 30, 30)).astype(np.float32)
+    roi = np.array([[0, 64, 80, 320, 336]], np.float32)
+    a = oracle.roi_align(f, roi, (7, 7), 1 / 16, 2, True)
+    shifted = roi.copy()
+    shifted[:, 1:] -= 8.0            # 0.5 feature px * stride 16
+    b = oracle.roi_align(f, shifted, (7, 7), 1 / 16, 2, False)
+    np.testing.assert_allclose(a, b, atol=1e-6)
+
+
+def test_degenerate_and_ragged(oracle):
+    f = np.ones((2, 1, 8, 8), np.float32)
+    assert oracle.roi_align(f, np.zeros((0, 5), np.float32), (7, 7), 1 / 16).shape == (0, 1, 7, 7)
+    # zero-area and inverted boxes with aligned=True: grid = ceil(<=0) -> no samples -> 0
+    rois = np.array([[1, 32, 32, 32, 32], [0, 64, 64, 32, 32]], np.float32)
+    out = oracle.roi_align(f, rois, (7, 7), 1 / 16, 0, True)
+    assert np.all(out == 0)
+    # legacy mode forces them to 1x1 feature px instead
+    out = oracle.roi_align(f, rois[:1], (7, 7), 1 / 16, 0, False)
+    np.testing.assert_allclose(out, 1.0)
+
+
+def _numpy_roi_align(f, rois, P, s, sr, aligned):
+    """Independent float64 evaluation with np broadcasting (different code path from the C)."""
+    N, C, H, W = f.shape
+    out = np.zeros((len(rois), C, P, P))
+    for r, roi in enumerate(rois):
+        b = int(roi[0])
+        off = 0.5 if aligned else 0.0
+        x0, y0, x1, y1 = [np.float32(np.float32(v) * np.float32(s)) - np.float32(off) for v in roi[1:]]
+        rw, rh = np.float32(x1 - x0), np.float32(y1 - y0)
+        if not aligned:
+            rw, rh = max(rw, np.float32(1)), max(rh, np.float32(1))
+        gh = sr if sr > 0 else int(math.ceil(rh / np.float32(P)))
+        gw = sr if sr > 0 else int(math.ceil(rw / np.float32(P)))
+        bh, bw = np.float32(rh / np.float32(P)), np.float32(rw / np.float32(P))
+        for ph in range(P):
+            for pw in range(P):
+                acc = np.zeros(C)
+                for iy in range(gh):
+                    y = np.float32(y0 + np.float32(ph * bh)) + np.float32(np.float32((iy + 0.5) * bh) / np.float32(gh))
+                    for ix in range(gw):
+                        x = np.float32(x0 + np.float32(pw * bw)) + np.float32(np.float32((ix + 0.5) * bw) / np.float32(gw))
+                        if y < -1 or y > H or x < -1 or x > W:
+                            continue
+                        yy, xx = max(float(y), 0.0), max(float(x), 0.0)
+                        yl, xl = int(yy), int(xx)
+                        if yl >= H - 1:
+                            yl = yh = H - 1
+                            yy = float(yl)
+                        else:
+                            yh = yl + 1
+                        if xl >= W - 1:
+                            xl = xh = W - 1
+                            xx = float(xl)
+                        else:
+                            xh = xl + 1
+                        ly, lx = yy - yl, xx - xl
+                        acc += ((1 - ly) * (1 - lx) * f[b, :, yl, xl] + (1 - ly) * lx * f[b, :, yl, xh]
+                                + ly * (1 - lx) * f[b, :, yh, xl] + ly * lx * f[b, :, yh, xh])
+                out[r, :, ph, pw] = acc / max(gh * gw, 1)
+    return out
+
+
+def test_against_independent_numpy_eval(oracle):
+    rng = np.random.default_rng(5)
+    f = rng.standard_normal((2, 3, 25, 42)).astype(np.float32)
+    boxes = oracle.synth_boxes(rng, 24, 42 * 16.0, 25 * 16.0)
+    # a few boxes that stick out of the map (unclipped) to exercise the border rules
+    boxes[:4] += np.array([-90, -70, 60, 80], np.float32)
+    rois = np.concatenate([rng.integers(0, 2, (24, 1)).astype(np.float32), boxes], axis=1)
+    for sr, aligned in ((0, True), (2, True), (0, False)):
+        got = oracle.roi_align(f, rois, (7, 7), 1 / 16, sr, aligned)
+        want = _numpy_roi_align(f, rois, 7, 1 / 16, sr, aligned)
+        np.testing.assert_allclose(got, want, atol=2e-5)
+
+
+def test_backward_is_adjoint_of_forward(oracle):
+    rng = np.random.default_rng(6)
+    f = rng.standard_normal((2, 2, 12, 16)).astype(np.float32)
+    boxes = oracle.synth_boxes(rng, 9, 16 * 16.0, 12 * 16.0)
+    rois = np.concatenate([rng.integers(0, 2, (9, 1)).astype(np.float32), boxes], axis=1)
+    g = rng.standard_normal((9, 2, 7, 7)).astype(np.float32)
+    y = oracle.roi_align(f, rois, (7, 7), 1 / 16, 0, True)
+    gf = oracle.roi_align_backward(g, f.shape, rois, 1 / 16, 0, True)
+    # <g, A f> == <A^T g, f>
+    np.testing.assert_allclose((g.astype(np.float64) * y).sum(), (gf.astype(np.float64) * f).sum(), rtol=1e-4)
+
+
+def test_level_assignment_matches_torch_formula(oracle):
+    """[D2-upstream] assign_boxes_to_levels written with torch CPU ops, as Detectron2 does."""
+    rng = np.random.default_rng(7)
+    boxes = oracle.synth_boxes(rng, 20000)
+    # exact level boundaries: sqrt(area) = 224 * 2^k / 2  etc.
+    for k, side in enumerate((56.0, 112.0, 224.0, 448.0, 896.0)):
+        boxes[k] = (10, 10, 10 + side, 10 + side)
+    boxes[5] = (5, 5, 5, 5)                   # zero area -> log2(1e-8) -> clamps to min level
+    got = oracle.assign_boxes_to_levels(boxes, 2, 5, 224, 4)
+    t = torch.from_numpy(boxes)
+    sizes = torch.sqrt((t[:, 2] - t[:, 0]) * (t[:, 3] - t[:, 1]))
+    lv = torch.floor(4 + torch.log2(sizes / 224 + 1e-8))
+    lv = torch.clamp(lv, min=2, max=5).to(torch.int64) - 2
+    mism = np.nonzero(got != lv.numpy())[0]
+    assert len(mism) == 0, (mism[:10], got[mism[:10]], lv.numpy()[mism[:10]])
+    assert got[5] == 0 and got.min() == 0 and got.max() == 3
+    assert list(got[:5]) == [0, 1, 2, 3, 3]
+
+
+def test_roi_pooler_multilevel_scatter(oracle):
+    rng = np.random.default_rng(8)
+    feats = [rng.standard_normal((2, 3, 64 >> i, 96 >> i)).astype(np.float32) for i in range(4)]
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    box_lists = [oracle.synth_boxes(rng, 11, 384.0, 256.0), oracle.synth_boxes(rng, 6, 384.0, 256.0)]
+    out = oracle.roi_pooler(feats, box_lists, 7, scales, 0, "ROIAlignV2")
+    rois = oracle.boxes_to_pooler_format(box_lists)
+    assert rois.shape == (17, 5) and list(rois[:, 0]) == [0.0] * 11 + [1.0] * 6
+    lv = oracle.assign_boxes_to_levels(rois[:, 1:], 2, 5)
+    for i in range(17):
+        want = oracle.roi_align(feats[lv[i]], rois[i:i + 1], (7, 7), scales[lv[i]], 0, True)
+        np.testing.assert_array_equal(out[i:i + 1], want)
