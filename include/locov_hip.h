@@ -1,0 +1,178 @@
+/*
+ * locov_hip.h -- C ABI of the MI355X (gfx950) LSM ROI-head library, liblocov_hip.so.
+ *
+ * This is the drop-in boundary for LocOV's Localized-Semantic-Matching ROI-head hot
+ * path.  LocOV itself is 100 % Python and reaches its kernels
+ * through Detectron2 / torchvision / torch; every entry point below names the
+ * reference interface (file:line under the LocOV tree) whose device arithmetic it
+ * replaces.  The Python classes in locov_amd/ (same names, config keys and checkpoint
+ * keys as the reference's) are the only callers; they bind these symbols with ctypes
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / HIP types in signatures.
+ *   - Every pointer is a DEVICE pointer unless the parameter name ends in `_host`.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *     Calls only enqueue work on that stream: no allocation, no synchronisation, no
+ *     hidden global state -> safe to capture in a hipGraph.
+ *   - Outputs are caller-allocated.  Tensors are dense row-major in the stated shape.
+ *   - Return value: 0 on success, <0 on error (LOCOV_ERR_*); locov_last_error() returns
+ *     a thread-local message for the last failing call on this thread.
+ *   - Threading: re-entrant; one call stream per thread as with any HIP stream.
+ */
+#ifndef LOCOV_HIP_H
+#define LOCOV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOCOV_ABI_VERSION 1
+
+#define LOCOV_OK 0
+#define LOCOV_ERR_INVALID_ARG (-1)
+#define LOCOV_ERR_LAUNCH (-2)
+#define LOCOV_ERR_UNSUPPORTED (-3)
+
+/* element types for the mixed-precision entry points */
+#define LOCOV_F32 0
+#define LOCOV_BF16 1
+
+/* row-normalisation modes (locov_rownorm_fwd) */
+#define LOCOV_NORM_NONE 0
+#define LOCOV_NORM_L2 1          /* normalize_vec   : logged_module.py:55-65 */
+#define LOCOV_NORM_STANDARDIZE 2 /* standardize_vec : logged_module.py:68-72 */
+
+/* epilogue flags of the GEMM entry points */
+#define LOCOV_EPI_RELU 1u
+
+typedef void *locov_stream_t;
+
+int locov_abi_version(void);
+const char *locov_last_error(void);
+
+/* Number of compute units / XCDs of the current device (for grid sizing in callers/bench). */
+int locov_device_info(int *cu_count, int *wave_size, int *lds_bytes_per_cu);
+
+/* ---------------------------------------------------------------------------------------
+ * a-2  proposal -> FPN level assignment.
+ * Replaces [D2-upstream] detectron2.modeling.poolers.assign_boxes_to_levels, reached from
+ * ovr/modeling/roi_heads/roi_emb_heads.py:244 (self.pooler(features, boxes)) when the
+ * pooler has >1 level.  boxes [R,4] XYXY fp32 -> levels [R] int64 in [0, max-min].
+ * Bit-exact integer output (north_star).
+ * ------------------------------------------------------------------------------------- */
+int locov_level_assign(const float *boxes, int64_t R, int min_level, int max_level,
+                       int canonical_box_size, int canonical_level, int64_t *levels,
+                       locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a-1  ROIAlign forward / backward, NCHW fp32 -- the stand-alone pooler contract.
+ * Replaces [D2-upstream] ROIPooler -> ROIAlign -> torchvision.ops.roi_align, call site
+ * ovr/modeling/roi_heads/roi_emb_heads.py:243-245 (_shared_roi_transform), pooler built
+ * at :182-187 (output_size=14, scales=(1/16,), sampling_ratio=0, "ROIAlignV2").
+ *   feat [N,C,H,W]; rois [R,5] = (batch_idx, x0, y0, x1, y1); out [R,C,pooled_h,pooled_w].
+ *   sampling_ratio <= 0 -> adaptive ceil(roi/pooled) grid.  aligned != 0 -> ROIAlignV2.
+ * Backward accumulates into grad_feat [N,C,H,W] (caller zeroes it) with fp32 atomics.
+ * ------------------------------------------------------------------------------------- */
+int locov_roi_align_fwd(const float *feat, int N, int C, int H, int W, const float *rois,
+                        int64_t R, int pooled_h, int pooled_w, float spatial_scale,
+                        int sampling_ratio, int aligned, float *out, locov_stream_t stream);
+
+int locov_roi_align_bwd(const float *grad_out, int N, int C, int H, int W, const float *rois,
+                        int64_t R, int pooled_h, int pooled_w, float spatial_scale,
+                        int sampling_ratio, int aligned, float *grad_feat,
+                        locov_stream_t stream);
+
+/* Multi-level pooler in ONE launch: ROI r samples level levels[r] (output of
+ * locov_level_assign).  Host arrays describe up to LOCOV_MAX_LEVELS feature maps that
+ * share N and C.  Replaces the per-level nonzero / index_put_ loop of ROIPooler.forward. */
+#define LOCOV_MAX_LEVELS 8
+int locov_roi_align_levels_fwd(const float *const *feats_host, const int *H_host,
+                               const int *W_host, const float *scales_host, int num_levels,
+                               int N, int C, const float *rois, const int64_t *levels,
+                               int64_t R, int pooled_h, int pooled_w, int sampling_ratio,
+                               int aligned, float *out, locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * MI355X-native layout path: channels-last feature map, channels on the
+ * lanes, coalesced 16-byte gathers.
+ *   locov_nchw_to_nhwc : [N,C,H,W] f32 -> [N,H,W,C] (f32 or bf16)
+ *   locov_roi_align_nhwc_fwd : feat [N,H,W,C] -> out [R, ceil(ph/bin_stride), ceil(pw/bin_stride), C]
+ *     bin_stride = 1: every bin.  bin_stride = 2: only even bins (ph, pw even) -- exactly
+ *     the positions the stride-2 1x1 convs of Res5 block 0 read (STRIDE_IN_1X1=True,
+ *     roi_emb_heads.py:217-241), so downstream results are unchanged.
+ * ------------------------------------------------------------------------------------- */
+int locov_nchw_to_nhwc(const float *in, int N, int C, int H, int W, void *out, int out_dtype,
+                       locov_stream_t stream);
+
+int locov_roi_align_nhwc_fwd(const void *feat, int feat_dtype, int N, int H, int W, int C,
+                             const float *rois, int64_t R, int pooled_h, int pooled_w,
+                             float spatial_scale, int sampling_ratio, int aligned,
+                             int bin_stride, void *out, int out_dtype, locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a-4  spatial mean.  Replaces box_features.mean(dim=[2,3])
+ * (roi_emb_heads.py:262,344,356).  x [R,C,HW] -> out [R,C].
+ * channels_last != 0: x is [R,HW,C] instead.
+ * ------------------------------------------------------------------------------------- */
+int locov_spatial_mean_fwd(const float *x, int64_t R, int C, int HW, int channels_last,
+                           float *out, locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a-5 / a-6 / a-8  y[M,N] = epi(x[M,K] . W[N,K]^T), fp32 in / fp32 accumulate on the
+ * f32 MFMA pipe (exact fp32 products, no TF32).  nn.Linear layout (weight [out,in]).
+ * Replaces self.bbox_pred(x) (box_emb_head.py:196), self.emb_pred(x) (:206) and, in fp32
+ * mode, self.cls_score(x) (:211).
+ *   epi: v = acc * scale[n] (if scale) + shift[n] (if shift) + residual[m,n] (if residual);
+ *        ReLU if (flags & LOCOV_EPI_RELU).     shift == bias for nn.Linear.
+ *   lda / ldc: row strides (elements) of x and y (>= K / >= N); residual uses ldc.
+ * ------------------------------------------------------------------------------------- */
+int locov_gemm_nt_f32(const float *x, int64_t lda, const float *W, const float *scale,
+                      const float *shift, const float *residual, float *y, int64_t ldc,
+                      int64_t M, int N, int K, unsigned flags, locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a-7  row normalisation of [R,D] fp32: L2 (x / max(||x||, eps)) or standardise
+ * ((x - mean) / (std_unbiased + eps)).  Replaces normalize_vec / standardize_vec
+ * (logged_module.py:55-72) applied at box_emb_head.py:207-210 and to the bank at :223-232.
+ * In-place allowed (y == x).
+ * ------------------------------------------------------------------------------------- */
+int locov_rownorm_fwd(const float *x, int64_t R, int D, int mode, float eps, float *y,
+                      locov_stream_t stream);
+
+/* fp32 -> bf16 (round-to-nearest-even, NaN preserved) for packing the text bank / embeddings */
+int locov_f32_to_bf16(const float *x, int64_t n, uint16_t *y, locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a-8  region x text similarity GEMM, bf16 operands / fp32 accumulate on the bf16 MFMA pipe:
+ *   logits[R,K1] = emb[R,D] . bank[K1,D]^T          (bias is identically zero,
+ *   box_emb_head.py:234).  emb, bank are bf16 (uint16 storage).  Config 3 of BASELINE.json.
+ * ------------------------------------------------------------------------------------- */
+int locov_sim_gemm_bf16(const uint16_t *emb, const uint16_t *bank, int64_t R, int D, int K1,
+                        float *logits, int64_t ldc, locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a-4...a-8 in one call: EmbeddingFastRCNNOutputLayers.forward (box_emb_head.py:179-212)
+ * preceded by the spatial mean of its caller (roi_emb_heads.py:262,344,356).
+ *   x        [R,C5,HW] fp32 (HW may be 1)            pooled  [R,C5]  (out; == x when HW==1 is allowed)
+ *   emb_w    [D,C5], emb_b [D]                        emb     [R,D]   (out, after optional norm)
+ *   bbox_w   [4,C5], bbox_b [4]                       deltas  [R,4]   (out)
+ *   bank     [K1,D] fp32 (already normalised by set_class_embeddings if enabled)
+ *   bank_bf16 optional packed copy; used when sim_dtype == LOCOV_BF16 (emb_bf16 [R,D] scratch)
+ *   logits   [R,K1] (out)
+ * Weights are read at call time (the reference re-assigns emb_pred.weight/bias to the
+ * grounding head's parameters, distill_prop_mmss_gcnn.py:121-125).
+ * ------------------------------------------------------------------------------------- */
+int locov_box_head_fwd(const float *x, int64_t R, int C5, int HW, int channels_last,
+                       const float *emb_w, const float *emb_b, const float *bbox_w,
+                       const float *bbox_b, const float *bank, const uint16_t *bank_bf16,
+                       int D, int K1, int norm_mode, int sim_dtype, float *pooled,
+                       float *deltas, float *emb, uint16_t *emb_bf16, float *logits,
+                       locov_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOCOV_HIP_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of liblocov_hip.so (the C ABI of include/locov_hip.h).
+
+The library is loaded on first use and the import fails loudly if it is missing or lacks a
+symbol: there is no PyTorch / CPU fallback for the hot path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint, c_void_p, POINTER
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liblocov_hip.so")
+
+OK = 0
+F32, BF16 = 0, 1
+NORM_NONE, NORM_L2, NORM_STANDARDIZE = 0, 1, 2
+EPI_RELU = 1
+MAX_LEVELS = 8
+ABI_VERSION = 1
+
+_p = c_void_p  # device pointer
+
+# name -> (restype, argtypes); mirrors include/locov_hip.h declaration by declaration
+SIGNATURES = {
+    "locov_abi_version": (c_int, []),
+    "locov_last_error": (c_char_p, []),
+    "locov_device_info": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "locov_level_assign": (c_int, [_p, c_int64, c_int, c_int, c_int, c_int, _p, _p]),
+    "locov_roi_align_fwd": (c_int, [_p, c_int, c_int, c_int, c_int, _p, c_int64, c_int, c_int, c_float,
+                                    c_int, c_int, _p, _p]),
+    "locov_roi_align_bwd": (c_int, [_p, c_int, c_int, c_int, c_int, _p, c_int64, c_int, c_int, c_float,
+                                    c_int, c_int, _p, _p]),
+    "locov_roi_align_levels_fwd": (c_int, [POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_float),
+                                           c_int, c_int, c_int, _p, _p, c_int64, c_int, c_int, c_int, c_int,
+                                           _p, _p]),
+    "locov_nchw_to_nhwc": (c_int, [_p, c_int, c_int, c_int, c_int, _p, c_int, _p]),
+    "locov_roi_align_nhwc_fwd": (c_int, [_p, c_int, c_int, c_int, c_int, c_int, _p, c_int64, c_int, c_int,
+                                         c_float, c_int, c_int, c_int, _p, c_int, _p]),
+    "locov_spatial_mean_fwd": (c_int, [_p, c_int64, c_int, c_int, c_int, _p, _p]),
+    "locov_gemm_nt_f32": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, _p]),
+    "locov_rownorm_fwd": (c_int, [_p, c_int64, c_int, c_int, c_float, _p, _p]),
+    "locov_f32_to_bf16": (c_int, [_p, c_int64, _p, _p]),
+    "locov_sim_gemm_bf16": (c_int, [_p, _p, c_int64, c_int, c_int, _p, c_int64, _p]),
+    "locov_box_head_fwd": (c_int, [_p, c_int64, c_int, c_int, c_int, _p, _p, _p, _p, _p, _p, c_int, c_int,
+                                   c_int, c_int, _p, _p, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+class LocovError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load liblocov_hip.so and bind every symbol of the header; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LocovError(
+            f"{LIB_PATH} not found: build it with `python -m locov_amd.build` "
+            "(or __graft_entry__.build()).  The LSM ROI-head path has no fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise LocovError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.locov_abi_version() != ABI_VERSION:
+        raise LocovError(f"ABI version mismatch: library {lib.locov_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != OK:
+        msg = load().locov_last_error()
+        raise LocovError(f"{what or 'liblocov_hip'} failed (code {rc}): {msg.decode() if msg else ''}")

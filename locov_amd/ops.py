@@ -1,0 +1,280 @@
+"""Tensor-level wrappers over the C ABI (include/locov_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every function below checks
+its arguments, allocates the outputs and enqueues the hand-written gfx950 kernels on
+torch's current stream.  Nothing in this module computes with torch ops, and there is no
+CPU path: tensors must live on a ROCm device.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, NORM_L2, NORM_NONE, NORM_STANDARDIZE, LocovError, check
+
+__all__ = [
+    "level_assign", "roi_align", "roi_align_levels", "nchw_to_nhwc", "roi_align_nhwc", "spatial_mean",
+    "linear", "rownorm", "to_bf16", "sim_gemm_bf16", "box_head", "NORM_NONE", "NORM_L2",
+    "NORM_STANDARDIZE", "F32", "BF16",
+]
+
+
+def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise LocovError(f"{name} is on {t.device}: the LSM ROI-head kernels only run on a ROCm GPU "
+                         "(there is no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _stream(t: torch.Tensor) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def _dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {dt}")
+
+
+# --------------------------------------------------------------------------------------
+def level_assign(boxes: torch.Tensor, min_level: int, max_level: int, canonical_box_size: int = 224,
+                 canonical_level: int = 4) -> torch.Tensor:
+    """boxes [R,4] XYXY fp32 -> int64 [R] level index in [0, max_level-min_level]."""
+    boxes = _dev(boxes, "boxes")
+    if boxes.dim() != 2 or boxes.shape[1] != 4:
+        raise ValueError(f"boxes must be [R,4], got {tuple(boxes.shape)}")
+    out = torch.empty((boxes.shape[0],), dtype=torch.int64, device=boxes.device)
+    with torch.cuda.device(boxes.device):
+        check(_lib.load().locov_level_assign(_ptr(boxes), boxes.shape[0], int(min_level), int(max_level),
+                                             int(canonical_box_size), int(canonical_level), _ptr(out),
+                                             _stream(boxes)), "locov_level_assign")
+    return out
+
+
+class _ROIAlignFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, ph, pw, scale, sampling_ratio, aligned):
+        N, C, H, W = feat.shape
+        R = rois.shape[0]
+        out = torch.empty((R, C, ph, pw), dtype=torch.float32, device=feat.device)
+        with torch.cuda.device(feat.device):
+            check(_lib.load().locov_roi_align_fwd(_ptr(feat), N, C, H, W, _ptr(rois), R, ph, pw, float(scale),
+                                                  int(sampling_ratio), int(aligned), _ptr(out), _stream(feat)),
+                  "locov_roi_align_fwd")
+        ctx.save_for_backward(rois)
+        ctx.args = (N, C, H, W, ph, pw, scale, sampling_ratio, aligned)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (rois,) = ctx.saved_tensors
+        N, C, H, W, ph, pw, scale, sampling_ratio, aligned = ctx.args
+        grad_out = _dev(grad_out, "grad_out")
+        gf = torch.zeros((N, C, H, W), dtype=torch.float32, device=grad_out.device)
+        with torch.cuda.device(gf.device):
+            check(_lib.load().locov_roi_align_bwd(_ptr(grad_out), N, C, H, W, _ptr(rois), rois.shape[0], ph, pw,
+                                                  float(scale), int(sampling_ratio), int(aligned), _ptr(gf),
+                                                  _stream(gf)), "locov_roi_align_bwd")
+        return gf, None, None, None, None, None, None
+
+
+def roi_align(feat: torch.Tensor, rois: torch.Tensor, output_size, spatial_scale: float,
+              sampling_ratio: int = 0, aligned: bool = True) -> torch.Tensor:
+    """feat [N,C,H,W] fp32, rois [R,5] (batch_idx,x0,y0,x1,y1) -> [R,C,ph,pw] (differentiable in feat)."""
+    feat = _dev(feat, "feat")
+    rois = _dev(rois, "rois")
+    if feat.dim() != 4:
+        raise ValueError(f"feat must be [N,C,H,W], got {tuple(feat.shape)}")
+    if rois.dim() != 2 or rois.shape[1] != 5:
+        raise ValueError(f"rois must be [R,5], got {tuple(rois.shape)}")
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    return _ROIAlignFn.apply(feat, rois, int(ph), int(pw), float(spatial_scale), int(sampling_ratio), bool(aligned))
+
+
+def roi_align_levels(feats: Sequence[torch.Tensor], scales: Sequence[float], rois: torch.Tensor,
+                     levels: Optional[torch.Tensor], output_size: int, sampling_ratio: int = 0,
+                     aligned: bool = True) -> torch.Tensor:
+    """Multi-level pooler in one launch: ROI r reads feats[levels[r]]."""
+    L = len(feats)
+    if not (1 <= L <= _lib.MAX_LEVELS) or len(scales) != L:
+        raise ValueError("need 1..8 feature levels with one scale each")
+    feats = [_dev(f, f"feats[{i}]") for i, f in enumerate(feats)]
+    rois = _dev(rois, "rois")
+    N, C = feats[0].shape[:2]
+    for f in feats:
+        if f.shape[0] != N or f.shape[1] != C:
+            raise ValueError("all levels must share N and C")
+    if L > 1:
+        levels = _dev(levels, "levels", torch.int64)
+        if levels.shape[0] != rois.shape[0]:
+            raise ValueError("levels must have one entry per ROI")
+    R = rois.shape[0]
+    out = torch.empty((R, C, output_size, output_size), dtype=torch.float32, device=rois.device)
+    fp = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+    hh = (ctypes.c_int * L)(*[f.shape[2] for f in feats])
+    ww = (ctypes.c_int * L)(*[f.shape[3] for f in feats])
+    sc = (ctypes.c_float * L)(*[float(s) for s in scales])
+    with torch.cuda.device(rois.device):
+        check(_lib.load().locov_roi_align_levels_fwd(fp, hh, ww, sc, L, N, C, _ptr(rois),
+                                                     _ptr(levels if L > 1 else None), R, output_size, output_size,
+                                                     int(sampling_ratio), int(aligned), _ptr(out), _stream(rois)),
+              "locov_roi_align_levels_fwd")
+    return out
+
+
+def nchw_to_nhwc(feat: torch.Tensor, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    feat = _dev(feat, "feat")
+    N, C, H, W = feat.shape
+    out = torch.empty((N, H, W, C), dtype=dtype, device=feat.device)
+    with torch.cuda.device(feat.device):
+        check(_lib.load().locov_nchw_to_nhwc(_ptr(feat), N, C, H, W, _ptr(out), _dtype_code(dtype), _stream(feat)),
+              "locov_nchw_to_nhwc")
+    return out
+
+
+def roi_align_nhwc(feat: torch.Tensor, rois: torch.Tensor, output_size: int, spatial_scale: float,
+                   sampling_ratio: int = 0, aligned: bool = True, bin_stride: int = 1,
+                   out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """feat [N,H,W,C] (fp32|bf16) -> [R, ceil(P/bin_stride), ceil(P/bin_stride), C]."""
+    feat = _dev(feat, "feat", None)
+    rois = _dev(rois, "rois")
+    N, H, W, C = feat.shape
+    R = rois.shape[0]
+    o = (output_size + bin_stride - 1) // bin_stride
+    out = torch.empty((R, o, o, C), dtype=out_dtype, device=feat.device)
+    with torch.cuda.device(feat.device):
+        check(_lib.load().locov_roi_align_nhwc_fwd(_ptr(feat), _dtype_code(feat.dtype), N, H, W, C, _ptr(rois), R,
+                                                   output_size, output_size, float(spatial_scale),
+                                                   int(sampling_ratio), int(aligned), int(bin_stride), _ptr(out),
+                                                   _dtype_code(out_dtype), _stream(feat)),
+              "locov_roi_align_nhwc_fwd")
+    return out
+
+
+def spatial_mean(x: torch.Tensor, channels_last: bool = False) -> torch.Tensor:
+    """[R,C,h,w] (or [R,h,w,C] when channels_last) -> [R,C]."""
+    x = _dev(x, "x")
+    if x.dim() == 2:
+        return x
+    R = x.shape[0]
+    if channels_last:
+        C = x.shape[-1]
+        hw = x[0].numel() // C if R else 1
+    else:
+        C = x.shape[1]
+        hw = x[0].numel() // C if R else 1
+    out = torch.empty((R, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_spatial_mean_fwd(_ptr(x), R, C, max(hw, 1), int(channels_last), _ptr(out),
+                                                 _stream(x)), "locov_spatial_mean_fwd")
+    return out
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+           scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+           relu: bool = False) -> torch.Tensor:
+    """y = epi(x . weight^T): fp32 on the f32 MFMA pipe.  x [M,K], weight [N,K]."""
+    x = _dev(x, "x")
+    weight = _dev(weight, "weight")
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError(f"shape mismatch: x {tuple(x.shape)} weight {tuple(weight.shape)}")
+    bias = _dev(bias, "bias") if bias is not None else None
+    scale = _dev(scale, "scale") if scale is not None else None
+    residual = _dev(residual, "residual") if residual is not None else None
+    if residual is not None and tuple(residual.shape) != (M, N):
+        raise ValueError("residual must be [M,N]")
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_gemm_nt_f32(_ptr(x), K, _ptr(weight), _ptr(scale), _ptr(bias), _ptr(residual),
+                                            _ptr(y), N, M, N, K, _lib.EPI_RELU if relu else 0, _stream(x)),
+              "locov_gemm_nt_f32")
+    return y
+
+
+def rownorm(x: torch.Tensor, mode: int, eps: float = 1e-12) -> torch.Tensor:
+    x = _dev(x, "x")
+    R, D = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_rownorm_fwd(_ptr(x), R, D, int(mode), float(eps), _ptr(y), _stream(x)),
+              "locov_rownorm_fwd")
+    return y
+
+
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    x = _dev(x, "x")
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_f32_to_bf16(_ptr(x), x.numel(), _ptr(y), _stream(x)), "locov_f32_to_bf16")
+    return y
+
+
+def sim_gemm_bf16(emb: torch.Tensor, bank: torch.Tensor) -> torch.Tensor:
+    """logits[R,K1] = emb[R,D] . bank[K1,D]^T, bf16 operands, fp32 accumulate / output."""
+    emb = _dev(emb, "emb", torch.bfloat16)
+    bank = _dev(bank, "bank", torch.bfloat16)
+    R, D = emb.shape
+    K1 = bank.shape[0]
+    if bank.shape[1] != D:
+        raise ValueError("emb / bank embedding dims differ")
+    out = torch.empty((R, K1), dtype=torch.float32, device=emb.device)
+    with torch.cuda.device(emb.device):
+        check(_lib.load().locov_sim_gemm_bf16(_ptr(emb), _ptr(bank), R, D, K1, _ptr(out), K1, _stream(emb)),
+              "locov_sim_gemm_bf16")
+    return out
+
+
+def box_head(x: torch.Tensor, emb_w: torch.Tensor, emb_b: torch.Tensor, bbox_w: torch.Tensor,
+             bbox_b: torch.Tensor, bank: torch.Tensor, bank_bf16: Optional[torch.Tensor] = None,
+             norm_mode: int = NORM_NONE, sim_dtype: int = F32, channels_last: bool = False
+             ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Spatial mean + EmbeddingFastRCNNOutputLayers.forward in one C call.
+    Returns (pooled [R,C5], deltas [R,4], emb [R,D], logits [R,K1])."""
+    x = _dev(x, "x")
+    R = x.shape[0]
+    if x.dim() == 2:
+        C5, HW = x.shape[1], 1
+    elif channels_last:
+        C5 = x.shape[-1]
+        HW = x[0].numel() // C5 if R else 1
+    else:
+        C5 = x.shape[1]
+        HW = x[0].numel() // C5 if R else 1
+    emb_w, emb_b = _dev(emb_w, "emb_w"), _dev(emb_b, "emb_b")
+    bbox_w, bbox_b = _dev(bbox_w, "bbox_w"), _dev(bbox_b, "bbox_b")
+    bank = _dev(bank, "bank")
+    D, K1 = emb_w.shape[0], bank.shape[0]
+    if emb_w.shape[1] != C5 or bbox_w.shape != (4, C5) or bank.shape[1] != D:
+        raise ValueError("box_head: inconsistent weight shapes")
+    dev = x.device
+    pooled = torch.empty((R, C5), dtype=torch.float32, device=dev)
+    deltas = torch.empty((R, 4), dtype=torch.float32, device=dev)
+    emb = torch.empty((R, D), dtype=torch.float32, device=dev)
+    logits = torch.empty((R, K1), dtype=torch.float32, device=dev)
+    emb_bf16 = None
+    if sim_dtype == BF16:
+        if bank_bf16 is None:
+            bank_bf16 = to_bf16(bank)
+        bank_bf16 = _dev(bank_bf16, "bank_bf16", torch.bfloat16)
+        emb_bf16 = torch.empty((R, D), dtype=torch.bfloat16, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().locov_box_head_fwd(_ptr(x), R, C5, max(HW, 1), int(channels_last), _ptr(emb_w), _ptr(emb_b),
+                                             _ptr(bbox_w), _ptr(bbox_b), _ptr(bank), _ptr(bank_bf16), D, K1,
+                                             int(norm_mode), int(sim_dtype), _ptr(pooled), _ptr(deltas), _ptr(emb),
+                                             _ptr(emb_bf16), _ptr(logits), _stream(x)), "locov_box_head_fwd")
+    return pooled, deltas, emb, logits
