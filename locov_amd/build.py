@@ -23,6 +23,15 @@ CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rd
             "-Wall", "-Wno-unused-function"]
 
 
+# ROIAlign coordinates/weights must be un-fused fp32 (bit-exact with the oracle).  HIP's
+# default -ffp-contract=fast lets the backend fuse globally, which a source pragma cannot
+# veto, so these files are compiled with contraction off (they call fmaf() where they want it).
+FILE_FLAGS = {
+    "roi_align.hip": ["-ffp-contract=off"],
+    "roi_align_nhwc.hip": ["-ffp-contract=off"],
+}
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -50,7 +59,7 @@ def _stale(target: str, deps) -> bool:
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
     if force or _stale(obj, [src] + _headers()):
-        cmd = [_hipcc()] + CXXFLAGS + ["-c", src, "-o", obj]
+        cmd = [_hipcc()] + CXXFLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")

@@ -10,10 +10,20 @@
 // math.  For a fixed ROI the output block out[r, c0:c0+CT, :, :] is one contiguous run of
 // CT*ph*pw floats, so lanes write consecutive addresses (the kernel is HBM-write-bound:
 // 0.80 MB per proposal at C=1024, P=14).  Coordinates and weights use un-fused fp32
-// (__f*_rn never contracts to FMA), which makes the result bit-identical to the oracle.
+// (FMA contraction off), which makes the result bit-identical to the oracle.
 #include "common.h"
 
+// The oracle defines un-fused fp32 arithmetic; HIP's __f*_rn helpers are plain operators and
+// would be contracted to FMA, so contraction is switched off for this whole file.
+#pragma clang fp contract(off)
+
 namespace locov {
+
+// plain operators compiled under contract(off): one IEEE rounding each, never fused
+__device__ __forceinline__ float f_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float f_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float f_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float f_div(float a, float b) { return a / b; }
 
 struct LevelDesc {
     const float *feat;
@@ -39,8 +49,8 @@ __device__ __forceinline__ AxisSample axis_sample(float start, float bin, int p,
                                                   int stride)
 {
     // v = start + p*bin + ((i + .5f) * bin) / grid      -- left-to-right, un-fused
-    float v = __fadd_rn(__fadd_rn(start, __fmul_rn((float)p, bin)),
-                        __fdiv_rn(__fmul_rn(__fadd_rn((float)i, .5f), bin), (float)grid));
+    float v = f_add(f_add(start, f_mul((float)p, bin)),
+                        f_div(f_mul(f_add((float)i, .5f), bin), (float)grid));
     AxisSample s;
     if (v < -1.0f || v > (float)size) {  // sample outside the map contributes zero
         s.lo = 0; s.hi = 0; s.wl = 0.f; s.wh = 0.f;
@@ -54,9 +64,9 @@ __device__ __forceinline__ AxisSample axis_sample(float start, float bin, int p,
     } else {
         hi = lo + 1;
     }
-    const float l = __fsub_rn(v, (float)lo);
+    const float l = f_sub(v, (float)lo);
     s.lo = lo * stride; s.hi = hi * stride;
-    s.wl = l; s.wh = __fsub_rn(1.f, l);
+    s.wl = l; s.wh = f_sub(1.f, l);
     return s;
 }
 
@@ -65,17 +75,17 @@ __device__ __forceinline__ RoiGeom roi_geom(const float *roi, float scale, int p
 {
     RoiGeom g;
     const float off = aligned ? 0.5f : 0.0f;
-    g.start_w = __fsub_rn(__fmul_rn(roi[1], scale), off);
-    g.start_h = __fsub_rn(__fmul_rn(roi[2], scale), off);
-    const float end_w = __fsub_rn(__fmul_rn(roi[3], scale), off);
-    const float end_h = __fsub_rn(__fmul_rn(roi[4], scale), off);
-    float rw = __fsub_rn(end_w, g.start_w), rh = __fsub_rn(end_h, g.start_h);
+    g.start_w = f_sub(f_mul(roi[1], scale), off);
+    g.start_h = f_sub(f_mul(roi[2], scale), off);
+    const float end_w = f_sub(f_mul(roi[3], scale), off);
+    const float end_h = f_sub(f_mul(roi[4], scale), off);
+    float rw = f_sub(end_w, g.start_w), rh = f_sub(end_h, g.start_h);
     if (!aligned) {
         rw = fmaxf(rw, 1.f);
         rh = fmaxf(rh, 1.f);
     }
-    g.bin_h = __fdiv_rn(rh, (float)ph);
-    g.bin_w = __fdiv_rn(rw, (float)pw);
+    g.bin_h = f_div(rh, (float)ph);
+    g.bin_w = f_div(rw, (float)pw);
     int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(g.bin_h);
     int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(g.bin_w);
     const int prod = gh * gw;
@@ -144,16 +154,16 @@ __global__ __launch_bounds__(kRoiThreads) void roi_align_nchw_kernel(
                                                   : axis_sample(g.start_w, g.bin_w, pw, ix, g.grid_w, L.W, 1);
                     const float v1 = plane[ys.lo + xs.lo], v2 = plane[ys.lo + xs.hi];
                     const float v3 = plane[ys.hi + xs.lo], v4 = plane[ys.hi + xs.hi];
-                    const float w1 = __fmul_rn(ys.wh, xs.wh), w2 = __fmul_rn(ys.wh, xs.wl);
-                    const float w3 = __fmul_rn(ys.wl, xs.wh), w4 = __fmul_rn(ys.wl, xs.wl);
+                    const float w1 = f_mul(ys.wh, xs.wh), w2 = f_mul(ys.wh, xs.wl);
+                    const float w3 = f_mul(ys.wl, xs.wh), w4 = f_mul(ys.wl, xs.wl);
                     // ((w1*v1 + w2*v2) + w3*v3) + w4*v4, then accumulate: oracle order
-                    const float s = __fadd_rn(
-                        __fadd_rn(__fadd_rn(__fmul_rn(w1, v1), __fmul_rn(w2, v2)), __fmul_rn(w3, v3)),
-                        __fmul_rn(w4, v4));
-                    acc = __fadd_rn(acc, s);
+                    const float s = f_add(
+                        f_add(f_add(f_mul(w1, v1), f_mul(w2, v2)), f_mul(w3, v3)),
+                        f_mul(w4, v4));
+                    acc = f_add(acc, s);
                 }
             }
-            out_or_gradfeat[obase + o] = __fdiv_rn(acc, g.count);
+            out_or_gradfeat[obase + o] = f_div(acc, g.count);
         } else {
             float *plane = out_or_gradfeat + ((int64_t)b * C + c0 + c) * plane_sz;
             const float gv = grad_out[obase + o];
@@ -184,11 +194,11 @@ __global__ __launch_bounds__(256) void level_assign_kernel(const float *__restri
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
     const float4 b = reinterpret_cast<const float4 *>(boxes)[i];
-    const float area = __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y));
+    const float area = f_mul(f_sub(b.z, b.x), f_sub(b.w, b.y));
     const float size = __fsqrt_rn(area);
-    const float arg = __fadd_rn(__fdiv_rn(size, canon_size), 1e-8f);
+    const float arg = f_add(f_div(size, canon_size), 1e-8f);
     const float l2 = (float)log2((double)arg);
-    float lvl = floorf(__fadd_rn(canon_level, l2));
+    float lvl = floorf(f_add(canon_level, l2));
     if (!(lvl >= (float)min_level)) lvl = (float)min_level;  // also maps NaN to min_level
     if (lvl > (float)max_level) lvl = (float)max_level;
     out[i] = (int64_t)lvl - min_level;

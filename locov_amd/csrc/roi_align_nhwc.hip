@@ -122,10 +122,12 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
                     const float w1 = ys.wh * xs.wh, w2 = ys.wh * xs.wl, w3 = ys.wl * xs.wh, w4 = ys.wl * xs.wl;
                     const float4 v1 = load4(row_lo + (int64_t)xs.lo * C), v2 = load4(row_lo + (int64_t)xs.hi * C);
                     const float4 v3 = load4(row_hi + (int64_t)xs.lo * C), v4 = load4(row_hi + (int64_t)xs.hi * C);
-                    acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
-                    acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
-                    acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
-                    acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+                    // this file is built with -ffp-contract=off (exact coordinates); the
+                    // accumulation asks for FMA explicitly
+                    acc.x = fmaf(w4, v4.x, fmaf(w3, v3.x, fmaf(w2, v2.x, fmaf(w1, v1.x, acc.x))));
+                    acc.y = fmaf(w4, v4.y, fmaf(w3, v3.y, fmaf(w2, v2.y, fmaf(w1, v1.y, acc.y))));
+                    acc.z = fmaf(w4, v4.z, fmaf(w3, v3.z, fmaf(w2, v2.z, fmaf(w1, v1.z, acc.z))));
+                    acc.w = fmaf(w4, v4.w, fmaf(w3, v3.w, fmaf(w2, v2.w, fmaf(w1, v1.w, acc.w))));
                 }
             }
         }
