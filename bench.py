@@ -1,0 +1,283 @@
+#!/usr/bin/env python
+"""bench.py -- proposals/sec through the LSM ROI head on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of synthetic input resident in HBM:
+`--images` res4 feature maps [B,1024,50,84] (1333x800 images, stride 16) x `--proposals`
+boxes each -> ROIAlign 14x14 -> Res5 -> spatial mean -> bbox_pred / emb_pred -> (norm) ->
+similarity GEMM against a (`--classes`+1) x `--dim` text bank.  Images shard over
+ranks with no data-path collective (inference needs none): weak scaling.
+
+`value` is scope S2 = the full head as the reference executes it (Res5 included).  Scope S1 =
+the north-star kernel list only (ROIAlign + mean/FCs/similarity on a stand-in for the Res5
+output) is reported beside it in "scopes".  One JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import platform
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # f32-input MFMA peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--images", type=int, default=4, help="images per GPU per step")
+    p.add_argument("--proposals", type=int, default=1000)
+    p.add_argument("--classes", type=int, default=1203)
+    p.add_argument("--dim", type=int, default=768)
+    p.add_argument("--sim-dtype", choices=["fp32", "bf16"], default="fp32")
+    p.add_argument("--res5", choices=["miopen", "hip"], default="hip")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
+    return p.parse_args()
+
+
+def synth_rois(gen: torch.Generator, n_img: int, r: int, device) -> torch.Tensor:
+    """SURVEY.md 8d boxes: centre uniform, log2(side) U[4, log2 800], aspect U[0.5,2], clipped."""
+    n = n_img * r
+    cx = torch.rand(n, generator=gen) * 1333.0
+    cy = torch.rand(n, generator=gen) * 800.0
+    side = 2.0 ** (4.0 + torch.rand(n, generator=gen) * (np.log2(800.0) - 4.0))
+    aspect = 0.5 + 1.5 * torch.rand(n, generator=gen)
+    w, h = side * aspect.sqrt(), side / aspect.sqrt()
+    b = torch.stack([(cx - w / 2).clamp(0, 1333), (cy - h / 2).clamp(0, 800),
+                     (cx + w / 2).clamp(0, 1333), (cy + h / 2).clamp(0, 800)], dim=1)
+    idx = torch.arange(n_img, dtype=torch.float32).repeat_interleave(r)[:, None]
+    return torch.cat([idx, b], dim=1).to(torch.float32).to(device)
+
+
+class Workload:
+    def __init__(self, args, device):
+        from locov_amd import ops
+        from locov_amd.config import get_cfg
+        from locov_amd.res5 import build_res5_block
+        self.ops, self.args, self.device = ops, args, device
+        gen = torch.Generator().manual_seed(1992)          # configs/coco_lsm.yaml:126
+        B, R, K, D = args.images, args.proposals, args.classes, args.dim
+        self.feat = torch.randn(B, 1024, 50, 84, generator=gen).to(device)
+        self.rois = synth_rois(gen, B, R, device)
+        res5, _ = build_res5_block(get_cfg())
+        self.res5 = res5.to(device).eval()
+        self.emb_w = (torch.randn(D, 2048, generator=gen) * 0.01).to(device)
+        self.emb_b = torch.zeros(D, device=device)
+        self.bbox_w = (torch.randn(4, 2048, generator=gen) * 0.001).to(device)
+        self.bbox_b = torch.zeros(4, device=device)
+        bank = torch.randn(K + 1, D, generator=gen) * 0.05
+        bank[-1] = 0
+        self.bank = bank.to(device)
+        self.bank16 = ops.to_bf16(self.bank) if args.sim_dtype == "bf16" else None
+        self.sim = ops.BF16 if args.sim_dtype == "bf16" else ops.F32
+        self.r5_standin = torch.randn(B * R, 2048, 7, 7, generator=gen).clamp_(min=0).to(device)
+        self.ev = []        # (start, end) HIP events around every launch of the dominant kernel
+        self.timing = False
+        if args.res5 == "hip":
+            # dominant kernel = the implicit-GEMM 3x3 convolution (47 % of the head's FLOPs)
+            inner = ops.conv3x3_nhwc
+
+            def timed_conv(*a, **k):
+                if not self.timing:
+                    return inner(*a, **k)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = inner(*a, **k)
+                e1.record()
+                self.ev.append((e0, e1))
+                return out
+            ops.conv3x3_nhwc = timed_conv
+
+    def head(self, x, channels_last=False):
+        ops = self.ops
+        return ops.box_head(x, self.emb_w, self.emb_b, self.bbox_w, self.bbox_b, self.bank, self.bank16,
+                            ops.NORM_NONE, self.sim, channels_last=channels_last)
+
+    @torch.no_grad()
+    def step_s2(self, timed=False):
+        ops = self.ops
+        self.timing = timed
+        if self.args.res5 == "hip":
+            # channels-last pipeline: even-grid ROIAlign -> Res5 as MFMA GEMMs on pixel rows
+            nhwc = ops.nchw_to_nhwc(self.feat)
+            x0 = ops.roi_align_nhwc(nhwc, self.rois, 14, 1.0 / 16, 0, True, bin_stride=2)
+            R = x0.shape[0]
+            y = self.res5.forward_rows(x0.view(R * 49, 1024), 7, 7)
+            out = self.head(y.view(R, 7, 7, 2048), channels_last=True)
+        else:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            pooled = ops.roi_align(self.feat, self.rois, 14, 1.0 / 16, 0, True)
+            if timed:
+                e1.record()
+                self.ev.append((e0, e1))
+            out = self.head(self.res5(pooled))
+        self.timing = False
+        return out
+
+    @torch.no_grad()
+    def step_s1(self):
+        self.ops.roi_align(self.feat, self.rois, 14, 1.0 / 16, 0, True)
+        return self.head(self.r5_standin)
+
+
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole host and oversubscribes a quota-limited container)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(args, seconds: float):
+    """The oracle (a port: the reference's Python cannot run here) timed on this
+    host's cores over a bounded sample of the same workload."""
+    from oracle import lsm_oracle as oracle
+    oracle.build()
+    ncores = usable_cores()
+    torch.set_num_threads(ncores)
+    os.environ["OMP_NUM_THREADS"] = str(ncores)
+    rng = np.random.default_rng(1992)
+    feat = rng.standard_normal((1, 1024, 50, 84)).astype(np.float32)
+    params = oracle.make_res5_params(0)
+    head = oracle.synth_head(rng, 2048, args.dim, args.classes)
+
+    def run(n):
+        boxes = oracle.synth_boxes(rng, n)
+        t0 = time.perf_counter()
+        oracle.roi_head_forward(feat, [boxes], params, head)
+        return time.perf_counter() - t0
+
+    run(8)                                   # warm-up (thread pools, page-in)
+    t_probe = run(50)
+    n = int(max(50, min(args.proposals, 50 * seconds / max(t_probe, 1e-3) / 2)))
+    times = [run(n) for _ in range(2)]
+    t = float(np.median(times))
+    return {"value": n / t, "unit": "proposals/s", "cores": ncores, "kind": "port",
+            "sample": f"{n} proposals of one 1333x800 image, full head (ROIAlign+Res5+mean+FCs+sim K={args.classes}), "
+                      f"median of 2 runs, {t:.2f} s each; torch CPU convs + OpenMP C oracle, "
+                      f"cpu={platform.processor() or platform.machine()}"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from locov_amd import _lib
+    _lib.load()
+    wl = Workload(args, device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps, warmup, **kw):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn(**kw)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    props_per_step = args.images * args.proposals * world
+    dt2 = timed(wl.step_s2, args.steps, args.warmup, timed=True)
+    # dominant hand-written kernel: average launch duration over the timed region (HIP events on
+    # the launch stream)
+    dom_ms = float(np.mean([a.elapsed_time(b) for a, b in wl.ev])) if wl.ev else float("nan")
+    dt1 = timed(wl.step_s1, args.steps, args.warmup)
+
+    if rank == 0:
+        R_local = args.images * args.proposals
+        if args.res5 == "hip":
+            # 3x3 conv as implicit GEMM: M = R*49 pixel rows, N = 512, K = 9*512
+            alg_flops = 2.0 * R_local * 49 * 512 * 9 * 512
+            achieved = alg_flops / (dom_ms * 1e-3) / 1e12
+            roof = {"kernel": "gemm_nt_kernel<float,float,128,128,2,2,CONV3> (Res5 3x3 conv, implicit GEMM)",
+                    "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": dom_ms,
+                    "algorithmic_flops_per_launch": alg_flops}
+        else:
+            alg_bytes = args.images * 1024 * 50 * 84 * 4 + R_local * 5 * 4 + R_local * 1024 * 14 * 14 * 4
+            achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+            roof = {"kernel": "roi_align_nchw_kernel<fwd> (dominant HAND-WRITTEN kernel; Res5 is MIOpen here)",
+                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": dom_ms,
+                    "algorithmic_bytes_per_launch": alg_bytes}
+        out = {
+            "metric": "proposals/sec through LSM ROI-head (1333x800, 1000 prop, 1203-class text bank)",
+            "value": props_per_step * args.steps / dt2,
+            "unit": "proposals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt2 / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.sim_dtype == "fp32" else "f32 (bf16 similarity operands)",
+            "data": "synthetic",
+            "config": {"workload": f"{args.images} img/GPU x {args.proposals} proposals, res4 [B,1024,50,84] fp32, "
+                                   f"ROIAlign 14x14 -> Res5({args.res5}) -> mean -> bbox_pred/emb_pred(2048->{args.dim}) -> "
+                                   f"similarity GEMM x {args.classes + 1}-row bank ({args.sim_dtype}); forward only",
+                       "scope": "S2 (full ROI head incl. Res5)", "images_per_gpu": args.images,
+                       "proposals_per_image": args.proposals, "classes": args.classes, "emb_dim": args.dim,
+                       "res5_backend": args.res5,
+                       "parallelism": f"image-sharded x{world}, no collective"},
+            "scopes": {"S2_full_head_proposals_per_s": props_per_step * args.steps / dt2,
+                       "S1_handwritten_kernels_proposals_per_s": props_per_step * args.steps / dt1,
+                       "S1_ms_per_step": dt1 / args.steps * 1e3},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

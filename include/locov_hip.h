@@ -134,6 +134,28 @@ int locov_gemm_nt_f32(const float *x, int64_t lda, const float *W, const float *
                       int64_t M, int N, int K, unsigned flags, locov_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * a-3  Res5 stage building blocks on channels-last pixel matrices.
+ * Replace [D2-upstream] BottleneckBlock's conv2d + FrozenBatchNorm2d + ReLU (+ residual add)
+ * as built by roi_emb_heads.py:217-241 and applied at :245,:323.
+ *   - 1x1 convolutions are locov_gemm_nt_f32 on x [R*H*W, Cin] (weight [N,Cin,1,1] == [N,Cin]).
+ *   - locov_conv3x3_nhwc_f32: 3x3 / pad 1 / stride 1 as an implicit GEMM (K = 9*Cin) over R
+ *     independent HxW tiles; w_packed [N, 9*Cin] comes from locov_pack_conv3x3_weight
+ *     ([N,Cin,3,3] -> k = (ky*3+kx)*Cin + c).  Same epilogue as locov_gemm_nt_f32.
+ *   - locov_frozen_bn_fold: scale = weight*rsqrt(var+eps), shift = bias - mean*scale, the
+ *     per-channel affine FrozenBatchNorm2d applies; feeds the GEMM epilogue's scale/shift.
+ * ------------------------------------------------------------------------------------- */
+int locov_conv3x3_nhwc_f32(const float *x, int64_t R, int H, int W, int Cin, const float *w_packed,
+                           const float *scale, const float *shift, const float *residual, float *y,
+                           int N, unsigned flags, locov_stream_t stream);
+
+int locov_pack_conv3x3_weight(const float *w, int N, int Cin, void *out, int out_dtype,
+                              locov_stream_t stream);
+
+int locov_frozen_bn_fold(const float *weight, const float *bias, const float *running_mean,
+                         const float *running_var, float eps, int C, float *scale, float *shift,
+                         locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * a-7  row normalisation of [R,D] fp32: L2 (x / max(||x||, eps)) or standardise
  * ((x - mean) / (std_unbiased + eps)).  Replaces normalize_vec / standardize_vec
  * (logged_module.py:55-72) applied at box_emb_head.py:207-210 and to the bank at :223-232.

@@ -1,4 +1,4 @@
-// Internal interface of gemm_nt.hip (shared with head.hip / res5.hip).
+// Internal interface of gemm_nt.hip (shared with head.hip).
 #pragma once
 #include "common.h"
 
@@ -11,9 +11,15 @@ struct Epilogue {
     unsigned flags;
 };
 
+// H == 0: plain GEMM.  H > 0: A is the pixel matrix of independent HxW tiles with Cin channels
+// and the GEMM is the implicit form of a 3x3 / pad 1 / stride 1 convolution (K = 9*Cin).
+struct ConvGeom {
+    int H, W, Cin;
+};
+
 // y[M,N] = epi(A[M,K] . B[N,K]^T); T = float (f32 MFMA) or __bf16 (bf16 MFMA, fp32 accumulate)
-template <typename T>
-int launch_gemm_nt(const T *A, int64_t lda, const T *B, int64_t ldb, float *C, int64_t ldc, int64_t M, int N,
-                   int K, const Epilogue &epi, hipStream_t s, const char *what);
+template <typename T, typename TOut>
+int launch_gemm_nt(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C, int64_t ldc, int64_t M, int N, int K,
+                   const Epilogue &epi, hipStream_t s, const char *what, const ConvGeom &cg = ConvGeom{0, 0, 0});
 
 }  // namespace locov

@@ -199,10 +199,10 @@ int locov_box_head_fwd(const float *x, int64_t R, int C5, int HW, int channels_l
     int rc = spatial_mean(x, R, C5, HW, channels_last, pooled, s);                     // roi_emb_heads.py:262
     if (rc) return rc;
     Epilogue e_box{nullptr, bbox_b, nullptr, 0u};                                        // box_emb_head.py:196
-    rc = launch_gemm_nt<float>(pooled, C5, bbox_w, C5, deltas, 4, R, 4, C5, e_box, s, "locov_box_head_fwd(bbox_pred)");
+    rc = launch_gemm_nt<float, float>(pooled, C5, bbox_w, C5, deltas, 4, R, 4, C5, e_box, s, "locov_box_head_fwd(bbox_pred)");
     if (rc) return rc;
     Epilogue e_emb{nullptr, emb_b, nullptr, 0u};                                         // :206
-    rc = launch_gemm_nt<float>(pooled, C5, emb_w, C5, emb, D, R, D, C5, e_emb, s, "locov_box_head_fwd(emb_pred)");
+    rc = launch_gemm_nt<float, float>(pooled, C5, emb_w, C5, emb, D, R, D, C5, e_emb, s, "locov_box_head_fwd(emb_pred)");
     if (rc) return rc;
     if (norm_mode != LOCOV_NORM_NONE) {                                                  // :207-210
         rc = rownorm(emb, R, D, norm_mode, 1e-12f, emb, s);
@@ -214,7 +214,7 @@ int locov_box_head_fwd(const float *x, int64_t R, int C5, int HW, int channels_l
         return locov_sim_gemm_bf16(emb_bf16, bank_bf16, R, D, K1, logits, K1, stream);
     }
     Epilogue e_sim{nullptr, nullptr, nullptr, 0u};
-    return launch_gemm_nt<float>(emb, D, bank, D, logits, K1, R, K1, D, e_sim, s, "locov_box_head_fwd(cls_score)");
+    return launch_gemm_nt<float, float>(emb, D, bank, D, logits, K1, R, K1, D, e_sim, s, "locov_box_head_fwd(cls_score)");
 }
 
 }  // extern "C"

@@ -206,6 +206,54 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return y
 
 
+def conv3x3_nhwc(x: torch.Tensor, w_packed: torch.Tensor, H: int, W: int, *, scale=None, shift=None,
+                 residual=None, relu: bool = False) -> torch.Tensor:
+    """3x3 / pad 1 / stride 1 convolution over R independent HxW channels-last tiles.
+    x [R*H*W, Cin], w_packed [N, 9*Cin] (pack_conv3x3_weight) -> [R*H*W, N]."""
+    x = _dev(x, "x")
+    w_packed = _dev(w_packed, "w_packed")
+    M, Cin = x.shape
+    N = w_packed.shape[0]
+    if w_packed.shape[1] != 9 * Cin or M % (H * W) != 0:
+        raise ValueError("conv3x3_nhwc: inconsistent shapes")
+    scale = _dev(scale, "scale") if scale is not None else None
+    shift = _dev(shift, "shift") if shift is not None else None
+    residual = _dev(residual, "residual") if residual is not None else None
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_conv3x3_nhwc_f32(_ptr(x), M // (H * W), H, W, Cin, _ptr(w_packed), _ptr(scale),
+                                                 _ptr(shift), _ptr(residual), _ptr(y), N,
+                                                 _lib.EPI_RELU if relu else 0, _stream(x)), "locov_conv3x3_nhwc_f32")
+    return y
+
+
+def pack_conv3x3_weight(w: torch.Tensor, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """[N,Cin,3,3] -> [N, 9*Cin] with k = (ky*3+kx)*Cin + c."""
+    w = _dev(w, "w")
+    N, Cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3):
+        raise ValueError("pack_conv3x3_weight expects [N,Cin,3,3]")
+    out = torch.empty((N, 9 * Cin), dtype=dtype, device=w.device)
+    with torch.cuda.device(w.device):
+        check(_lib.load().locov_pack_conv3x3_weight(_ptr(w), N, Cin, _ptr(out), _dtype_code(dtype), _stream(w)),
+              "locov_pack_conv3x3_weight")
+    return out
+
+
+def frozen_bn_fold(weight, bias, running_mean, running_var, eps: float = 1e-5):
+    """FrozenBatchNorm2d -> per-channel (scale, shift)."""
+    weight = _dev(weight, "weight")
+    C = weight.numel()
+    scale = torch.empty(C, dtype=torch.float32, device=weight.device)
+    shift = torch.empty(C, dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        check(_lib.load().locov_frozen_bn_fold(_ptr(weight), _ptr(_dev(bias, "bias")),
+                                               _ptr(_dev(running_mean, "running_mean")),
+                                               _ptr(_dev(running_var, "running_var")), float(eps), C, _ptr(scale),
+                                               _ptr(shift), _stream(weight)), "locov_frozen_bn_fold")
+    return scale, shift
+
+
 def rownorm(x: torch.Tensor, mode: int, eps: float = 1e-12) -> torch.Tensor:
     x = _dev(x, "x")
     R, D = x.shape
@@ -262,7 +310,8 @@ def box_head(x: torch.Tensor, emb_w: torch.Tensor, emb_b: torch.Tensor, bbox_w: 
     if emb_w.shape[1] != C5 or bbox_w.shape != (4, C5) or bank.shape[1] != D:
         raise ValueError("box_head: inconsistent weight shapes")
     dev = x.device
-    pooled = torch.empty((R, C5), dtype=torch.float32, device=dev)
+    # HW == 1: the mean is the identity and the C side skips the copy when pooled aliases x
+    pooled = x.reshape(R, C5) if HW == 1 else torch.empty((R, C5), dtype=torch.float32, device=dev)
     deltas = torch.empty((R, 4), dtype=torch.float32, device=dev)
     emb = torch.empty((R, D), dtype=torch.float32, device=dev)
     logits = torch.empty((R, K1), dtype=torch.float32, device=dev)

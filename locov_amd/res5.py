@@ -1,0 +1,176 @@
+"""The Res5 stage of the C4 ROI head, with Detectron2's module / checkpoint-key layout.
+
+[D2-upstream] ResNet.make_stage(BottleneckBlock, 3, stride_per_block=[2,1,1], in=1024,
+bottleneck=512, out=2048, stride_in_1x1=True, norm="FrozenBN") as built by
+ovr/modeling/roi_heads/roi_emb_heads.py:217-241 and applied at :245 (per-region) and :323
+(whole grid).  State-dict keys: res5.{0,1,2}.{conv1,conv2,conv3,shortcut}.{weight,norm.*}
+(SURVEY.md 8b "Checkpoint keys"), so LocOV.pth loads unchanged.
+
+Row a-3 is outside north_star's hand-written kernel list; the `backend`
+switch selects how the convolutions run on the MI355X:
+  "miopen" : torch conv2d (MIOpen) -- the stock library path
+  "hip"    : the hand-written channels-last MFMA GEMM path of this package (ops_res5)
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """[D2-upstream] FrozenBatchNorm2d: fixed statistics and affine, y = x*scale + shift."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5):
+        super().__init__()
+        self.num_features = num_features
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+    def scale_shift(self):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        shift = self.bias - self.running_mean * scale
+        return scale, shift
+
+    def forward(self, x):
+        scale, shift = self.scale_shift()
+        return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+
+
+class Conv2d(nn.Conv2d):
+    """[D2-upstream] detectron2.layers.Conv2d: conv -> norm (sub-module `norm`)."""
+
+    def __init__(self, *args, norm: Optional[nn.Module] = None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.norm = norm
+
+    def forward(self, x):
+        x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if self.norm is not None:
+            x = self.norm(x)
+        return x
+
+
+def get_norm(norm: str, ch: int):
+    if norm in ("FrozenBN", "FrozenBatchNorm2d"):
+        return FrozenBatchNorm2d(ch)
+    if norm in ("", None):
+        return None
+    if norm == "BN":
+        return nn.BatchNorm2d(ch)
+    raise ValueError(f"unsupported norm {norm!r} for the Res5 head")
+
+
+class BottleneckBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, *, bottleneck_channels, stride=1, num_groups=1,
+                 norm="FrozenBN", stride_in_1x1=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        self.stride_in_1x1 = stride_in_1x1
+        if in_channels != out_channels:
+            self.shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=stride, bias=False,
+                                   norm=get_norm(norm, out_channels))
+        else:
+            self.shortcut = None
+        s1, s3 = (stride, 1) if stride_in_1x1 else (1, stride)
+        self.conv1 = Conv2d(in_channels, bottleneck_channels, kernel_size=1, stride=s1, bias=False,
+                            norm=get_norm(norm, bottleneck_channels))
+        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, kernel_size=3, stride=s3, padding=1,
+                            bias=False, groups=num_groups, norm=get_norm(norm, bottleneck_channels))
+        self.conv3 = Conv2d(bottleneck_channels, out_channels, kernel_size=1, bias=False,
+                            norm=get_norm(norm, out_channels))
+        for layer in (self.conv1, self.conv2, self.conv3, self.shortcut):
+            if layer is not None:   # [D2-upstream] c2_msra_fill
+                nn.init.kaiming_normal_(layer.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        out = F.relu_(self.conv1(x))
+        out = F.relu_(self.conv2(out))
+        out = self.conv3(out)
+        shortcut = self.shortcut(x) if self.shortcut is not None else x
+        out = out + shortcut
+        return F.relu_(out)
+
+
+class Res5Stage(nn.Sequential):
+    """nn.Sequential of the three bottlenecks (so the state-dict keys stay res5.{0,1,2}....) with an
+    additional hand-written forward on channels-last pixel rows.
+
+    forward(x)                    NCHW in / NCHW out through torch conv2d (MIOpen); differentiable; any norm.
+    forward_rows(x0, H, W)        x0 [R*H*W, Cin] = the stage input ALREADY sub-sampled by block 0's
+                                  stride (the even positions, STRIDE_IN_1X1=True) -> [R*H*W, Cout];
+                                  every convolution is an MFMA GEMM of this package with FrozenBN, ReLU
+                                  and the residual add fused into its epilogue.  Inference only.
+    """
+
+    def __init__(self, *blocks):
+        super().__init__(*blocks)
+        self._cache = {}
+
+    def supports_rows_path(self) -> bool:
+        b0 = self[0]
+        return (all(isinstance(c.norm, FrozenBatchNorm2d) for blk in self for c in
+                    (blk.conv1, blk.conv2, blk.conv3)) and b0.stride_in_1x1 and all(blk.conv2.groups == 1 for blk in self))
+
+    def _packed(self, conv: Conv2d):
+        """(weight as GEMM operand, scale, shift), re-packed only when a tensor was modified in place or
+        re-assigned (checkpoint load, optimizer step)."""
+        from . import ops
+        n = conv.norm
+        key = (id(conv), conv.weight.data_ptr(), conv.weight._version, n.weight._version, n.bias._version,
+               n.running_mean._version, n.running_var._version, n.weight.data_ptr())
+        hit = self._cache.get(id(conv))
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        w = conv.weight.detach()
+        if w.shape[2] == 3:
+            wp = ops.pack_conv3x3_weight(w)
+        else:
+            wp = w.reshape(w.shape[0], w.shape[1])
+        scale, shift = ops.frozen_bn_fold(n.weight, n.bias, n.running_mean, n.running_var, n.eps)
+        val = (wp, scale, shift)
+        self._cache[id(conv)] = (key, val)
+        return val
+
+    @torch.no_grad()
+    def forward_rows(self, x0: torch.Tensor, H: int, W: int) -> torch.Tensor:
+        from . import ops
+        assert self.supports_rows_path(), "forward_rows needs FrozenBN, STRIDE_IN_1X1 and ungrouped convs"
+        x = x0
+        for blk in self:
+            w1, s1, b1 = self._packed(blk.conv1)
+            w2, s2, b2 = self._packed(blk.conv2)
+            w3, s3, b3 = self._packed(blk.conv3)
+            y = ops.linear(x, w1, b1, scale=s1, relu=True)                        # 1x1 (+stride via x0) + FBN + ReLU
+            y = ops.conv3x3_nhwc(y, w2, H, W, scale=s2, shift=b2, relu=True)      # 3x3 + FBN + ReLU
+            if blk.shortcut is not None:
+                ws, ss, bs = self._packed(blk.shortcut)
+                sc = ops.linear(x, ws, bs, scale=ss)                              # 1x1 shortcut + FBN
+            else:
+                sc = x
+            x = ops.linear(y, w3, b3, scale=s3, residual=sc, relu=True)           # 1x1 + FBN + add + ReLU
+        return x
+
+
+def build_res5_block(cfg):
+    """roi_emb_heads.py:217-241 _build_res5_block."""
+    stage_channel_factor = 2 ** 3
+    num_groups = cfg.MODEL.RESNETS.NUM_GROUPS
+    width_per_group = cfg.MODEL.RESNETS.WIDTH_PER_GROUP
+    bottleneck_channels = num_groups * width_per_group * stage_channel_factor
+    out_channels = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS * stage_channel_factor
+    stride_in_1x1 = cfg.MODEL.RESNETS.STRIDE_IN_1X1
+    norm = cfg.MODEL.RESNETS.NORM
+    assert not cfg.MODEL.RESNETS.DEFORM_ON_PER_STAGE[-1], "Deformable conv is not yet supported in res5 head."
+    blocks = []
+    in_ch = out_channels // 2
+    for stride in (2, 1, 1):
+        blocks.append(BottleneckBlock(in_ch, out_channels, bottleneck_channels=bottleneck_channels, stride=stride,
+                                      num_groups=num_groups, norm=norm, stride_in_1x1=stride_in_1x1))
+        in_ch = out_channels
+    return Res5Stage(*blocks), out_channels

@@ -1,0 +1,470 @@
+"""Box predictor of the LSM ROI head: bbox_pred FC, emb_pred FC, optional row normalisation and
+the region x text similarity GEMM against the frozen noun bank -- on the gfx950 kernels.
+
+Mirrors ovr/modeling/roi_heads/box_emb_head.py (class, method, attribute, config and
+checkpoint-key names):
+    EmbeddingFastRCNNOutputLayers.__init__            :69-149
+    .from_config                                      :152-177
+    .forward / .forward_cls_prediction                :179-212
+    .set_class_embeddings                             :214-236
+    build_box_predictor                               :239-249
+and the parts of its Detectron2 base class the reference relies on ([D2-upstream]
+FastRCNNOutputLayers: bbox_pred creation/init, losses, inference, predict_boxes,
+predict_probs; Box2BoxTransform; fast_rcnn_inference).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple, Union
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .. import ops
+from ..registry import configurable
+from ..structures import Boxes, Instances, ShapeSpec
+
+__all__ = ["Box2BoxTransform", "FastRCNNOutputLayers", "EmbeddingFastRCNNOutputLayers", "build_box_predictor",
+           "fast_rcnn_inference", "batched_nms"]
+
+_DEFAULT_SCALE_CLAMP = math.log(1000.0 / 16)
+
+
+class Box2BoxTransform:
+    """[D2-upstream] R-CNN box parameterisation (dx, dy, dw, dh) with weights (10,10,5,5)."""
+
+    def __init__(self, weights: Tuple[float, float, float, float], scale_clamp: float = _DEFAULT_SCALE_CLAMP):
+        self.weights = tuple(float(w) for w in weights)
+        self.scale_clamp = scale_clamp
+
+    def get_deltas(self, src_boxes: torch.Tensor, target_boxes: torch.Tensor) -> torch.Tensor:
+        src_w = src_boxes[:, 2] - src_boxes[:, 0]
+        src_h = src_boxes[:, 3] - src_boxes[:, 1]
+        src_cx = src_boxes[:, 0] + 0.5 * src_w
+        src_cy = src_boxes[:, 1] + 0.5 * src_h
+        tgt_w = target_boxes[:, 2] - target_boxes[:, 0]
+        tgt_h = target_boxes[:, 3] - target_boxes[:, 1]
+        tgt_cx = target_boxes[:, 0] + 0.5 * tgt_w
+        tgt_cy = target_boxes[:, 1] + 0.5 * tgt_h
+        wx, wy, ww, wh = self.weights
+        dx = wx * (tgt_cx - src_cx) / src_w
+        dy = wy * (tgt_cy - src_cy) / src_h
+        dw = ww * torch.log(tgt_w / src_w)
+        dh = wh * torch.log(tgt_h / src_h)
+        deltas = torch.stack((dx, dy, dw, dh), dim=1)
+        assert (src_w > 0).all().item(), "Input boxes to Box2BoxTransform are not valid!"
+        return deltas
+
+    def apply_deltas(self, deltas: torch.Tensor, boxes: torch.Tensor) -> torch.Tensor:
+        deltas = deltas.float()
+        boxes = boxes.to(deltas.dtype)
+        widths = boxes[:, 2] - boxes[:, 0]
+        heights = boxes[:, 3] - boxes[:, 1]
+        ctr_x = boxes[:, 0] + 0.5 * widths
+        ctr_y = boxes[:, 1] + 0.5 * heights
+        wx, wy, ww, wh = self.weights
+        dx = deltas[:, 0::4] / wx
+        dy = deltas[:, 1::4] / wy
+        dw = deltas[:, 2::4] / ww
+        dh = deltas[:, 3::4] / wh
+        dw = torch.clamp(dw, max=self.scale_clamp)
+        dh = torch.clamp(dh, max=self.scale_clamp)
+        pred_ctr_x = dx * widths[:, None] + ctr_x[:, None]
+        pred_ctr_y = dy * heights[:, None] + ctr_y[:, None]
+        pred_w = torch.exp(dw) * widths[:, None]
+        pred_h = torch.exp(dh) * heights[:, None]
+        x1 = pred_ctr_x - 0.5 * pred_w
+        y1 = pred_ctr_y - 0.5 * pred_h
+        x2 = pred_ctr_x + 0.5 * pred_w
+        y2 = pred_ctr_y + 0.5 * pred_h
+        return torch.stack((x1, y1, x2, y2), dim=-1).reshape(deltas.shape)
+
+
+def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """[D2-upstream] torchvision.ops.nms semantics (greedy, score-descending, IoU > thr suppressed).
+    torchvision is not available on the ROCm box; the IoU matrix is built on the device and the
+    greedy sweep (inherently sequential, a few hundred candidates) runs over its boolean mask."""
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.int64, device=boxes.device)
+    order = torch.argsort(scores, descending=True, stable=True)
+    b = boxes[order]
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = torch.max(b[:, None, :2], b[None, :, :2])
+    rb = torch.min(b[:, None, 2:], b[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    iou = inter / (area[:, None] + area[None, :] - inter)
+    over = (iou > iou_threshold).cpu().numpy()
+    keep = []
+    suppressed = np.zeros(n, dtype=bool)
+    for i in range(n):
+        if suppressed[i]:
+            continue
+        keep.append(i)
+        suppressed[i + 1:] |= over[i, i + 1:]
+    return order[torch.as_tensor(keep, dtype=torch.int64, device=boxes.device)]
+
+
+def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """[D2-upstream] class-wise NMS via per-class coordinate offsets."""
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+    return nms(boxes + offsets[:, None], scores, iou_threshold)
+
+
+def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh: float, nms_thresh: float,
+                                     topk_per_image: int):
+    valid_mask = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
+    if not valid_mask.all():
+        boxes, scores = boxes[valid_mask], scores[valid_mask]
+    scores = scores[:, :-1]
+    num_bbox_reg_classes = boxes.shape[1] // 4
+    boxes = Boxes(boxes.reshape(-1, 4))
+    boxes.clip(image_shape)
+    boxes = boxes.tensor.view(-1, num_bbox_reg_classes, 4)
+    filter_mask = scores > score_thresh
+    filter_inds = filter_mask.nonzero()
+    if num_bbox_reg_classes == 1:
+        boxes = boxes[filter_inds[:, 0], 0]
+    else:
+        boxes = boxes[filter_mask]
+    scores = scores[filter_mask]
+    keep = batched_nms(boxes, scores, filter_inds[:, 1], nms_thresh)
+    if topk_per_image >= 0:
+        keep = keep[:topk_per_image]
+    boxes, scores, filter_inds = boxes[keep], scores[keep], filter_inds[keep]
+    result = Instances(image_shape)
+    result.pred_boxes = Boxes(boxes)
+    result.scores = scores
+    result.pred_classes = filter_inds[:, 1]
+    return result, filter_inds[:, 0]
+
+
+def fast_rcnn_inference(boxes: List[torch.Tensor], scores: List[torch.Tensor], image_shapes, score_thresh: float,
+                        nms_thresh: float, topk_per_image: int):
+    result_per_image = [
+        fast_rcnn_inference_single_image(b, s, shape, score_thresh, nms_thresh, topk_per_image)
+        for s, b, shape in zip(scores, boxes, image_shapes)
+    ]
+    return [x[0] for x in result_per_image], [x[1] for x in result_per_image]
+
+
+def smooth_l1_loss(input: torch.Tensor, target: torch.Tensor, beta: float, reduction: str = "none"):
+    """[fvcore] smooth_l1_loss; beta < 1e-5 -> plain L1."""
+    if beta < 1e-5:
+        loss = torch.abs(input - target)
+    else:
+        n = torch.abs(input - target)
+        loss = torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta)
+    if reduction == "mean":
+        return loss.mean() if loss.numel() > 0 else 0.0 * loss.sum()
+    if reduction == "sum":
+        return loss.sum()
+    return loss
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the f32 MFMA NT-GEMM kernel; backward re-uses the same kernel on
+    transposed operands (grad_x = g W, grad_W = g^T x, grad_b = sum g)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return ops.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.linear(g, weight.t().contiguous())               # [M,N] . ([K,N])^T
+        if ctx.needs_input_grad[1]:
+            gw = ops.linear(g.t().contiguous(), x.t().contiguous())   # [N,M] . ([K,M])^T
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(dim=0)
+        return gx, gw, gb
+
+
+def hip_linear(x: torch.Tensor, layer: nn.Linear) -> torch.Tensor:
+    """nn.Linear forward on the hand-written kernel; weights are read at call time
+    (emb_pred.weight/bias are re-assigned by the meta-arch, distill_prop_mmss_gcnn.py:121-125)."""
+    w, b = layer.weight, layer.bias
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
+        return _LinearFn.apply(x, w, b)
+    return ops.linear(x.detach(), w.detach(), b.detach() if b is not None else None)
+
+
+class FastRCNNOutputLayers(nn.Module):
+    """[D2-upstream] the parts of FastRCNNOutputLayers the reference inherits: the bbox_pred
+    layer, losses(), inference(), predict_boxes(), predict_probs()."""
+
+    @configurable
+    def __init__(self, input_shape, *, box2box_transform, num_classes: int, test_score_thresh: float = 0.0,
+                 test_nms_thresh: float = 0.5, test_topk_per_image: int = 100, cls_agnostic_bbox_reg: bool = False,
+                 smooth_l1_beta: float = 0.0, box_reg_loss_type: str = "smooth_l1",
+                 loss_weight: Union[float, Dict[str, float]] = 1.0):
+        super().__init__()
+        if isinstance(input_shape, int):
+            input_shape = ShapeSpec(channels=input_shape)
+        self.num_classes = num_classes
+        input_size = input_shape.channels * (input_shape.width or 1) * (input_shape.height or 1)
+        self.cls_score = nn.Linear(input_size, num_classes + 1)
+        num_bbox_reg_classes = 1 if cls_agnostic_bbox_reg else num_classes
+        box_dim = len(box2box_transform.weights)
+        self.bbox_pred = nn.Linear(input_size, num_bbox_reg_classes * box_dim)
+        nn.init.normal_(self.cls_score.weight, std=0.01)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        for l in [self.cls_score, self.bbox_pred]:
+            nn.init.constant_(l.bias, 0)
+        self.box2box_transform = box2box_transform
+        self.smooth_l1_beta = smooth_l1_beta
+        self.test_score_thresh = test_score_thresh
+        self.test_nms_thresh = test_nms_thresh
+        self.test_topk_per_image = test_topk_per_image
+        self.box_reg_loss_type = box_reg_loss_type
+        if isinstance(loss_weight, float):
+            loss_weight = {"loss_cls": loss_weight, "loss_box_reg": loss_weight}
+        self.loss_weight = dict(loss_weight)
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        return {
+            "input_shape": input_shape,
+            "box2box_transform": Box2BoxTransform(weights=cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS),
+            "num_classes": cfg.MODEL.ROI_HEADS.NUM_CLASSES,
+            "cls_agnostic_bbox_reg": cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG,
+            "smooth_l1_beta": cfg.MODEL.ROI_BOX_HEAD.SMOOTH_L1_BETA,
+            "test_score_thresh": cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST,
+            "test_nms_thresh": cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST,
+            "test_topk_per_image": cfg.TEST.DETECTIONS_PER_IMAGE,
+            "box_reg_loss_type": cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE,
+            "loss_weight": {"loss_box_reg": cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT},
+        }
+
+    def forward(self, x):
+        if x.dim() > 2:
+            x = torch.flatten(x, start_dim=1)
+        return hip_linear(x, self.cls_score), hip_linear(x, self.bbox_pred)
+
+    def losses(self, predictions, proposals):
+        scores, proposal_deltas = predictions
+        gt_classes = (torch.cat([p.gt_classes for p in proposals], dim=0) if len(proposals)
+                      else torch.empty(0, dtype=torch.int64, device=scores.device))
+        if len(proposals):
+            proposal_boxes = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+            assert not proposal_boxes.requires_grad, "Proposals should not require gradients!"
+            gt_boxes = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals],
+                                 dim=0)
+        else:
+            proposal_boxes = gt_boxes = torch.empty((0, 4), device=proposal_deltas.device)
+        if gt_classes.numel() == 0:
+            loss_cls = scores.sum() * 0.0
+        else:
+            loss_cls = F.cross_entropy(scores, gt_classes, reduction="mean")
+        losses = {"loss_cls": loss_cls,
+                  "loss_box_reg": self.box_reg_loss(proposal_boxes, gt_boxes, proposal_deltas, gt_classes)}
+        return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+
+    def box_reg_loss(self, proposal_boxes, gt_boxes, pred_deltas, gt_classes):
+        box_dim = proposal_boxes.shape[1]
+        fg_inds = torch.nonzero((gt_classes >= 0) & (gt_classes < self.num_classes), as_tuple=True)[0]
+        if pred_deltas.shape[1] == box_dim:
+            fg_pred_deltas = pred_deltas[fg_inds]
+        else:
+            fg_pred_deltas = pred_deltas.view(-1, self.num_classes, box_dim)[fg_inds, gt_classes[fg_inds]]
+        if self.box_reg_loss_type != "smooth_l1":
+            raise ValueError(f"Invalid bbox reg loss type '{self.box_reg_loss_type}'")
+        gt_pred_deltas = self.box2box_transform.get_deltas(proposal_boxes[fg_inds], gt_boxes[fg_inds])
+        loss_box_reg = smooth_l1_loss(fg_pred_deltas, gt_pred_deltas, self.smooth_l1_beta, reduction="sum")
+        return loss_box_reg / max(gt_classes.numel(), 1.0)
+
+    def inference(self, predictions, proposals):
+        boxes = self.predict_boxes(predictions, proposals)
+        scores = self.predict_probs(predictions, proposals)
+        image_shapes = [x.image_size for x in proposals]
+        return fast_rcnn_inference(boxes, scores, image_shapes, self.test_score_thresh, self.test_nms_thresh,
+                                   self.test_topk_per_image)
+
+    def predict_boxes(self, predictions, proposals):
+        if not len(proposals):
+            return []
+        _, proposal_deltas = predictions
+        num_prop_per_image = [len(p) for p in proposals]
+        proposal_boxes = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+        predict_boxes = self.box2box_transform.apply_deltas(proposal_deltas, proposal_boxes)
+        return predict_boxes.split(num_prop_per_image)
+
+    def predict_probs(self, predictions, proposals):
+        scores, _ = predictions
+        num_inst_per_image = [len(p) for p in proposals]
+        probs = F.softmax(scores, dim=-1)
+        return probs.split(num_inst_per_image, dim=0)
+
+
+class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
+    """ovr/modeling/roi_heads/box_emb_head.py:60 -- same constructor arguments, attributes
+    (emb_pred, bbox_pred, cls_score, embedding_based, emb_dim, num_classes, normalize_emb,
+    standardize_emb, detach_cls_predictor, loss_weight) and state-dict keys."""
+
+    @configurable
+    def __init__(self, input_shape, *, box2box_transform, num_classes: int, test_score_thresh: float = 0.0,
+                 test_nms_thresh: float = 0.5, test_topk_per_image: int = 100, cls_agnostic_bbox_reg: bool = False,
+                 smooth_l1_beta: float = 0.0, box_reg_loss_type: str = "smooth_l1",
+                 loss_weight: Union[float, Dict[str, float]] = 1.0, emb_dim: int = 768,
+                 embedding_based: bool = True, freeze_emb_pred: bool = True, normalize_emb: bool = False,
+                 standardize_emb: bool = False, detach_cls_predictor: bool = False, sim_gemm_dtype: str = "fp32"):
+        FastRCNNOutputLayers.__init__(
+            self, input_shape, box2box_transform=box2box_transform, num_classes=num_classes,
+            test_score_thresh=test_score_thresh, test_nms_thresh=test_nms_thresh,
+            test_topk_per_image=test_topk_per_image, cls_agnostic_bbox_reg=cls_agnostic_bbox_reg,
+            smooth_l1_beta=smooth_l1_beta, box_reg_loss_type=box_reg_loss_type, loss_weight=loss_weight)
+        if isinstance(input_shape, int):
+            input_shape = ShapeSpec(channels=input_shape)
+        num_inputs = input_shape.channels * (input_shape.width or 1) * (input_shape.height or 1)
+        self.embedding_based = embedding_based
+        assert sim_gemm_dtype in ("fp32", "bf16")
+        self.sim_gemm_dtype = sim_gemm_dtype
+        self._bank_bf16 = None          # packed copy of cls_score.weight for the bf16 MFMA path
+        if self.embedding_based:
+            self.normalize_emb = normalize_emb
+            self.standardize_emb = standardize_emb
+            self.emb_dim = emb_dim
+            self.emb_pred = nn.Linear(num_inputs, self.emb_dim)
+            nn.init.normal_(self.emb_pred.weight, mean=0, std=0.01)       # :135
+            nn.init.constant_(self.emb_pred.bias, 0)                      # :136
+            assert cls_agnostic_bbox_reg
+            # forward() can't be used until set_class_embeddings() has run (:138-140)
+            self.num_classes = None
+            self.cls_score = None
+            if freeze_emb_pred:
+                self.emb_pred.weight.requires_grad = False
+                self.emb_pred.bias.requires_grad = False
+        self.detach_cls_predictor = detach_cls_predictor
+        if self.detach_cls_predictor:
+            self.loss_weight.update({"loss_cls": 0.0})                    # :147-149
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        ret = FastRCNNOutputLayers.from_config.__func__(cls, cfg, input_shape)
+        box_head = cfg.MODEL.ROI_BOX_HEAD
+        ret.update({
+            "emb_dim": box_head.EMB_DIM,
+            "embedding_based": box_head.EMBEDDING_BASED,
+            "freeze_emb_pred": box_head.FREEZE_EMB_PRED,
+            "normalize_emb": box_head.NORMALIZE_EMB_PRED,
+            "standardize_emb": box_head.STANDARDIZE_EMB_PRED,
+            "detach_cls_predictor": cfg.MODEL.ROI_HEADS.DETACH_CLASS_PREDICTOR,
+            "sim_gemm_dtype": box_head.get("SIM_GEMM_DTYPE", "fp32") if hasattr(box_head, "get") else "fp32",
+        })
+        return ret
+
+    # ------------------------------------------------------------------ forward (:179-212)
+    def _norm_mode(self) -> int:
+        if self.normalize_emb and self.standardize_emb:
+            return -1       # both: apply in sequence (the reference applies normalise then standardise)
+        if self.normalize_emb:
+            return ops.NORM_L2
+        if self.standardize_emb:
+            return ops.NORM_STANDARDIZE
+        return ops.NORM_NONE
+
+    def forward(self, x):
+        """x: per-region features [R, ...] (flattened like the reference, :189-190).
+        Returns (scores [R,K+1], proposal_deltas [R,4])."""
+        if x.dim() > 2:
+            x = torch.flatten(x, start_dim=1)
+        if not self.embedding_based:
+            return hip_linear(x, self.cls_score), hip_linear(x, self.bbox_pred)
+        if self.cls_score is None:
+            raise RuntimeError("set_class_embeddings() must be called before forward() (box_emb_head.py:138-140)")
+        needs_grad = torch.is_grad_enabled() and (
+            x.requires_grad or self.bbox_pred.weight.requires_grad
+            or (not self.detach_cls_predictor and self.emb_pred.weight.requires_grad))
+        mode = self._norm_mode()
+        if not needs_grad and mode >= 0:
+            # inference: one C call -> bbox_pred, emb_pred, (norm,) similarity GEMM launches
+            x = x.detach()
+            _, deltas, _, scores = ops.box_head(
+                x, self.emb_pred.weight.detach(), self.emb_pred.bias.detach(), self.bbox_pred.weight.detach(),
+                self.bbox_pred.bias.detach(), self.cls_score.weight, self._packed_bank(), mode,
+                ops.BF16 if self.sim_gemm_dtype == "bf16" else ops.F32)
+            return scores, deltas
+        proposal_deltas = hip_linear(x, self.bbox_pred)                   # :196
+        if self.detach_cls_predictor:                                     # :197-201
+            with torch.no_grad():
+                scores = self.forward_cls_prediction(x.detach())
+        else:
+            scores = self.forward_cls_prediction(x)
+        return scores, proposal_deltas
+
+    def forward_cls_prediction(self, x):                                  # :204-212
+        if self.embedding_based:
+            x = hip_linear(x, self.emb_pred)
+            if self.normalize_emb:
+                x = _rownorm(x, ops.NORM_L2)
+            if self.standardize_emb:
+                x = _rownorm(x, ops.NORM_STANDARDIZE)
+        if self.sim_gemm_dtype == "bf16" and not (torch.is_grad_enabled() and x.requires_grad):
+            return ops.sim_gemm_bf16(ops.to_bf16(x), self._packed_bank())
+        return hip_linear(x, self.cls_score)
+
+    def _packed_bank(self):
+        if self.sim_gemm_dtype != "bf16":
+            return None
+        w = self.cls_score.weight
+        if self._bank_bf16 is None or self._bank_bf16.shape != w.shape or self._bank_bf16.device != w.device:
+            self._bank_bf16 = ops.to_bf16(w.detach())
+        return self._bank_bf16
+
+    # ------------------------------------------------------------------ bank install (:214-236)
+    def set_class_embeddings(self, embs):
+        device = self.emb_pred.weight.device
+        self.num_classes = embs.shape[0] - 1          # includes background
+        self.cls_score = nn.Linear(self.emb_dim, self.num_classes + 1)
+        self.cls_score.to(device)
+        if torch.is_tensor(embs):
+            embs = embs.clone().detach().to(device)
+        else:
+            embs = torch.tensor(embs, device=device)
+        embs = embs.to(torch.float32)
+        if self.normalize_emb:
+            assert embs.shape[1] == self.emb_dim, "The embedding dimension has to match the one saved in the model"
+            embs = _rownorm(embs, ops.NORM_L2)
+        if self.standardize_emb:
+            assert embs.shape[1] == self.emb_dim, "The embedding dimension has to match the one saved in the model"
+            embs = _rownorm(embs, ops.NORM_STANDARDIZE)
+        self.cls_score.weight.data = embs.contiguous()
+        self.cls_score.bias.data = torch.zeros_like(self.cls_score.bias.data)
+        self.cls_score.weight.requires_grad = False
+        self.cls_score.bias.requires_grad = False
+        self._bank_bf16 = None
+
+
+def _rownorm(x: torch.Tensor, mode: int) -> torch.Tensor:
+    if torch.is_grad_enabled() and x.requires_grad:
+        # differentiable form (training with a non-detached class predictor): torch autograd
+        if mode == ops.NORM_L2:
+            return F.normalize(x, p=2, dim=1)
+        return (x - x.mean(1, keepdim=True)) / (x.std(1, keepdim=True) + 1e-12)
+    return ops.rownorm(x.detach(), mode)
+
+
+def build_box_predictor(cfg, input_shape):
+    """box_emb_head.py:239-249."""
+    name = cfg.MODEL.ROI_BOX_HEAD.NAME
+    predictors = {
+        "FastRCNNOutputLayers": FastRCNNOutputLayers,
+        "EmbeddingFastRCNNOutputLayers": EmbeddingFastRCNNOutputLayers,
+        # "EmbeddingGroundingFastRCNNOutputLayers": unreachable with the reference's configs
+        # (cfg.MODEL.ROI_HEADS.MAX_TOKENS is never defined)
+    }
+    if name not in predictors:
+        raise KeyError(f"box predictor {name!r} is not part of the LSM ROI-head path")
+    return predictors[name](cfg, input_shape)

@@ -1,0 +1,338 @@
+"""ROI heads of the LSM path: proposal labelling/sampling, ROIAlign, Res5, spatial mean, box
+predictor, losses / inference -- Detectron2's plugin surface, gfx950 kernels underneath.
+
+Mirrors ovr/modeling/roi_heads/roi_emb_heads.py:
+    SampleAllROIHeads.label_and_sample_proposals      :25-118
+    EmbeddingRes5ROIHeads                              :122-306
+    EmbeddingProposalsRes5ROIHeads                     :310-360
+and the [D2-upstream] ROIHeads base pieces it inherits (Matcher, subsample_labels,
+add_ground_truth_to_proposals, _sample_proposals, from_config).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from ..poolers import ROIPooler, convert_boxes_to_pooler_format
+from ..registry import Registry, configurable
+from ..res5 import build_res5_block
+from ..structures import Boxes, Instances, ShapeSpec, pairwise_iou
+from .box_emb_head import build_box_predictor
+
+ROI_HEADS_REGISTRY = Registry("ROI_HEADS")
+
+__all__ = ["ROI_HEADS_REGISTRY", "build_roi_heads", "Matcher", "subsample_labels", "add_ground_truth_to_proposals",
+           "ROIHeads", "SampleAllROIHeads", "EmbeddingRes5ROIHeads", "EmbeddingProposalsRes5ROIHeads"]
+
+
+class _Events:
+    """Scalar sink standing in for detectron2.utils.events.get_event_storage()."""
+
+    def __init__(self):
+        self.scalars: Dict[str, float] = {}
+
+    def put_scalar(self, name, value):
+        self.scalars[name] = float(value)
+
+
+_EVENTS = _Events()
+
+
+def get_event_storage():
+    try:    # use Detectron2's storage when training under its trainer
+        from detectron2.utils.events import get_event_storage as _g
+        return _g()
+    except Exception:
+        return _EVENTS
+
+
+class Matcher:
+    """[D2-upstream] Matcher: per-prediction best GT and a label from IoU thresholds."""
+
+    def __init__(self, thresholds: List[float], labels: List[int], allow_low_quality_matches: bool = False):
+        thresholds = list(thresholds)
+        assert thresholds[0] > 0
+        thresholds.insert(0, -float("inf"))
+        thresholds.append(float("inf"))
+        assert all(low <= high for (low, high) in zip(thresholds[:-1], thresholds[1:]))
+        assert all(l in [-1, 0, 1] for l in labels)
+        assert len(labels) == len(thresholds) - 1
+        self.thresholds, self.labels = thresholds, labels
+        self.allow_low_quality_matches = allow_low_quality_matches
+
+    def __call__(self, match_quality_matrix: torch.Tensor):
+        assert match_quality_matrix.dim() == 2
+        if match_quality_matrix.numel() == 0:
+            default_matches = match_quality_matrix.new_full((match_quality_matrix.size(1),), 0, dtype=torch.int64)
+            default_match_labels = match_quality_matrix.new_full((match_quality_matrix.size(1),), self.labels[0],
+                                                                 dtype=torch.int8)
+            return default_matches, default_match_labels
+        assert torch.all(match_quality_matrix >= 0)
+        matched_vals, matches = match_quality_matrix.max(dim=0)
+        match_labels = matches.new_full(matches.size(), 1, dtype=torch.int8)
+        for (l, low, high) in zip(self.labels, self.thresholds[:-1], self.thresholds[1:]):
+            low_high = (matched_vals >= low) & (matched_vals < high)
+            match_labels[low_high] = l
+        if self.allow_low_quality_matches:
+            highest, _ = match_quality_matrix.max(dim=1)
+            _, pred_inds = torch.nonzero(match_quality_matrix == highest[:, None], as_tuple=True)
+            match_labels[pred_inds] = 1
+        return matches, match_labels
+
+
+def subsample_labels(labels: torch.Tensor, num_samples: int, positive_fraction: float, bg_label: int):
+    """[D2-upstream] subsample_labels: random fg/bg subset (torch.randperm)."""
+    positive = torch.nonzero((labels != -1) & (labels != bg_label), as_tuple=True)[0]
+    negative = torch.nonzero(labels == bg_label, as_tuple=True)[0]
+    num_pos = int(num_samples * positive_fraction)
+    num_pos = min(positive.numel(), num_pos)
+    num_neg = num_samples - num_pos
+    num_neg = min(negative.numel(), num_neg)
+    perm1 = torch.randperm(positive.numel(), device=positive.device)[:num_pos]
+    perm2 = torch.randperm(negative.numel(), device=negative.device)[:num_neg]
+    return positive[perm1], negative[perm2]
+
+
+def add_ground_truth_to_proposals(targets: List[Instances], proposals: List[Instances]) -> List[Instances]:
+    """[D2-upstream] append the GT boxes to the proposals (objectness = logit(1 - 1e-10))."""
+    assert len(proposals) == len(targets)
+    if len(proposals) == 0:
+        return proposals
+    out = []
+    for gt_i, prop_i in zip(targets, proposals):
+        gt_boxes = gt_i.gt_boxes if isinstance(gt_i, Instances) else gt_i
+        device = prop_i.objectness_logits.device if prop_i.has("objectness_logits") else gt_boxes.device
+        gt_logit_value = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
+        gt_proposal = Instances(prop_i.image_size)
+        gt_proposal.proposal_boxes = gt_boxes
+        if prop_i.has("objectness_logits"):
+            gt_proposal.objectness_logits = gt_logit_value * torch.ones(len(gt_boxes), device=device)
+        keep = Instances(prop_i.image_size)
+        for k in gt_proposal.get_fields():
+            keep.set(k, prop_i.get(k))
+        out.append(Instances.cat([keep, gt_proposal]))
+    return out
+
+
+class ROIHeads(nn.Module):
+    """[D2-upstream] ROIHeads base: sampling hyper-parameters + proposal matcher."""
+
+    def __init__(self, *, num_classes, batch_size_per_image, positive_fraction, proposal_matcher,
+                 proposal_append_gt=True):
+        super().__init__()
+        self.batch_size_per_image = batch_size_per_image
+        self.positive_fraction = positive_fraction
+        self.num_classes = num_classes
+        self.proposal_matcher = proposal_matcher
+        self.proposal_append_gt = proposal_append_gt
+
+    @classmethod
+    def from_config(cls, cfg):
+        return {
+            "batch_size_per_image": cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE,
+            "positive_fraction": cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION,
+            "num_classes": cfg.MODEL.ROI_HEADS.NUM_CLASSES,
+            "proposal_append_gt": cfg.MODEL.ROI_HEADS.PROPOSAL_APPEND_GT,
+            "proposal_matcher": Matcher(cfg.MODEL.ROI_HEADS.IOU_THRESHOLDS, cfg.MODEL.ROI_HEADS.IOU_LABELS,
+                                        allow_low_quality_matches=False),
+        }
+
+    def _sample_proposals(self, matched_idxs, matched_labels, gt_classes):
+        has_gt = gt_classes.numel() > 0
+        if has_gt:
+            gt_classes = gt_classes[matched_idxs]
+            gt_classes[matched_labels == 0] = self.num_classes
+            gt_classes[matched_labels == -1] = -1
+        else:
+            gt_classes = torch.zeros_like(matched_idxs) + self.num_classes
+        sampled_fg_idxs, sampled_bg_idxs = subsample_labels(gt_classes, self.batch_size_per_image,
+                                                            self.positive_fraction, self.num_classes)
+        sampled_idxs = torch.cat([sampled_fg_idxs, sampled_bg_idxs], dim=0)
+        return sampled_idxs, gt_classes[sampled_idxs]
+
+
+class SampleAllROIHeads(ROIHeads):
+    @torch.no_grad()
+    def label_and_sample_proposals(self, proposals: List[Instances], targets: List[Instances]) -> List[Instances]:
+        """roi_emb_heads.py:25-118.  Differences from stock Detectron2 kept on purpose: ALL target
+        fields are copied onto the sampled proposals (:97-100) and `fg_proposal` is set (:102-104)."""
+        if self.proposal_append_gt:
+            proposals = add_ground_truth_to_proposals(targets, proposals)
+        proposals_with_gt = []
+        num_fg_samples, num_bg_samples = [], []
+        for proposals_per_image, targets_per_image in zip(proposals, targets):
+            has_gt = len(targets_per_image) > 0
+            match_quality_matrix = pairwise_iou(targets_per_image.gt_boxes, proposals_per_image.proposal_boxes)
+            matched_idxs, matched_labels = self.proposal_matcher(match_quality_matrix)
+            sampled_idxs, gt_classes = self._sample_proposals(matched_idxs, matched_labels,
+                                                              targets_per_image.gt_classes)
+            proposals_per_image = proposals_per_image[sampled_idxs]
+            proposals_per_image.gt_classes = gt_classes
+            if has_gt:
+                sampled_targets = matched_idxs[sampled_idxs]
+                for (trg_name, trg_value) in targets_per_image.get_fields().items():
+                    if not proposals_per_image.has(trg_name):
+                        proposals_per_image.set(trg_name, trg_value[sampled_targets])
+            fg_classes = torch.ones_like(gt_classes)
+            fg_classes[gt_classes == self.num_classes] = 0
+            proposals_per_image.set("fg_proposal", fg_classes)
+            num_bg_samples.append((gt_classes == self.num_classes).sum().item())
+            num_fg_samples.append(gt_classes.numel() - num_bg_samples[-1])
+            proposals_with_gt.append(proposals_per_image)
+        storage = get_event_storage()
+        storage.put_scalar("roi_head/num_fg_samples", np.mean(num_fg_samples))
+        storage.put_scalar("roi_head/num_bg_samples", np.mean(num_bg_samples))
+        return proposals_with_gt
+
+
+@ROI_HEADS_REGISTRY.register()
+class EmbeddingRes5ROIHeads(SampleAllROIHeads):
+    """roi_emb_heads.py:122 -- C4 ROI heads: pooler -> res5 -> mean -> box predictor."""
+
+    @configurable
+    def __init__(self, *, in_features: List[str], pooler: ROIPooler, res5: nn.Module, box_predictor: nn.Module,
+                 mask_head: Optional[nn.Module] = None, output_shape: Optional[int] = 0,
+                 res5_backend: str = "hip", **kwargs):
+        super().__init__(**kwargs)
+        assert res5_backend in ("hip", "miopen")
+        self.res5_backend = res5_backend      # extension: how the Res5 convolutions run (see res5.py)
+        self.in_features = in_features
+        self.pooler = pooler
+        if isinstance(res5, (list, tuple)):
+            res5 = nn.Sequential(*res5)
+        self.res5 = res5
+        self.output_shape = output_shape
+        self.box_predictor = box_predictor
+        self.mask_on = mask_head is not None
+        if self.mask_on:
+            raise NotImplementedError("mask heads are outside the LSM ROI-head path (MODEL.MASK_ON is False "
+                                      "in both reference configs)")
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        ret = ROIHeads.from_config.__func__(cls, cfg)
+        in_features = ret["in_features"] = cfg.MODEL.ROI_HEADS.IN_FEATURES
+        pooler_resolution = cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION
+        pooler_type = cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE
+        pooler_scales = (1.0 / input_shape[in_features[0]].stride,)
+        sampling_ratio = cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO
+        assert not cfg.MODEL.KEYPOINT_ON
+        assert len(in_features) == 1
+        assert not cfg.MODEL.MASK_ON, "mask heads are outside the LSM ROI-head path"
+        ret["pooler"] = ROIPooler(output_size=pooler_resolution, scales=pooler_scales,
+                                  sampling_ratio=sampling_ratio, pooler_type=pooler_type)
+        ret["res5"], out_channels = cls._build_res5_block(cfg)
+        ret["box_predictor"] = build_box_predictor(cfg, input_shape=out_channels)
+        ret["output_shape"] = out_channels
+        box_head = cfg.MODEL.ROI_BOX_HEAD
+        ret["res5_backend"] = box_head.get("RES5_BACKEND", "hip") if hasattr(box_head, "get") else "hip"
+        return ret
+
+    @classmethod
+    def _build_res5_block(cls, cfg):
+        return build_res5_block(cfg)
+
+    def _fused_path_ok(self, features: List[torch.Tensor]) -> bool:
+        """The channels-last hand-written path: inference (no autograd graph needed), one feature
+        level, FrozenBN Res5 whose block 0 strides in its 1x1 convs, even pooler resolution."""
+        if self.res5_backend != "hip" or len(features) != 1:
+            return False
+        if torch.is_grad_enabled() and (features[0].requires_grad or any(p.requires_grad for p in self.res5.parameters())):
+            return False
+        ph, pw = self.pooler.output_size
+        return (hasattr(self.res5, "forward_rows") and self.res5.supports_rows_path() and self.res5[0].stride == 2
+                and ph == pw and ph % 2 == 0 and features[0].shape[1] % 32 == 0)
+
+    def _shared_roi_transform(self, features: List[torch.Tensor], boxes: List[Boxes]):
+        """roi_emb_heads.py:243-245: res5(pooler(features, boxes)) -> [R, C5, P/2, P/2].
+
+        MI355X path: ROIAlign is evaluated on a channels-last copy of the map and only at the even
+        bins the stride-2 1x1 convs of block 0 read; Res5 then runs as MFMA GEMMs over pixel rows.
+        The result is returned as a logical NCHW tensor in channels-last memory."""
+        if not self._fused_path_ok(features):
+            x = self.pooler(features, boxes)                 # :244
+            return self.res5(x)                              # :245
+        assert len(boxes) == features[0].shape[0]
+        rois = convert_boxes_to_pooler_format(boxes)
+        P = self.pooler.output_size[0]
+        nhwc = ops.nchw_to_nhwc(features[0].detach())
+        x0 = ops.roi_align_nhwc(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio,
+                                self.pooler.aligned, bin_stride=2)
+        R, oh, ow, C = x0.shape
+        y = self.res5.forward_rows(x0.view(R * oh * ow, C), oh, ow)
+        return y.view(R, oh, ow, y.shape[1]).permute(0, 3, 1, 2)
+
+    def _pooled_mean(self, box_features: torch.Tensor) -> torch.Tensor:
+        """box_features.mean(dim=[2,3]) (:262,:344,:356) on the HIP kernel."""
+        if torch.is_grad_enabled() and box_features.requires_grad:
+            return box_features.mean(dim=[2, 3])         # differentiable form for training
+        if not box_features.is_contiguous() and box_features.permute(0, 2, 3, 1).is_contiguous():
+            return ops.spatial_mean(box_features.permute(0, 2, 3, 1), channels_last=True)
+        return ops.spatial_mean(box_features)
+
+    def forward(self, images, features, proposals, targets=None):
+        """roi_emb_heads.py:247-282."""
+        del images
+        if self.training:
+            assert targets
+            proposals = self.label_and_sample_proposals(proposals, targets)
+        del targets
+        proposal_boxes = [x.proposal_boxes for x in proposals]
+        box_features = self._shared_roi_transform([features[f] for f in self.in_features], proposal_boxes)
+        predictions = self.box_predictor(self._pooled_mean(box_features))
+        if self.training:
+            del features
+            losses = self.box_predictor.losses(predictions, proposals)
+            return [], losses
+        pred_instances, _ = self.box_predictor.inference(predictions, proposals)
+        pred_instances = self.forward_with_given_boxes(features, pred_instances)
+        return pred_instances, {}
+
+    def forward_with_given_boxes(self, features, instances):
+        """roi_emb_heads.py:284-306 (mask branch not part of this path)."""
+        assert not self.training
+        assert instances[0].has("pred_boxes") and instances[0].has("pred_classes")
+        return instances
+
+
+@ROI_HEADS_REGISTRY.register()
+class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
+    """roi_emb_heads.py:310 -- the LSM variant: also returns the whole-grid Res5 features and
+    the per-image region features for the grounding branch."""
+
+    def forward(self, images, features, proposals, targets=None):
+        del images
+        if targets is None:                              # keyed on targets, not self.training (:316)
+            return self.inference_detection(features, proposals)
+        proposals = self.label_and_sample_proposals(proposals, targets)
+        del targets
+        visual_grid_features = self.res5(features[self.in_features[0]])          # :323
+        proposal_boxes = [x.proposal_boxes for x in proposals]
+        boxes_per_image = [len(x) for x in proposals]
+        box_features = self._shared_roi_transform([features[f] for f in self.in_features], proposal_boxes)
+        del features
+        losses = {}
+        box_features = self._pooled_mean(box_features)                           # :344
+        predictions = self.box_predictor(box_features)                           # :345
+        box_features = list(box_features.split(boxes_per_image, dim=0))          # :346
+        losses.update(self.box_predictor.losses(predictions, proposals))         # :347
+        return visual_grid_features, box_features, proposals, losses
+
+    def inference_detection(self, features, proposals):
+        """roi_emb_heads.py:351-360."""
+        proposal_boxes = [x.proposal_boxes for x in proposals]
+        box_features = self._shared_roi_transform([features[f] for f in self.in_features], proposal_boxes)
+        predictions = self.box_predictor(self._pooled_mean(box_features))
+        pred_instances, _ = self.box_predictor.inference(predictions, proposals)
+        pred_instances = self.forward_with_given_boxes(features, pred_instances)
+        return pred_instances, {}
+
+
+def build_roi_heads(cfg, input_shape: Dict[str, ShapeSpec]):
+    """[D2-upstream] build_roi_heads: cfg.MODEL.ROI_HEADS.NAME -> registry."""
+    return ROI_HEADS_REGISTRY.get(cfg.MODEL.ROI_HEADS.NAME)(cfg, input_shape)

@@ -1,0 +1,193 @@
+"""GPU parity of the plugin-level path: the Detectron2-shaped ROI heads / box predictor of
+locov_amd against the CPU oracle on the same seeded inputs.
+Gate: fp32 logits within 1e-4 of the oracle (north_star)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device")
+    import locov_amd
+    from locov_amd import _lib
+    _lib.load()
+    return locov_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_conv3x3_nhwc_vs_torch_cpu(pkg):
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(3)
+    for (R, H, W, Cin, N) in ((37, 7, 7, 64, 96), (3, 25, 42, 32, 40), (130, 7, 7, 128, 128)):
+        x = torch.randn(R, Cin, H, W, generator=g)
+        w = torch.randn(N, Cin, 3, 3, generator=g) * 0.05
+        sc = torch.rand(N, generator=g) + 0.5
+        sh = torch.randn(N, generator=g)
+        want = F.relu(F.conv2d(x.double(), w.double(), padding=1) * sc.double().view(1, -1, 1, 1)
+                      + sh.double().view(1, -1, 1, 1))
+        rows = x.permute(0, 2, 3, 1).reshape(R * H * W, Cin).contiguous().cuda()
+        wp = ops.pack_conv3x3_weight(w.cuda())
+        np.testing.assert_array_equal(wp.cpu().numpy(), w.permute(0, 2, 3, 1).reshape(N, 9 * Cin).numpy())
+        got = ops.conv3x3_nhwc(rows, wp, H, W, scale=sc.cuda(), shift=sh.cuda(), relu=True)
+        got = got.view(R, H, W, N).permute(0, 3, 1, 2).cpu().double()
+        assert (got - want).abs().max().item() < 2e-5
+
+
+def _small_cfg(pkg):
+    cfg = pkg.config.get_cfg()
+    cfg.MODEL.RESNETS.RES2_OUT_CHANNELS = 32        # res5: 128 -> (64) -> 256
+    cfg.MODEL.RESNETS.WIDTH_PER_GROUP = 8
+    cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
+    cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED = True
+    cfg.MODEL.ROI_BOX_HEAD.EMB_DIM = 96
+    cfg.MODEL.ROI_HEADS.NAME = "EmbeddingProposalsRes5ROIHeads"
+    return cfg
+
+
+def test_res5_rows_path_vs_oracle(pkg, oracle):
+    from locov_amd.res5 import build_res5_block
+    res5, out_ch = build_res5_block(_small_cfg(pkg))
+    params = oracle.make_res5_params(5, in_ch=128, mid=64, out_ch=256)
+    res5.load_state_dict(params)
+    res5 = res5.cuda().eval()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(21, 128, 14, 14, generator=g)
+    want = oracle.res5_stage(x, params).numpy()
+    # stock path (torch conv2d on the GPU = MIOpen)
+    with torch.no_grad():
+        got_m = res5(x.cuda()).cpu().numpy()
+    np.testing.assert_allclose(got_m, want, atol=2e-4, rtol=1e-4)
+    # hand-written rows path on the even positions
+    x0 = x[:, :, ::2, ::2].permute(0, 2, 3, 1).reshape(21 * 49, 128).contiguous().cuda()
+    got = res5.forward_rows(x0, 7, 7).view(21, 7, 7, out_ch).permute(0, 3, 1, 2).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5)
+
+
+def _make_heads(pkg, oracle, cfg, k_classes, seed, res5_dims=None):
+    from locov_amd.structures import ShapeSpec
+    c_in = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS * 4
+    heads = pkg.build_roi_heads(cfg, {"res4": ShapeSpec(channels=c_in, stride=16)})
+    c5, mid = heads.output_shape, cfg.MODEL.RESNETS.WIDTH_PER_GROUP * 8
+    params = oracle.make_res5_params(seed, in_ch=c_in, mid=mid, out_ch=c5)
+    heads.res5.load_state_dict(params)
+    rng = np.random.default_rng(seed)
+    h = oracle.synth_head(rng, c5, cfg.MODEL.ROI_BOX_HEAD.EMB_DIM, k_classes)
+    bp = heads.box_predictor
+    with torch.no_grad():
+        bp.emb_pred.weight.copy_(torch.from_numpy(h["emb_w"]))
+        bp.emb_pred.bias.copy_(torch.from_numpy(h["emb_b"]))
+        bp.bbox_pred.weight.copy_(torch.from_numpy(h["bbox_w"]))
+        bp.bbox_pred.bias.copy_(torch.from_numpy(h["bbox_b"]))
+    heads = heads.cuda().eval()
+    bp.set_class_embeddings(h["cls_w"])           # trainer.py:365-396 load_embeddings contract
+    heads.num_classes = bp.num_classes
+    return heads, params, h
+
+
+def _proposals(pkg, oracle, rng, n_img, r, device="cuda"):
+    from locov_amd.structures import Boxes, Instances
+    out, boxes = [], []
+    for _ in range(n_img):
+        b = oracle.synth_boxes(rng, r)
+        boxes.append(b)
+        inst = Instances((800, 1333))
+        inst.proposal_boxes = Boxes(torch.from_numpy(b).to(device))
+        inst.objectness_logits = torch.zeros(r, device=device)
+        out.append(inst)
+    return out, boxes
+
+
+@pytest.mark.parametrize("backend", ["hip", "miopen"])
+def test_roi_heads_small_vs_oracle(pkg, oracle, backend):
+    cfg = _small_cfg(pkg)
+    cfg.MODEL.ROI_BOX_HEAD.RES5_BACKEND = backend
+    heads, params, h = _make_heads(pkg, oracle, cfg, 80, 7)
+    rng = np.random.default_rng(17)
+    feat = rng.standard_normal((2, 128, 50, 84)).astype(np.float32)
+    props, boxes = _proposals(pkg, oracle, rng, 2, 60)
+    want = oracle.roi_head_forward(feat, boxes, params, h)
+    with torch.no_grad():
+        bf = heads._shared_roi_transform([dev(feat)], [p.proposal_boxes for p in props])
+        assert tuple(bf.shape) == (120, 256, 7, 7)
+        pooled = heads._pooled_mean(bf)
+        scores, deltas = heads.box_predictor(pooled)
+    tol = 2e-5 if backend == "hip" else 2e-4
+    np.testing.assert_allclose(bf.cpu().numpy(), want["res5"], atol=tol, rtol=1e-4)
+    np.testing.assert_allclose(pooled.cpu().numpy(), want["box_features"], atol=tol, rtol=1e-4)
+    np.testing.assert_allclose(scores.cpu().numpy(), want["scores"], atol=1e-4)
+    np.testing.assert_allclose(deltas.cpu().numpy(), want["deltas"], atol=1e-5)
+    # full inference entry point: same detections as the oracle's post-processing of ITS logits
+    with torch.no_grad():
+        inst, losses = heads(None, {"res4": dev(feat)}, props, None)
+    assert losses == {} and len(inst) == 2
+    probs = oracle.softmax(want["scores"])
+    for i in range(2):
+        sl = slice(i * 60, (i + 1) * 60)
+        pb = oracle.apply_deltas(want["deltas"][sl], boxes[i])
+        wb, ws, wc = oracle.fast_rcnn_inference_single_image(pb, probs[sl], (800, 1333), 0.05, 0.5, 100)
+        assert len(inst[i]) == len(wb)
+        np.testing.assert_allclose(inst[i].pred_boxes.tensor.cpu().numpy(), wb, atol=1e-2)
+        np.testing.assert_allclose(inst[i].scores.cpu().numpy(), ws, atol=1e-5)
+        np.testing.assert_array_equal(inst[i].pred_classes.cpu().numpy(), wc)
+
+
+def test_roi_heads_reference_config_vs_oracle(pkg, oracle):
+    """configs/coco_lsm.yaml shapes (config 1 of BASELINE.json, fewer proposals to keep the CPU
+    oracle's Res5 within seconds): res4 [2,1024,50,84], Res5 1024->2048, D=768, 80-class bank."""
+    cfg = pkg.config.get_cfg()
+    cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
+    cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED = True
+    cfg.MODEL.ROI_HEADS.NAME = "EmbeddingProposalsRes5ROIHeads"
+    cfg.MODEL.ROI_HEADS.DETACH_CLASS_PREDICTOR = True
+    heads, params, h = _make_heads(pkg, oracle, cfg, 80, 1992)
+    rng = np.random.default_rng(1992)
+    feat = rng.standard_normal((2, 1024, 50, 84)).astype(np.float32)
+    props, boxes = _proposals(pkg, oracle, rng, 2, 40)
+    want = oracle.roi_head_forward(feat, boxes, params, h)
+    with torch.no_grad():
+        bf = heads._shared_roi_transform([dev(feat)], [p.proposal_boxes for p in props])
+        scores, deltas = heads.box_predictor(heads._pooled_mean(bf))
+    err = np.abs(scores.cpu().numpy() - want["scores"]).max()
+    assert err <= 1e-4, err                                  # north_star gate
+    np.testing.assert_allclose(deltas.cpu().numpy(), want["deltas"], atol=1e-5)
+    assert np.all(scores.cpu().numpy()[:, -1] == 0)          # zero background row
+
+
+def test_training_forward_contract(pkg, oracle):
+    """EmbeddingProposalsRes5ROIHeads.forward with targets: 4-tuple, sampled proposals with
+    gt_classes / fg_proposal, losses with loss_cls weight 0 under DETACH_CLASS_PREDICTOR
+    (roi_emb_heads.py:311-349, box_emb_head.py:147-149)."""
+    from locov_amd.structures import Boxes, Instances
+    cfg = _small_cfg(pkg)
+    cfg.MODEL.ROI_HEADS.DETACH_CLASS_PREDICTOR = True
+    cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 32
+    cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION = 1.0
+    heads, params, h = _make_heads(pkg, oracle, cfg, 80, 9)
+    heads.train()
+    rng = np.random.default_rng(23)
+    feat = dev(rng.standard_normal((2, 128, 50, 84)).astype(np.float32)).requires_grad_(True)
+    props, boxes = _proposals(pkg, oracle, rng, 2, 50)
+    targets = []
+    for i in range(2):
+        t = Instances((800, 1333))
+        t.gt_boxes = Boxes(torch.from_numpy(boxes[i][:3] + 2.0).cuda())
+        t.gt_classes = torch.tensor([1, 1, 1], device="cuda")       # OLN pseudo-GT (coco_mappers.py:88-106)
+        targets.append(t)
+    grid, box_feats, sampled, losses = heads(None, {"res4": feat}, props, targets)
+    assert tuple(grid.shape) == (2, 256, 25, 42)
+    assert len(box_feats) == 2 and all(b.shape[1] == 256 for b in box_feats)
+    assert all(s.has("gt_classes") and s.has("fg_proposal") and s.has("gt_boxes") for s in sampled)
+    assert [len(s) for s in sampled] == [b.shape[0] for b in box_feats]
+    assert set(losses) == {"loss_cls", "loss_box_reg"} and float(losses["loss_cls"]) == 0.0
+    assert torch.isfinite(losses["loss_box_reg"])
+    (losses["loss_box_reg"] + sum(b.sum() for b in box_feats) * 1e-3).backward()
+    assert feat.grad is not None and torch.isfinite(feat.grad).all() and feat.grad.abs().sum() > 0
+    assert heads.box_predictor.bbox_pred.weight.grad is not None
