@@ -11,17 +11,30 @@
 // Both operands are K-contiguous (nn.Linear / conv weights are [out, in...]), so A and B tiles
 // are staged the same way: 16-byte global loads -> registers -> ds_write_b128 into LDS rows
 // padded to 144 B (stride 9 x 16 B: any 16 distinct rows hit 16 distinct 16-byte slots, so the
-// ds_read_b128 fragment reads are conflict-free), register double-buffered so the next
-// K-tile's loads are in flight under the MFMAs.  A wave owns a (BM/WM)x(BN/WN) sub-tile as
+// ds_read_b128 fragment reads are conflict-free).  A wave owns a (BM/WM)x(BN/WN) sub-tile as
 // 32x32 accumulators.  Lane l supplies row (l&31), 16 bytes at k-offset 16B*(l>>5):
 //   fp32 -> 4 consecutive 32x32x2 MFMAs use .x .y .z .w (lane-half h covers k = 4h+j),
 //   bf16 -> one 32x32x16 MFMA (lane-half h covers k = 8h..8h+7)          [guide section 3].
+//
+// K-loop = a 4-phase software pipeline per K-tile (one phase per quarter of the tile's MFMAs),
+// built so that a single wave per SIMD keeps the matrix pipe fed (the f32 MFMA occupies the
+// pipe 64 cycles; everything else has to fit in its shadow):
+//   A: MFMA q0 | read fragments q1 from LDS
+//   B: MFMA q1 | read fragments q2 | write tile t+1 (global data loaded one tile ago) to the OTHER LDS stage
+//   C: MFMA q2 | read fragments q3 | issue the global loads of tile t+2
+//      barrier (tile t+1 is now visible; nobody still reads the stage it went to)
+//   D: MFMA q3 | read fragments q0 of tile t+1
+// Two LDS stages -> one barrier per tile; fragments are double-buffered in registers; global
+// data is prefetched two tiles ahead.  sched_barriers pin the phase order, inside a phase the
+// compiler interleaves memory instructions with the MFMAs.
 //
 // CONV3 (3x3, pad 1, stride 1): A is the [R*H*W, Cin] pixel matrix of R independent HxW
 // tiles; GEMM column k = tap*Cin + c reads pixel (y+dy, x+dx) of the same tile, zero outside
 // it.  A K-tile never straddles a tap (Cin % BK == 0), so (dy,dx) is uniform per tile and the
 // gather is just a row offset plus a per-row validity mask.
 #include "gemm_nt.h"
+
+#include <cstdlib>
 
 namespace locov {
 
@@ -67,11 +80,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return base + (bid >> 3);
 }
 
-template <typename T, typename TOut, int BM, int BN, int WM, int WN, bool CONV3>
-__global__ __launch_bounds__(64 * WM *WN) void gemm_nt_kernel(const T *__restrict__ A, int64_t lda,
-                                                               const T *__restrict__ B, int64_t ldb,
-                                                               TOut *__restrict__ Cout, int64_t ldc, int64_t M,
-                                                               int N, int K, Epilogue epi, ConvGeom cg)
+// OCC = waves per SIMD the register allocator must leave room for (= workgroups per CU for the
+// 4-wave configurations; the two LDS stages allow as many).
+template <typename T, typename TOut, int BM, int BN, int WM, int WN, int OCC, bool CONV3>
+__global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__restrict__ A, int64_t lda,
+                                                                    const T *__restrict__ B, int64_t ldb,
+                                                                    TOut *__restrict__ Cout, int64_t ldc, int64_t M,
+                                                                    int N, int K, Epilogue epi, ConvGeom cg)
 {
     typedef typename Frag<T>::type frag_t;
     constexpr int E = Frag<T>::kPer16B;    // elements per 16 B
@@ -84,9 +99,10 @@ __global__ __launch_bounds__(64 * WM *WN) void gemm_nt_kernel(const T *__restric
     constexpr int A_CH = BM * BK16 / NT;   // 16-byte chunks per thread per tile
     constexpr int B_CH = BN * BK16 / NT;
     static_assert(BM * BK16 % NT == 0 && BN * BK16 % NT == 0, "tile must divide evenly over threads");
+    static_assert(A_CH <= 16 && B_CH <= 16, "ok_mask holds 16 chunks per operand");
 
-    __shared__ frag_t lds[(BM + BN) * LDS16];
-    frag_t *As = lds, *Bs = lds + BM * LDS16;
+    constexpr int STAGE = (BM + BN) * LDS16;
+    __shared__ frag_t lds[2 * STAGE];
 
     const int tiles_n = (N + BN - 1) / BN;
     const int nwg = gridDim.x;
@@ -97,60 +113,86 @@ __global__ __launch_bounds__(64 * WM *WN) void gemm_nt_kernel(const T *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave / WN) * TM, wn = (wave % WN) * TN;
 
-    // per-thread A rows are the same for every K-tile: decode their tile coordinates once
+    // Per-thread staging rows are the same for every K-tile: resolve pointers / validity once.
+    // Loads are branch-free: an out-of-range row reads a clamped (in-bounds) address and is zeroed
+    // by a select at store time, so the K-loop has no exec-masked branches and no per-load waits.
+    const T *a_ptr[A_CH];
+    const T *b_ptr[B_CH];
+    bool a_ok[A_CH], b_ok[B_CH];
     int a_y[A_CH], a_x[A_CH];
-    if (CONV3) {
 #pragma unroll
-        for (int i = 0; i < A_CH; i++) {
-            const int64_t gm = m0 + (tid + i * NT) / BK16;
-            const int rem = (int)(gm % (cg.H * cg.W));
+    for (int i = 0; i < A_CH; i++) {
+        const int idx = tid + i * NT, row = idx / BK16, ch = idx % BK16;
+        const int64_t gm = m0 + row;
+        a_ok[i] = gm < M;
+        const int64_t gmc = a_ok[i] ? gm : M - 1;
+        a_ptr[i] = A + gmc * lda + ch * E;
+        if (CONV3) {
+            const int rem = (int)(gmc % (cg.H * cg.W));
             a_y[i] = rem / cg.W;
             a_x[i] = rem - a_y[i] * cg.W;
         }
     }
+#pragma unroll
+    for (int i = 0; i < B_CH; i++) {
+        const int idx = tid + i * NT, row = idx / BK16, ch = idx % BK16;
+        const int gn = n0 + row;
+        b_ok[i] = gn < N;
+        b_ptr[i] = B + (int64_t)(b_ok[i] ? gn : N - 1) * ldb + ch * E;
+    }
 
     frag_t ra[A_CH], rb[B_CH];
+    unsigned ok_mask = 0;                 // bit i: A chunk i is data, bit 16+i: B chunk i is data
     const frag_t zero = {};
 
+    // Raw 16-byte loads of the K-tile at k0 (nothing here depends on their results); records which
+    // chunks are real data.  A ragged K tail is handled per 16-byte chunk (K % E == 0).
     auto load_tiles = [&](int k0) {
-        int dy = 0, dx = 0, kc = k0;
+        ok_mask = 0;
+        int64_t aoff = k0;
+        int dy = 0, dx = 0;
         if (CONV3) {
             const int tap = k0 / cg.Cin;
-            kc = k0 - tap * cg.Cin;
             dy = tap / 3 - 1;
             dx = tap - (tap / 3) * 3 - 1;
+            aoff = (int64_t)(dy * cg.W + dx) * lda + (k0 - tap * cg.Cin);
         }
 #pragma unroll
         for (int i = 0; i < A_CH; i++) {
-            const int idx = tid + i * NT, row = idx / BK16, ch = idx % BK16;
-            const int64_t gm = m0 + row;
+            const int ch = (tid + i * NT) % BK16;
+            bool ok = a_ok[i];
+            int64_t off = aoff;
             if (CONV3) {
-                const bool ok = gm < M && (unsigned)(a_y[i] + dy) < (unsigned)cg.H &&
-                                (unsigned)(a_x[i] + dx) < (unsigned)cg.W;
-                ra[i] = ok ? *reinterpret_cast<const frag_t *>(A + (gm + dy * cg.W + dx) * lda + kc + ch * E) : zero;
+                const bool in = (unsigned)(a_y[i] + dy) < (unsigned)cg.H && (unsigned)(a_x[i] + dx) < (unsigned)cg.W;
+                ok = ok && in;
+                off = in ? aoff : (int64_t)(k0 % cg.Cin);      // padding tap: stay inside the tensor
             } else {
-                const int gk = k0 + ch * E;
-                ra[i] = (gm < M && gk < K) ? *reinterpret_cast<const frag_t *>(A + gm * lda + gk) : zero;
+                const bool kin = k0 + ch * E < K;
+                ok = ok && kin;
+                off = kin ? aoff : 0;
             }
+            ra[i] = *reinterpret_cast<const frag_t *>(a_ptr[i] + off);
+            ok_mask |= ok ? (1u << i) : 0u;
         }
 #pragma unroll
         for (int i = 0; i < B_CH; i++) {
-            const int idx = tid + i * NT, row = idx / BK16, ch = idx % BK16;
-            const int gn = n0 + row;
-            const int gk = k0 + ch * E;
-            rb[i] = (gn < N && gk < K) ? *reinterpret_cast<const frag_t *>(B + (int64_t)gn * ldb + gk) : zero;
+            const int ch = (tid + i * NT) % BK16;
+            const bool kin = k0 + ch * E < K;
+            rb[i] = *reinterpret_cast<const frag_t *>(b_ptr[i] + (kin ? k0 : 0));
+            ok_mask |= (b_ok[i] && kin) ? (1u << (16 + i)) : 0u;
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int stage) {
+        frag_t *As = lds + stage * STAGE, *Bs = As + BM * LDS16;
 #pragma unroll
         for (int i = 0; i < A_CH; i++) {
             const int idx = tid + i * NT;
-            As[(idx / BK16) * LDS16 + idx % BK16] = ra[i];
+            As[(idx / BK16) * LDS16 + idx % BK16] = (ok_mask >> i) & 1u ? ra[i] : zero;
         }
 #pragma unroll
         for (int i = 0; i < B_CH; i++) {
             const int idx = tid + i * NT;
-            Bs[(idx / BK16) * LDS16 + idx % BK16] = rb[i];
+            Bs[(idx / BK16) * LDS16 + idx % BK16] = (ok_mask >> (16 + i)) & 1u ? rb[i] : zero;
         }
     };
 
@@ -160,80 +202,198 @@ __global__ __launch_bounds__(64 * WM *WN) void gemm_nt_kernel(const T *__restric
 #pragma unroll
         for (int j = 0; j < NI; j++) acc[i][j] = f32x16{};
 
-    load_tiles(0);
-    store_tiles();
-    __syncthreads();
-
+    // register double buffer of MFMA fragments: quarter q of a tile = 16-byte chunks 2q, 2q+1
+    frag_t fa0[MI], fb0[NI], fa1[MI], fb1[NI];
     const int frow = lane & 31, fch = lane >> 5;
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        const bool more = k0 + BK < K;
-        if (more) load_tiles(k0 + BK);  // in flight under the MFMAs below
+    auto read_frags = [&](int stage, int q, frag_t(&fa)[MI], frag_t(&fb)[NI]) {
+        const frag_t *As = lds + stage * STAGE, *Bs = As + BM * LDS16;
 #pragma unroll
-        for (int kk = 0; kk < BK16; kk += 2) {
-            frag_t a[MI], b[NI];
+        for (int i = 0; i < MI; i++) fa[i] = As[(wm + i * 32 + frow) * LDS16 + 2 * q + fch];
 #pragma unroll
-            for (int i = 0; i < MI; i++) a[i] = As[(wm + i * 32 + frow) * LDS16 + kk + fch];
+        for (int j = 0; j < NI; j++) fb[j] = Bs[(wn + j * 32 + frow) * LDS16 + 2 * q + fch];
+    };
+    auto mma = [&](const frag_t(&fa)[MI], const frag_t(&fb)[NI]) {
 #pragma unroll
-            for (int j = 0; j < NI; j++) b[j] = Bs[(wn + j * 32 + frow) * LDS16 + kk + fch];
+        for (int i = 0; i < MI; i++)
 #pragma unroll
-            for (int i = 0; i < MI; i++)
+            for (int j = 0; j < NI; j++) mma_step(fa[i], fb[j], acc[i][j]);
+    };
+
+    // one half of a quarter's MFMAs (row tiles split in two; MI == 1: first half does everything)
+    auto mma_half = [&](const frag_t(&fa)[MI], const frag_t(&fb)[NI], int half) {
 #pragma unroll
-                for (int j = 0; j < NI; j++) mma_step(a[i], b[j], acc[i][j]);
+        for (int i = 0; i < MI; i++) {
+            if ((MI == 1 ? 0 : (i * 2) / MI) != half) continue;
+#pragma unroll
+            for (int j = 0; j < NI; j++) mma_step(fa[i], fb[j], acc[i][j]);
         }
+    };
+
+    const int k_last = ((K + BK - 1) / BK - 1) * BK;        // k0 of the last K-tile
+    // prologue: tile 0 -> LDS stage 0, tile 1 -> staging registers, fragments q0 of tile 0
+    load_tiles(0);
+    store_tiles(0);
+    load_tiles(BK < k_last ? BK : k_last);
+    __syncthreads();
+    read_frags(0, 0, fa0, fb0);
+    int s = 0;
+    for (int k0 = 0; k0 < k_last; k0 += BK) {               // tile at k0 has a successor
+        // (each phase issues its fragment reads FIRST so their LDS latency sits under 16 MFMAs)
+        // A
+        read_frags(s, 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        // B: staging registers (tile t+1) -> other LDS stage
+        read_frags(s, 2, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tiles(s ^ 1);
+        mma(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        // C: refill the staging registers with tile t+2 (clamped: a redundant reload at the end)
+        read_frags(s, 3, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tiles(k0 + 2 * BK < k_last ? k0 + 2 * BK : k_last);
+        mma(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        // D: the barrier sits in the MIDDLE of this quarter's MFMAs: the first half is issued from
+        // registers while the waves rendezvous, the second half covers the LDS latency of the next
+        // tile's first fragments
+        mma_half(fa1, fb1, 0);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        if (more) {
-            store_tiles();
-            __syncthreads();
+        read_frags(s ^ 1, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(fa1, fb1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        s ^= 1;
+    }
+    // last tile
+    read_frags(s, 1, fa1, fb1);
+    mma(fa0, fb0);
+    read_frags(s, 2, fa0, fb0);
+    mma(fa1, fb1);
+    read_frags(s, 3, fa1, fb1);
+    mma(fa0, fb0);
+    mma(fa1, fb1);
+
+    // Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // Runtime options are wave-uniform and hoisted; residual values of a 32x32 tile are fetched as
+    // one batch of 16 independent loads before they are consumed.
+    const bool relu = (epi.flags & LOCOV_EPI_RELU) != 0;
+
+    // Fast path: a row-per-lane store tail is store-ISSUE-bound (64 dword stores per lane), so each
+    // wave re-lays its sub-tile out through LDS (free after the K-loop) and writes 16 bytes per lane:
+    // 4x fewer store (and residual load) instructions, 256-byte contiguous runs per row.
+    const bool vec_ok = sizeof(TOut) == 4 && !(epi.flags & 0x800u) && (N % 4 == 0) && (ldc % 4 == 0) &&
+                        ((uintptr_t)Cout % 16 == 0) && (!epi.residual || (uintptr_t)epi.residual % 16 == 0);
+    if (vec_ok) {
+        constexpr int EPS = TN + 4;                       // padded row (floats): conflict-free b128 reads
+        static_assert(WM * WN * TM * EPS * 4 <= 2 * STAGE * 16, "epilogue staging must fit the K-loop LDS");
+        __syncthreads();                                  // every wave is done reading the last stage
+        float *ep = reinterpret_cast<float *>(lds) + wave * (TM * EPS);
+#pragma unroll
+        for (int i = 0; i < MI; i++)
+#pragma unroll
+            for (int j = 0; j < NI; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPS + j * 32 + (lane & 31)] = acc[i][j][r];
+        __syncthreads();
+        constexpr int LPR = TN / 4;                       // lanes per row
+        constexpr int RPI = 64 / LPR;                     // rows per wave instruction
+        const int c4 = (lane % LPR) * 4, rr = lane / LPR;
+        const int n = n0 + wn + c4;
+        if (n < N) {
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (epi.scale) sc = *reinterpret_cast<const f32x4 *>(epi.scale + n);
+            if (epi.shift) sh = *reinterpret_cast<const f32x4 *>(epi.shift + n);
+#pragma unroll 4
+            for (int it = 0; it < TM / RPI; it++) {
+                const int row = it * RPI + rr;
+                const int64_t m = m0 + wm + row;
+                if (m >= M) continue;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(ep + row * EPS + c4);
+                v = v * sc + sh;
+                if (epi.residual) v += *reinterpret_cast<const f32x4 *>(epi.residual + m * ldc + n);
+                if (relu) {
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                }
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + m * ldc + n) = v;
+            }
         }
+        return;
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // General path (odd N / ldc, bf16 output): one element per lane.
 #pragma unroll
     for (int j = 0; j < NI; j++) {
         const int n = n0 + wn + j * 32 + (lane & 31);
-        if (n >= N) continue;
-        const float sc = epi.scale ? epi.scale[n] : 1.f;
-        const float sh = epi.shift ? epi.shift[n] : 0.f;
+        const bool n_ok = n < N;
+        const int nc = n_ok ? n : N - 1;
+        const float sc = epi.scale ? epi.scale[nc] : 1.f;
+        const float sh = epi.shift ? epi.shift[nc] : 0.f;
 #pragma unroll
         for (int i = 0; i < MI; i++) {
+            const int64_t mb = m0 + wm + i * 32 + 4 * (lane >> 5);
+            float res[16];
+            if (epi.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int64_t m = mb + (r & 3) + 8 * (r >> 2);
+                    res[r] = epi.residual[(m < M ? m : M - 1) * ldc + nc];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) res[r] = 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int64_t m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= M) continue;
-                float v = acc[i][j][r];
-                if (epi.scale) v *= sc;
-                v += sh;
-                if (epi.residual) v += epi.residual[m * ldc + n];
-                if (epi.flags & LOCOV_EPI_RELU) v = fmaxf(v, 0.f);
-                store_out(Cout + m * ldc + n, v);
+                const int64_t m = mb + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] * sc + sh + res[r];
+                if (relu) v = fmaxf(v, 0.f);
+                if (n_ok && m < M) store_out(Cout + m * ldc + n, v);
             }
         }
     }
 }
 
-template <typename T, typename TOut, int BM, int BN, int WM, int WN>
+template <typename T, typename TOut, int BM, int BN, int WM, int WN, int OCC>
 static int launch_cfg(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C, int64_t ldc, int64_t M, int N,
                       int K, const Epilogue &epi, const ConvGeom &cg, hipStream_t s, const char *what)
 {
     const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
     if (tiles > 0x7fffffffLL) return set_error(LOCOV_ERR_INVALID_ARG, "%s: problem too large", what);
     if (cg.H > 0)
-        hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, true>), dim3((unsigned)tiles), dim3(64 * WM * WN),
-                           0, s, A, lda, B, ldb, C, ldc, M, N, K, epi, cg);
+        hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, OCC, true>), dim3((unsigned)tiles),
+                           dim3(64 * WM * WN), 0, s, A, lda, B, ldb, C, ldc, M, N, K, epi, cg);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, false>), dim3((unsigned)tiles),
+        hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, OCC, false>), dim3((unsigned)tiles),
                            dim3(64 * WM * WN), 0, s, A, lda, B, ldb, C, ldc, M, N, K, epi, cg);
     return check_launch(what);
+}
+
+// developer knob (tools/bench_gemm.py): LOCOV_GEMM_CFG=1 forces the small-tile configuration
+static int forced_cfg()
+{
+    static const int v = [] {
+        const char *e = getenv("LOCOV_GEMM_CFG");
+        return e ? atoi(e) : -1;
+    }();
+    return v;
 }
 
 template <typename T, typename TOut>
 int launch_gemm_nt(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C, int64_t ldc, int64_t M, int N, int K,
                    const Epilogue &epi, hipStream_t s, const char *what, const ConvGeom &cg)
 {
-    if (N <= 32) return launch_cfg<T, TOut, 128, 32, 4, 1>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
+    if (N <= 32) return launch_cfg<T, TOut, 128, 32, 4, 1, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
     if (N <= 64 || (N <= 192 && N % 128 != 0 && N % 128 <= 64))
-        return launch_cfg<T, TOut, 128, 64, 4, 1>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
-    return launch_cfg<T, TOut, 128, 128, 2, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
+        return launch_cfg<T, TOut, 128, 64, 4, 1, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
+    if (forced_cfg() == 1)
+        return launch_cfg<T, TOut, 64, 64, 2, 2, 4>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
+    return launch_cfg<T, TOut, 128, 128, 2, 2, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
 }
 
 #define LOCOV_INST(T, TOut)                                                                                        \
