@@ -110,12 +110,13 @@ int locov_nchw_to_nhwc(const float *in, int N, int C, int H, int W, void *out, i
 int locov_roi_align_nhwc_fwd(const void *feat, int feat_dtype, int N, int H, int W, int C,
                              const float *rois, int64_t R, int pooled_h, int pooled_w,
                              float spatial_scale, int sampling_ratio, int aligned,
-                             int bin_stride, void *out, int out_dtype, locov_stream_t stream);
+                             int bin_stride, int pos_major, void *out, int out_dtype,
+                             locov_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * a-4  spatial mean.  Replaces box_features.mean(dim=[2,3])
  * (roi_emb_heads.py:262,344,356).  x [R,C,HW] -> out [R,C].
- * channels_last != 0: x is [R,HW,C] instead.
+ * channels_last == 1: x is [R,HW,C] (ROI-major pixel rows); == 2: x is [HW,R,C] (position-major).
  * ------------------------------------------------------------------------------------- */
 int locov_spatial_mean_fwd(const float *x, int64_t R, int C, int HW, int channels_last,
                            float *out, locov_stream_t stream);
@@ -141,12 +142,17 @@ int locov_gemm_nt_f32(const float *x, int64_t lda, const float *W, const float *
  *   - locov_conv3x3_nhwc_f32: 3x3 / pad 1 / stride 1 as an implicit GEMM (K = 9*Cin) over R
  *     independent HxW tiles; w_packed [N, 9*Cin] comes from locov_pack_conv3x3_weight
  *     ([N,Cin,3,3] -> k = (ky*3+kx)*Cin + c).  Same epilogue as locov_gemm_nt_f32.
+ *     Row order of x / y / residual: pos_major == 0 -> ROI-major  row = r*H*W + (y*W + x);
+ *                                    pos_major != 0 -> POSITION-major row = (y*W + x)*R + r.
+ *     Position-major is the fast layout: tap validity is then uniform per workgroup and the
+ *     zero-padding taps are skipped instead of multiplied (18 % of a 7x7 tile's MACs).
  *   - locov_frozen_bn_fold: scale = weight*rsqrt(var+eps), shift = bias - mean*scale, the
  *     per-channel affine FrozenBatchNorm2d applies; feeds the GEMM epilogue's scale/shift.
  * ------------------------------------------------------------------------------------- */
-int locov_conv3x3_nhwc_f32(const float *x, int64_t R, int H, int W, int Cin, const float *w_packed,
-                           const float *scale, const float *shift, const float *residual, float *y,
-                           int N, unsigned flags, locov_stream_t stream);
+int locov_conv3x3_nhwc_f32(const float *x, int64_t R, int H, int W, int Cin, int pos_major,
+                           const float *w_packed, const float *scale, const float *shift,
+                           const float *residual, float *y, int N, unsigned flags,
+                           locov_stream_t stream);
 
 int locov_pack_conv3x3_weight(const float *w, int N, int Cin, void *out, int out_dtype,
                               locov_stream_t stream);

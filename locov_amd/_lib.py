@@ -36,10 +36,11 @@ SIGNATURES = {
                                            _p, _p]),
     "locov_nchw_to_nhwc": (c_int, [_p, c_int, c_int, c_int, c_int, _p, c_int, _p]),
     "locov_roi_align_nhwc_fwd": (c_int, [_p, c_int, c_int, c_int, c_int, c_int, _p, c_int64, c_int, c_int,
-                                         c_float, c_int, c_int, c_int, _p, c_int, _p]),
+                                         c_float, c_int, c_int, c_int, c_int, _p, c_int, _p]),
     "locov_spatial_mean_fwd": (c_int, [_p, c_int64, c_int, c_int, c_int, _p, _p]),
     "locov_gemm_nt_f32": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, _p]),
-    "locov_conv3x3_nhwc_f32": (c_int, [_p, c_int64, c_int, c_int, c_int, _p, _p, _p, _p, _p, c_int, c_uint, _p]),
+    "locov_conv3x3_nhwc_f32": (c_int, [_p, c_int64, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, c_int, c_uint,
+                                       _p]),
     "locov_pack_conv3x3_weight": (c_int, [_p, c_int, c_int, _p, c_int, _p]),
     "locov_frozen_bn_fold": (c_int, [_p, _p, _p, _p, c_float, c_int, _p, _p, _p]),
     "locov_rownorm_fwd": (c_int, [_p, c_int64, c_int, c_int, c_float, _p, _p]),

@@ -56,8 +56,11 @@ __global__ __launch_bounds__(256) void spatial_mean_wave_kernel(const float *__r
 }
 
 // channels-last: x [R, HW, C] -> out [R, C]; lanes across channels (16 B each), loop over HW.
+// roi_stride / pos_stride (in float4 units) select the row order: ROI-major [R,HW,C] -> (HW*C/4, C/4),
+// position-major [HW,R,C] -> (C/4, R*C/4).
 __global__ __launch_bounds__(256) void spatial_mean_nhwc_kernel(const float *__restrict__ x, int64_t R, int C,
-                                                                int HW, float *__restrict__ out)
+                                                                int HW, int64_t roi_stride, int64_t pos_stride,
+                                                                float *__restrict__ out)
 {
     const int c4n = C >> 2;
     const int64_t total = R * c4n;
@@ -65,10 +68,10 @@ __global__ __launch_bounds__(256) void spatial_mean_nhwc_kernel(const float *__r
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / c4n;
         const int c4 = (int)(i - r * c4n);
-        const float4 *p = reinterpret_cast<const float4 *>(x + r * HW * C) + c4;
+        const float4 *p = reinterpret_cast<const float4 *>(x) + r * roi_stride + c4;
         float4 s = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < HW; k++) {
-            const float4 v = p[(int64_t)k * c4n];
+            const float4 v = p[(int64_t)k * pos_stride];
             s.x = __fadd_rn(s.x, v.x); s.y = __fadd_rn(s.y, v.y);
             s.z = __fadd_rn(s.z, v.z); s.w = __fadd_rn(s.w, v.w);
         }
@@ -133,7 +136,11 @@ static int spatial_mean(const float *x, int64_t R, int C, int HW, int channels_l
         const int64_t total = R * (C / 4);
         const int64_t want = ceil_div(total, 256);
         const int grid = (int)(want < 256 * 8 ? want : 256 * 8);
-        hipLaunchKernelGGL(spatial_mean_nhwc_kernel, dim3(grid), dim3(256), 0, s, x, R, C, HW, out);
+        const int64_t c4n = C / 4;
+        const int64_t roi_stride = channels_last == 2 ? c4n : (int64_t)HW * c4n;
+        const int64_t pos_stride = channels_last == 2 ? R * c4n : c4n;
+        hipLaunchKernelGGL(spatial_mean_nhwc_kernel, dim3(grid), dim3(256), 0, s, x, R, C, HW, roi_stride, pos_stride,
+                           out);
         return check_launch("locov_spatial_mean_fwd");
     }
     const int64_t rows = R * C;

@@ -64,7 +64,8 @@ constexpr int kMaxAxisN = 1024;
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
     const TIn *__restrict__ feat, int N, int H, int W, int C, const float *__restrict__ rois, int PH, int PW,
-    float scale, int sampling_ratio, int aligned, int bin_stride, int OH, int OW, TOut *__restrict__ out)
+    float scale, int sampling_ratio, int aligned, int bin_stride, int OH, int OW, int pos_major,
+    TOut *__restrict__ out)
 {
     __shared__ AxisSampleN ytab[kMaxAxisN];
     __shared__ AxisSampleN xtab[kMaxAxisN];
@@ -106,7 +107,9 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
     const int total = OW * c4n;
     const bool valid_b = b >= 0 && b < N;
     const TIn *img = feat + (int64_t)(valid_b ? b : 0) * H * W * C;
-    TOut *orow = out + ((r * OH + oh) * (int64_t)OW) * C;
+    // ROI-major: out[r][oh][ow][c]; position-major: out[oh][ow][r][c] (R = gridDim.x rows per position)
+    const int64_t ow_stride = pos_major ? (int64_t)gridDim.x * C : (int64_t)C;
+    TOut *orow = pos_major ? out + ((int64_t)oh * OW * gridDim.x + r) * C : out + ((r * OH + oh) * (int64_t)OW) * C;
     for (int o = threadIdx.x; o < total; o += kNhwcThreads) {
         const int ow = o / c4n;
         const int c = (o - ow * c4n) << 2;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
             }
         }
         acc.x *= inv_count; acc.y *= inv_count; acc.z *= inv_count; acc.w *= inv_count;
-        store4(orow + (int64_t)ow * C + c, acc);
+        store4(orow + ow * ow_stride + c, acc);
     }
 }
 
@@ -182,7 +185,7 @@ int locov_nchw_to_nhwc(const float *in, int N, int C, int H, int W, void *out, i
 
 int locov_roi_align_nhwc_fwd(const void *feat, int feat_dtype, int N, int H, int W, int C, const float *rois,
                              int64_t R, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
-                             int aligned, int bin_stride, void *out, int out_dtype, locov_stream_t stream)
+                             int aligned, int bin_stride, int pos_major, void *out, int out_dtype, locov_stream_t stream)
 {
     LOCOV_REQUIRE(R >= 0, "locov_roi_align_nhwc_fwd: R < 0");
     LOCOV_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "locov_roi_align_nhwc_fwd: bad feature shape");
@@ -200,7 +203,7 @@ int locov_roi_align_nhwc_fwd(const void *feat, int feat_dtype, int N, int H, int
     hipStream_t s = as_stream(stream);
 #define LOCOV_LAUNCH_NHWC(TI, TO)                                                                                   \
     hipLaunchKernelGGL((roi_align_nhwc_kernel<TI, TO>), grid, dim3(kNhwcThreads), 0, s, (const TI *)feat, N, H, W, C, \
-                       rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, bin_stride, OH, OW, (TO *)out)
+                       rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, bin_stride, OH, OW, pos_major, (TO *)out)
     if (feat_dtype == LOCOV_F32 && out_dtype == LOCOV_F32) LOCOV_LAUNCH_NHWC(float, float);
     else if (feat_dtype == LOCOV_F32 && out_dtype == LOCOV_BF16) LOCOV_LAUNCH_NHWC(float, __bf16);
     else if (feat_dtype == LOCOV_BF16 && out_dtype == LOCOV_F32) LOCOV_LAUNCH_NHWC(__bf16, float);

@@ -147,39 +147,48 @@ def nchw_to_nhwc(feat: torch.Tensor, dtype: torch.dtype = torch.float32) -> torc
 
 def roi_align_nhwc(feat: torch.Tensor, rois: torch.Tensor, output_size: int, spatial_scale: float,
                    sampling_ratio: int = 0, aligned: bool = True, bin_stride: int = 1,
-                   out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
-    """feat [N,H,W,C] (fp32|bf16) -> [R, ceil(P/bin_stride), ceil(P/bin_stride), C]."""
+                   out_dtype: torch.dtype = torch.float32, pos_major: bool = False) -> torch.Tensor:
+    """feat [N,H,W,C] (fp32|bf16) -> [R, o, o, C] with o = ceil(P/bin_stride), or, with pos_major,
+    [o, o, R, C] (position-major pixel rows, the fast layout of the Res5 GEMMs)."""
     feat = _dev(feat, "feat", None)
     rois = _dev(rois, "rois")
     N, H, W, C = feat.shape
     R = rois.shape[0]
     o = (output_size + bin_stride - 1) // bin_stride
-    out = torch.empty((R, o, o, C), dtype=out_dtype, device=feat.device)
+    out = torch.empty((o, o, R, C) if pos_major else (R, o, o, C), dtype=out_dtype, device=feat.device)
     with torch.cuda.device(feat.device):
         check(_lib.load().locov_roi_align_nhwc_fwd(_ptr(feat), _dtype_code(feat.dtype), N, H, W, C, _ptr(rois), R,
                                                    output_size, output_size, float(spatial_scale),
-                                                   int(sampling_ratio), int(aligned), int(bin_stride), _ptr(out),
-                                                   _dtype_code(out_dtype), _stream(feat)),
+                                                   int(sampling_ratio), int(aligned), int(bin_stride),
+                                                   int(pos_major), _ptr(out), _dtype_code(out_dtype), _stream(feat)),
               "locov_roi_align_nhwc_fwd")
     return out
 
 
-def spatial_mean(x: torch.Tensor, channels_last: bool = False) -> torch.Tensor:
-    """[R,C,h,w] (or [R,h,w,C] when channels_last) -> [R,C]."""
+def _layout_dims(x: torch.Tensor, channels_last) -> Tuple[int, int, int, int]:
+    """(R, C, HW, layout code) of a region-feature tensor: False/0 = [R,C,h,w]; True/1 = [R,h,w,C];
+    2 = position-major [h,w,R,C]."""
+    code = int(channels_last)
+    if x.dim() == 2:
+        return x.shape[0], x.shape[1], 1, 0
+    if code == 2:
+        R, C = x.shape[-2], x.shape[-1]
+        return R, C, (x.numel() // (R * C) if R else 1), 2
+    R = x.shape[0]
+    C = x.shape[-1] if code == 1 else x.shape[1]
+    return R, C, (x[0].numel() // C if R else 1), code
+
+
+def spatial_mean(x: torch.Tensor, channels_last=False) -> torch.Tensor:
+    """[R,C,h,w] (channels_last=1: [R,h,w,C]; =2: position-major [h,w,R,C]) -> [R,C]."""
     x = _dev(x, "x")
     if x.dim() == 2:
         return x
-    R = x.shape[0]
-    if channels_last:
-        C = x.shape[-1]
-        hw = x[0].numel() // C if R else 1
-    else:
-        C = x.shape[1]
-        hw = x[0].numel() // C if R else 1
+    R, C, hw, code = _layout_dims(x, channels_last)
     out = torch.empty((R, C), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        check(_lib.load().locov_spatial_mean_fwd(_ptr(x), R, C, max(hw, 1), int(channels_last), _ptr(out),
-                                                 _stream(x)), "locov_spatial_mean_fwd")
+        check(_lib.load().locov_spatial_mean_fwd(_ptr(x), R, C, max(hw, 1), code, _ptr(out), _stream(x)),
+              "locov_spatial_mean_fwd")
     return out
 
 
@@ -207,9 +216,10 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 
 def conv3x3_nhwc(x: torch.Tensor, w_packed: torch.Tensor, H: int, W: int, *, scale=None, shift=None,
-                 residual=None, relu: bool = False) -> torch.Tensor:
+                 residual=None, relu: bool = False, pos_major: bool = False) -> torch.Tensor:
     """3x3 / pad 1 / stride 1 convolution over R independent HxW channels-last tiles.
-    x [R*H*W, Cin], w_packed [N, 9*Cin] (pack_conv3x3_weight) -> [R*H*W, N]."""
+    x [R*H*W, Cin], w_packed [N, 9*Cin] (pack_conv3x3_weight) -> [R*H*W, N].
+    Rows are ROI-major (r*H*W + pos) or, with pos_major, position-major (pos*R + r)."""
     x = _dev(x, "x")
     w_packed = _dev(w_packed, "w_packed")
     M, Cin = x.shape
@@ -221,7 +231,7 @@ def conv3x3_nhwc(x: torch.Tensor, w_packed: torch.Tensor, H: int, W: int, *, sca
     residual = _dev(residual, "residual") if residual is not None else None
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        check(_lib.load().locov_conv3x3_nhwc_f32(_ptr(x), M // (H * W), H, W, Cin, _ptr(w_packed), _ptr(scale),
+        check(_lib.load().locov_conv3x3_nhwc_f32(_ptr(x), M // (H * W), H, W, Cin, int(pos_major), _ptr(w_packed), _ptr(scale),
                                                  _ptr(shift), _ptr(residual), _ptr(y), N,
                                                  _lib.EPI_RELU if relu else 0, _stream(x)), "locov_conv3x3_nhwc_f32")
     return y
@@ -289,20 +299,13 @@ def sim_gemm_bf16(emb: torch.Tensor, bank: torch.Tensor) -> torch.Tensor:
 
 def box_head(x: torch.Tensor, emb_w: torch.Tensor, emb_b: torch.Tensor, bbox_w: torch.Tensor,
              bbox_b: torch.Tensor, bank: torch.Tensor, bank_bf16: Optional[torch.Tensor] = None,
-             norm_mode: int = NORM_NONE, sim_dtype: int = F32, channels_last: bool = False
+             norm_mode: int = NORM_NONE, sim_dtype: int = F32, channels_last=False
              ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """Spatial mean + EmbeddingFastRCNNOutputLayers.forward in one C call.
+    x: [R,C5] | [R,C5,h,w] | channels_last=1: [R,h,w,C5] | channels_last=2: position-major [h,w,R,C5].
     Returns (pooled [R,C5], deltas [R,4], emb [R,D], logits [R,K1])."""
     x = _dev(x, "x")
-    R = x.shape[0]
-    if x.dim() == 2:
-        C5, HW = x.shape[1], 1
-    elif channels_last:
-        C5 = x.shape[-1]
-        HW = x[0].numel() // C5 if R else 1
-    else:
-        C5 = x.shape[1]
-        HW = x[0].numel() // C5 if R else 1
+    R, C5, HW, channels_last = _layout_dims(x, channels_last)
     emb_w, emb_b = _dev(emb_w, "emb_w"), _dev(emb_b, "emb_b")
     bbox_w, bbox_b = _dev(bbox_w, "bbox_w"), _dev(bbox_b, "bbox_b")
     bank = _dev(bank, "bank")

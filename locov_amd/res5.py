@@ -138,7 +138,9 @@ class Res5Stage(nn.Sequential):
         return val
 
     @torch.no_grad()
-    def forward_rows(self, x0: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    def forward_rows(self, x0: torch.Tensor, H: int, W: int, pos_major: bool = False) -> torch.Tensor:
+        """Rows are ROI-major (r*H*W + pos) or position-major (pos*R + r); the 1x1 convolutions do not
+        care, the 3x3 one skips its zero-padding taps in the position-major order."""
         from . import ops
         assert self.supports_rows_path(), "forward_rows needs FrozenBN, STRIDE_IN_1X1 and ungrouped convs"
         x = x0
@@ -147,7 +149,8 @@ class Res5Stage(nn.Sequential):
             w2, s2, b2 = self._packed(blk.conv2)
             w3, s3, b3 = self._packed(blk.conv3)
             y = ops.linear(x, w1, b1, scale=s1, relu=True)                        # 1x1 (+stride via x0) + FBN + ReLU
-            y = ops.conv3x3_nhwc(y, w2, H, W, scale=s2, shift=b2, relu=True)      # 3x3 + FBN + ReLU
+            y = ops.conv3x3_nhwc(y, w2, H, W, scale=s2, shift=b2, relu=True,      # 3x3 + FBN + ReLU
+                                 pos_major=pos_major)
             if blk.shortcut is not None:
                 ws, ss, bs = self._packed(blk.shortcut)
                 sc = ops.linear(x, ws, bs, scale=ss)                              # 1x1 shortcut + FBN

@@ -261,18 +261,23 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         rois = convert_boxes_to_pooler_format(boxes)
         P = self.pooler.output_size[0]
         nhwc = ops.nchw_to_nhwc(features[0].detach())
+        # position-major pixel rows [oh, ow, R, C]: a GEMM tile then holds one tile position of many
+        # ROIs, which lets the 3x3 convolutions skip their zero-padding taps
         x0 = ops.roi_align_nhwc(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio,
-                                self.pooler.aligned, bin_stride=2)
-        R, oh, ow, C = x0.shape
-        y = self.res5.forward_rows(x0.view(R * oh * ow, C), oh, ow)
-        return y.view(R, oh, ow, y.shape[1]).permute(0, 3, 1, 2)
+                                self.pooler.aligned, bin_stride=2, pos_major=True)
+        oh, ow, R, C = x0.shape
+        y = self.res5.forward_rows(x0.view(oh * ow * R, C), oh, ow, pos_major=True)
+        return y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)      # logical [R, C5, oh, ow]
 
     def _pooled_mean(self, box_features: torch.Tensor) -> torch.Tensor:
         """box_features.mean(dim=[2,3]) (:262,:344,:356) on the HIP kernel."""
         if torch.is_grad_enabled() and box_features.requires_grad:
             return box_features.mean(dim=[2, 3])         # differentiable form for training
-        if not box_features.is_contiguous() and box_features.permute(0, 2, 3, 1).is_contiguous():
-            return ops.spatial_mean(box_features.permute(0, 2, 3, 1), channels_last=True)
+        if not box_features.is_contiguous():
+            if box_features.permute(2, 3, 0, 1).is_contiguous():       # position-major [h,w,R,C]
+                return ops.spatial_mean(box_features.permute(2, 3, 0, 1), channels_last=2)
+            if box_features.permute(0, 2, 3, 1).is_contiguous():       # channels-last [R,h,w,C]
+                return ops.spatial_mean(box_features.permute(0, 2, 3, 1), channels_last=1)
         return ops.spatial_mean(box_features)
 
     def forward(self, images, features, proposals, targets=None):

@@ -149,7 +149,9 @@ def test_roi_align_nhwc(ops, oracle, in_dt, out_dt, bin_stride):
                                   torch.from_numpy(feat).permute(0, 2, 3, 1).to(in_dt).float().numpy())
     feat_seen = f_nhwc.float().permute(0, 3, 1, 2).contiguous().cpu().numpy()   # what the kernel reads
     want = oracle.roi_align(feat_seen, rois, (P, P), 1 / 16, 0, True)[:, :, ::bin_stride, ::bin_stride]
+    got_p = ops.roi_align_nhwc(f_nhwc, dev(rois), P, 1 / 16, 0, True, bin_stride, out_dt, pos_major=True)
     got = ops.roi_align_nhwc(f_nhwc, dev(rois), P, 1 / 16, 0, True, bin_stride, out_dt)
+    assert torch.equal(got_p.permute(2, 0, 1, 3), got)              # same values, position-major rows
     assert got.shape == (29, want.shape[2], want.shape[3], C) and got.dtype == out_dt
     got = got.float().permute(0, 3, 1, 2).cpu().numpy()
     if out_dt == torch.float32:
@@ -169,6 +171,8 @@ def test_spatial_mean_bit_exact(ops, oracle):
     x = rng.standard_normal((33, 7, 7, 64)).astype(np.float32)       # channels-last
     want = oracle.spatial_mean(np.ascontiguousarray(x.transpose(0, 3, 1, 2)))
     np.testing.assert_array_equal(ops.spatial_mean(dev(x), channels_last=True).cpu().numpy(), want)
+    xp = np.ascontiguousarray(x.transpose(1, 2, 0, 3))               # position-major [h,w,R,C]
+    np.testing.assert_array_equal(ops.spatial_mean(dev(xp), channels_last=2).cpu().numpy(), want)
 
 
 def test_rownorm_matches_reference_vectors(ops, golden_dir):

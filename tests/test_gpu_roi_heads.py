@@ -39,6 +39,15 @@ def test_conv3x3_nhwc_vs_torch_cpu(pkg):
         got = ops.conv3x3_nhwc(rows, wp, H, W, scale=sc.cuda(), shift=sh.cuda(), relu=True)
         got = got.view(R, H, W, N).permute(0, 3, 1, 2).cpu().double()
         assert (got - want).abs().max().item() < 2e-5
+        # position-major rows [H,W,R,C]: same convolution, zero-padding taps skipped instead of multiplied
+        rows_p = x.permute(2, 3, 0, 1).reshape(H * W * R, Cin).contiguous().cuda()
+        res_p = torch.randn(H * W * R, N, generator=g)
+        got = ops.conv3x3_nhwc(rows_p, wp, H, W, scale=sc.cuda(), shift=sh.cuda(), residual=res_p.cuda(),
+                               relu=True, pos_major=True)
+        want_p = F.relu(F.conv2d(x.double(), w.double(), padding=1) * sc.double().view(1, -1, 1, 1)
+                        + sh.double().view(1, -1, 1, 1) + res_p.double().view(H, W, R, N).permute(2, 3, 0, 1))
+        got = got.view(H, W, R, N).permute(2, 3, 0, 1).cpu().double()
+        assert (got - want_p).abs().max().item() < 2e-5
 
 
 def _small_cfg(pkg):
@@ -68,6 +77,10 @@ def test_res5_rows_path_vs_oracle(pkg, oracle):
     # hand-written rows path on the even positions
     x0 = x[:, :, ::2, ::2].permute(0, 2, 3, 1).reshape(21 * 49, 128).contiguous().cuda()
     got = res5.forward_rows(x0, 7, 7).view(21, 7, 7, out_ch).permute(0, 3, 1, 2).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5)
+    # same, position-major rows
+    x0p = x[:, :, ::2, ::2].permute(2, 3, 0, 1).reshape(49 * 21, 128).contiguous().cuda()
+    got = res5.forward_rows(x0p, 7, 7, pos_major=True).view(7, 7, 21, out_ch).permute(2, 3, 0, 1).cpu().numpy()
     np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5)
 
 
