@@ -10,7 +10,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_uint, c_void_p, POINTER
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liblocov_hip.so")
+# LOCOV_HIP_LIB: developer override to A/B an experimental build of the same ABI (tools/)
+LIB_PATH = os.environ.get("LOCOV_HIP_LIB") or os.path.join(HERE, "liblocov_hip.so")
 
 OK = 0
 F32, BF16 = 0, 1

@@ -86,7 +86,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 // rows [pos][r] (cg.R rows per position).  In mode 2 an M-tile holds ONE tile position of up to
 // BM different ROIs, so tap validity is uniform per workgroup: padding taps are skipped outright
 // (361 of the 441 (position, tap) pairs of a 7x7 tile are real -> 18 % fewer MFMAs, no masking).
-template <typename T, typename TOut, int BM, int BN, int WM, int WN, int OCC, int CONV>
+//
+// MASKED = false is the fast staging path: K % BK == 0 and no per-row tap masks (CONV != 1).  Rows
+// past M / N are simply read from a clamped in-bounds row -- they only feed output rows / columns
+// that are never stored -- so no select is needed, and the per-lane global pointers just advance by
+// a wave-uniform delta per K-tile.  MASKED = true keeps the general path (ragged K, ROI-major conv).
+template <typename T, typename TOut, int BM, int BN, int WM, int WN, int OCC, int CONV, bool MASKED>
 __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__restrict__ A, int64_t lda,
                                                                     const T *__restrict__ B, int64_t ldb,
                                                                     TOut *__restrict__ Cout, int64_t ldc, int64_t M_,
@@ -94,6 +99,7 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
 {
     constexpr bool CONV3 = CONV == 1;     // ROI-major: per-row tap masks
     constexpr bool CONVP = CONV == 2;     // position-major: per-workgroup tap list
+    static_assert(MASKED || !CONV3, "the ROI-major convolution needs the masked staging path");
     typedef typename Frag<T>::type frag_t;
     constexpr int E = Frag<T>::kPer16B;    // elements per 16 B
     constexpr int BK16 = 8;                // 16-byte chunks per tile row: BK = 8*E (32 f32 / 64 bf16)
@@ -108,7 +114,9 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
     static_assert(A_CH <= 16 && B_CH <= 16, "ok_mask holds 16 chunks per operand");
 
     constexpr int STAGE = (BM + BN) * LDS16;
-    __shared__ frag_t lds[2 * STAGE];
+    // OCC == 1 (developer experiment): pad LDS past half a CU so that only one workgroup is resident
+    constexpr int LDS_PAD = OCC == 1 ? (88 * 1024 / 16 - 2 * STAGE > 0 ? 88 * 1024 / 16 - 2 * STAGE : 0) : 0;
+    __shared__ frag_t lds[2 * STAGE + LDS_PAD];
 
     const int tiles_n = (N + BN - 1) / BN;
     const int nwg = gridDim.x;
@@ -120,9 +128,12 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
     unsigned long long taps = 0;          // CONVP: valid tap ids, 4 bits each, in ascending order
     int64_t pos_stride = 0;               // CONVP: elements between the same ROI at adjacent positions
     if (CONVP) {
-        const int rbs = (cg.R + BM - 1) / BM;             // M-tiles per position
-        const int tm = tile / tiles_n, pos = tm / rbs;
-        m0 = (int64_t)pos * cg.R + (int64_t)(tm - pos * rbs) * BM;
+        // M-tile order: ROI block outer, position inner -- consecutive workgroups (same XCD after
+        // the remap) then work on neighbouring positions of the SAME ROIs, whose A rows they share
+        // through the 3x3 window, so those rows are served from that XCD's L2
+        const int npos = cg.H * cg.W;
+        const int tm = tile / tiles_n, rb = tm / npos, pos = tm - rb * npos;
+        m0 = (int64_t)pos * cg.R + (int64_t)rb * BM;
         M = (int64_t)(pos + 1) * cg.R;                    // rows of this position end here
         const int py = pos / cg.W, px = pos - py * cg.W;
         int nt = 0;
@@ -172,7 +183,51 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
 
     // Raw 16-byte loads of the K-tile at k0 (nothing here depends on their results); records which
     // chunks are real data.  A ragged K tail is handled per 16-byte chunk (K % E == 0).
+    // element offsets of K-tile k0 relative to a row start: into A (aoff) and into B's row (kb)
+    auto tile_offsets = [&](int k0, int64_t &aoff, int &kb) {
+        aoff = k0;
+        kb = k0;
+        if (CONVP) {
+            const int ti = k0 / cg.Cin, kc = k0 - ti * cg.Cin;
+            const int tap = (int)((taps >> (4 * ti)) & 15u);
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            aoff = (int64_t)(dy * cg.W + dx) * pos_stride + kc;    // same ROI, neighbouring position
+            kb = tap * cg.Cin + kc;
+        }
+    };
+    int k_ptr = 0;                        // fast path: the K-tile a_ptr / b_ptr currently point at
+    if (!MASKED) {
+        int64_t ao;
+        int bo;
+        tile_offsets(0, ao, bo);
+#pragma unroll
+        for (int i = 0; i < A_CH; i++) a_ptr[i] += ao;
+#pragma unroll
+        for (int i = 0; i < B_CH; i++) b_ptr[i] += bo;
+    }
+
     auto load_tiles = [&](int k0) {
+        if (!MASKED) {
+            // advance every per-lane pointer by the same wave-uniform delta, then 16-byte loads
+            int64_t ao0, ao1;
+            int bo0, bo1;
+            tile_offsets(k_ptr, ao0, bo0);
+            tile_offsets(k0, ao1, bo1);
+            const int64_t da = ao1 - ao0;
+            const int db = bo1 - bo0;
+            k_ptr = k0;
+#pragma unroll
+            for (int i = 0; i < A_CH; i++) {
+                a_ptr[i] += da;
+                ra[i] = *reinterpret_cast<const frag_t *>(a_ptr[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < B_CH; i++) {
+                b_ptr[i] += db;
+                rb[i] = *reinterpret_cast<const frag_t *>(b_ptr[i]);
+            }
+            return;
+        }
         ok_mask = 0;
         int64_t aoff = k0;
         int kb = k0;                      // column offset into B
@@ -218,6 +273,13 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
     };
     auto store_tiles = [&](int stage) {
         frag_t *As = lds + stage * STAGE, *Bs = As + BM * LDS16;
+        if (!MASKED) {
+#pragma unroll
+            for (int i = 0; i < A_CH; i++) As[((tid + i * NT) / BK16) * LDS16 + (tid + i * NT) % BK16] = ra[i];
+#pragma unroll
+            for (int i = 0; i < B_CH; i++) Bs[((tid + i * NT) / BK16) * LDS16 + (tid + i * NT) % BK16] = rb[i];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_CH; i++) {
             const int idx = tid + i * NT;
@@ -253,6 +315,22 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
             for (int j = 0; j < NI; j++) mma_step(fa[i], fb[j], acc[i][j]);
     };
 
+    // MFMAs p0..p1-1 of a quarter (fp32: 4 per accumulator tile, one per k-pair; bf16: 1 per tile)
+    constexpr int MPT = sizeof(T) == 4 ? 4 : 1;
+    constexpr int NMFMA = MI * NI * MPT;
+    auto mma_range = [&](const frag_t(&fa)[MI], const frag_t(&fb)[NI], int p0, int p1) {
+#pragma unroll
+        for (int p = 0; p < NMFMA; p++) {
+            if (p < p0 || p >= p1) continue;
+            const int t = p / MPT, i = t / NI, j = t % NI;
+            if constexpr (sizeof(T) == 4) {
+                const int ks = p % MPT;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+            } else {
+                mma_step(fa[i], fb[j], acc[i][j]);
+            }
+        }
+    };
     // one half of a quarter's MFMAs (row tiles split in two; MI == 1: first half does everything)
     auto mma_half = [&](const frag_t(&fa)[MI], const frag_t(&fb)[NI], int half) {
 #pragma unroll
@@ -271,24 +349,77 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
     __syncthreads();
     read_frags(0, 0, fa0, fb0);
     int s = 0;
+    constexpr int NCH = A_CH + B_CH;                        // staging chunks per thread and tile
+    // Fast path: chunks [g0,g1) of the staged tile t+1 go registers -> LDS stage `ws`, their pointers
+    // advance by (da, db) and the refill loads of tile t+2 are issued, each chunk followed by its
+    // share of the quarter's MFMAs (hand-interleaved: LDS write bandwidth is ~80 B/clk/CU, so the
+    // 32 KiB a workgroup stages per tile must be spread over the tile, not written in one burst).
+    auto stage_and_mma = [&](int g0, int g1, int ws, int64_t da, int db, const frag_t(&fa)[MI],
+                             const frag_t(&fb)[NI]) {
+        frag_t *As = lds + ws * STAGE, *Bs = As + BM * LDS16;
+        const int n = g1 - g0;
+#pragma unroll
+        for (int g = 0; g < NCH; g++) {
+            if (g < g0 || g >= g1) continue;
+            if (g < A_CH) {
+                const int idx = tid + g * NT;
+                As[(idx / BK16) * LDS16 + idx % BK16] = ra[g];
+                a_ptr[g] += da;
+                ra[g] = *reinterpret_cast<const frag_t *>(a_ptr[g]);
+            } else {
+                const int h = g - A_CH, idx = tid + h * NT;
+                Bs[(idx / BK16) * LDS16 + idx % BK16] = rb[h];
+                b_ptr[h] += db;
+                rb[h] = *reinterpret_cast<const frag_t *>(b_ptr[h]);
+            }
+            mma_range(fa, fb, (g - g0) * NMFMA / n, (g - g0 + 1) * NMFMA / n);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // chunk split over phases A | B | C.  Measured on MI355X: everything in C (0, 0) = everything in
+    // B = 129-133 TF; an even spread (NCH/3, 2*NCH/3) and everything in A are ~5-8 % slower.
+    constexpr int G1 = 0, G2 = 0;
+
     for (int k0 = 0; k0 < k_last; k0 += BK) {               // tile at k0 has a successor
         // (each phase issues its fragment reads FIRST so their LDS latency sits under 16 MFMAs)
+        const int kn = k0 + 2 * BK < k_last ? k0 + 2 * BK : k_last;   // tile to prefetch (clamped)
+        int64_t da = 0;
+        int db = 0;
+        if (!MASKED) {
+            int64_t ao0, ao1;
+            int bo0, bo1;
+            tile_offsets(k_ptr, ao0, bo0);
+            tile_offsets(kn, ao1, bo1);
+            da = ao1 - ao0;
+            db = bo1 - bo0;
+            k_ptr = kn;
+        }
         // A
         read_frags(s, 1, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
-        mma(fa0, fb0);
+        if (MASKED) mma(fa0, fb0);
+        else if (G1 > 0) stage_and_mma(0, G1, s ^ 1, da, db, fa0, fb0);
+        else mma(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
-        // B: staging registers (tile t+1) -> other LDS stage
+        // B
         read_frags(s, 2, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
-        store_tiles(s ^ 1);
-        mma(fa1, fb1);
+        if (MASKED) mma(fa1, fb1);
+        else if (G2 > G1) stage_and_mma(G1, G2, s ^ 1, da, db, fa1, fb1);
+        else mma(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
-        // C: refill the staging registers with tile t+2 (clamped: a redundant reload at the end)
+        // C: (masked path: staging registers -> other LDS stage, then refill them with tile t+2)
         read_frags(s, 3, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
-        load_tiles(k0 + 2 * BK < k_last ? k0 + 2 * BK : k_last);
-        mma(fa0, fb0);
+        if (MASKED) {
+            store_tiles(s ^ 1);
+            load_tiles(kn);
+            mma(fa0, fb0);
+        } else if (G2 < NCH) {
+            stage_and_mma(G2, NCH, s ^ 1, da, db, fa0, fb0);
+        } else {
+            mma(fa0, fb0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         // D: the barrier sits in the MIDDLE of this quarter's MFMAs: the first half is issued from
         // registers while the waves rendezvous, the second half covers the LDS latency of the next
@@ -401,15 +532,23 @@ static int launch_cfg(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C,
     const int64_t tiles_m = posm ? (int64_t)cg.H * cg.W * ceil_div(cg.R, BM) : ceil_div(M, BM);
     const int64_t tiles = tiles_m * ceil_div(N, BN);
     if (tiles > 0x7fffffffLL) return set_error(LOCOV_ERR_INVALID_ARG, "%s: problem too large", what);
-    if (posm)
-        hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, OCC, 2>), dim3((unsigned)tiles),
-                           dim3(64 * WM * WN), 0, s, A, lda, B, ldb, C, ldc, M, N, K, epi, cg);
-    else if (cg.H > 0)
-        hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, OCC, 1>), dim3((unsigned)tiles),
-                           dim3(64 * WM * WN), 0, s, A, lda, B, ldb, C, ldc, M, N, K, epi, cg);
-    else
-        hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, OCC, 0>), dim3((unsigned)tiles),
-                           dim3(64 * WM * WN), 0, s, A, lda, B, ldb, C, ldc, M, N, K, epi, cg);
+    constexpr int BK = 8 * Frag<T>::kPer16B;
+    const bool ragged_k = (posm ? cg.Cin : K) % BK != 0;
+    const dim3 grid((unsigned)tiles), block(64 * WM * WN);
+#define LOCOV_LAUNCH(CONV, MASKED)                                                                                 \
+    hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, OCC, CONV, MASKED>), grid, block, 0, s, A, lda, B, ldb, \
+                       C, ldc, M, N, K, epi, cg)
+    if (posm) {
+        if (ragged_k) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: Cin must be a multiple of %d", what, BK);
+        LOCOV_LAUNCH(2, false);
+    } else if (cg.H > 0) {
+        LOCOV_LAUNCH(1, true);
+    } else if (ragged_k) {
+        LOCOV_LAUNCH(0, true);
+    } else {
+        LOCOV_LAUNCH(0, false);
+    }
+#undef LOCOV_LAUNCH
     return check_launch(what);
 }
 
@@ -432,6 +571,8 @@ int launch_gemm_nt(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C, in
         return launch_cfg<T, TOut, 128, 64, 4, 1, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
     if (forced_cfg() == 1)
         return launch_cfg<T, TOut, 64, 64, 2, 2, 4>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
+    if (forced_cfg() == 2)   // one workgroup per CU: how well does a single wave per SIMD feed the pipe?
+        return launch_cfg<T, TOut, 128, 128, 2, 2, 1>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
     return launch_cfg<T, TOut, 128, 128, 2, 2, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
 }
 
