@@ -222,11 +222,8 @@ def main():
             fn(**kw)
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        from locov_amd.sharding import max_over_ranks
+        return max_over_ranks(dt, device)        # the slowest rank defines the job's time
 
     props_per_step = args.images * args.proposals * world
     dt2 = timed(wl.step_s2, args.steps, args.warmup, timed=True)
