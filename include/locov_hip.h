@@ -182,6 +182,27 @@ int locov_sim_gemm_bf16(const uint16_t *emb, const uint16_t *bank, int64_t R, in
                         float *logits, int64_t ldc, locov_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * a-12  LSM grounding: word<->region alignment -> [caption, image] cost matrices.
+ * Replaces the B^2-replicated chain of GroundingHead.forward
+ * (ovr/modeling/mmss_heads/grounding_head.py:116-243) for LOCAL_METRIC "dot", ALIGNMENT
+ * "softmax", GLOBAL_METRIC "aligned_local" (configs/coco_lsm.yaml).
+ *   S [B*T, B*NR] = caption token embeddings [B*T, L] . region embeddings [B*NR, L]^T
+ *     (one locov_gemm_nt_f32 call; the region embeddings are v2l_projection(region_features),
+ *     grounding_head.py:111, itself a locov_gemm_nt_f32 call)
+ *   caption_mask [B,T] = attention_mask * (1 - special_tokens_mask) as fp32, region_mask [B,NR] fp32
+ *   cost_w2r / cost_r2w [B,B] (row = caption, column = image): global_dist_w2r / _r2w of :219-228,
+ *     before the all-empty fix-up of :232-243 (a [B,B] select the host applies).
+ * The backward returns dS given the gradients of the two cost matrices.
+ * ------------------------------------------------------------------------------------- */
+int locov_grounding_fwd(const float *S, int B, int T, int NR, const float *caption_mask,
+                        const float *region_mask, float temperature, float *cost_w2r,
+                        float *cost_r2w, locov_stream_t stream);
+
+int locov_grounding_bwd(const float *S, int B, int T, int NR, const float *caption_mask,
+                        const float *region_mask, float temperature, const float *grad_w2r,
+                        const float *grad_r2w, float *grad_S, locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * a-4...a-8 in one call: EmbeddingFastRCNNOutputLayers.forward (box_emb_head.py:179-212)
  * preceded by the spatial mean of its caller (roi_emb_heads.py:262,344,356).
  *   x        [R,C5,HW] fp32 (HW may be 1)            pooled  [R,C5]  (out; == x when HW==1 is allowed)

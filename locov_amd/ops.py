@@ -202,6 +202,12 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     N = weight.shape[0]
     if weight.shape[1] != K:
         raise ValueError(f"shape mismatch: x {tuple(x.shape)} weight {tuple(weight.shape)}")
+    if K % 4 != 0:
+        # the kernel stages 16-byte chunks: zero-pad the contraction dim (rows stay 16-byte aligned)
+        pad = 4 - K % 4
+        x = torch.nn.functional.pad(x, (0, pad))
+        weight = torch.nn.functional.pad(weight, (0, pad))
+        K += pad
     bias = _dev(bias, "bias") if bias is not None else None
     scale = _dev(scale, "scale") if scale is not None else None
     residual = _dev(residual, "residual") if residual is not None else None
@@ -262,6 +268,77 @@ def frozen_bn_fold(weight, bias, running_mean, running_var, eps: float = 1e-5):
                                                _ptr(_dev(running_var, "running_var")), float(eps), C, _ptr(scale),
                                                _ptr(shift), _stream(weight)), "locov_frozen_bn_fold")
     return scale, shift
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the f32 MFMA NT-GEMM kernel; backward re-uses the same kernel on transposed
+    operands (grad_x = g W, grad_W = g^T x, grad_b = sum g)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = linear(g, weight.t().contiguous())               # [M,N] . ([K,N])^T
+        if ctx.needs_input_grad[1]:
+            gw = linear(g.t().contiguous(), x.t().contiguous())   # [N,M] . ([K,M])^T
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(dim=0)
+        return gx, gw, gb
+
+
+def linear_autograd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable x W^T + b (both operands may require grad)."""
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        return _LinearFn.apply(x, weight, bias)
+    return linear(x.detach(), weight.detach(), bias.detach() if bias is not None else None)
+
+
+class _GroundingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, S, cmask, rmask, B, T, NR, temperature):
+        S = _dev(S, "S")
+        cmask, rmask = _dev(cmask, "caption_mask"), _dev(rmask, "region_mask")
+        w2r = torch.empty((B, B), dtype=torch.float32, device=S.device)
+        r2w = torch.empty((B, B), dtype=torch.float32, device=S.device)
+        with torch.cuda.device(S.device):
+            check(_lib.load().locov_grounding_fwd(_ptr(S), B, T, NR, _ptr(cmask), _ptr(rmask), float(temperature),
+                                                  _ptr(w2r), _ptr(r2w), _stream(S)), "locov_grounding_fwd")
+        ctx.save_for_backward(S, cmask, rmask)
+        ctx.dims = (B, T, NR, temperature)
+        return w2r, r2w
+
+    @staticmethod
+    def backward(ctx, g_w2r, g_r2w):
+        S, cmask, rmask = ctx.saved_tensors
+        B, T, NR, temperature = ctx.dims
+        g_w2r = _dev(g_w2r if g_w2r is not None else torch.zeros(B, B, device=S.device), "grad_w2r")
+        g_r2w = _dev(g_r2w if g_r2w is not None else torch.zeros(B, B, device=S.device), "grad_r2w")
+        dS = torch.empty_like(S)
+        with torch.cuda.device(S.device):
+            check(_lib.load().locov_grounding_bwd(_ptr(S), B, T, NR, _ptr(cmask), _ptr(rmask), float(temperature),
+                                                  _ptr(g_w2r), _ptr(g_r2w), _ptr(dS), _stream(S)),
+                  "locov_grounding_bwd")
+        return dS, None, None, None, None, None, None
+
+
+def grounding_costs(S: torch.Tensor, caption_mask: torch.Tensor, region_mask: torch.Tensor,
+                    temperature: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """S [B*T, B*NR] (caption tokens x region embeddings), masks [B,T] / [B,NR] fp32 ->
+    (cost_w2r, cost_r2w) [B,B] with rows = captions, columns = images.  Differentiable in S."""
+    B, T = caption_mask.shape
+    NR = region_mask.shape[1]
+    if tuple(S.shape) != (B * T, B * NR):
+        raise ValueError(f"S must be [{B * T},{B * NR}], got {tuple(S.shape)}")
+    return _GroundingFn.apply(S, caption_mask.to(torch.float32), region_mask.to(torch.float32), B, T, NR,
+                              float(temperature))
 
 
 def rownorm(x: torch.Tensor, mode: int, eps: float = 1e-12) -> torch.Tensor:

@@ -168,37 +168,10 @@ def smooth_l1_loss(input: torch.Tensor, target: torch.Tensor, beta: float, reduc
     return loss
 
 
-class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b on the f32 MFMA NT-GEMM kernel; backward re-uses the same kernel on
-    transposed operands (grad_x = g W, grad_W = g^T x, grad_b = sum g)."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return ops.linear(x, weight, bias)
-
-    @staticmethod
-    def backward(ctx, g):
-        x, weight = ctx.saved_tensors
-        g = g.contiguous()
-        gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = ops.linear(g, weight.t().contiguous())               # [M,N] . ([K,N])^T
-        if ctx.needs_input_grad[1]:
-            gw = ops.linear(g.t().contiguous(), x.t().contiguous())   # [N,M] . ([K,M])^T
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum(dim=0)
-        return gx, gw, gb
-
-
 def hip_linear(x: torch.Tensor, layer: nn.Linear) -> torch.Tensor:
-    """nn.Linear forward on the hand-written kernel; weights are read at call time
-    (emb_pred.weight/bias are re-assigned by the meta-arch, distill_prop_mmss_gcnn.py:121-125)."""
-    w, b = layer.weight, layer.bias
-    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
-        return _LinearFn.apply(x, w, b)
-    return ops.linear(x.detach(), w.detach(), b.detach() if b is not None else None)
+    """nn.Linear forward (and backward) on the hand-written f32 MFMA kernel; the weights are read at
+    call time (emb_pred.weight/bias are re-assigned by the meta-arch, distill_prop_mmss_gcnn.py:121-125)."""
+    return ops.linear_autograd(x, layer.weight, layer.bias)
 
 
 class FastRCNNOutputLayers(nn.Module):

@@ -51,3 +51,19 @@ def test_g3_box_predictor(oracle, golden_dir):
         np.testing.assert_allclose(deltas, g[f"deltas_{tag}"], atol=1e-6)
         np.testing.assert_allclose(scores, g[f"scores_{tag}"], atol=1e-4, rtol=1e-5)
         assert np.all(scores[:, -1] == 0)
+
+
+def test_g4_grounding_head(oracle, golden_dir):
+    """GroundingHead.forward restatement vs the reference's own outputs (B = 1, 2, 4; ragged masks)."""
+    g = _load(golden_dir, "g4_grounding_head.npz")
+    for B in (1, 2, 4):
+        p = f"b{B}_"
+        losses, info, w2r, r2w = oracle.grounding_head_forward(
+            g[p + "region_features"], g[p + "region_mask"], g[p + "input_embeddings"], g[p + "attention_mask"],
+            g[p + "special_tokens_mask"], g["v2l_w"], g["v2l_b"], temperature=10.0)
+        np.testing.assert_allclose(w2r, g[p + "w2r"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(r2w, g[p + "r2w"], rtol=2e-5, atol=2e-6)
+        for name, want in zip(g[p + "loss_names"], g[p + "losses"]):
+            assert abs(losses[str(name)] - float(want)) <= 2e-5, (B, name)
+        for name, want in zip(g[p + "info_names"], g[p + "info"]):
+            assert info[str(name)] == float(want), (B, name)
