@@ -139,6 +139,23 @@ class Workload:
         return self.head(self.r5_standin)
 
 
+def recorded_traffic(args, kernel_key: str):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r01b_pmc_traffic.json; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    same command, corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be collected from
+    inside the timed run, so this is null unless the workload is the one that was profiled."""
+    if (args.images, args.proposals, args.classes, args.dim, args.res5) != (4, 1000, 1203, 768, "hip"):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")) as f:
+            for name, v in json.load(f)["kernels"].items():
+                if kernel_key in name:
+                    return v["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def usable_cores() -> int:
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota
     (os.cpu_count() reports the whole host and oversubscribes a quota-limited container)."""
@@ -245,7 +262,10 @@ def main():
             roof = {"kernel": "gemm_nt_kernel<float,float,128,128,2,2,2,CONV=2> (Res5 3x3 conv, implicit GEMM, "
                               "position-major rows)",
                     "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": dom_ms,
+                    "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                    "traffic": recorded_traffic(args, "gemm_nt_kernel<float, float, 128, 128, 2, 2, 2, 2, false>"),
+                    "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r01b_pmc_traffic.json)",
+                    "avg_launch_ms": dom_ms,
                     "algorithmic_flops_per_launch": alg_flops, "executed_tflops": executed,
                     "executed_frac_of_peak": executed / MFMA_F32_PEAK_TFLOPS}
         else:
