@@ -107,6 +107,15 @@ int locov_roi_align_levels_fwd(const float *const *feats_host, const int *H_host
 int locov_nchw_to_nhwc(const float *in, int N, int C, int H, int W, void *out, int out_dtype,
                        locov_stream_t stream);
 
+/* The pooler contract at HBM speed: same result as locov_roi_align_fwd, bit for bit
+ * (out [R,C,pooled_h,pooled_w] fp32), but gathering from a channels-last COPY of the map
+ * (feat_nhwc [N,H,W,C] fp32 from locov_nchw_to_nhwc; 17 MB per 1333x800 image, written once per
+ * call) and transposing in LDS, so that both the taps and the output are fully coalesced. */
+int locov_roi_align_from_nhwc_fwd(const float *feat_nhwc, int N, int H, int W, int C,
+                                  const float *rois, int64_t R, int pooled_h, int pooled_w,
+                                  float spatial_scale, int sampling_ratio, int aligned, float *out,
+                                  locov_stream_t stream);
+
 int locov_roi_align_nhwc_fwd(const void *feat, int feat_dtype, int N, int H, int W, int C,
                              const float *rois, int64_t R, int pooled_h, int pooled_w,
                              float spatial_scale, int sampling_ratio, int aligned,

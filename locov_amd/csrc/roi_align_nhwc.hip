@@ -162,11 +162,156 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The pooler contract ([R,C,ph,pw] out of an NCHW map) at HBM speed: gather from a channels-last
+// COPY of the map, transpose in LDS, write NCHW.
+//
+// Gathering from NCHW costs one scattered dword per lane and tap (5-10 cache lines per wave
+// instruction: the texture-address path, not HBM, bounds the kernel at ~0.6 TB/s).  From a
+// channels-last copy a tap is one contiguous C-vector: 16 lanes x 16 B cover 64 channels, a wave
+// covers several bins per instruction.  One workgroup = one ROI x kT2Ch channels: results go to an
+// LDS tile [ch][ph*pw] (odd row stride) and leave as one contiguous, fully coalesced run of
+// kT2Ch*ph*pw floats -- exactly the layout of out[r, c0:c0+kT2Ch, :, :].
+// Arithmetic and summation order per output element are those of roi_align_nchw_kernel (and of
+// the oracle): the result is bit-identical.
+// ---------------------------------------------------------------------------------------------
+constexpr int kT2Threads = 256;
+constexpr int kT2Ch = 32;          // channels per workgroup (one 128-byte line per tap; ~25 KiB LDS tile)
+constexpr int kT2Axis = 256;       // per-axis LDS table entries (larger sampling grids: computed on the fly)
+
+__global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
+    const float *__restrict__ feat, int N, int H, int W, int C, const float *__restrict__ rois, int PH, int PW,
+    float scale, int sampling_ratio, int aligned, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bins = PH * PW;
+    const int ts = bins | 1;                                  // odd row stride of the transpose tile
+    float *tile = smem;                                       // [kT2Ch][ts]
+    AxisSampleN *ytab = reinterpret_cast<AxisSampleN *>(smem + kT2Ch * ts + (4 - (kT2Ch * ts) % 4) % 4);
+    AxisSampleN *xtab = ytab + kT2Axis;
+
+    const int64_t r = blockIdx.x;
+    const int c0 = blockIdx.y * kT2Ch;
+    const float *roi = rois + r * 5;
+    const int b = (int)roi[0];
+    const float off = aligned ? 0.5f : 0.0f;
+    const float start_w = roi[1] * scale - off, start_h = roi[2] * scale - off;
+    const float end_w = roi[3] * scale - off, end_h = roi[4] * scale - off;
+    float rw = end_w - start_w, rh = end_h - start_h;
+    if (!aligned) {
+        rw = fmaxf(rw, 1.f);
+        rh = fmaxf(rh, 1.f);
+    }
+    const float bin_h = rh / (float)PH, bin_w = rw / (float)PW;
+    int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(bin_h);
+    int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(bin_w);
+    const int prod = gh * gw;
+    const float count = (float)(prod > 1 ? prod : 1);
+    const bool valid_b = b >= 0 && b < N;
+    gh = (gh > 0 && valid_b) ? gh : 0;
+    gw = (gw > 0 && valid_b) ? gw : 0;
+    const int ny = PH * gh, nx = PW * gw;
+    const bool use_lds = ny <= kT2Axis && nx <= kT2Axis;
+    if (use_lds) {
+        for (int t = threadIdx.x; t < ny; t += kT2Threads) ytab[t] = axis_sample_n(start_h, bin_h, t / gh, t % gh, gh, H);
+        for (int t = threadIdx.x; t < nx; t += kT2Threads) xtab[t] = axis_sample_n(start_w, bin_w, t / gw, t % gw, gw, W);
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int QN = kT2Ch / 4;                             // lanes (channel quads) per bin
+    constexpr int BPW = 64 / QN;                              // bins per wave instruction
+    const int q = lane % QN, sub = lane / QN;
+    const int cq = c0 + 4 * q;
+    const bool c_ok = cq < C;                                 // C % 4 == 0: a quad is all-in or all-out
+    const float *img = feat + (int64_t)(valid_b ? b : 0) * H * W * C + (c_ok ? cq : 0);
+    const int ns = gh * gw;                                   // samples per bin
+    constexpr int U = 4;                                      // samples in flight per lane (16 x 16-byte loads)
+    for (int g0 = 0; g0 < bins; g0 += 4 * BPW) {
+        const int bin = g0 + wave * BPW + sub;
+        const bool bin_ok = bin < bins;
+        const int ph = bin_ok ? bin / PW : 0, pw = bin_ok ? bin - (bin / PW) * PW : 0;
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (bin_ok && c_ok) {
+            // The gather is latency-bound (taps come from L2 / Infinity Cache), so the loads of U
+            // samples are issued back to back before any of them is consumed; the accumulation
+            // below still runs in sample order (iy outer, ix inner), i.e. the oracle's order.
+            for (int s0 = 0; s0 < ns; s0 += U) {
+                float4 v[U][4];
+                float w[U][4];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int sidx = s0 + u < ns ? s0 + u : ns - 1;
+                    const int iy = sidx / gw, ix = sidx - iy * gw;
+                    const AxisSampleN ys = use_lds ? ytab[ph * gh + iy] : axis_sample_n(start_h, bin_h, ph, iy, gh, H);
+                    const AxisSampleN xs = use_lds ? xtab[pw * gw + ix] : axis_sample_n(start_w, bin_w, pw, ix, gw, W);
+                    const float *row_lo = img + (int64_t)ys.lo * W * C, *row_hi = img + (int64_t)ys.hi * W * C;
+                    w[u][0] = ys.wh * xs.wh; w[u][1] = ys.wh * xs.wl; w[u][2] = ys.wl * xs.wh; w[u][3] = ys.wl * xs.wl;
+                    v[u][0] = load4(row_lo + (int64_t)xs.lo * C);
+                    v[u][1] = load4(row_lo + (int64_t)xs.hi * C);
+                    v[u][2] = load4(row_hi + (int64_t)xs.lo * C);
+                    v[u][3] = load4(row_hi + (int64_t)xs.hi * C);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (s0 + u < ns) {
+                        // ((w1*v1 + w2*v2) + w3*v3) + w4*v4, then accumulate -- un-fused (file built
+                        // with -ffp-contract=off)
+                        acc.x = acc.x + (((w[u][0] * v[u][0].x + w[u][1] * v[u][1].x) + w[u][2] * v[u][2].x) + w[u][3] * v[u][3].x);
+                        acc.y = acc.y + (((w[u][0] * v[u][0].y + w[u][1] * v[u][1].y) + w[u][2] * v[u][2].y) + w[u][3] * v[u][3].y);
+                        acc.z = acc.z + (((w[u][0] * v[u][0].z + w[u][1] * v[u][1].z) + w[u][2] * v[u][2].z) + w[u][3] * v[u][3].z);
+                        acc.w = acc.w + (((w[u][0] * v[u][0].w + w[u][1] * v[u][1].w) + w[u][2] * v[u][2].w) + w[u][3] * v[u][3].w);
+                    }
+                }
+            }
+        }
+        if (bin_ok) {
+            float *t = tile + (4 * q) * ts + bin;
+            t[0] = acc.x / count;
+            t[ts] = acc.y / count;
+            t[2 * ts] = acc.z / count;
+            t[3 * ts] = acc.w / count;
+        }
+    }
+    __syncthreads();
+    const int cn = min(kT2Ch, C - c0);
+    float *dst = out + (r * C + c0) * (int64_t)bins;
+    for (int idx = threadIdx.x; idx < cn * bins; idx += kT2Threads) {
+        const int c = idx / bins;
+        dst[idx] = tile[c * ts + (idx - c * bins)];
+    }
+}
+
 }  // namespace locov
 
 using namespace locov;
 
 extern "C" {
+
+int locov_roi_align_from_nhwc_fwd(const float *feat_nhwc, int N, int H, int W, int C, const float *rois, int64_t R,
+                                  int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, int aligned,
+                                  float *out, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(R >= 0, "locov_roi_align_from_nhwc_fwd: R < 0");
+    LOCOV_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "locov_roi_align_from_nhwc_fwd: bad feature shape");
+    LOCOV_REQUIRE(pooled_h > 0 && pooled_w > 0, "locov_roi_align_from_nhwc_fwd: bad pooled size");
+    LOCOV_REQUIRE(spatial_scale > 0.f, "locov_roi_align_from_nhwc_fwd: spatial_scale must be > 0");
+    LOCOV_REQUIRE(C % 4 == 0, "locov_roi_align_from_nhwc_fwd: C must be a multiple of 4");
+    if (R == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(feat_nhwc && rois && out, "locov_roi_align_from_nhwc_fwd: null pointer");
+    LOCOV_REQUIRE(R <= 0x7fffffffLL, "locov_roi_align_from_nhwc_fwd: R too large");
+    const int bins = pooled_h * pooled_w, ts = bins | 1;
+    const size_t lds = ((size_t)kT2Ch * ts + 4) * sizeof(float) + 2 * kT2Axis * sizeof(AxisSampleN);
+    LOCOV_REQUIRE(lds <= 150 * 1024, "locov_roi_align_from_nhwc_fwd: pooled size %dx%d too large for the LDS tile", pooled_h,
+                  pooled_w);
+    if (lds > 64 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(roi_align_nhwc2nchw_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((unsigned)R, (unsigned)ceil_div(C, kT2Ch));
+    hipLaunchKernelGGL(roi_align_nhwc2nchw_kernel, grid, dim3(kT2Threads), lds, as_stream(stream), feat_nhwc, N, H, W, C,
+                       rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, out);
+    return check_launch("locov_roi_align_from_nhwc_fwd");
+}
 
 int locov_nchw_to_nhwc(const float *in, int N, int C, int H, int W, void *out, int out_dtype, locov_stream_t stream)
 {

@@ -71,9 +71,19 @@ class _ROIAlignFn(torch.autograd.Function):
         R = rois.shape[0]
         out = torch.empty((R, C, ph, pw), dtype=torch.float32, device=feat.device)
         with torch.cuda.device(feat.device):
-            check(_lib.load().locov_roi_align_fwd(_ptr(feat), N, C, H, W, _ptr(rois), R, ph, pw, float(scale),
-                                                  int(sampling_ratio), int(aligned), _ptr(out), _stream(feat)),
-                  "locov_roi_align_fwd")
+            if C % 4 == 0 and R > 0 and ph * pw <= 2048:
+                # fast path (same bits): gather from a channels-last copy, transpose in LDS
+                nhwc = torch.empty((N, H, W, C), dtype=torch.float32, device=feat.device)
+                check(_lib.load().locov_nchw_to_nhwc(_ptr(feat), N, C, H, W, _ptr(nhwc), F32, _stream(feat)),
+                      "locov_nchw_to_nhwc")
+                check(_lib.load().locov_roi_align_from_nhwc_fwd(_ptr(nhwc), N, H, W, C, _ptr(rois), R, ph, pw,
+                                                                float(scale), int(sampling_ratio), int(aligned),
+                                                                _ptr(out), _stream(feat)),
+                      "locov_roi_align_from_nhwc_fwd")
+            else:
+                check(_lib.load().locov_roi_align_fwd(_ptr(feat), N, C, H, W, _ptr(rois), R, ph, pw, float(scale),
+                                                      int(sampling_ratio), int(aligned), _ptr(out), _stream(feat)),
+                      "locov_roi_align_fwd")
         ctx.save_for_backward(rois)
         ctx.args = (N, C, H, W, ph, pw, scale, sampling_ratio, aligned)
         return out

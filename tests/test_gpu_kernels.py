@@ -93,7 +93,7 @@ def test_roi_align_edge_cases(ops):
     out = ops.roi_align(feat, rois, 7, 1 / 16)
     assert torch.all(out[:2] == 0) and torch.any(out[2] != 0)
     # huge box: sampling grid larger than the LDS tables -> on-the-fly path, still finite
-    big = torch.tensor([[0, -4e5, -4e5, 4e5, 4e5]], device="cuda", dtype=torch.float32)
+    big = torch.tensor([[0, -3e4, -3e4, 3e4, 3e4]], device="cuda", dtype=torch.float32)   # grid 536 per axis
     out = ops.roi_align(feat, big, 7, 1 / 16)
     assert torch.isfinite(out).all()
     with pytest.raises(ValueError):
@@ -102,11 +102,12 @@ def test_roi_align_edge_cases(ops):
 
 def test_roi_align_huge_grid_matches_oracle(ops, oracle):
     rng = np.random.default_rng(3)
-    feat = rng.standard_normal((1, 3, 40, 40)).astype(np.float32)
-    rois = np.array([[0, -30000, -200, 31000, 900], [0, 10, 10, 500, 30000]], np.float32)  # grid 273 > table
-    want = oracle.roi_align(feat, rois, (7, 7), 1 / 16, 0, True)
-    got = ops.roi_align(dev(feat), dev(rois), 7, 1 / 16, 0, True).cpu().numpy()
-    np.testing.assert_array_equal(got, want)
+    rois = np.array([[0, -30000, -200, 31000, 900], [0, 10, 10, 500, 30000]], np.float32)  # grid 545 > LDS table
+    for C in (3, 4):        # C % 4 != 0 -> NCHW-gather kernel; C % 4 == 0 -> channels-last gather + LDS transpose
+        feat = rng.standard_normal((1, C, 40, 40)).astype(np.float32)
+        want = oracle.roi_align(feat, rois, (7, 7), 1 / 16, 0, True)
+        got = ops.roi_align(dev(feat), dev(rois), 7, 1 / 16, 0, True).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
 
 
 def test_roi_align_backward(ops, oracle):
