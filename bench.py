@@ -48,6 +48,9 @@ def parse():
     p.add_argument("--res5", choices=["miopen", "hip"], default="hip")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
+    # developer/test knobs: rehearse the multi-process flow on a box with fewer GPUs than ranks
+    p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl")
+    p.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (needs --dist-backend gloo)")
     return p.parse_args()
 
 
@@ -216,10 +219,15 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the hot path has no CPU fallback)")
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":       # RCCL over xGMI; only the timing max-reduce and barriers use it
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     from locov_amd import _lib
     _lib.load()
@@ -240,7 +248,8 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         from locov_amd.sharding import max_over_ranks
-        return max_over_ranks(dt, device)        # the slowest rank defines the job's time
+        # the slowest rank defines the job's time
+        return max_over_ranks(dt, device if args.dist_backend == "nccl" else None)
 
     props_per_step = args.images * args.proposals * world
     dt2 = timed(wl.step_s2, args.steps, args.warmup, timed=True)
