@@ -91,7 +91,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 // past M / N are simply read from a clamped in-bounds row -- they only feed output rows / columns
 // that are never stored -- so no select is needed, and the per-lane global pointers just advance by
 // a wave-uniform delta per K-tile.  MASKED = true keeps the general path (ragged K, ROI-major conv).
-template <typename T, typename TOut, int BM, int BN, int WM, int WN, int OCC, int CONV, bool MASKED>
+template <typename T, typename TOut, int BM, int BN, int WM, int WN, int OCC, int CONV, bool MASKED, int BK16>
 __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__restrict__ A, int64_t lda,
                                                                     const T *__restrict__ B, int64_t ldb,
                                                                     TOut *__restrict__ Cout, int64_t ldc, int64_t M_,
@@ -102,9 +102,10 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
     static_assert(MASKED || !CONV3, "the ROI-major convolution needs the masked staging path");
     typedef typename Frag<T>::type frag_t;
     constexpr int E = Frag<T>::kPer16B;    // elements per 16 B
-    constexpr int BK16 = 8;                // 16-byte chunks per tile row: BK = 8*E (32 f32 / 64 bf16)
+    // BK16 = 16-byte chunks per tile row: BK = BK16*E (8 -> 32 f32 / 64 bf16; 16 -> 64 f32 / 128 bf16)
+    static_assert(BK16 == 8 || BK16 == 16, "BK16 must be 8 or 16");
     constexpr int BK = BK16 * E;
-    constexpr int LDS16 = BK16 + 1;        // padded row length in 16-byte units (144 B)
+    constexpr int LDS16 = BK16 + 1;        // padded row length in 16-byte units (odd: conflict-free b128 reads)
     constexpr int NT = 64 * WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 32, NI = TN / 32;
@@ -114,9 +115,7 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
     static_assert(A_CH <= 16 && B_CH <= 16, "ok_mask holds 16 chunks per operand");
 
     constexpr int STAGE = (BM + BN) * LDS16;
-    // OCC == 1 (developer experiment): pad LDS past half a CU so that only one workgroup is resident
-    constexpr int LDS_PAD = OCC == 1 ? (88 * 1024 / 16 - 2 * STAGE > 0 ? 88 * 1024 / 16 - 2 * STAGE : 0) : 0;
-    __shared__ frag_t lds[2 * STAGE + LDS_PAD];
+    __shared__ frag_t lds[2 * STAGE];
 
     const int tiles_n = (N + BN - 1) / BN;
     const int nwg = gridDim.x;
@@ -298,64 +297,64 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
 #pragma unroll
         for (int j = 0; j < NI; j++) acc[i][j] = f32x16{};
 
-    // register double buffer of MFMA fragments: quarter q of a tile = 16-byte chunks 2q, 2q+1
-    frag_t fa0[MI], fb0[NI], fa1[MI], fb1[NI];
+    // register double buffer of MFMA fragments: sub-step q of a tile = 16-byte chunks 2q, 2q+1
+    // (index [q & 1]; every use below is fully unrolled, so the indices are compile-time constants)
+    frag_t fa[2][MI], fb[2][NI];
     const int frow = lane & 31, fch = lane >> 5;
-    auto read_frags = [&](int stage, int q, frag_t(&fa)[MI], frag_t(&fb)[NI]) {
+    auto read_frags = [&](int stage, int q, int set) {
         const frag_t *As = lds + stage * STAGE, *Bs = As + BM * LDS16;
 #pragma unroll
-        for (int i = 0; i < MI; i++) fa[i] = As[(wm + i * 32 + frow) * LDS16 + 2 * q + fch];
+        for (int i = 0; i < MI; i++) fa[set][i] = As[(wm + i * 32 + frow) * LDS16 + 2 * q + fch];
 #pragma unroll
-        for (int j = 0; j < NI; j++) fb[j] = Bs[(wn + j * 32 + frow) * LDS16 + 2 * q + fch];
+        for (int j = 0; j < NI; j++) fb[set][j] = Bs[(wn + j * 32 + frow) * LDS16 + 2 * q + fch];
     };
-    auto mma = [&](const frag_t(&fa)[MI], const frag_t(&fb)[NI]) {
+    auto mma = [&](int set) {
 #pragma unroll
         for (int i = 0; i < MI; i++)
 #pragma unroll
-            for (int j = 0; j < NI; j++) mma_step(fa[i], fb[j], acc[i][j]);
+            for (int j = 0; j < NI; j++) mma_step(fa[set][i], fb[set][j], acc[i][j]);
     };
 
-    // MFMAs p0..p1-1 of a quarter (fp32: 4 per accumulator tile, one per k-pair; bf16: 1 per tile)
+    // MFMAs p0..p1-1 of a sub-step (fp32: 4 per accumulator tile, one per k-pair; bf16: 1 per tile)
     constexpr int MPT = sizeof(T) == 4 ? 4 : 1;
     constexpr int NMFMA = MI * NI * MPT;
-    auto mma_range = [&](const frag_t(&fa)[MI], const frag_t(&fb)[NI], int p0, int p1) {
+    auto mma_range = [&](int set, int p0, int p1) {
 #pragma unroll
         for (int p = 0; p < NMFMA; p++) {
             if (p < p0 || p >= p1) continue;
             const int t = p / MPT, i = t / NI, j = t % NI;
             if constexpr (sizeof(T) == 4) {
                 const int ks = p % MPT;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][ks], fb[set][j][ks], acc[i][j], 0, 0, 0);
             } else {
-                mma_step(fa[i], fb[j], acc[i][j]);
+                mma_step(fa[set][i], fb[set][j], acc[i][j]);
             }
         }
     };
-    // one half of a quarter's MFMAs (row tiles split in two; MI == 1: first half does everything)
-    auto mma_half = [&](const frag_t(&fa)[MI], const frag_t(&fb)[NI], int half) {
+    // one half of a sub-step's MFMAs (row tiles split in two; MI == 1: first half does everything)
+    auto mma_half = [&](int set, int half) {
 #pragma unroll
         for (int i = 0; i < MI; i++) {
             if ((MI == 1 ? 0 : (i * 2) / MI) != half) continue;
 #pragma unroll
-            for (int j = 0; j < NI; j++) mma_step(fa[i], fb[j], acc[i][j]);
+            for (int j = 0; j < NI; j++) mma_step(fa[set][i], fb[set][j], acc[i][j]);
         }
     };
 
     const int k_last = ((K + BK - 1) / BK - 1) * BK;        // k0 of the last K-tile
-    // prologue: tile 0 -> LDS stage 0, tile 1 -> staging registers, fragments q0 of tile 0
+    // prologue: tile 0 -> LDS stage 0, tile 1 -> staging registers, fragments of sub-step 0
     load_tiles(0);
     store_tiles(0);
     load_tiles(BK < k_last ? BK : k_last);
     __syncthreads();
-    read_frags(0, 0, fa0, fb0);
+    read_frags(0, 0, 0);
     int s = 0;
     constexpr int NCH = A_CH + B_CH;                        // staging chunks per thread and tile
     // Fast path: chunks [g0,g1) of the staged tile t+1 go registers -> LDS stage `ws`, their pointers
     // advance by (da, db) and the refill loads of tile t+2 are issued, each chunk followed by its
-    // share of the quarter's MFMAs (hand-interleaved: LDS write bandwidth is ~80 B/clk/CU, so the
-    // 32 KiB a workgroup stages per tile must be spread over the tile, not written in one burst).
-    auto stage_and_mma = [&](int g0, int g1, int ws, int64_t da, int db, const frag_t(&fa)[MI],
-                             const frag_t(&fb)[NI]) {
+    // share of the sub-step's MFMAs (hand-interleaved, so the staging traffic sits evenly in the
+    // shadow of the matrix pipe).
+    auto stage_and_mma = [&](int g0, int g1, int ws, int64_t da, int db, int set) {
         frag_t *As = lds + ws * STAGE, *Bs = As + BM * LDS16;
         const int n = g1 - g0;
 #pragma unroll
@@ -372,16 +371,18 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
                 b_ptr[h] += db;
                 rb[h] = *reinterpret_cast<const frag_t *>(b_ptr[h]);
             }
-            mma_range(fa, fb, (g - g0) * NMFMA / n, (g - g0 + 1) * NMFMA / n);
+            mma_range(set, (g - g0) * NMFMA / n, (g - g0 + 1) * NMFMA / n);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // chunk split over phases A | B | C.  Measured on MI355X: everything in C (0, 0) = everything in
-    // B = 129-133 TF; an even spread (NCH/3, 2*NCH/3) and everything in A are ~5-8 % slower.
-    constexpr int G1 = 0, G2 = 0;
+    // Sub-steps per tile and where the staging goes: the SQ sub-steps right before the last one
+    // carry at most 8 chunks each (measured on MI355X: staging late in the tile beats an even spread
+    // or an early burst by 5-8 %); the LAST sub-step holds the barrier.
+    constexpr int NQ = BK16 / 2;
+    constexpr int SQ = (NCH + 7) / 8;
+    static_assert(NQ % 2 == 0 && NQ >= SQ + 2, "sub-step schedule needs room for the staging phases");
 
     for (int k0 = 0; k0 < k_last; k0 += BK) {               // tile at k0 has a successor
-        // (each phase issues its fragment reads FIRST so their LDS latency sits under 16 MFMAs)
         const int kn = k0 + 2 * BK < k_last ? k0 + 2 * BK : k_last;   // tile to prefetch (clamped)
         int64_t da = 0;
         int db = 0;
@@ -394,53 +395,45 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
             db = bo1 - bo0;
             k_ptr = kn;
         }
-        // A
-        read_frags(s, 1, fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (MASKED) mma(fa0, fb0);
-        else if (G1 > 0) stage_and_mma(0, G1, s ^ 1, da, db, fa0, fb0);
-        else mma(fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        // B
-        read_frags(s, 2, fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (MASKED) mma(fa1, fb1);
-        else if (G2 > G1) stage_and_mma(G1, G2, s ^ 1, da, db, fa1, fb1);
-        else mma(fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        // C: (masked path: staging registers -> other LDS stage, then refill them with tile t+2)
-        read_frags(s, 3, fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (MASKED) {
-            store_tiles(s ^ 1);
-            load_tiles(kn);
-            mma(fa0, fb0);
-        } else if (G2 < NCH) {
-            stage_and_mma(G2, NCH, s ^ 1, da, db, fa0, fb0);
-        } else {
-            mma(fa0, fb0);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int cur = q & 1, nxt = cur ^ 1;
+            if (q < NQ - 1) {
+                // fragment reads of the NEXT sub-step first: their LDS latency sits under this one's MFMAs
+                read_frags(s, q + 1, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+                const int sq = q - (NQ - 1 - SQ);             // staging slot of this sub-step, if any
+                if (!MASKED && sq >= 0) {
+                    stage_and_mma(sq * NCH / SQ, (sq + 1) * NCH / SQ, s ^ 1, da, db, cur);
+                } else if (MASKED && q == NQ - 2) {
+                    store_tiles(s ^ 1);                        // staging registers (tile t+1) -> other stage,
+                    load_tiles(kn);                            // then refill them with tile t+2
+                    mma(cur);
+                } else {
+                    mma(cur);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                // last sub-step: the barrier sits in the MIDDLE of its MFMAs -- the first half is issued
+                // from registers while the waves rendezvous, the second half covers the LDS latency of
+                // the next tile's first fragments
+                mma_half(cur, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                read_frags(s ^ 1, 0, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_half(cur, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // D: the barrier sits in the MIDDLE of this quarter's MFMAs: the first half is issued from
-        // registers while the waves rendezvous, the second half covers the LDS latency of the next
-        // tile's first fragments
-        mma_half(fa1, fb1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        read_frags(s ^ 1, 0, fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_half(fa1, fb1, 1);
-        __builtin_amdgcn_sched_barrier(0);
         s ^= 1;
     }
     // last tile
-    read_frags(s, 1, fa1, fb1);
-    mma(fa0, fb0);
-    read_frags(s, 2, fa0, fb0);
-    mma(fa1, fb1);
-    read_frags(s, 3, fa1, fb1);
-    mma(fa0, fb0);
-    mma(fa1, fb1);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        if (q < NQ - 1) read_frags(s, q + 1, (q & 1) ^ 1);
+        mma(q & 1);
+    }
 
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // Runtime options are wave-uniform and hoisted; residual values of a 32x32 tile are fetched as
@@ -524,7 +517,7 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
     }
 }
 
-template <typename T, typename TOut, int BM, int BN, int WM, int WN, int OCC>
+template <typename T, typename TOut, int BM, int BN, int WM, int WN, int OCC, int BK16 = 8>
 static int launch_cfg(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C, int64_t ldc, int64_t M, int N,
                       int K, const Epilogue &epi, const ConvGeom &cg, hipStream_t s, const char *what)
 {
@@ -532,11 +525,12 @@ static int launch_cfg(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C,
     const int64_t tiles_m = posm ? (int64_t)cg.H * cg.W * ceil_div(cg.R, BM) : ceil_div(M, BM);
     const int64_t tiles = tiles_m * ceil_div(N, BN);
     if (tiles > 0x7fffffffLL) return set_error(LOCOV_ERR_INVALID_ARG, "%s: problem too large", what);
-    constexpr int BK = 8 * Frag<T>::kPer16B;
+    constexpr int BK = BK16 * Frag<T>::kPer16B;
     const bool ragged_k = (posm ? cg.Cin : K) % BK != 0;
     const dim3 grid((unsigned)tiles), block(64 * WM * WN);
 #define LOCOV_LAUNCH(CONV, MASKED)                                                                                 \
-    hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, OCC, CONV, MASKED>), grid, block, 0, s, A, lda, B, ldb, \
+    hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, OCC, CONV, MASKED, BK16>), grid, block, 0, s, A, lda, B, \
+                       ldb, \
                        C, ldc, M, N, K, epi, cg)
     if (posm) {
         if (ragged_k) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: Cin must be a multiple of %d", what, BK);
@@ -571,8 +565,8 @@ int launch_gemm_nt(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C, in
         return launch_cfg<T, TOut, 128, 64, 4, 1, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
     if (forced_cfg() == 1)
         return launch_cfg<T, TOut, 64, 64, 2, 2, 4>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
-    if (forced_cfg() == 2)   // one workgroup per CU: how well does a single wave per SIMD feed the pipe?
-        return launch_cfg<T, TOut, 128, 128, 2, 2, 1>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
+    if (forced_cfg() == 2)   // deep tile: BK = 64 (f32) / 128 (bf16), 136 KiB LDS, one workgroup per CU
+        return launch_cfg<T, TOut, 128, 128, 2, 2, 1, 16>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
     return launch_cfg<T, TOut, 128, 128, 2, 2, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
 }
 
