@@ -191,6 +191,20 @@ int locov_sim_gemm_bf16(const uint16_t *emb, const uint16_t *bank, int64_t R, in
                         float *logits, int64_t ldc, locov_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * a-10  greedy NMS on the device.  Replaces [D2-upstream] torchvision.ops.nms as reached from
+ * box_predictor.inference -> fast_rcnn_inference -> batched_nms
+ * (ovr/modeling/roi_heads/roi_emb_heads.py:280,357).
+ *   boxes_sorted [K,4] XYXY fp32, ALREADY in descending score order (class-aware NMS: the caller
+ *   adds the per-class coordinate offsets first, exactly as torchvision's batched_nms does)
+ *   keep [K] bytes (1 = kept), num_keep [1] int32 -- both on the device; no host sync.
+ *   workspace: locov_nms_workspace_bytes(K) bytes of device memory.
+ * ------------------------------------------------------------------------------------- */
+int64_t locov_nms_workspace_bytes(int64_t K);
+
+int locov_nms_sorted(const float *boxes_sorted, int64_t K, float iou_threshold, void *workspace,
+                     unsigned char *keep, int *num_keep, locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * a-12  LSM grounding: word<->region alignment -> [caption, image] cost matrices.
  * Replaces the B^2-replicated chain of GroundingHead.forward
  * (ovr/modeling/mmss_heads/grounding_head.py:116-243) for LOCAL_METRIC "dot", ALIGNMENT

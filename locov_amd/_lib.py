@@ -46,6 +46,8 @@ SIGNATURES = {
                                        _p]),
     "locov_pack_conv3x3_weight": (c_int, [_p, c_int, c_int, _p, c_int, _p]),
     "locov_frozen_bn_fold": (c_int, [_p, _p, _p, _p, c_float, c_int, _p, _p, _p]),
+    "locov_nms_workspace_bytes": (c_int64, [c_int64]),
+    "locov_nms_sorted": (c_int, [_p, c_int64, c_float, _p, _p, _p, _p]),
     "locov_grounding_fwd": (c_int, [_p, c_int, c_int, c_int, _p, _p, c_float, _p, _p, _p]),
     "locov_grounding_bwd": (c_int, [_p, c_int, c_int, c_int, _p, _p, c_float, _p, _p, _p, _p]),
     "locov_rownorm_fwd": (c_int, [_p, c_int64, c_int, c_int, c_float, _p, _p]),

@@ -448,6 +448,22 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
     if (vec_ok) {
         constexpr int EPS = TN + 4;                       // padded row (floats): conflict-free b128 reads
         static_assert(WM * WN * TM * EPS * 4 <= 2 * STAGE * 16, "epilogue staging must fit the K-loop LDS");
+        constexpr int LPR = TN / 4;                       // lanes per row
+        constexpr int RPI = 64 / LPR;                     // rows per wave instruction
+        constexpr int NIT = TM / RPI;
+        const int c4 = (lane % LPR) * 4, rr = lane / LPR;
+        const int n = n0 + wn + c4;
+        const bool n_ok = n < N;
+        // residual rows are fetched FIRST (16-byte loads, all in flight) so that their latency sits
+        // under the LDS re-layout below
+        f32x4 res[NIT];
+        if (epi.residual && n_ok) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int64_t m = m0 + wm + it * RPI + rr;
+                res[it] = *reinterpret_cast<const f32x4 *>(epi.residual + (m < M ? m : M - 1) * ldc + n);
+            }
+        }
         __syncthreads();                                  // every wave is done reading the last stage
         float *ep = reinterpret_cast<float *>(lds) + wave * (TM * EPS);
 #pragma unroll
@@ -458,27 +474,22 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
                 for (int r = 0; r < 16; r++)
                     ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPS + j * 32 + (lane & 31)] = acc[i][j][r];
         __syncthreads();
-        constexpr int LPR = TN / 4;                       // lanes per row
-        constexpr int RPI = 64 / LPR;                     // rows per wave instruction
-        const int c4 = (lane % LPR) * 4, rr = lane / LPR;
-        const int n = n0 + wn + c4;
-        if (n < N) {
+        if (n_ok) {
             f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
             if (epi.scale) sc = *reinterpret_cast<const f32x4 *>(epi.scale + n);
             if (epi.shift) sh = *reinterpret_cast<const f32x4 *>(epi.shift + n);
-#pragma unroll 4
-            for (int it = 0; it < TM / RPI; it++) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
                 const int row = it * RPI + rr;
                 const int64_t m = m0 + wm + row;
-                if (m >= M) continue;
                 f32x4 v = *reinterpret_cast<const f32x4 *>(ep + row * EPS + c4);
                 v = v * sc + sh;
-                if (epi.residual) v += *reinterpret_cast<const f32x4 *>(epi.residual + m * ldc + n);
+                if (epi.residual) v += res[it];
                 if (relu) {
                     v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
                     v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
                 }
-                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + m * ldc + n) = v;
+                if (m < M) *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + m * ldc + n) = v;
             }
         }
         return;

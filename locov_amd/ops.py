@@ -280,6 +280,27 @@ def frozen_bn_fold(weight, bias, running_mean, running_var, eps: float = 1e-5):
     return scale, shift
 
 
+def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """torchvision.ops.nms semantics on the device: indices of the kept boxes in descending score
+    order.  The sort uses torch (plumbing); the IoU bit matrix and the greedy sweep are HIP kernels
+    and nothing is copied to the host except the final count."""
+    boxes = _dev(boxes, "boxes")
+    scores = _dev(scores, "scores")
+    K = boxes.shape[0]
+    if K == 0:
+        return torch.zeros((0,), dtype=torch.int64, device=boxes.device)
+    order = torch.argsort(scores, descending=True, stable=True)
+    sorted_boxes = boxes[order].contiguous()
+    lib = _lib.load()
+    ws = torch.empty((int(lib.locov_nms_workspace_bytes(K)),), dtype=torch.uint8, device=boxes.device)
+    keep = torch.empty((K,), dtype=torch.uint8, device=boxes.device)
+    num = torch.empty((1,), dtype=torch.int32, device=boxes.device)
+    with torch.cuda.device(boxes.device):
+        check(lib.locov_nms_sorted(_ptr(sorted_boxes), K, float(iou_threshold), _ptr(ws), _ptr(keep), _ptr(num),
+                                   _stream(boxes)), "locov_nms_sorted")
+    return order[keep.bool()]
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x W^T + b on the f32 MFMA NT-GEMM kernel; backward re-uses the same kernel on transposed
     operands (grad_x = g W, grad_W = g^T x, grad_b = sum g)."""

@@ -89,6 +89,9 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torc
     n = boxes.shape[0]
     if n == 0:
         return torch.zeros((0,), dtype=torch.int64, device=boxes.device)
+    if boxes.is_cuda:
+        return ops.nms(boxes.float(), scores.float(), iou_threshold)     # HIP bit-matrix + on-device sweep
+    # CPU tensors (host-logic unit tests only): same algorithm with a numpy sweep
     order = torch.argsort(scores, descending=True, stable=True)
     b = boxes[order]
     area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])

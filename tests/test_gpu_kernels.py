@@ -296,3 +296,32 @@ def test_full_size_properties(ops):
     full = ops.roi_align(f1, rois, 14, 1 / 16)
     even = ops.roi_align_nhwc(ops.nchw_to_nhwc(f1), rois, 14, 1 / 16, 0, True, 2)
     assert (even.permute(0, 3, 1, 2) - full[:, :, ::2, ::2]).abs().max().item() < 1e-5
+
+
+# ------------------------------------------------------------------ NMS on the device
+@pytest.mark.parametrize("K", [1, 63, 64, 65, 300, 2500])
+def test_nms_matches_oracle(ops, oracle, K):
+    rng = np.random.default_rng(K)
+    boxes = oracle.synth_boxes(rng, K)
+    boxes[K // 2] = boxes[0]                                   # exact duplicate
+    if K > 10:
+        boxes[5] = (10, 10, 10, 40)                            # zero-area box
+    scores = rng.uniform(0, 1, K).astype(np.float32)
+    if K > 3:
+        scores[3] = scores[2]                                  # tie: stable order
+    for thr in (0.5, 0.3):
+        keep = ops.nms(dev(boxes), dev(scores), thr).cpu().numpy()
+        np.testing.assert_array_equal(keep, oracle.nms(boxes, scores, thr))
+    assert ops.nms(dev(boxes[:0]), dev(scores[:0]), 0.5).numel() == 0
+
+
+def test_batched_nms_and_inference_on_device(ops, oracle):
+    from locov_amd.roi_heads import box_emb_head as beh
+    rng = np.random.default_rng(4)
+    boxes = oracle.synth_boxes(rng, 1000)
+    probs = oracle.softmax(rng.standard_normal((1000, 81)).astype(np.float32) * 2.5)
+    inst, _ = beh.fast_rcnn_inference_single_image(dev(boxes), dev(probs), (800, 1333), 0.05, 0.5, 100)
+    wb, ws, wc = oracle.fast_rcnn_inference_single_image(boxes, probs, (800, 1333), 0.05, 0.5, 100)
+    np.testing.assert_allclose(inst.pred_boxes.tensor.cpu().numpy(), wb, atol=1e-4)
+    np.testing.assert_allclose(inst.scores.cpu().numpy(), ws, atol=1e-6)
+    np.testing.assert_array_equal(inst.pred_classes.cpu().numpy(), wc)

@@ -17,11 +17,10 @@ def rep(a, b, cnt=1):
 rep('namespace locov {\n', 'namespace locov {\n' + stamp)
 rep('    for (int k0 = 0; k0 < k_last; k0 += BK) {               // tile at k0 has a successor',
     '    unsigned long long dsum[8] = {0,0,0,0,0,0,0,0}, tprev = 0;\n    for (int k0 = 0; k0 < k_last; k0 += BK) {\n        LOCOV_STAMP(-1);')
-rep('        // B\n', '        LOCOV_STAMP(0);\n        // B\n')
-rep('        // C: (masked path', '        LOCOV_STAMP(1);\n        // C: (masked path')
-rep('        // D: the barrier sits', '        LOCOV_STAMP(2);\n        // D: the barrier sits')
-rep('        __syncthreads();\n        read_frags(s ^ 1, 0, fa0, fb0);', '        LOCOV_STAMP(3);\n        __syncthreads();\n        LOCOV_STAMP(4);\n        read_frags(s ^ 1, 0, fa0, fb0);')
-rep('        s ^= 1;\n    }\n', '        LOCOV_STAMP(5);\n        s ^= 1;\n    }\n')
+# generic sub-step loop: stamp index = q for q < NQ-1 (NQ = 4: A,B,C), then D1 / barrier / D2
+rep('                __builtin_amdgcn_sched_barrier(0);\n            } else {\n                // last sub-step', '                __builtin_amdgcn_sched_barrier(0);\n                LOCOV_STAMP(q);\n            } else {\n                // last sub-step')
+rep('                __syncthreads();\n                read_frags(s ^ 1, 0, nxt);', '                LOCOV_STAMP(3);\n                __syncthreads();\n                LOCOV_STAMP(4);\n                read_frags(s ^ 1, 0, nxt);')
+rep('        s ^= 1;\n    }\n    // last tile', '        LOCOV_STAMP(5);\n        s ^= 1;\n    }\n    // last tile')
 rep('    // Epilogue.  C/D layout', '''    if (blockIdx.x == 300 && threadIdx.x == 0 && (epi.flags & 0x2000u)) {
         unsigned long long *dbg = (unsigned long long *)epi.scale;
         for (int i = 0; i < 8; i++) dbg[i] = dsum[i];
@@ -35,6 +34,11 @@ rep('    if (blockIdx.x == 300 && threadIdx.x == 0 && (epi.flags & 0x2000u)) {',
 # end-of-kernel stamp for the vec epilogue path: before its return
 rep('        return;\n    }\n\n    // General path', '        if (blockIdx.x == 300 && threadIdx.x == 0 && dbgp_) { unsigned long long te_, re_; asm volatile("s_memtime %0\\n\\ts_memrealtime %1\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(te_), "=s"(re_) :: "memory"); dbgp_[12] = te_; dbgp_[13] = re_; }\n        return;\n    }\n\n    // General path')
 rep('    if (epi.flags & 0x2000u) epi.scale = nullptr;', '    unsigned long long *dbgp_ = (epi.flags & 0x2000u) ? (unsigned long long *)epi.scale : nullptr;\n    if (epi.flags & 0x2000u) epi.scale = nullptr;')
+# ablation switches for the staging phase (timing only -- results are wrong when set)
+rep('                As[(idx / BK16) * LDS16 + idx % BK16] = ra[g];\n                a_ptr[g] += da;\n                ra[g] = *reinterpret_cast<const frag_t *>(a_ptr[g]);',
+    '                if (!(epi.flags & 0x10000u)) As[(idx / BK16) * LDS16 + idx % BK16] = ra[g];\n                a_ptr[g] += da;\n                if (!(epi.flags & 0x20000u)) ra[g] = *reinterpret_cast<const frag_t *>(a_ptr[g]);')
+rep('                Bs[(idx / BK16) * LDS16 + idx % BK16] = rb[h];\n                b_ptr[h] += db;\n                rb[h] = *reinterpret_cast<const frag_t *>(b_ptr[h]);',
+    '                if (!(epi.flags & 0x10000u)) Bs[(idx / BK16) * LDS16 + idx % BK16] = rb[h];\n                b_ptr[h] += db;\n                if (!(epi.flags & 0x20000u)) rb[h] = *reinterpret_cast<const frag_t *>(b_ptr[h]);')
 open('/tmp/gemm_stamp.hip', 'w').write(s)
 cs = os.path.join(ROOT, "locov_amd/csrc")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-w", "-c", "/tmp/gemm_stamp.hip", "-o", "/tmp/gemm_stamp.o"])

@@ -9,7 +9,7 @@ M, N, K = 196000, 512, 2048
 x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.02; y = torch.empty(M, N, device="cuda")
 st = vp(torch.cuda.current_stream().cuda_stream)
 names = ["A(16 mfma)", "B(16 mfma)", "C(stage+16 mfma)", "D1(8 mfma)", "barrier", "D2(read+8 mfma)"]
-for label, extra in (("HBM-streamed A", 0), ("A aliased to 128 rows (L2-resident)", 0x4000)):
+for label, extra in (("normal", 0), ("no ds_write in staging", 0x10000), ("no refill loads in staging", 0x20000), ("neither", 0x30000)):
     dbg = torch.zeros(16, dtype=torch.int64, device="cuda")
     for it in range(20):
         assert lib.locov_gemm_nt_f32(vp(x.data_ptr()), K, vp(w.data_ptr()), vp(dbg.data_ptr()), None, None, vp(y.data_ptr()), N, M, N, K, 0x2000 | extra, st) == 0
