@@ -576,6 +576,8 @@ int launch_gemm_nt(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C, in
         return launch_cfg<T, TOut, 128, 64, 4, 1, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
     if (forced_cfg() == 1)
         return launch_cfg<T, TOut, 64, 64, 2, 2, 4>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
+    if (forced_cfg() == 3)   // 8 waves per workgroup (64x32 per wave): 4 waves per SIMD with two resident workgroups
+        return launch_cfg<T, TOut, 128, 128, 2, 4, 4>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
     if (forced_cfg() == 2)   // deep tile: BK = 64 (f32) / 128 (bf16), 136 KiB LDS, one workgroup per CU
         return launch_cfg<T, TOut, 128, 128, 2, 2, 1, 16>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
     return launch_cfg<T, TOut, 128, 128, 2, 2, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);

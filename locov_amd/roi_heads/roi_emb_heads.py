@@ -157,37 +157,45 @@ class ROIHeads(nn.Module):
 
 
 class SampleAllROIHeads(ROIHeads):
+    """Proposal labelling / sampling of ovr/modeling/roi_heads/roi_emb_heads.py:25-118.
+
+    Kept from the reference (and different from stock Detectron2): EVERY field of the matched target
+    is copied onto the sampled proposals, not only the gt_* ones (:97-100), and a 0/1 `fg_proposal`
+    field is attached (:102-104).  Changed in HOW: the per-image fg/bg counters stay on the device and
+    are read back once per call instead of two `.item()` host syncs per image (:109-110)."""
+
+    def _label_one_image(self, props: Instances, tgt: Instances):
+        iou = pairwise_iou(tgt.gt_boxes, props.proposal_boxes)                 # [num_gt, num_proposals]
+        gt_index, match_label = self.proposal_matcher(iou)
+        picked, classes = self._sample_proposals(gt_index, match_label, tgt.gt_classes)
+        out = props[picked]
+        out.gt_classes = classes
+        if len(tgt) > 0:
+            src = gt_index[picked]
+            for name, value in tgt.get_fields().items():
+                if not out.has(name):
+                    out.set(name, value[src])
+        is_bg = classes == self.num_classes
+        out.set("fg_proposal", (~is_bg).to(classes.dtype))
+        return out, is_bg.sum(), classes.numel()
+
     @torch.no_grad()
     def label_and_sample_proposals(self, proposals: List[Instances], targets: List[Instances]) -> List[Instances]:
-        """roi_emb_heads.py:25-118.  Differences from stock Detectron2 kept on purpose: ALL target
-        fields are copied onto the sampled proposals (:97-100) and `fg_proposal` is set (:102-104)."""
         if self.proposal_append_gt:
             proposals = add_ground_truth_to_proposals(targets, proposals)
-        proposals_with_gt = []
-        num_fg_samples, num_bg_samples = [], []
-        for proposals_per_image, targets_per_image in zip(proposals, targets):
-            has_gt = len(targets_per_image) > 0
-            match_quality_matrix = pairwise_iou(targets_per_image.gt_boxes, proposals_per_image.proposal_boxes)
-            matched_idxs, matched_labels = self.proposal_matcher(match_quality_matrix)
-            sampled_idxs, gt_classes = self._sample_proposals(matched_idxs, matched_labels,
-                                                              targets_per_image.gt_classes)
-            proposals_per_image = proposals_per_image[sampled_idxs]
-            proposals_per_image.gt_classes = gt_classes
-            if has_gt:
-                sampled_targets = matched_idxs[sampled_idxs]
-                for (trg_name, trg_value) in targets_per_image.get_fields().items():
-                    if not proposals_per_image.has(trg_name):
-                        proposals_per_image.set(trg_name, trg_value[sampled_targets])
-            fg_classes = torch.ones_like(gt_classes)
-            fg_classes[gt_classes == self.num_classes] = 0
-            proposals_per_image.set("fg_proposal", fg_classes)
-            num_bg_samples.append((gt_classes == self.num_classes).sum().item())
-            num_fg_samples.append(gt_classes.numel() - num_bg_samples[-1])
-            proposals_with_gt.append(proposals_per_image)
-        storage = get_event_storage()
-        storage.put_scalar("roi_head/num_fg_samples", np.mean(num_fg_samples))
-        storage.put_scalar("roi_head/num_bg_samples", np.mean(num_bg_samples))
-        return proposals_with_gt
+        sampled, bg_counts, totals = [], [], []
+        for props, tgt in zip(proposals, targets):
+            out, n_bg, n = self._label_one_image(props, tgt)
+            sampled.append(out)
+            bg_counts.append(n_bg)
+            totals.append(n)
+        if sampled:
+            bg = torch.stack(bg_counts).to(torch.float64).cpu().numpy()        # one sync for the whole batch
+            tot = np.asarray(totals, dtype=np.float64)
+            storage = get_event_storage()
+            storage.put_scalar("roi_head/num_fg_samples", float(np.mean(tot - bg)))
+            storage.put_scalar("roi_head/num_bg_samples", float(np.mean(bg)))
+        return sampled
 
 
 @ROI_HEADS_REGISTRY.register()
