@@ -1,0 +1,136 @@
+"""Edge cases of the plugin-level path on the GPU (SURVEY.md section 3 "cover the edge cases the
+reference tests": empty and ragged inputs, normalised / standardised classifier, odd sizes)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device")
+    import locov_amd
+    from locov_amd import _lib
+    _lib.load()
+    return locov_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _cfg(pkg, **box_head):
+    cfg = pkg.config.get_cfg()
+    cfg.MODEL.RESNETS.RES2_OUT_CHANNELS = 32
+    cfg.MODEL.RESNETS.WIDTH_PER_GROUP = 8
+    cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
+    cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED = True
+    cfg.MODEL.ROI_BOX_HEAD.EMB_DIM = 96
+    cfg.MODEL.ROI_HEADS.NAME = "EmbeddingProposalsRes5ROIHeads"
+    for k, v in box_head.items():
+        cfg.MODEL.ROI_BOX_HEAD[k] = v
+    return cfg
+
+
+def _heads(pkg, oracle, cfg, k=17, seed=3):
+    from locov_amd.structures import ShapeSpec
+    heads = pkg.build_roi_heads(cfg, {"res4": ShapeSpec(channels=128, stride=16)})
+    params = oracle.make_res5_params(seed, in_ch=128, mid=64, out_ch=256)
+    heads.res5.load_state_dict(params)
+    h = oracle.synth_head(np.random.default_rng(seed), 256, 96, k)
+    bp = heads.box_predictor
+    with torch.no_grad():
+        bp.emb_pred.weight.copy_(torch.from_numpy(h["emb_w"]))
+        bp.emb_pred.bias.copy_(torch.from_numpy(h["emb_b"]) + 0.01)
+        h["emb_b"] = h["emb_b"] + np.float32(0.01)
+        bp.bbox_pred.weight.copy_(torch.from_numpy(h["bbox_w"]))
+        bp.bbox_pred.bias.copy_(torch.from_numpy(h["bbox_b"]))
+    heads = heads.cuda().eval()
+    bp.set_class_embeddings(h["cls_w"])
+    heads.num_classes = bp.num_classes
+    return heads, params, h
+
+
+def _props(boxes_list):
+    from locov_amd.structures import Boxes, Instances
+    out = []
+    for b in boxes_list:
+        inst = Instances((800, 1333))
+        inst.proposal_boxes = Boxes(torch.from_numpy(b).cuda())
+        inst.objectness_logits = torch.zeros(len(b), device="cuda")
+        out.append(inst)
+    return out
+
+
+@pytest.mark.parametrize("norm,std", [(True, False), (False, True)])
+def test_normalised_and_standardised_classifier(pkg, oracle, norm, std):
+    """NORMALIZE_EMB_PRED / STANDARDIZE_EMB_PRED (box_emb_head.py:207-210 on the embeddings, :223-232
+    on the bank)."""
+    cfg = _cfg(pkg, NORMALIZE_EMB_PRED=norm, STANDARDIZE_EMB_PRED=std)
+    heads, params, h = _heads(pkg, oracle, cfg)
+    rng = np.random.default_rng(5)
+    feat = rng.standard_normal((2, 128, 50, 84)).astype(np.float32)
+    boxes = [oracle.synth_boxes(rng, 33), oracle.synth_boxes(rng, 20)]
+    cls_w, _, _ = oracle.set_class_embeddings(h["cls_w"], norm, std)
+    np.testing.assert_allclose(heads.box_predictor.cls_score.weight.cpu().numpy(), cls_w, rtol=2e-5, atol=2e-6)
+    want = oracle.roi_head_forward(feat, boxes, params, dict(h, cls_w=cls_w), normalize_emb=norm, standardize_emb=std)
+    with torch.no_grad():
+        bf = heads._shared_roi_transform([dev(feat)], [p.proposal_boxes for p in _props(boxes)])
+        scores, deltas = heads.box_predictor(heads._pooled_mean(bf))
+    np.testing.assert_allclose(scores.cpu().numpy(), want["scores"], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(deltas.cpu().numpy(), want["deltas"], atol=1e-5)
+
+
+def test_ragged_and_empty_images(pkg, oracle):
+    """One image without proposals, one with a single proposal, one with 130 (not a tile multiple)."""
+    heads, params, h = _heads(pkg, oracle, _cfg(pkg))
+    rng = np.random.default_rng(6)
+    feat = rng.standard_normal((3, 128, 50, 84)).astype(np.float32)
+    boxes = [np.zeros((0, 4), np.float32), oracle.synth_boxes(rng, 1), oracle.synth_boxes(rng, 130)]
+    want = oracle.roi_head_forward(feat, boxes, params, h)
+    props = _props(boxes)
+    with torch.no_grad():
+        inst, _ = heads(None, {"res4": dev(feat)}, props, None)
+        bf = heads._shared_roi_transform([dev(feat)], [p.proposal_boxes for p in props])
+        scores, deltas = heads.box_predictor(heads._pooled_mean(bf))
+    assert len(inst) == 3 and len(inst[0]) == 0
+    assert tuple(bf.shape) == (131, 256, 7, 7)
+    np.testing.assert_allclose(scores.cpu().numpy(), want["scores"], atol=1e-4)
+    np.testing.assert_allclose(deltas.cpu().numpy(), want["deltas"], atol=1e-5)
+
+
+def test_no_proposals_at_all(pkg, oracle):
+    heads, _, _ = _heads(pkg, oracle, _cfg(pkg))
+    feat = torch.randn(2, 128, 50, 84, device="cuda")
+    props = _props([np.zeros((0, 4), np.float32)] * 2)
+    with torch.no_grad():
+        inst, losses = heads(None, {"res4": feat}, props, None)
+    assert losses == {} and [len(i) for i in inst] == [0, 0]
+
+
+def test_miopen_and_hip_backends_agree(pkg, oracle):
+    rng = np.random.default_rng(8)
+    feat = dev(rng.standard_normal((2, 128, 50, 84)).astype(np.float32))
+    boxes = [oracle.synth_boxes(rng, 70), oracle.synth_boxes(rng, 45)]
+    outs = []
+    for backend in ("hip", "miopen"):
+        heads, _, _ = _heads(pkg, oracle, _cfg(pkg, RES5_BACKEND=backend))
+        with torch.no_grad():
+            bf = heads._shared_roi_transform([feat], [p.proposal_boxes for p in _props(boxes)])
+            outs.append(heads.box_predictor(heads._pooled_mean(bf))[0].cpu().numpy())
+    np.testing.assert_allclose(outs[0], outs[1], atol=2e-4)
+
+
+def test_bf16_similarity_mode_through_the_predictor(pkg, oracle):
+    heads, params, h = _heads(pkg, oracle, _cfg(pkg, SIM_GEMM_DTYPE="bf16"), k=1203)
+    rng = np.random.default_rng(9)
+    x = np.maximum(rng.standard_normal((257, 256)), 0).astype(np.float32)
+    scores32, _, emb = oracle.box_predictor_forward(x, h["emb_w"], h["emb_b"], h["bbox_w"], h["bbox_b"], h["cls_w"])
+    with torch.no_grad():
+        scores, _ = heads.box_predictor(dev(x))
+    want = (torch.from_numpy(emb).to(torch.bfloat16).double() @ torch.from_numpy(h["cls_w"]).to(torch.bfloat16).double().t())
+    assert (scores.cpu().double() - want).abs().max().item() <= 2e-4      # fp64 on the same bf16-rounded operands
+    assert np.abs(scores.cpu().numpy() - scores32).max() < 5e-2            # vs pure fp32: bf16 input rounding
+    assert torch.all(scores[:, -1] == 0)
