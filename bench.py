@@ -46,6 +46,8 @@ def parse():
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--sim-dtype", choices=["fp32", "bf16"], default="fp32")
     p.add_argument("--res5", choices=["miopen", "hip"], default="hip")
+    p.add_argument("--conv3x3", choices=["winograd", "direct"], default="winograd",
+                   help="form of the Res5 3x3 convolutions on the hip backend")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
     # developer/test knobs: rehearse the multi-process flow on a box with fewer GPUs than ranks
@@ -90,22 +92,8 @@ class Workload:
         self.bank16 = ops.to_bf16(self.bank) if args.sim_dtype == "bf16" else None
         self.sim = ops.BF16 if args.sim_dtype == "bf16" else ops.F32
         self.r5_standin = torch.randn(B * R, 2048, 7, 7, generator=gen).clamp_(min=0).to(device)
-        self.ev = []        # (start, end) HIP events around every launch of the dominant kernel
+        self.ev = []        # (start, end) HIP events around the dominant kernel (miopen mode: ROIAlign)
         self.timing = False
-        if args.res5 == "hip":
-            # dominant kernel = the implicit-GEMM 3x3 convolution (47 % of the head's FLOPs)
-            inner = ops.conv3x3_nhwc
-
-            def timed_conv(*a, **k):
-                if not self.timing:
-                    return inner(*a, **k)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                out = inner(*a, **k)
-                e1.record()
-                self.ev.append((e0, e1))
-                return out
-            ops.conv3x3_nhwc = timed_conv
 
     def head(self, x, channels_last=False):
         ops = self.ops
@@ -122,7 +110,8 @@ class Workload:
             # (position-major pixel rows [7,7,R,C]: the 3x3 convs skip their zero-padding taps)
             x0 = ops.roi_align_nhwc(nhwc, self.rois, 14, 1.0 / 16, 0, True, bin_stride=2, pos_major=True)
             R = x0.shape[2]
-            y = self.res5.forward_rows(x0.view(49 * R, 1024), 7, 7, pos_major=True)
+            y = self.res5.forward_rows(x0.view(49 * R, 1024), 7, 7, pos_major=True,
+                                       winograd=self.args.conv3x3 == "winograd")
             out = self.head(y.view(7, 7, R, 2048), channels_last=2)
         else:
             if timed:
@@ -142,18 +131,23 @@ class Workload:
         return self.head(self.r5_standin)
 
 
+TRAFFIC_FILE = "r01d_pmc_traffic.json"
+
+
 def recorded_traffic(args, kernel_key: str):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r01b_pmc_traffic.json; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    (profiles/<TRAFFIC_FILE>; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
     same command, corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be collected from
     inside the timed run, so this is null unless the workload is the one that was profiled."""
-    if (args.images, args.proposals, args.classes, args.dim, args.res5) != (4, 1000, 1203, 768, "hip"):
-        return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")) as f:
-            for name, v in json.load(f)["kernels"].items():
-                if kernel_key in name:
-                    return v["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
+            rec = json.load(f)
+        wl = rec["workload"]
+        if any(wl[k] != getattr(args, k) for k in ("images", "proposals", "classes", "dim", "res5", "conv3x3")):
+            return None
+        for name, v in rec["kernels"].items():
+            if kernel_key in name:
+                return v["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
     return None
@@ -238,10 +232,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn, steps, warmup, **kw):
+    def timed(fn, steps, warmup, on_start=None, **kw):
         for _ in range(warmup):
             fn()
         barrier()
+        if on_start is not None:
+            on_start()
         t0 = time.perf_counter()
         for _ in range(steps):
             fn(**kw)
@@ -252,31 +248,49 @@ def main():
         return max_over_ranks(dt, device if args.dist_backend == "nccl" else None)
 
     props_per_step = args.images * args.proposals * world
-    dt2 = timed(wl.step_s2, args.steps, args.warmup, timed=True)
-    # dominant hand-written kernel: average launch duration over the timed region (HIP events on
-    # the launch stream)
+    lib = _lib.load()
+    # dominant kernel: the library brackets each of its GEMM-kernel launches with HIP events on the
+    # launch stream while this is enabled (include/locov_hip.h, locov_gemm_timing_*)
+    dt2 = timed(wl.step_s2, args.steps, args.warmup, on_start=lambda: lib.locov_gemm_timing_enable(1), timed=True)
+
+    def gemm_class(cls):
+        import ctypes
+        n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(lib.locov_gemm_timing_read(cls, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)))
+        return n.value, ms.value, fl.value
+    gemm_plain, gemm_conv = gemm_class(0), gemm_class(1)
+    lib.locov_gemm_timing_enable(0)
     dom_ms = float(np.mean([a.elapsed_time(b) for a, b in wl.ev])) if wl.ev else float("nan")
     dt1 = timed(wl.step_s1, args.steps, args.warmup)
 
     if rank == 0:
         R_local = args.images * args.proposals
         if args.res5 == "hip":
-            # 3x3 conv as implicit GEMM: M = R*49 pixel rows, N = 512, K = 9*512
-            # Algorithmic = SURVEY.md 8d's count (every tap of every pixel).  The position-major kernel
-            # does not execute the zero-padding taps (361 of 441 (pixel, tap) pairs of a 7x7 tile are
-            # real), so the MFMA pipe's own utilisation is the "executed" figure.
-            alg_flops = 2.0 * R_local * 49 * 512 * 9 * 512
-            achieved = alg_flops / (dom_ms * 1e-3) / 1e12
-            executed = achieved * 361.0 / 441.0
-            roof = {"kernel": "gemm_nt_kernel<float,float,128,128,2,2,2,CONV=2> (Res5 3x3 conv, implicit GEMM, "
-                              "position-major rows)",
+            # Dominant kernel = the 128x128 NT GEMM (template instance CONV=0): the seven 1x1 convolutions of
+            # Res5, the three 121-problem Winograd-domain batched GEMMs, emb_pred and the similarity GEMM.
+            # achieved = the FLOPs those launches execute (2*M*N*K each, = SURVEY 8d's count for the 1x1
+            # convs / FCs; the Winograd GEMMs execute 121/441 of SURVEY's 3x3 count) / their summed
+            # durations, both taken per launch inside the timed region.
+            n0, ms0, fl0 = gemm_plain
+            n1, ms1, fl1 = gemm_conv
+            achieved = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else float("nan")
+            survey_res5_flops = 2.0 * 732.2e6 * R_local * args.steps          # 732.2 M MAC per ROI
+            roof = {"kernel": "gemm_nt_kernel<float,float,128,128,2,2,2,CONV=0,false,8> (Res5 1x1 convs, "
+                              "Winograd-domain batched GEMMs, emb_pred, similarity GEMM)",
                     "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                    "traffic": recorded_traffic(args, "gemm_nt_kernel<float, float, 128, 128, 2, 2, 2, 2, false>"),
-                    "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r01b_pmc_traffic.json)",
-                    "avg_launch_ms": dom_ms,
-                    "algorithmic_flops_per_launch": alg_flops, "executed_tflops": executed,
-                    "executed_frac_of_peak": executed / MFMA_F32_PEAK_TFLOPS}
+                    "traffic": recorded_traffic(args, "gemm_nt_kernel<float, float, 128, 128, 2, 2, 2, 0, false, 8>"),
+                    "traffic_unit": f"HBM-side bytes per launch, averaged over this kernel's launches (PMC, profiles/{TRAFFIC_FILE})",
+                    "launches_per_step": n0 / args.steps, "avg_launch_ms": ms0 / max(n0, 1),
+                    "share_of_step_time": ms0 * 1e-3 / dt2,
+                    "executed_flops_per_step": fl0 / args.steps,
+                    "survey_flop_count_rate_tflops": survey_res5_flops / ((ms0 + ms1) * 1e-3) / 1e12,
+                    "note": "survey_flop_count_rate = SURVEY 8d's direct-convolution FLOP count of Res5 over the "
+                            "GEMM kernels' time; it exceeds the executed rate because the 3x3 convolutions run in "
+                            "the Winograd domain (121 instead of 441 products per tile and channel pair)"}
+            if n1:
+                roof["direct_conv3x3"] = {"launches_per_step": n1 / args.steps, "avg_launch_ms": ms1 / n1,
+                                          "executed_tflops": fl1 / (ms1 * 1e-3) / 1e12}
         else:
             alg_bytes = args.images * 1024 * 50 * 84 * 4 + R_local * 5 * 4 + R_local * 1024 * 14 * 14 * 4
             achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
@@ -298,7 +312,7 @@ def main():
                                    f"similarity GEMM x {args.classes + 1}-row bank ({args.sim_dtype}); forward only",
                        "scope": "S2 (full ROI head incl. Res5)", "images_per_gpu": args.images,
                        "proposals_per_image": args.proposals, "classes": args.classes, "emb_dim": args.dim,
-                       "res5_backend": args.res5,
+                       "res5_backend": args.res5, "res5_conv3x3": args.conv3x3 if args.res5 == "hip" else "miopen",
                        "parallelism": f"image-sharded x{world}, no collective"},
             "scopes": {"S2_full_head_proposals_per_s": props_per_step * args.steps / dt2,
                        "S1_handwritten_kernels_proposals_per_s": props_per_step * args.steps / dt1,

@@ -166,6 +166,42 @@ int locov_conv3x3_nhwc_f32(const float *x, int64_t R, int H, int W, int Cin, int
 int locov_pack_conv3x3_weight(const float *w, int N, int Cin, void *out, int out_dtype,
                               locov_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * a-3  The same 3x3 / pad 1 / stride 1 convolution (BottleneckBlock.conv2 + FrozenBN + ReLU,
+ * roi_emb_heads.py:217-241 applied at :245,:323) on 7x7 POSITION-major tiles, evaluated in
+ * the minimal-filtering (Winograd) domain: each row of 7 outputs is an F(4,3) | F(3,3) pair,
+ * 121 products per (ROI, cin, cout) instead of 361 real taps -> 3x fewer MFMA FLOPs.
+ *   U  = locov_winograd_pack_weight(w [N,Cin,3,3])  -> [121, N, Cin] fp32 (transform in fp64)
+ *   y[(p*R + r), n] = relu?( conv(x)[..] * scale[n] + shift[n] ),  x rows [(p*R + r), Cin], p = y*7+x
+ *   workspace: locov_winograd_workspace_bytes(R, Cin, N) bytes of device memory, 16-B aligned
+ *   flags: 0 or LOCOV_EPI_RELU.  Cin % 32 == 0, N % 4 == 0.
+ * fp32 throughout; differs from the direct form by rounding only (~5e-6 of the activation
+ * range over the whole stage; the 1e-4 logits gate holds, tests/test_gpu_winograd.py).
+ * locov_gemm_nt_batched_f32 is the batched NT GEMM it runs on: problem b uses
+ * x + b*stride_x, W + b*stride_w ([N,K] rows of K), y + b*stride_y (elements).
+ * ------------------------------------------------------------------------------------- */
+int64_t locov_winograd_workspace_bytes(int64_t R, int Cin, int N);
+
+int locov_winograd_pack_weight(const float *w, int N, int Cin, float *U, locov_stream_t stream);
+
+int locov_winograd_conv3x3_f32(const float *x, int64_t R, int Cin, const float *U,
+                               const float *scale, const float *shift, float *y, int N,
+                               unsigned flags, void *workspace, int64_t workspace_bytes,
+                               locov_stream_t stream);
+
+int locov_gemm_nt_batched_f32(const float *x, int64_t lda, int64_t stride_x, const float *W,
+                              int64_t stride_w, float *y, int64_t ldc, int64_t stride_y,
+                              int64_t M, int N, int K, int batch, locov_stream_t stream);
+
+/* Measurement aid (bench.py's roofline block): while enabled, every GEMM-kernel launch made by
+ * this library is bracketed by HIP events on its launch stream.  read() waits for them and
+ * returns, for one kernel class, the number of launches, the sum of their durations (ms) and
+ * the FLOPs they executed.  cls: 0 = gemm_nt_kernel<128x128, plain / batched> (1x1 convs, FCs,
+ * Winograd-domain GEMMs), 1 = the position-major direct 3x3 conv, 2 = the other tile shapes.
+ * enable(on) clears what was recorded. */
+int locov_gemm_timing_enable(int on);
+int locov_gemm_timing_read(int cls, int64_t *launches, double *ms, double *flops);
+
 int locov_frozen_bn_fold(const float *weight, const float *bias, const float *running_mean,
                          const float *running_var, float eps, int C, float *scale, float *shift,
                          locov_stream_t stream);

@@ -45,6 +45,13 @@ SIGNATURES = {
     "locov_conv3x3_nhwc_f32": (c_int, [_p, c_int64, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, c_int, c_uint,
                                        _p]),
     "locov_pack_conv3x3_weight": (c_int, [_p, c_int, c_int, _p, c_int, _p]),
+    "locov_winograd_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "locov_winograd_pack_weight": (c_int, [_p, c_int, c_int, _p, _p]),
+    "locov_winograd_conv3x3_f32": (c_int, [_p, c_int64, c_int, _p, _p, _p, _p, c_int, c_uint, _p, c_int64, _p]),
+    "locov_gemm_nt_batched_f32": (c_int, [_p, c_int64, c_int64, _p, c_int64, _p, c_int64, c_int64, c_int64, c_int,
+                                          c_int, c_int, _p]),
+    "locov_gemm_timing_enable": (c_int, [c_int]),
+    "locov_gemm_timing_read": (c_int, [c_int, _p, _p, _p]),
     "locov_frozen_bn_fold": (c_int, [_p, _p, _p, _p, c_float, c_int, _p, _p, _p]),
     "locov_nms_workspace_bytes": (c_int64, [c_int64]),
     "locov_nms_sorted": (c_int, [_p, c_int64, c_float, _p, _p, _p, _p]),

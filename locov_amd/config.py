@@ -110,6 +110,7 @@ def get_cfg() -> CfgNode:
                 "SIM_GEMM_DTYPE": "fp32",
                 # extension: "hip" = hand-written channels-last MFMA GEMM Res5, "miopen" = torch conv2d
                 "RES5_BACKEND": "hip",
+                "RES5_CONV3X3": "winograd",
             },
             "RESNETS": {
                 "NUM_GROUPS": 1, "WIDTH_PER_GROUP": 64, "RES2_OUT_CHANNELS": 256,

@@ -14,13 +14,22 @@ struct Epilogue {
 // H == 0: plain GEMM.  H > 0: A is the pixel matrix of independent HxW tiles with Cin channels
 // and the GEMM is the implicit form of a 3x3 / pad 1 / stride 1 convolution (K = 9*Cin).
 // R > 0 additionally says the rows are POSITION-major ([H*W][R] instead of [R][H*W]).
+// group: ROI blocks per lock-step tile group of the position-major convolution (0 = default).
 struct ConvGeom {
-    int H, W, Cin, R;
+    int H, W, Cin, R, group;
+};
+
+// count > 1: `count` independent GEMMs of the same shape in one launch; problem b uses
+// A + b*sa, B + b*sb, C + b*sc (elements).  Plain GEMM only (no conv geometry, no residual).
+struct Batch {
+    int count;
+    int64_t sa, sb, sc;
 };
 
 // y[M,N] = epi(A[M,K] . B[N,K]^T); T = float (f32 MFMA) or __bf16 (bf16 MFMA, fp32 accumulate)
 template <typename T, typename TOut>
 int launch_gemm_nt(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C, int64_t ldc, int64_t M, int N, int K,
-                   const Epilogue &epi, hipStream_t s, const char *what, const ConvGeom &cg = ConvGeom{0, 0, 0, 0});
+                   const Epilogue &epi, hipStream_t s, const char *what, const ConvGeom &cg = ConvGeom{0, 0, 0, 0, 0},
+                   const Batch &bt = Batch{1, 0, 0, 0});
 
 }  // namespace locov

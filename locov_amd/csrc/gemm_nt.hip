@@ -35,8 +35,39 @@
 #include "gemm_nt.h"
 
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 namespace locov {
+
+// Optional per-launch timing of the GEMM kernels (locov_gemm_timing_*): HIP events recorded on the
+// launch stream right around each kernel, so that a caller (bench.py) gets the kernels' own
+// durations and FLOP counts over its timed region without a profiler attached.
+struct TimingRec {
+    hipEvent_t e0, e1;
+    int cls;
+    double flops;
+};
+static std::mutex g_timing_mutex;
+static bool g_timing_on = false;
+static std::vector<TimingRec> g_timing;
+
+static int timing_begin(hipStream_t s, int cls, double flops)
+{
+    std::lock_guard<std::mutex> lock(g_timing_mutex);
+    if (!g_timing_on) return -1;
+    TimingRec r{nullptr, nullptr, cls, flops};
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
+    (void)hipEventRecord(r.e0, s);
+    g_timing.push_back(r);
+    return (int)g_timing.size() - 1;
+}
+static void timing_end(int idx, hipStream_t s)
+{
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lock(g_timing_mutex);
+    if (idx < (int)g_timing.size()) (void)hipEventRecord(g_timing[idx].e1, s);
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -95,7 +126,7 @@ template <typename T, typename TOut, int BM, int BN, int WM, int WN, int OCC, in
 __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__restrict__ A, int64_t lda,
                                                                     const T *__restrict__ B, int64_t ldb,
                                                                     TOut *__restrict__ Cout, int64_t ldc, int64_t M_,
-                                                                    int N, int K_, Epilogue epi, ConvGeom cg)
+                                                                    int N, int K_, Epilogue epi, ConvGeom cg, Batch bt)
 {
     constexpr bool CONV3 = CONV == 1;     // ROI-major: per-row tap masks
     constexpr bool CONVP = CONV == 2;     // position-major: per-workgroup tap list
@@ -119,19 +150,38 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
 
     const int tiles_n = (N + BN - 1) / BN;
     const int nwg = gridDim.x;
-    const int tile = xcd_remap(blockIdx.x, nwg);
+    int tile = xcd_remap(blockIdx.x, nwg);
+    if (CONV == 0 && bt.count > 1) {
+        // batched: consecutive tiles (one XCD's run) belong to the same problem and share its B in L2
+        const int per = nwg / bt.count, b = tile / per;
+        tile -= b * per;
+        A += b * bt.sa;
+        B += b * bt.sb;
+        Cout += b * bt.sc;
+    }
     int64_t m0 = (int64_t)(tile / tiles_n) * BM;
-    const int n0 = (tile % tiles_n) * BN;
+    int n0 = (tile % tiles_n) * BN;
     int64_t M = M_;
     int K = K_;
     unsigned long long taps = 0;          // CONVP: valid tap ids, 4 bits each, in ascending order
     int64_t pos_stride = 0;               // CONVP: elements between the same ROI at adjacent positions
     if (CONVP) {
-        // M-tile order: ROI block outer, position inner -- consecutive workgroups (same XCD after
-        // the remap) then work on neighbouring positions of the SAME ROIs, whose A rows they share
-        // through the 3x3 window, so those rows are served from that XCD's L2
+        // Tile order: groups of G ROI blocks; inside a group position-outer, then (ROI block, N tile).
+        // The G*tiles_n workgroups of one position have the same tap list, hence the same length:
+        // they start together, stay in step and finish together, so the weight slice they stream
+        // (and, across the N tiles, the A rows) is fetched into the XCD's L2 once per group instead of
+        // once per workgroup.  Positions of a group run back to back on the same XCD, which keeps the
+        // 3x3 window's re-reads of those ROIs' rows close in time (served by the Infinity Cache).
         const int npos = cg.H * cg.W;
-        const int tm = tile / tiles_n, rb = tm / npos, pos = tm - rb * npos;
+        const int nrb = (int)((cg.R + BM - 1) / BM);
+        const int G = cg.group > 0 ? cg.group : 4;
+        const int per_group = G * npos * tiles_n;
+        const int rbg = tile / per_group;
+        const int gsz = min(G, nrb - rbg * G);
+        const int rem = tile - rbg * per_group;
+        const int pos = rem / (gsz * tiles_n), rem2 = rem - pos * (gsz * tiles_n);
+        const int rb = rbg * G + rem2 / tiles_n;
+        n0 = (rem2 % tiles_n) * BN;
         m0 = (int64_t)pos * cg.R + (int64_t)rb * BM;
         M = (int64_t)(pos + 1) * cg.R;                    // rows of this position end here
         const int py = pos / cg.W, px = pos - py * cg.W;
@@ -142,7 +192,7 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
                 taps |= (unsigned long long)t << (4 * nt++);
         }
         K = nt * cg.Cin;                                  // virtual K: only the real taps
-        pos_stride = (int64_t)cg.R * lda;
+                pos_stride = (int64_t)cg.R * lda;
     }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -180,6 +230,11 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
     unsigned ok_mask = 0;                 // bit i: A chunk i is data, bit 16+i: B chunk i is data
     const frag_t zero = {};
 
+    // CONVP: K-tile k0 -> (index into the tap list, first channel); K runs tap-outer, channel-inner
+    auto convp_split = [&](int k0, int &ti, int &kc) {
+        ti = k0 / cg.Cin;
+        kc = k0 - ti * cg.Cin;
+    };
     // Raw 16-byte loads of the K-tile at k0 (nothing here depends on their results); records which
     // chunks are real data.  A ragged K tail is handled per 16-byte chunk (K % E == 0).
     // element offsets of K-tile k0 relative to a row start: into A (aoff) and into B's row (kb)
@@ -187,7 +242,8 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
         aoff = k0;
         kb = k0;
         if (CONVP) {
-            const int ti = k0 / cg.Cin, kc = k0 - ti * cg.Cin;
+            int ti, kc;
+            convp_split(k0, ti, kc);
             const int tap = (int)((taps >> (4 * ti)) & 15u);
             const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
             aoff = (int64_t)(dy * cg.W + dx) * pos_stride + kc;    // same ROI, neighbouring position
@@ -238,7 +294,8 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
             aoff = (int64_t)(dy * cg.W + dx) * lda + (k0 - tap * cg.Cin);
         }
         if (CONVP) {
-            const int ti = k0 / cg.Cin, kc = k0 - ti * cg.Cin;
+            int ti, kc;
+            convp_split(k0, ti, kc);
             const int tap = (int)((taps >> (4 * ti)) & 15u);
             dy = tap / 3 - 1;
             dx = tap - (tap / 3) * 3 - 1;
@@ -530,19 +587,27 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
 
 template <typename T, typename TOut, int BM, int BN, int WM, int WN, int OCC, int BK16 = 8>
 static int launch_cfg(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C, int64_t ldc, int64_t M, int N,
-                      int K, const Epilogue &epi, const ConvGeom &cg, hipStream_t s, const char *what)
+                      int K, const Epilogue &epi, const ConvGeom &cg, const Batch &bt, hipStream_t s, const char *what)
 {
     const bool posm = cg.H > 0 && cg.R > 0;
     const int64_t tiles_m = posm ? (int64_t)cg.H * cg.W * ceil_div(cg.R, BM) : ceil_div(M, BM);
-    const int64_t tiles = tiles_m * ceil_div(N, BN);
+    const int64_t tiles = tiles_m * ceil_div(N, BN) * (bt.count > 1 ? bt.count : 1);
+    if (bt.count > 1 && (cg.H > 0 || epi.residual))
+        return set_error(LOCOV_ERR_UNSUPPORTED, "%s: batched launches are plain GEMMs without residual", what);
     if (tiles > 0x7fffffffLL) return set_error(LOCOV_ERR_INVALID_ARG, "%s: problem too large", what);
+    // timing class: 0 = the 128x128 plain / batched GEMM, 1 = position-major 3x3 conv, 2 = everything else;
+    // FLOPs = what the kernel executes (the position-major conv skips its padding taps)
+    const int tcls = posm ? 1 : (cg.H == 0 && BM == 128 && BN == 128 ? 0 : 2);
+    const double tflops = posm ? 2.0 * cg.R * (3.0 * cg.H - 2) * (3.0 * cg.W - 2) * cg.Cin * N
+                               : 2.0 * (double)M * N * K * (bt.count > 1 ? bt.count : 1);
+    const int trec = timing_begin(s, tcls, tflops);
     constexpr int BK = BK16 * Frag<T>::kPer16B;
     const bool ragged_k = (posm ? cg.Cin : K) % BK != 0;
     const dim3 grid((unsigned)tiles), block(64 * WM * WN);
 #define LOCOV_LAUNCH(CONV, MASKED)                                                                                 \
     hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, OCC, CONV, MASKED, BK16>), grid, block, 0, s, A, lda, B, \
                        ldb, \
-                       C, ldc, M, N, K, epi, cg)
+                       C, ldc, M, N, K, epi, cg, bt)
     if (posm) {
         if (ragged_k) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: Cin must be a multiple of %d", what, BK);
         LOCOV_LAUNCH(2, false);
@@ -554,6 +619,7 @@ static int launch_cfg(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C,
         LOCOV_LAUNCH(0, false);
     }
 #undef LOCOV_LAUNCH
+    timing_end(trec, s);
     return check_launch(what);
 }
 
@@ -569,23 +635,23 @@ static int forced_cfg()
 
 template <typename T, typename TOut>
 int launch_gemm_nt(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C, int64_t ldc, int64_t M, int N, int K,
-                   const Epilogue &epi, hipStream_t s, const char *what, const ConvGeom &cg)
+                   const Epilogue &epi, hipStream_t s, const char *what, const ConvGeom &cg, const Batch &bt)
 {
-    if (N <= 32) return launch_cfg<T, TOut, 128, 32, 4, 1, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
+    if (N <= 32) return launch_cfg<T, TOut, 128, 32, 4, 1, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, bt, s, what);
     if (N <= 64 || (N <= 192 && N % 128 != 0 && N % 128 <= 64))
-        return launch_cfg<T, TOut, 128, 64, 4, 1, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
+        return launch_cfg<T, TOut, 128, 64, 4, 1, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, bt, s, what);
     if (forced_cfg() == 1)
-        return launch_cfg<T, TOut, 64, 64, 2, 2, 4>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
+        return launch_cfg<T, TOut, 64, 64, 2, 2, 4>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, bt, s, what);
     if (forced_cfg() == 3)   // 8 waves per workgroup (64x32 per wave): 4 waves per SIMD with two resident workgroups
-        return launch_cfg<T, TOut, 128, 128, 2, 4, 4>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
+        return launch_cfg<T, TOut, 128, 128, 2, 4, 4>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, bt, s, what);
     if (forced_cfg() == 2)   // deep tile: BK = 64 (f32) / 128 (bf16), 136 KiB LDS, one workgroup per CU
-        return launch_cfg<T, TOut, 128, 128, 2, 2, 1, 16>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
-    return launch_cfg<T, TOut, 128, 128, 2, 2, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, s, what);
+        return launch_cfg<T, TOut, 128, 128, 2, 2, 1, 16>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, bt, s, what);
+    return launch_cfg<T, TOut, 128, 128, 2, 2, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, bt, s, what);
 }
 
 #define LOCOV_INST(T, TOut)                                                                                        \
     template int launch_gemm_nt<T, TOut>(const T *, int64_t, const T *, int64_t, TOut *, int64_t, int64_t, int, int, \
-                                         const Epilogue &, hipStream_t, const char *, const ConvGeom &);
+                                         const Epilogue &, hipStream_t, const char *, const ConvGeom &, const Batch &);
 LOCOV_INST(float, float)
 LOCOV_INST(__bf16, float)
 LOCOV_INST(__bf16, __bf16)
@@ -640,6 +706,37 @@ int locov_gemm_nt_f32(const float *x, int64_t lda, const float *W, const float *
                                         "locov_gemm_nt_f32");
 }
 
+int locov_gemm_timing_enable(int on)
+{
+    std::lock_guard<std::mutex> lock(g_timing_mutex);
+    for (auto &r : g_timing) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_timing.clear();
+    g_timing_on = on != 0;
+    return LOCOV_OK;
+}
+
+int locov_gemm_timing_read(int cls, int64_t *launches, double *ms, double *flops)
+{
+    LOCOV_REQUIRE(launches && ms && flops, "locov_gemm_timing_read: null pointer");
+    std::lock_guard<std::mutex> lock(g_timing_mutex);
+    *launches = 0;
+    *ms = 0.0;
+    *flops = 0.0;
+    for (auto &r : g_timing) {
+        if (r.cls != cls) continue;
+        float t = 0.f;
+        if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess)
+            return set_error(LOCOV_ERR_LAUNCH, "locov_gemm_timing_read: event query failed");
+        *launches += 1;
+        *ms += (double)t;
+        *flops += r.flops;
+    }
+    return LOCOV_OK;
+}
+
 int locov_conv3x3_nhwc_f32(const float *x, int64_t R, int H, int W, int Cin, int pos_major, const float *w_packed,
                            const float *scale, const float *shift, const float *residual, float *y, int N,
                            unsigned flags, locov_stream_t stream)
@@ -651,7 +748,8 @@ int locov_conv3x3_nhwc_f32(const float *x, int64_t R, int H, int W, int Cin, int
     LOCOV_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w_packed % 16 == 0, "locov_conv3x3_nhwc_f32: misaligned pointer");
     LOCOV_REQUIRE(R <= 0x7fffffffLL / (H * W), "locov_conv3x3_nhwc_f32: R too large");
     Epilogue epi{scale, shift, residual, flags};
-    ConvGeom cg{H, W, Cin, pos_major ? (int)R : 0};
+    static const int group = [] { const char *e = getenv("LOCOV_CONV_GROUP"); return e ? atoi(e) : 0; }();
+    ConvGeom cg{H, W, Cin, pos_major ? (int)R : 0, group};
     return launch_gemm_nt<float, float>(x, (int64_t)Cin, w_packed, (int64_t)9 * Cin, y, (int64_t)N, R * H * W, N,
                                         9 * Cin, epi, as_stream(stream), "locov_conv3x3_nhwc_f32", cg);
 }

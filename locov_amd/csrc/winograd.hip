@@ -1,0 +1,243 @@
+// 3x3 / pad 1 / stride 1 convolution of 7x7 position-major tiles in the minimal-filtering
+// (Toom-Cook / Winograd) domain -- the Res5 conv2 of [D2-upstream] BottleneckBlock as built by
+// roi_emb_heads.py:217-241 and applied at :245,:323.
+//
+// A row of 7 outputs is split into an F(4,3) and an F(3,3) segment: 11 products per axis, 121 per
+// (input channel, output channel, ROI) instead of the 361 real taps of the direct form (441 with
+// the padding taps), i.e. 3x fewer matrix-core FLOPs for the layer that is 42 % of the stage:
+//
+//   V[f][r][c] = (BT (x) BT) x[.][r][c]          input transform   (HBM-bound, this file)
+//   M[f][r][n] = sum_c V[f][r][c] * U[f][n][c]   121 GEMMs [R,Cin]x[N,Cin]^T in ONE batched launch (gemm_nt.hip)
+//   y[.][r][n] = epi((AT (x) AT) M[.][r][n])     output transform + FrozenBN scale/shift + ReLU
+//
+// with f = fy*11 + fx and U = (G (x) G) w computed once, in fp64, when the weights are packed.
+// BT and AT are small integers (exact in fp32); tables and their derivation: winograd_tables.h /
+// tools/gen_winograd_tables.py.  fp32 error of the whole stage vs the direct form stays ~5e-6 of
+// the activation range (tests/test_gpu_winograd.py; logits gate 1e-4).
+//
+// The transforms keep two channels per lane (8-byte accesses, 512 contiguous bytes per wave and
+// row) so that a 7x7 patch (49 x 2 registers) or the 7x7 accumulators fit without spilling.
+#include "gemm_nt.h"
+#include "winograd_tables.h"
+
+#include <cstdlib>
+
+namespace locov {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+using wino::AT;
+using wino::BT;
+using wino::G;
+using wino::NF;
+
+// w [N, Cin, 3, 3] -> U [NF*NF, N, Cin]
+__global__ __launch_bounds__(256) void wino_pack_weight_kernel(const float *__restrict__ w, int64_t NC,
+                                                               float *__restrict__ U)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    double g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) g[a][b] = (double)w[i * 9 + a * 3 + b];
+#pragma unroll
+    for (int fy = 0; fy < NF; fy++) {
+        double t[3];
+#pragma unroll
+        for (int b = 0; b < 3; b++) t[b] = G[fy][0] * g[0][b] + G[fy][1] * g[1][b] + G[fy][2] * g[2][b];
+#pragma unroll
+        for (int fx = 0; fx < NF; fx++)
+            U[(int64_t)(fy * NF + fx) * NC + i] = (float)(G[fx][0] * t[0] + G[fx][1] * t[1] + G[fx][2] * t[2]);
+    }
+}
+
+// x rows [(y*7+x)*ld_pos + r0 + r][C]  ->  V [NF*NF][Rc][C]
+__global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, int64_t ld_pos, int64_t Rc, int C,
+                                                         float *__restrict__ V)
+{
+    const int c2 = C >> 1;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Rc * c2) return;
+    const int64_t r = t / c2;
+    const int c = (int)(t - r * c2) * 2;
+    const float *src = x + r * C + c;
+    f32x2 d[7][7];
+#pragma unroll
+    for (int y = 0; y < 7; y++)
+#pragma unroll
+        for (int xx = 0; xx < 7; xx++)
+            d[y][xx] = *reinterpret_cast<const f32x2 *>(src + (int64_t)(y * 7 + xx) * ld_pos * C);
+    float *dst = V + r * C + c;
+    const int64_t fstride = Rc * C;
+#pragma unroll
+    for (int fy = 0; fy < NF; fy++) {
+        f32x2 wv[7];
+#pragma unroll
+        for (int xx = 0; xx < 7; xx++) {
+            f32x2 a = {0.f, 0.f};
+#pragma unroll
+            for (int y = 0; y < 7; y++)
+                if (BT[fy][y] != 0.f) a += BT[fy][y] * d[y][xx];
+            wv[xx] = a;
+        }
+#pragma unroll
+        for (int fx = 0; fx < NF; fx++) {
+            f32x2 a = {0.f, 0.f};
+#pragma unroll
+            for (int xx = 0; xx < 7; xx++)
+                if (BT[fx][xx] != 0.f) a += BT[fx][xx] * wv[xx];
+            __builtin_nontemporal_store(a, reinterpret_cast<f32x2 *>(dst + (int64_t)(fy * NF + fx) * fstride));
+        }
+    }
+}
+
+// M [NF*NF][Rc][N]  ->  y rows [(y*7+x)*ld_pos + r0 + r][N] = relu?(acc * scale[n] + shift[n])
+__global__ __launch_bounds__(256) void wino_output_kernel(const float *__restrict__ Mv, int64_t ld_pos, int64_t Rc, int N,
+                                                          const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, int relu,
+                                                          float *__restrict__ y)
+{
+    const int n2 = N >> 1;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Rc * n2) return;
+    const int64_t r = t / n2;
+    const int n = (int)(t - r * n2) * 2;
+    const float *src = Mv + r * N + n;
+    const int64_t fstride = Rc * N;
+    f32x2 acc[7][7];
+#pragma unroll
+    for (int yy = 0; yy < 7; yy++)
+#pragma unroll
+        for (int xx = 0; xx < 7; xx++) acc[yy][xx] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int fy = 0; fy < NF; fy++) {
+        f32x2 m[NF];
+#pragma unroll
+        for (int fx = 0; fx < NF; fx++)
+            m[fx] = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(src + (int64_t)(fy * NF + fx) * fstride));
+        f32x2 tx[7];
+#pragma unroll
+        for (int xx = 0; xx < 7; xx++) {
+            f32x2 a = {0.f, 0.f};
+#pragma unroll
+            for (int fx = 0; fx < NF; fx++)
+                if (AT[xx][fx] != 0.f) a += AT[xx][fx] * m[fx];
+            tx[xx] = a;
+        }
+#pragma unroll
+        for (int yy = 0; yy < 7; yy++)
+            if (AT[yy][fy] != 0.f) {
+#pragma unroll
+                for (int xx = 0; xx < 7; xx++) acc[yy][xx] += AT[yy][fy] * tx[xx];
+            }
+    }
+    f32x2 sc = {1.f, 1.f}, sh = {0.f, 0.f};
+    if (scale) sc = *reinterpret_cast<const f32x2 *>(scale + n);
+    if (shift) sh = *reinterpret_cast<const f32x2 *>(shift + n);
+    float *dst = y + r * N + n;
+#pragma unroll
+    for (int yy = 0; yy < 7; yy++)
+#pragma unroll
+        for (int xx = 0; xx < 7; xx++) {
+            f32x2 v = acc[yy][xx] * sc + sh;
+            if (relu) {
+                v[0] = fmaxf(v[0], 0.f);
+                v[1] = fmaxf(v[1], 0.f);
+            }
+            *reinterpret_cast<f32x2 *>(dst + (int64_t)(yy * 7 + xx) * ld_pos * N) = v;
+        }
+}
+
+// ROIs per pass: the two transform-domain buffers of a pass (121 * chunk * (Cin + N) floats) are
+// sized to stay inside the 256 MB Infinity Cache between the three kernels that produce / consume them.
+static int64_t chunk_rois(int64_t R, int Cin, int N)
+{
+    static const int64_t forced = [] {
+        const char *e = getenv("LOCOV_WINO_CHUNK");
+        return e ? (int64_t)atoll(e) : (int64_t)-1;
+    }();
+    int64_t c = forced >= 0 ? forced : 0;
+    if (c <= 0 || c > R) c = R;
+    (void)Cin;
+    (void)N;
+    return c;
+}
+
+}  // namespace locov
+
+using namespace locov;
+
+extern "C" {
+
+int64_t locov_winograd_workspace_bytes(int64_t R, int Cin, int N)
+{
+    if (R <= 0 || Cin <= 0 || N <= 0) return 0;
+    const int64_t c = chunk_rois(R, Cin, N);
+    return (int64_t)NF * NF * c * ((int64_t)Cin + N) * (int64_t)sizeof(float);
+}
+
+int locov_winograd_pack_weight(const float *w, int N, int Cin, float *U, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(N > 0 && Cin > 0, "locov_winograd_pack_weight: bad shape");
+    LOCOV_REQUIRE(w && U, "locov_winograd_pack_weight: null pointer");
+    const int64_t NC = (int64_t)N * Cin;
+    hipLaunchKernelGGL(wino_pack_weight_kernel, dim3((unsigned)ceil_div(NC, 256)), dim3(256), 0, as_stream(stream), w, NC, U);
+    return check_launch("locov_winograd_pack_weight");
+}
+
+int locov_winograd_conv3x3_f32(const float *x, int64_t R, int Cin, const float *U, const float *scale,
+                               const float *shift, float *y, int N, unsigned flags, void *workspace,
+                               int64_t workspace_bytes, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(R >= 0 && Cin > 0 && N > 0, "locov_winograd_conv3x3_f32: bad shape");
+    if (R == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(x && U && y && workspace, "locov_winograd_conv3x3_f32: null pointer");
+    LOCOV_REQUIRE(Cin % 32 == 0 && N % 4 == 0, "locov_winograd_conv3x3_f32: Cin %% 32 and N %% 4 must be 0 (got %d, %d)",
+                  Cin, N);
+    LOCOV_REQUIRE(((uintptr_t)x | (uintptr_t)U | (uintptr_t)y | (uintptr_t)workspace) % 16 == 0,
+                  "locov_winograd_conv3x3_f32: misaligned pointer");
+    LOCOV_REQUIRE(!(flags & ~(unsigned)LOCOV_EPI_RELU), "locov_winograd_conv3x3_f32: unsupported flags 0x%x", flags);
+    LOCOV_REQUIRE(workspace_bytes >= locov_winograd_workspace_bytes(R, Cin, N),
+                  "locov_winograd_conv3x3_f32: workspace too small (%lld bytes)", (long long)workspace_bytes);
+    const int64_t chunk = chunk_rois(R, Cin, N);
+    float *V = static_cast<float *>(workspace);
+    float *Mv = V + (int64_t)NF * NF * chunk * Cin;
+    hipStream_t s = as_stream(stream);
+    for (int64_t r0 = 0; r0 < R; r0 += chunk) {
+        const int64_t rc = R - r0 < chunk ? R - r0 : chunk;
+        const int64_t tin = rc * (Cin / 2), tout = rc * (N / 2);
+        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(tin, 256)), dim3(256), 0, s, x + r0 * Cin, R, rc, Cin, V);
+        int rcode = check_launch("locov_winograd_conv3x3_f32 (input transform)");
+        if (rcode) return rcode;
+        Epilogue epi{nullptr, nullptr, nullptr, 0u};
+        rcode = launch_gemm_nt<float, float>(V, (int64_t)Cin, U, (int64_t)Cin, Mv, (int64_t)N, rc, N, Cin, epi, s,
+                                             "locov_winograd_conv3x3_f32 (batched GEMM)", ConvGeom{0, 0, 0, 0, 0},
+                                             Batch{NF * NF, rc * Cin, (int64_t)N * Cin, rc * N});
+        if (rcode) return rcode;
+        hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)ceil_div(tout, 256)), dim3(256), 0, s, Mv, R, rc, N, scale, shift,
+                           (flags & LOCOV_EPI_RELU) ? 1 : 0, y + r0 * N);
+        rcode = check_launch("locov_winograd_conv3x3_f32 (output transform)");
+        if (rcode) return rcode;
+    }
+    return LOCOV_OK;
+}
+
+int locov_gemm_nt_batched_f32(const float *x, int64_t lda, int64_t stride_x, const float *W, int64_t stride_w, float *y,
+                              int64_t ldc, int64_t stride_y, int64_t M, int N, int K, int batch, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(M >= 0 && N > 0 && K > 0 && batch > 0, "locov_gemm_nt_batched_f32: bad shape");
+    if (M == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(x && W && y, "locov_gemm_nt_batched_f32: null pointer");
+    LOCOV_REQUIRE(K % 4 == 0 && lda % 4 == 0 && stride_x % 4 == 0 && stride_w % 4 == 0,
+                  "locov_gemm_nt_batched_f32: K, lda and the operand strides must be multiples of 4");
+    LOCOV_REQUIRE(lda >= K && ldc >= N, "locov_gemm_nt_batched_f32: lda < K or ldc < N");
+    LOCOV_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)W % 16 == 0, "locov_gemm_nt_batched_f32: misaligned pointer");
+    Epilogue epi{nullptr, nullptr, nullptr, 0u};
+    return launch_gemm_nt<float, float>(x, lda, W, (int64_t)K, y, ldc, M, N, K, epi, as_stream(stream),
+                                        "locov_gemm_nt_batched_f32", ConvGeom{0, 0, 0, 0, 0},
+                                        Batch{batch, stride_x, stride_w, stride_y});
+}
+
+}  // extern "C"

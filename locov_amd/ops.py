@@ -266,6 +266,62 @@ def pack_conv3x3_weight(w: torch.Tensor, dtype: torch.dtype = torch.float32) -> 
     return out
 
 
+_WINO_WS = {}      # device -> cached transform-domain workspace (grows to the largest request)
+
+
+def winograd_pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """[N,Cin,3,3] -> U [121, N, Cin]: the filter in the F(4,3)|F(3,3) minimal-filtering domain."""
+    w = _dev(w, "w")
+    N, Cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3):
+        raise ValueError("winograd_pack_weight expects [N,Cin,3,3]")
+    out = torch.empty((121, N, Cin), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        check(_lib.load().locov_winograd_pack_weight(_ptr(w), N, Cin, _ptr(out), _stream(w)), "locov_winograd_pack_weight")
+    return out
+
+
+def winograd_conv3x3(x: torch.Tensor, U: torch.Tensor, *, scale=None, shift=None, relu: bool = False) -> torch.Tensor:
+    """3x3 / pad 1 / stride 1 convolution of 7x7 position-major tiles in the Winograd domain.
+    x [49*R, Cin] (row = pos*R + r), U [121, N, Cin] (winograd_pack_weight) -> [49*R, N]."""
+    x = _dev(x, "x")
+    U = _dev(U, "U")
+    M, Cin = x.shape
+    if U.dim() != 3 or U.shape[0] != 121 or U.shape[2] != Cin or M % 49 != 0:
+        raise ValueError("winograd_conv3x3: inconsistent shapes")
+    N, R = U.shape[1], M // 49
+    scale = _dev(scale, "scale") if scale is not None else None
+    shift = _dev(shift, "shift") if shift is not None else None
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    need = int(lib.locov_winograd_workspace_bytes(R, Cin, N))
+    ws = _WINO_WS.get(x.device)
+    if ws is None or ws.numel() < need:
+        ws = None
+        _WINO_WS.pop(x.device, None)
+        ws = _WINO_WS[x.device] = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.locov_winograd_conv3x3_f32(_ptr(x), R, Cin, _ptr(U), _ptr(scale), _ptr(shift), _ptr(y), N,
+                                             _lib.EPI_RELU if relu else 0, _ptr(ws), ws.numel(), _stream(x)),
+              "locov_winograd_conv3x3_f32")
+    return y
+
+
+def gemm_nt_batched(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """x [B,M,K], w [B,N,K] -> [B,M,N] (fp32, one launch)."""
+    x = _dev(x, "x")
+    w = _dev(w, "w")
+    B, M, K = x.shape
+    if w.shape[0] != B or w.shape[2] != K:
+        raise ValueError("gemm_nt_batched: inconsistent shapes")
+    N = w.shape[1]
+    y = torch.empty((B, M, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_gemm_nt_batched_f32(_ptr(x), K, M * K, _ptr(w), N * K, _ptr(y), N, M * N, M, N, K, B,
+                                                    _stream(x)), "locov_gemm_nt_batched_f32")
+    return y
+
+
 def frozen_bn_fold(weight, bias, running_mean, running_var, eps: float = 1e-5):
     """FrozenBatchNorm2d -> per-channel (scale, shift)."""
     weight = _dev(weight, "weight")

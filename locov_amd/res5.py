@@ -117,40 +117,48 @@ class Res5Stage(nn.Sequential):
         return (all(isinstance(c.norm, FrozenBatchNorm2d) for blk in self for c in
                     (blk.conv1, blk.conv2, blk.conv3)) and b0.stride_in_1x1 and all(blk.conv2.groups == 1 for blk in self))
 
-    def _packed(self, conv: Conv2d):
+    def _packed(self, conv: Conv2d, winograd: bool = False):
         """(weight as GEMM operand, scale, shift), re-packed only when a tensor was modified in place or
-        re-assigned (checkpoint load, optimizer step)."""
+        re-assigned (checkpoint load, optimizer step).  winograd: the 3x3 weight in the transform domain."""
         from . import ops
         n = conv.norm
         key = (id(conv), conv.weight.data_ptr(), conv.weight._version, n.weight._version, n.bias._version,
                n.running_mean._version, n.running_var._version, n.weight.data_ptr())
-        hit = self._cache.get(id(conv))
+        slot = (id(conv), winograd)
+        hit = self._cache.get(slot)
         if hit is not None and hit[0] == key:
             return hit[1]
         w = conv.weight.detach()
         if w.shape[2] == 3:
-            wp = ops.pack_conv3x3_weight(w)
+            wp = ops.winograd_pack_weight(w) if winograd else ops.pack_conv3x3_weight(w)
         else:
             wp = w.reshape(w.shape[0], w.shape[1])
         scale, shift = ops.frozen_bn_fold(n.weight, n.bias, n.running_mean, n.running_var, n.eps)
         val = (wp, scale, shift)
-        self._cache[id(conv)] = (key, val)
+        self._cache[slot] = (key, val)
         return val
 
     @torch.no_grad()
-    def forward_rows(self, x0: torch.Tensor, H: int, W: int, pos_major: bool = False) -> torch.Tensor:
+    def forward_rows(self, x0: torch.Tensor, H: int, W: int, pos_major: bool = False,
+                     winograd: bool = True) -> torch.Tensor:
         """Rows are ROI-major (r*H*W + pos) or position-major (pos*R + r); the 1x1 convolutions do not
-        care, the 3x3 one skips its zero-padding taps in the position-major order."""
+        care.  The 3x3 one runs, on 7x7 position-major tiles, in the Winograd domain (121 instead of 361
+        products per tile and channel pair; `winograd=False` keeps the direct implicit GEMM, which skips
+        the zero-padding taps in the position-major order)."""
         from . import ops
         assert self.supports_rows_path(), "forward_rows needs FrozenBN, STRIDE_IN_1X1 and ungrouped convs"
         x = x0
         for blk in self:
             w1, s1, b1 = self._packed(blk.conv1)
-            w2, s2, b2 = self._packed(blk.conv2)
             w3, s3, b3 = self._packed(blk.conv3)
+            c2 = blk.conv2
             y = ops.linear(x, w1, b1, scale=s1, relu=True)                        # 1x1 (+stride via x0) + FBN + ReLU
-            y = ops.conv3x3_nhwc(y, w2, H, W, scale=s2, shift=b2, relu=True,      # 3x3 + FBN + ReLU
-                                 pos_major=pos_major)
+            if winograd and pos_major and H == 7 and W == 7 and c2.in_channels % 32 == 0 and c2.out_channels % 4 == 0:
+                u2, s2, b2 = self._packed(c2, winograd=True)
+                y = ops.winograd_conv3x3(y, u2, scale=s2, shift=b2, relu=True)    # 3x3 + FBN + ReLU
+            else:
+                w2, s2, b2 = self._packed(c2)
+                y = ops.conv3x3_nhwc(y, w2, H, W, scale=s2, shift=b2, relu=True, pos_major=pos_major)
             if blk.shortcut is not None:
                 ws, ss, bs = self._packed(blk.shortcut)
                 sc = ops.linear(x, ws, bs, scale=ss)                              # 1x1 shortcut + FBN

@@ -205,10 +205,11 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
     @configurable
     def __init__(self, *, in_features: List[str], pooler: ROIPooler, res5: nn.Module, box_predictor: nn.Module,
                  mask_head: Optional[nn.Module] = None, output_shape: Optional[int] = 0,
-                 res5_backend: str = "hip", **kwargs):
+                 res5_backend: str = "hip", res5_conv3x3: str = "winograd", **kwargs):
         super().__init__(**kwargs)
-        assert res5_backend in ("hip", "miopen")
+        assert res5_backend in ("hip", "miopen") and res5_conv3x3 in ("winograd", "direct")
         self.res5_backend = res5_backend      # extension: how the Res5 convolutions run (see res5.py)
+        self.res5_conv3x3 = res5_conv3x3      # extension: form of the 3x3 convolutions on the hip backend
         self.in_features = in_features
         self.pooler = pooler
         if isinstance(res5, (list, tuple)):
@@ -239,6 +240,7 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         ret["output_shape"] = out_channels
         box_head = cfg.MODEL.ROI_BOX_HEAD
         ret["res5_backend"] = box_head.get("RES5_BACKEND", "hip") if hasattr(box_head, "get") else "hip"
+        ret["res5_conv3x3"] = box_head.get("RES5_CONV3X3", "winograd") if hasattr(box_head, "get") else "winograd"
         return ret
 
     @classmethod
@@ -274,7 +276,8 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         x0 = ops.roi_align_nhwc(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio,
                                 self.pooler.aligned, bin_stride=2, pos_major=True)
         oh, ow, R, C = x0.shape
-        y = self.res5.forward_rows(x0.view(oh * ow * R, C), oh, ow, pos_major=True)
+        y = self.res5.forward_rows(x0.view(oh * ow * R, C), oh, ow, pos_major=True,
+                                   winograd=self.res5_conv3x3 == "winograd")
         return y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)      # logical [R, C5, oh, ow]
 
     def _pooled_mean(self, box_features: torch.Tensor) -> torch.Tensor:

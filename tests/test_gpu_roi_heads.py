@@ -80,8 +80,12 @@ def test_res5_rows_path_vs_oracle(pkg, oracle):
     np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5)
     # same, position-major rows
     x0p = x[:, :, ::2, ::2].permute(2, 3, 0, 1).reshape(49 * 21, 128).contiguous().cuda()
-    got = res5.forward_rows(x0p, 7, 7, pos_major=True).view(7, 7, 21, out_ch).permute(2, 3, 0, 1).cpu().numpy()
-    np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5)
+    got = res5.forward_rows(x0p, 7, 7, pos_major=True, winograd=False).view(7, 7, 21, out_ch).permute(2, 3, 0, 1)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=2e-5, rtol=1e-5)
+    # same, 3x3 convolutions in the Winograd domain (the default): rounding differs, bounded relative to
+    # the activation range (the logits gate of 1e-4 is checked in the heads tests below)
+    got = res5.forward_rows(x0p, 7, 7, pos_major=True, winograd=True).view(7, 7, 21, out_ch).permute(2, 3, 0, 1)
+    assert np.abs(got.cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max()
 
 
 def _make_heads(pkg, oracle, cfg, k_classes, seed, res5_dims=None):
@@ -118,10 +122,11 @@ def _proposals(pkg, oracle, rng, n_img, r, device="cuda"):
     return out, boxes
 
 
-@pytest.mark.parametrize("backend", ["hip", "miopen"])
+@pytest.mark.parametrize("backend", ["hip", "hip-winograd", "miopen"])
 def test_roi_heads_small_vs_oracle(pkg, oracle, backend):
     cfg = _small_cfg(pkg)
-    cfg.MODEL.ROI_BOX_HEAD.RES5_BACKEND = backend
+    cfg.MODEL.ROI_BOX_HEAD.RES5_BACKEND = backend.split("-")[0]
+    cfg.MODEL.ROI_BOX_HEAD.RES5_CONV3X3 = "winograd" if backend == "hip-winograd" else "direct"
     heads, params, h = _make_heads(pkg, oracle, cfg, 80, 7)
     rng = np.random.default_rng(17)
     feat = rng.standard_normal((2, 128, 50, 84)).astype(np.float32)
@@ -152,10 +157,12 @@ def test_roi_heads_small_vs_oracle(pkg, oracle, backend):
         np.testing.assert_array_equal(inst[i].pred_classes.cpu().numpy(), wc)
 
 
-def test_roi_heads_reference_config_vs_oracle(pkg, oracle):
+@pytest.mark.parametrize("conv3x3", ["winograd", "direct"])
+def test_roi_heads_reference_config_vs_oracle(pkg, oracle, conv3x3):
     """configs/coco_lsm.yaml shapes (config 1 of BASELINE.json, fewer proposals to keep the CPU
     oracle's Res5 within seconds): res4 [2,1024,50,84], Res5 1024->2048, D=768, 80-class bank."""
     cfg = pkg.config.get_cfg()
+    cfg.MODEL.ROI_BOX_HEAD.RES5_CONV3X3 = conv3x3
     cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
     cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED = True
     cfg.MODEL.ROI_HEADS.NAME = "EmbeddingProposalsRes5ROIHeads"
