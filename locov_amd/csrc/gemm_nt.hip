@@ -226,6 +226,35 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
         b_ptr[i] = B + (int64_t)(b_ok[i] ? gn : N - 1) * ldb + ch * E;
     }
 
+    // Fast path addressing: a wave-uniform base (SGPR pair, advanced once per K-tile by scalar adds)
+    // plus a per-lane 32-bit byte offset that never changes -> `global_load ... v_off, s[base]` with no
+    // per-lane pointer arithmetic in the K-loop (the matrix pipe cannot start an MFMA while the
+    // wave's VALU slot is taken by address math).
+    const char *a_base = reinterpret_cast<const char *>(A + m0 * lda);
+    const char *b_base = reinterpret_cast<const char *>(B + (int64_t)n0 * ldb);
+    unsigned a_off[A_CH], b_off[B_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; i++) {
+        const int idx = tid + i * NT, row = idx / BK16, ch = idx % BK16;
+        const int64_t gm = m0 + row;
+        a_off[i] = (unsigned)((((gm < M ? gm : M - 1) - m0) * lda + ch * E) * (int64_t)sizeof(T));
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; i++) {
+        const int idx = tid + i * NT, row = idx / BK16, ch = idx % BK16;
+        const int gn = n0 + row;
+        b_off[i] = (unsigned)(((int64_t)((gn < N ? gn : N - 1) - n0) * ldb + ch * E) * (int64_t)sizeof(T));
+    }
+    // raw buffer loads: descriptor (4 SGPRs) rebuilt from the running base by scalar ops, 32-bit VGPR offset
+    auto ld_a = [&](int i) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a_base), 0, 0xffffffff, 0x00020000);
+        return __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(r, a_off[i], 0, 0));
+    };
+    auto ld_b = [&](int i) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b_base), 0, 0xffffffff, 0x00020000);
+        return __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(r, b_off[i], 0, 0));
+    };
+
     frag_t ra[A_CH], rb[B_CH];
     unsigned ok_mask = 0;                 // bit i: A chunk i is data, bit 16+i: B chunk i is data
     const frag_t zero = {};
@@ -255,10 +284,8 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
         int64_t ao;
         int bo;
         tile_offsets(0, ao, bo);
-#pragma unroll
-        for (int i = 0; i < A_CH; i++) a_ptr[i] += ao;
-#pragma unroll
-        for (int i = 0; i < B_CH; i++) b_ptr[i] += bo;
+        a_base += ao * (int64_t)sizeof(T);
+        b_base += bo * (int64_t)sizeof(T);
     }
 
     auto load_tiles = [&](int k0) {
@@ -271,16 +298,12 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
             const int64_t da = ao1 - ao0;
             const int db = bo1 - bo0;
             k_ptr = k0;
+            a_base += da * (int64_t)sizeof(T);
+            b_base += db * (int64_t)sizeof(T);
 #pragma unroll
-            for (int i = 0; i < A_CH; i++) {
-                a_ptr[i] += da;
-                ra[i] = *reinterpret_cast<const frag_t *>(a_ptr[i]);
-            }
+            for (int i = 0; i < A_CH; i++) ra[i] = ld_a(i);
 #pragma unroll
-            for (int i = 0; i < B_CH; i++) {
-                b_ptr[i] += db;
-                rb[i] = *reinterpret_cast<const frag_t *>(b_ptr[i]);
-            }
+            for (int i = 0; i < B_CH; i++) rb[i] = ld_b(i);
             return;
         }
         ok_mask = 0;
@@ -405,13 +428,12 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
     load_tiles(BK < k_last ? BK : k_last);
     __syncthreads();
     read_frags(0, 0, 0);
-    int s = 0;
     constexpr int NCH = A_CH + B_CH;                        // staging chunks per thread and tile
-    // Fast path: chunks [g0,g1) of the staged tile t+1 go registers -> LDS stage `ws`, their pointers
-    // advance by (da, db) and the refill loads of tile t+2 are issued, each chunk followed by its
+    // Fast path: chunks [g0,g1) of the staged tile t+1 go registers -> LDS stage `ws` and the refill
+    // loads of tile t+2 (a_base / b_base already address it) are issued, each chunk followed by its
     // share of the sub-step's MFMAs (hand-interleaved, so the staging traffic sits evenly in the
     // shadow of the matrix pipe).
-    auto stage_and_mma = [&](int g0, int g1, int ws, int64_t da, int db, int set) {
+    auto stage_and_mma = [&](int g0, int g1, int ws, int set) {
         frag_t *As = lds + ws * STAGE, *Bs = As + BM * LDS16;
         const int n = g1 - g0;
 #pragma unroll
@@ -420,13 +442,11 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
             if (g < A_CH) {
                 const int idx = tid + g * NT;
                 As[(idx / BK16) * LDS16 + idx % BK16] = ra[g];
-                a_ptr[g] += da;
-                ra[g] = *reinterpret_cast<const frag_t *>(a_ptr[g]);
+                ra[g] = ld_a(g);
             } else {
                 const int h = g - A_CH, idx = tid + h * NT;
                 Bs[(idx / BK16) * LDS16 + idx % BK16] = rb[h];
-                b_ptr[h] += db;
-                rb[h] = *reinterpret_cast<const frag_t *>(b_ptr[h]);
+                rb[h] = ld_b(h);
             }
             mma_range(set, (g - g0) * NMFMA / n, (g - g0 + 1) * NMFMA / n);
             __builtin_amdgcn_sched_barrier(0);
@@ -439,17 +459,18 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
     constexpr int SQ = (NCH + 7) / 8;
     static_assert(NQ % 2 == 0 && NQ >= SQ + 2, "sub-step schedule needs room for the staging phases");
 
-    for (int k0 = 0; k0 < k_last; k0 += BK) {               // tile at k0 has a successor
+    // One K-tile that has a successor; `s` = LDS stage it computes from.  Always called with a literal
+    // stage (the loop below is unrolled by two), so every LDS address is a per-lane base register plus
+    // an immediate: no address arithmetic in the loop.
+    auto tile_step = [&](const int s, const int k0) __attribute__((always_inline)) {
         const int kn = k0 + 2 * BK < k_last ? k0 + 2 * BK : k_last;   // tile to prefetch (clamped)
-        int64_t da = 0;
-        int db = 0;
-        if (!MASKED) {
+        if (!MASKED) {                                      // bases now address tile kn (scalar adds only)
             int64_t ao0, ao1;
             int bo0, bo1;
             tile_offsets(k_ptr, ao0, bo0);
             tile_offsets(kn, ao1, bo1);
-            da = ao1 - ao0;
-            db = bo1 - bo0;
+            a_base += (ao1 - ao0) * (int64_t)sizeof(T);
+            b_base += (bo1 - bo0) * (int64_t)sizeof(T);
             k_ptr = kn;
         }
 #pragma unroll
@@ -461,7 +482,7 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
                 __builtin_amdgcn_sched_barrier(0);
                 const int sq = q - (NQ - 1 - SQ);             // staging slot of this sub-step, if any
                 if (!MASKED && sq >= 0) {
-                    stage_and_mma(sq * NCH / SQ, (sq + 1) * NCH / SQ, s ^ 1, da, db, cur);
+                    stage_and_mma(sq * NCH / SQ, (sq + 1) * NCH / SQ, s ^ 1, cur);
                 } else if (MASKED && q == NQ - 2) {
                     store_tiles(s ^ 1);                        // staging registers (tile t+1) -> other stage,
                     load_tiles(kn);                            // then refill them with tile t+2
@@ -483,13 +504,24 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        s ^= 1;
-    }
-    // last tile
+    };
+    auto last_tile = [&](const int s) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        if (q < NQ - 1) read_frags(s, q + 1, (q & 1) ^ 1);
-        mma(q & 1);
+        for (int q = 0; q < NQ; q++) {
+            if (q < NQ - 1) read_frags(s, q + 1, (q & 1) ^ 1);
+            mma(q & 1);
+        }
+    };
+    int k0 = 0;
+    for (; k0 + BK < k_last; k0 += 2 * BK) {
+        tile_step(0, k0);
+        tile_step(1, k0 + BK);
+    }
+    if (k0 < k_last) {
+        tile_step(0, k0);
+        last_tile(1);
+    } else {
+        last_tile(0);
     }
 
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
