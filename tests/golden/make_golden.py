@@ -15,6 +15,8 @@ which imports Detectron2):
         EmbeddingFastRCNNOutputLayers.{forward, forward_cls_prediction,
         set_class_embeddings}                                         (:179-236)
   G4  ovr/modeling/mmss_heads/grounding_head.py  GroundingHead.forward (:92-388)
+  G5  ovr/modeling/meta_arch/distill_mmss_gcnn.py  MultiDistillLoss, MultiDistillLossJS,
+      MultiDistillLossL2 .forward                                     (:211-433)
 
 Detectron2 / fvcore are not installed, so import-time names are satisfied with
 inert stand-ins (below).  The ONLY stand-in whose behaviour reaches a golden
@@ -246,6 +248,34 @@ def main():
         g4[p + "info_names"] = np.array(list(info.keys()))
         g4[p + "info"] = np.array([float(v) for v in info.values()], np.float32)
     np.savez_compressed(os.path.join(OUT, "g4_grounding_head.npz"), **g4)
+
+    # ---- G5: distillation losses over [B,B] cost matrices ---------------------------
+    # (module-scope imports of the meta-arch file are satisfied with inert names; only the three
+    # loss classes, plain torch arithmetic, are executed)
+    _mod("detectron2.modeling.backbone", build_backbone=None)
+    sys.modules["detectron2.modeling"].META_ARCH_REGISTRY = sys.modules["detectron2.utils.registry"].Registry("META_ARCH")
+    sys.modules["detectron2.structures"].ImageList = object
+    _mod("ovr.modeling.language")
+    _mod("ovr.modeling.language.backbone", build_backbone=None)
+    _mod("ovr.modeling.mmss_heads.mmss_heads", build_mmss_heads=None)
+    _mod("ovr.modeling.meta_arch")
+    dm = load("ovr.modeling.meta_arch.distill_mmss_gcnn", "ovr/modeling/meta_arch/distill_mmss_gcnn.py")
+    g5 = {}
+    case = 0
+    for B in (2, 4, 7):
+        for temp in (1.0, 2.5):
+            trans = torch.randn(B, B, generator=g) * 3.0
+            w2r = torch.randn(B, B, generator=g) * 2.0 + 1.0
+            r2w = torch.randn(B, B, generator=g) * 0.5 - 1.0
+            for name in ("MultiDistillLoss", "MultiDistillLossJS", "MultiDistillLossL2"):
+                for tt in (True, False):
+                    mod = getattr(dm, name)(temp, loss_weight=0.7, detach_teacher=True, transformer_teacher=tt)
+                    g5[f"c{case}_{name}_tt{int(tt)}"] = np.float32(mod(trans, w2r, r2w))
+            g5[f"c{case}_trans"], g5[f"c{case}_w2r"], g5[f"c{case}_r2w"] = trans.numpy(), w2r.numpy(), r2w.numpy()
+            g5[f"c{case}_temp"] = np.float32(temp)
+            case += 1
+    g5["num_cases"] = np.int64(case)
+    np.savez_compressed(os.path.join(OUT, "g5_distill_losses.npz"), **g5)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
