@@ -35,6 +35,7 @@
 #include "gemm_nt.h"
 
 #include <cstdlib>
+#include <type_traits>
 #include <mutex>
 #include <vector>
 
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
     constexpr int STAGE = (BM + BN) * LDS16;
     __shared__ frag_t lds[2 * STAGE];
 
+    __builtin_amdgcn_s_setprio(3);
     const int tiles_n = (N + BN - 1) / BN;
     const int nwg = gridDim.x;
     int tile = xcd_remap(blockIdx.x, nwg);
@@ -428,6 +430,12 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
     load_tiles(BK < k_last ? BK : k_last);
     __syncthreads();
     read_frags(0, 0, 0);
+    // The prologue above and the epilogue below run at raised wave priority, the K-loop at the lowest:
+    // a co-resident workgroup that is streaming MFMAs otherwise starves this wave's vector / memory
+    // instructions down to one issue per MFMA slot (measured: a 6k-cycle epilogue stretched to 60k+),
+    // both workgroups then finish together and their MFMA-free phases coincide instead of overlapping
+    // with the partner's matrix work.
+    __builtin_amdgcn_s_setprio(0);
     constexpr int NCH = A_CH + B_CH;                        // staging chunks per thread and tile
     // Fast path: chunks [g0,g1) of the staged tile t+1 go registers -> LDS stage `ws` and the refill
     // loads of tile t+2 (a_base / b_base already address it) are issued, each chunk followed by its
@@ -524,6 +532,7 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
         last_tile(0);
     }
 
+    __builtin_amdgcn_s_setprio(3);
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // Runtime options are wave-uniform and hoisted; residual values of a 32x32 tile are fetched as
     // one batch of 16 independent loads before they are consumed.
@@ -543,44 +552,66 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
         const int c4 = (lane % LPR) * 4, rr = lane / LPR;
         const int n = n0 + wn + c4;
         const bool n_ok = n < N;
-        // residual rows are fetched FIRST (16-byte loads, all in flight) so that their latency sits
-        // under the LDS re-layout below
-        f32x4 res[NIT];
-        if (epi.residual && n_ok) {
-#pragma unroll
-            for (int it = 0; it < NIT; it++) {
-                const int64_t m = m0 + wm + it * RPI + rr;
-                res[it] = *reinterpret_cast<const f32x4 *>(epi.residual + (m < M ? m : M - 1) * ldc + n);
-            }
-        }
-        __syncthreads();                                  // every wave is done reading the last stage
+        // Residual loads and output stores go through raw buffer descriptors based at the tile's first row,
+        // addressed by ONE per-lane 32-bit offset: a co-resident workgroup that streams MFMAs leaves this
+        // wave only one vector-ALU issue per MFMA slot, so every v_* instruction here costs ~64 cycles --
+        // the epilogue must be (nearly) free of vector address arithmetic and compares.
+        //   full tile    : the row step goes into the scalar offset operand (no vector math at all)
+        //   partial tile : the row step is added to the lane offset, so that rows >= M fall outside
+        //                  num_records and the hardware drops the store / zero-fills the load
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int64_t rows_here = M - m0 < BM ? M - m0 : BM;
+        const unsigned nrec = (unsigned)(rows_here * ldc * (int64_t)sizeof(float));
+        const unsigned voff = (unsigned)(((int64_t)(wm + rr) * ldc + n) * (int64_t)sizeof(float));
+        const unsigned vstep = (unsigned)(RPI * ldc * (int64_t)sizeof(float));
+        const __amdgpu_buffer_rsrc_t r_out =
+            __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(Cout) + m0 * ldc, 0, nrec, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(epi.residual ? epi.residual + m0 * ldc : reinterpret_cast<float *>(Cout) + m0 * ldc), 0, nrec,
+            0x00020000);
         float *ep = reinterpret_cast<float *>(lds) + wave * (TM * EPS);
+        auto tail = [&](auto full_tag) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            // residual rows are fetched FIRST (16-byte loads, all in flight) so that their latency sits
+            // under the LDS re-layout below
+            f32x4 res[NIT];
+            if (epi.residual && n_ok) {
 #pragma unroll
-        for (int i = 0; i < MI; i++)
-#pragma unroll
-            for (int j = 0; j < NI; j++)
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPS + j * 32 + (lane & 31)] = acc[i][j][r];
-        __syncthreads();
-        if (n_ok) {
-            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-            if (epi.scale) sc = *reinterpret_cast<const f32x4 *>(epi.scale + n);
-            if (epi.shift) sh = *reinterpret_cast<const f32x4 *>(epi.shift + n);
-#pragma unroll
-            for (int it = 0; it < NIT; it++) {
-                const int row = it * RPI + rr;
-                const int64_t m = m0 + wm + row;
-                f32x4 v = *reinterpret_cast<const f32x4 *>(ep + row * EPS + c4);
-                v = v * sc + sh;
-                if (epi.residual) v += res[it];
-                if (relu) {
-                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                }
-                if (m < M) *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + m * ldc + n) = v;
+                for (int it = 0; it < NIT; it++)
+                    res[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                            r_res, FULL ? voff : voff + it * vstep, FULL ? it * vstep : 0u, 0));
             }
-        }
+            __syncthreads();                              // every wave is done reading the last stage
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int j = 0; j < NI; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPS + j * 32 + (lane & 31)] = acc[i][j][r];
+            __syncthreads();
+            if (n_ok) {
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                if (epi.scale) sc = *reinterpret_cast<const f32x4 *>(epi.scale + n);
+                if (epi.shift) sh = *reinterpret_cast<const f32x4 *>(epi.shift + n);
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(ep + (it * RPI + rr) * EPS + c4);
+                    v = v * sc + sh;
+                    if (epi.residual) v += res[it];
+                    if (relu) {
+                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                        v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, FULL ? voff : voff + it * vstep,
+                                                           FULL ? it * vstep : 0u, 0);
+                }
+            }
+        };
+        if (rows_here == BM)
+            tail(std::true_type{});
+        else
+            tail(std::false_type{});
         return;
     }
 
@@ -617,6 +648,13 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
     }
 }
 
+// developer experiment: extra dynamic LDS per workgroup (lowers the workgroups-per-CU count)
+static unsigned dyn_lds_dbg()
+{
+    static const unsigned v = [] { const char *e = getenv("LOCOV_GEMM_DYNLDS"); return e ? (unsigned)atoi(e) : 0u; }();
+    return v;
+}
+
 template <typename T, typename TOut, int BM, int BN, int WM, int WN, int OCC, int BK16 = 8>
 static int launch_cfg(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C, int64_t ldc, int64_t M, int N,
                       int K, const Epilogue &epi, const ConvGeom &cg, const Batch &bt, hipStream_t s, const char *what)
@@ -636,8 +674,9 @@ static int launch_cfg(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C,
     constexpr int BK = BK16 * Frag<T>::kPer16B;
     const bool ragged_k = (posm ? cg.Cin : K) % BK != 0;
     const dim3 grid((unsigned)tiles), block(64 * WM * WN);
+
 #define LOCOV_LAUNCH(CONV, MASKED)                                                                                 \
-    hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, OCC, CONV, MASKED, BK16>), grid, block, 0, s, A, lda, B, \
+    hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, OCC, CONV, MASKED, BK16>), grid, block, dyn_lds_dbg(), s, A, lda, B, \
                        ldb, \
                        C, ldc, M, N, K, epi, cg, bt)
     if (posm) {
