@@ -108,10 +108,10 @@ class Workload:
             # channels-last pipeline: even-grid ROIAlign -> Res5 as MFMA GEMMs on pixel rows
             nhwc = ops.nchw_to_nhwc(self.feat)
             # (position-major pixel rows [7,7,R,C]: the 3x3 convs skip their zero-padding taps)
-            x0 = ops.roi_align_nhwc(nhwc, self.rois, 14, 1.0 / 16, 0, True, bin_stride=2, pos_major=True)
-            R = x0.shape[2]
-            y = self.res5.forward_rows(x0.view(49 * R, 1024), 7, 7, pos_major=True,
-                                       winograd=self.args.conv3x3 == "winograd")
+            R = self.rois.shape[0]
+            x0 = self.res5.rows_input(49 * R, self.device)
+            ops.roi_align_nhwc(nhwc, self.rois, 14, 1.0 / 16, 0, True, bin_stride=2, pos_major=True, out=x0)
+            y = self.res5.forward_rows(x0, 7, 7, pos_major=True, winograd=self.args.conv3x3 == "winograd")
             out = self.head(y.view(7, 7, R, 2048), channels_last=2)
         else:
             if timed:

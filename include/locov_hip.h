@@ -122,6 +122,15 @@ int locov_roi_align_nhwc_fwd(const void *feat, int feat_dtype, int N, int H, int
                              int bin_stride, int pos_major, void *out, int out_dtype,
                              locov_stream_t stream);
 
+/* Same, with out_ld elements between consecutive output pixel rows (>= C): lets the rows be a
+ * column block of a wider matrix (Res5 block 0 reads [conv2 output | pooled input] as one
+ * K-concatenated GEMM operand). */
+int locov_roi_align_nhwc_ld_fwd(const void *feat, int feat_dtype, int N, int H, int W, int C,
+                                const float *rois, int64_t R, int pooled_h, int pooled_w,
+                                float spatial_scale, int sampling_ratio, int aligned,
+                                int bin_stride, int pos_major, void *out, int64_t out_ld,
+                                int out_dtype, locov_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * a-4  spatial mean.  Replaces box_features.mean(dim=[2,3])
  * (roi_emb_heads.py:262,344,356).  x [R,C,HW] -> out [R,C].
@@ -173,6 +182,7 @@ int locov_pack_conv3x3_weight(const float *w, int N, int Cin, void *out, int out
  * 121 products per (ROI, cin, cout) instead of 361 real taps -> 3x fewer MFMA FLOPs.
  *   U  = locov_winograd_pack_weight(w [N,Cin,3,3])  -> [121, N, Cin] fp32 (transform in fp64)
  *   y[(p*R + r), n] = relu?( conv(x)[..] * scale[n] + shift[n] ),  x rows [(p*R + r), Cin], p = y*7+x
+ *   ldy: elements between consecutive rows of y (>= N; y may be a column block of a wider matrix)
  *   workspace: locov_winograd_workspace_bytes(R, Cin, N) bytes of device memory, 16-B aligned
  *   flags: 0 or LOCOV_EPI_RELU.  Cin % 32 == 0, N % 4 == 0.
  * fp32 throughout; differs from the direct form by rounding only (~5e-6 of the activation
@@ -185,8 +195,8 @@ int64_t locov_winograd_workspace_bytes(int64_t R, int Cin, int N);
 int locov_winograd_pack_weight(const float *w, int N, int Cin, float *U, locov_stream_t stream);
 
 int locov_winograd_conv3x3_f32(const float *x, int64_t R, int Cin, const float *U,
-                               const float *scale, const float *shift, float *y, int N,
-                               unsigned flags, void *workspace, int64_t workspace_bytes,
+                               const float *scale, const float *shift, float *y, int64_t ldy,
+                               int N, unsigned flags, void *workspace, int64_t workspace_bytes,
                                locov_stream_t stream);
 
 int locov_gemm_nt_batched_f32(const float *x, int64_t lda, int64_t stride_x, const float *W,

@@ -38,6 +38,8 @@ SIGNATURES = {
     "locov_nchw_to_nhwc": (c_int, [_p, c_int, c_int, c_int, c_int, _p, c_int, _p]),
     "locov_roi_align_nhwc_fwd": (c_int, [_p, c_int, c_int, c_int, c_int, c_int, _p, c_int64, c_int, c_int,
                                          c_float, c_int, c_int, c_int, c_int, _p, c_int, _p]),
+    "locov_roi_align_nhwc_ld_fwd": (c_int, [_p, c_int, c_int, c_int, c_int, c_int, _p, c_int64, c_int, c_int,
+                                            c_float, c_int, c_int, c_int, c_int, _p, c_int64, c_int, _p]),
     "locov_roi_align_from_nhwc_fwd": (c_int, [_p, c_int, c_int, c_int, c_int, _p, c_int64, c_int, c_int, c_float,
                                               c_int, c_int, _p, _p]),
     "locov_spatial_mean_fwd": (c_int, [_p, c_int64, c_int, c_int, c_int, _p, _p]),
@@ -47,7 +49,7 @@ SIGNATURES = {
     "locov_pack_conv3x3_weight": (c_int, [_p, c_int, c_int, _p, c_int, _p]),
     "locov_winograd_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
     "locov_winograd_pack_weight": (c_int, [_p, c_int, c_int, _p, _p]),
-    "locov_winograd_conv3x3_f32": (c_int, [_p, c_int64, c_int, _p, _p, _p, _p, c_int, c_uint, _p, c_int64, _p]),
+    "locov_winograd_conv3x3_f32": (c_int, [_p, c_int64, c_int, _p, _p, _p, _p, c_int64, c_int, c_uint, _p, c_int64, _p]),
     "locov_gemm_nt_batched_f32": (c_int, [_p, c_int64, c_int64, _p, c_int64, _p, c_int64, c_int64, c_int64, c_int,
                                           c_int, c_int, _p]),
     "locov_gemm_timing_enable": (c_int, [c_int]),

@@ -65,7 +65,7 @@ template <typename TIn, typename TOut>
 __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
     const TIn *__restrict__ feat, int N, int H, int W, int C, const float *__restrict__ rois, int PH, int PW,
     float scale, int sampling_ratio, int aligned, int bin_stride, int OH, int OW, int pos_major,
-    TOut *__restrict__ out)
+    TOut *__restrict__ out, int64_t out_ld)
 {
     __shared__ AxisSampleN ytab[kMaxAxisN];
     __shared__ AxisSampleN xtab[kMaxAxisN];
@@ -108,8 +108,9 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
     const bool valid_b = b >= 0 && b < N;
     const TIn *img = feat + (int64_t)(valid_b ? b : 0) * H * W * C;
     // ROI-major: out[r][oh][ow][c]; position-major: out[oh][ow][r][c] (R = gridDim.x rows per position)
-    const int64_t ow_stride = pos_major ? (int64_t)gridDim.x * C : (int64_t)C;
-    TOut *orow = pos_major ? out + ((int64_t)oh * OW * gridDim.x + r) * C : out + ((r * OH + oh) * (int64_t)OW) * C;
+    // (out_ld = elements between consecutive pixel rows, >= C: the rows may be a column block of a wider matrix)
+    const int64_t ow_stride = pos_major ? (int64_t)gridDim.x * out_ld : out_ld;
+    TOut *orow = pos_major ? out + ((int64_t)oh * OW * gridDim.x + r) * out_ld : out + ((r * OH + oh) * (int64_t)OW) * out_ld;
     for (int o = threadIdx.x; o < total; o += kNhwcThreads) {
         const int ow = o / c4n;
         const int c = (o - ow * c4n) << 2;
@@ -332,6 +333,16 @@ int locov_roi_align_nhwc_fwd(const void *feat, int feat_dtype, int N, int H, int
                              int64_t R, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
                              int aligned, int bin_stride, int pos_major, void *out, int out_dtype, locov_stream_t stream)
 {
+    return locov_roi_align_nhwc_ld_fwd(feat, feat_dtype, N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale,
+                                       sampling_ratio, aligned, bin_stride, pos_major, out, (int64_t)C, out_dtype, stream);
+}
+
+int locov_roi_align_nhwc_ld_fwd(const void *feat, int feat_dtype, int N, int H, int W, int C, const float *rois,
+                                int64_t R, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                                int aligned, int bin_stride, int pos_major, void *out, int64_t out_ld, int out_dtype,
+                                locov_stream_t stream)
+{
+    LOCOV_REQUIRE(out_ld >= C && out_ld % 4 == 0, "locov_roi_align_nhwc_fwd: out_ld must be >= C and a multiple of 4");
     LOCOV_REQUIRE(R >= 0, "locov_roi_align_nhwc_fwd: R < 0");
     LOCOV_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "locov_roi_align_nhwc_fwd: bad feature shape");
     LOCOV_REQUIRE(pooled_h > 0 && pooled_w > 0, "locov_roi_align_nhwc_fwd: bad pooled size");
@@ -348,7 +359,7 @@ int locov_roi_align_nhwc_fwd(const void *feat, int feat_dtype, int N, int H, int
     hipStream_t s = as_stream(stream);
 #define LOCOV_LAUNCH_NHWC(TI, TO)                                                                                   \
     hipLaunchKernelGGL((roi_align_nhwc_kernel<TI, TO>), grid, dim3(kNhwcThreads), 0, s, (const TI *)feat, N, H, W, C, \
-                       rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, bin_stride, OH, OW, pos_major, (TO *)out)
+                       rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, bin_stride, OH, OW, pos_major, (TO *)out, out_ld)
     if (feat_dtype == LOCOV_F32 && out_dtype == LOCOV_F32) LOCOV_LAUNCH_NHWC(float, float);
     else if (feat_dtype == LOCOV_F32 && out_dtype == LOCOV_BF16) LOCOV_LAUNCH_NHWC(float, __bf16);
     else if (feat_dtype == LOCOV_BF16 && out_dtype == LOCOV_F32) LOCOV_LAUNCH_NHWC(__bf16, float);

@@ -93,11 +93,11 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
     }
 }
 
-// M [NF*NF][Rc][N]  ->  y rows [(y*7+x)*ld_pos + r0 + r][N] = relu?(acc * scale[n] + shift[n])
+// M [NF*NF][Rc][N]  ->  y rows [(y*7+x)*ld_pos + r0 + r] (ldy elements apart) = relu?(acc * scale[n] + shift[n])
 __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restrict__ Mv, int64_t ld_pos, int64_t Rc, int N,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, int relu,
-                                                          float *__restrict__ y)
+                                                          float *__restrict__ y, int64_t ldy)
 {
     const int n2 = N >> 1;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
     f32x2 sc = {1.f, 1.f}, sh = {0.f, 0.f};
     if (scale) sc = *reinterpret_cast<const f32x2 *>(scale + n);
     if (shift) sh = *reinterpret_cast<const f32x2 *>(shift + n);
-    float *dst = y + r * N + n;
+    float *dst = y + r * ldy + n;
 #pragma unroll
     for (int yy = 0; yy < 7; yy++)
 #pragma unroll
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
                 v[0] = fmaxf(v[0], 0.f);
                 v[1] = fmaxf(v[1], 0.f);
             }
-            *reinterpret_cast<f32x2 *>(dst + (int64_t)(yy * 7 + xx) * ld_pos * N) = v;
+            *reinterpret_cast<f32x2 *>(dst + (int64_t)(yy * 7 + xx) * ld_pos * ldy) = v;
         }
 }
 
@@ -188,9 +188,10 @@ int locov_winograd_pack_weight(const float *w, int N, int Cin, float *U, locov_s
 }
 
 int locov_winograd_conv3x3_f32(const float *x, int64_t R, int Cin, const float *U, const float *scale,
-                               const float *shift, float *y, int N, unsigned flags, void *workspace,
+                               const float *shift, float *y, int64_t ldy, int N, unsigned flags, void *workspace,
                                int64_t workspace_bytes, locov_stream_t stream)
 {
+    LOCOV_REQUIRE(ldy >= N && ldy % 2 == 0, "locov_winograd_conv3x3_f32: ldy must be >= N and even");
     LOCOV_REQUIRE(R >= 0 && Cin > 0 && N > 0, "locov_winograd_conv3x3_f32: bad shape");
     if (R == 0) return LOCOV_OK;
     LOCOV_REQUIRE(x && U && y && workspace, "locov_winograd_conv3x3_f32: null pointer");
@@ -217,7 +218,7 @@ int locov_winograd_conv3x3_f32(const float *x, int64_t R, int Cin, const float *
                                              Batch{NF * NF, rc * Cin, (int64_t)N * Cin, rc * N});
         if (rcode) return rcode;
         hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)ceil_div(tout, 256)), dim3(256), 0, s, Mv, R, rc, N, scale, shift,
-                           (flags & LOCOV_EPI_RELU) ? 1 : 0, y + r0 * N);
+                           (flags & LOCOV_EPI_RELU) ? 1 : 0, y + r0 * ldy, ldy);
         rcode = check_launch("locov_winograd_conv3x3_f32 (output transform)");
         if (rcode) return rcode;
     }

@@ -33,6 +33,15 @@ def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _rows(t: torch.Tensor, name: str) -> torch.Tensor:
+    """2-D fp32 device matrix whose rows may be a column block of a wider matrix (stride(1) == 1, any
+    16-byte-aligned row stride); anything else is made contiguous."""
+    if (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[0] > 0
+            and t.stride(1) == 1 and t.stride(0) >= t.shape[1] and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0):
+        return t
+    return _dev(t, name)
+
+
 def _stream(t: torch.Tensor) -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -157,21 +166,32 @@ def nchw_to_nhwc(feat: torch.Tensor, dtype: torch.dtype = torch.float32) -> torc
 
 def roi_align_nhwc(feat: torch.Tensor, rois: torch.Tensor, output_size: int, spatial_scale: float,
                    sampling_ratio: int = 0, aligned: bool = True, bin_stride: int = 1,
-                   out_dtype: torch.dtype = torch.float32, pos_major: bool = False) -> torch.Tensor:
+                   out_dtype: torch.dtype = torch.float32, pos_major: bool = False,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """feat [N,H,W,C] (fp32|bf16) -> [R, o, o, C] with o = ceil(P/bin_stride), or, with pos_major,
-    [o, o, R, C] (position-major pixel rows, the fast layout of the Res5 GEMMs)."""
+    [o, o, R, C] (position-major pixel rows, the fast layout of the Res5 GEMMs).
+    out: optional destination given as the pixel-row matrix [o*o*R, C]; its rows may be a column block
+    of a wider matrix (row stride >= C)."""
     feat = _dev(feat, "feat", None)
     rois = _dev(rois, "rois")
     N, H, W, C = feat.shape
     R = rois.shape[0]
     o = (output_size + bin_stride - 1) // bin_stride
-    out = torch.empty((o, o, R, C) if pos_major else (R, o, o, C), dtype=out_dtype, device=feat.device)
+    ld = C
+    if out is None:
+        out = torch.empty((o, o, R, C) if pos_major else (R, o, o, C), dtype=out_dtype, device=feat.device)
+    else:
+        if (out.dim() != 2 or tuple(out.shape) != (o * o * R, C) or out.dtype != out_dtype or not out.is_cuda
+                or (R and (out.stride(1) != 1 or out.stride(0) < C or out.stride(0) % 4 or out.data_ptr() % 16))):
+            raise ValueError("roi_align_nhwc: out must be a [o*o*R, C] device matrix with unit column stride")
+        ld = out.stride(0) if R else C
     with torch.cuda.device(feat.device):
-        check(_lib.load().locov_roi_align_nhwc_fwd(_ptr(feat), _dtype_code(feat.dtype), N, H, W, C, _ptr(rois), R,
-                                                   output_size, output_size, float(spatial_scale),
-                                                   int(sampling_ratio), int(aligned), int(bin_stride),
-                                                   int(pos_major), _ptr(out), _dtype_code(out_dtype), _stream(feat)),
-              "locov_roi_align_nhwc_fwd")
+        check(_lib.load().locov_roi_align_nhwc_ld_fwd(_ptr(feat), _dtype_code(feat.dtype), N, H, W, C, _ptr(rois), R,
+                                                      output_size, output_size, float(spatial_scale),
+                                                      int(sampling_ratio), int(aligned), int(bin_stride),
+                                                      int(pos_major), _ptr(out), ld, _dtype_code(out_dtype),
+                                                      _stream(feat)),
+              "locov_roi_align_nhwc_ld_fwd")
     return out
 
 
@@ -205,8 +225,8 @@ def spatial_mean(x: torch.Tensor, channels_last=False) -> torch.Tensor:
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
            scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            relu: bool = False) -> torch.Tensor:
-    """y = epi(x . weight^T): fp32 on the f32 MFMA pipe.  x [M,K], weight [N,K]."""
-    x = _dev(x, "x")
+    """y = epi(x . weight^T): fp32 on the f32 MFMA pipe.  x [M,K] (rows may be strided), weight [N,K]."""
+    x = _rows(x, "x")
     weight = _dev(weight, "weight")
     M, K = x.shape
     N = weight.shape[0]
@@ -215,7 +235,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if K % 4 != 0:
         # the kernel stages 16-byte chunks: zero-pad the contraction dim (rows stay 16-byte aligned)
         pad = 4 - K % 4
-        x = torch.nn.functional.pad(x, (0, pad))
+        x = torch.nn.functional.pad(x, (0, pad)).contiguous()
         weight = torch.nn.functional.pad(weight, (0, pad))
         K += pad
     bias = _dev(bias, "bias") if bias is not None else None
@@ -225,7 +245,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         raise ValueError("residual must be [M,N]")
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        check(_lib.load().locov_gemm_nt_f32(_ptr(x), K, _ptr(weight), _ptr(scale), _ptr(bias), _ptr(residual),
+        check(_lib.load().locov_gemm_nt_f32(_ptr(x), x.stride(0) if M else K, _ptr(weight), _ptr(scale), _ptr(bias), _ptr(residual),
                                             _ptr(y), N, M, N, K, _lib.EPI_RELU if relu else 0, _stream(x)),
               "locov_gemm_nt_f32")
     return y
@@ -281,9 +301,11 @@ def winograd_pack_weight(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def winograd_conv3x3(x: torch.Tensor, U: torch.Tensor, *, scale=None, shift=None, relu: bool = False) -> torch.Tensor:
+def winograd_conv3x3(x: torch.Tensor, U: torch.Tensor, *, scale=None, shift=None, relu: bool = False,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """3x3 / pad 1 / stride 1 convolution of 7x7 position-major tiles in the Winograd domain.
-    x [49*R, Cin] (row = pos*R + r), U [121, N, Cin] (winograd_pack_weight) -> [49*R, N]."""
+    x [49*R, Cin] (row = pos*R + r), U [121, N, Cin] (winograd_pack_weight) -> [49*R, N].
+    out: optional [49*R, N] destination whose rows may be a column block of a wider matrix."""
     x = _dev(x, "x")
     U = _dev(U, "U")
     M, Cin = x.shape
@@ -292,7 +314,14 @@ def winograd_conv3x3(x: torch.Tensor, U: torch.Tensor, *, scale=None, shift=None
     N, R = U.shape[1], M // 49
     scale = _dev(scale, "scale") if scale is not None else None
     shift = _dev(shift, "shift") if shift is not None else None
-    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if out is None:
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    else:
+        y = out
+        if (y.dim() != 2 or tuple(y.shape) != (M, N) or y.dtype != torch.float32 or not y.is_cuda
+                or (M and (y.stride(1) != 1 or y.stride(0) < N or y.stride(0) % 2 or y.data_ptr() % 16))):
+            raise ValueError("winograd_conv3x3: out must be a [49*R, N] fp32 device matrix with unit column stride")
+    ldy = y.stride(0) if M else N
     lib = _lib.load()
     need = int(lib.locov_winograd_workspace_bytes(R, Cin, N))
     ws = _WINO_WS.get(x.device)
@@ -301,7 +330,7 @@ def winograd_conv3x3(x: torch.Tensor, U: torch.Tensor, *, scale=None, shift=None
         _WINO_WS.pop(x.device, None)
         ws = _WINO_WS[x.device] = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        check(lib.locov_winograd_conv3x3_f32(_ptr(x), R, Cin, _ptr(U), _ptr(scale), _ptr(shift), _ptr(y), N,
+        check(lib.locov_winograd_conv3x3_f32(_ptr(x), R, Cin, _ptr(U), _ptr(scale), _ptr(shift), _ptr(y), ldy, N,
                                              _lib.EPI_RELU if relu else 0, _ptr(ws), ws.numel(), _stream(x)),
               "locov_winograd_conv3x3_f32")
     return y

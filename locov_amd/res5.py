@@ -138,6 +138,37 @@ class Res5Stage(nn.Sequential):
         self._cache[slot] = (key, val)
         return val
 
+    def _packed_block0_tail(self):
+        """Block 0's conv3 and shortcut as ONE GEMM over the K-concatenated operand [conv2 output | stage
+        input]:  relu(s3*(W3 y) + b3 + ss*(Ws x) + bs) = relu([y | x] . [s3*W3 | ss*Ws]^T + (b3 + bs)).
+        The FrozenBN scales go into the weight rows (the sum of two differently scaled products cannot use
+        the epilogue's single scale).  Returns (Wcat [Cout, mid + Cin], shift)."""
+        b0 = self[0]
+        w3, s3, b3 = self._packed(b0.conv3)
+        ws, ss, bs = self._packed(b0.shortcut)
+        key = (id(w3), id(ws), id(s3), id(ss))
+        hit = self._cache.get("block0_tail")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        wcat = torch.cat([w3 * s3[:, None], ws * ss[:, None]], dim=1).contiguous()
+        val = (wcat, (b3 + bs).contiguous())
+        self._cache["block0_tail"] = (key, val, (w3, ws, s3, ss))      # keep the keyed tensors alive (ids stay unique)
+        return val
+
+    def rows_input(self, M: int, device) -> torch.Tensor:
+        """Destination for the stage input rows [M, Cin] (ROIAlign writes into it).  When block 0 has a
+        projection shortcut it is the right column block of a [M, mid + Cin] matrix whose left block later
+        receives block 0's conv2 output, so that conv3 + shortcut + add + ReLU run as one GEMM with
+        K = mid + Cin (no separate shortcut tensor, no residual read)."""
+        b0 = self[0]
+        cin, mid = b0.conv1.in_channels, b0.conv1.out_channels
+        if b0.shortcut is None or not self.supports_rows_path() or mid % 4 or cin % 4:
+            return torch.empty((M, cin), dtype=torch.float32, device=device)
+        buf = torch.empty((M, mid + cin), dtype=torch.float32, device=device)
+        x0 = buf[:, mid:]
+        x0._locov_cat = buf
+        return x0
+
     @torch.no_grad()
     def forward_rows(self, x0: torch.Tensor, H: int, W: int, pos_major: bool = False,
                      winograd: bool = True) -> torch.Tensor:
@@ -148,12 +179,20 @@ class Res5Stage(nn.Sequential):
         from . import ops
         assert self.supports_rows_path(), "forward_rows needs FrozenBN, STRIDE_IN_1X1 and ungrouped convs"
         x = x0
-        for blk in self:
+        cat = getattr(x0, "_locov_cat", None)            # rows_input(): x0 is the right block of [conv2 out | x0]
+        for bi, blk in enumerate(self):
             w1, s1, b1 = self._packed(blk.conv1)
             w3, s3, b3 = self._packed(blk.conv3)
             c2 = blk.conv2
             y = ops.linear(x, w1, b1, scale=s1, relu=True)                        # 1x1 (+stride via x0) + FBN + ReLU
-            if winograd and pos_major and H == 7 and W == 7 and c2.in_channels % 32 == 0 and c2.out_channels % 4 == 0:
+            use_wino = winograd and pos_major and H == 7 and W == 7 and c2.in_channels % 32 == 0 and c2.out_channels % 4 == 0
+            if use_wino and bi == 0 and cat is not None and blk.shortcut is not None:
+                u2, s2, b2 = self._packed(c2, winograd=True)
+                ops.winograd_conv3x3(y, u2, scale=s2, shift=b2, relu=True, out=cat[:, :c2.out_channels])
+                wcat, bcat = self._packed_block0_tail()
+                x = ops.linear(cat, wcat, bcat, relu=True)                        # conv3 + shortcut + add + ReLU, K-concatenated
+                continue
+            if use_wino:
                 u2, s2, b2 = self._packed(c2, winograd=True)
                 y = ops.winograd_conv3x3(y, u2, scale=s2, shift=b2, relu=True)    # 3x3 + FBN + ReLU
             else:

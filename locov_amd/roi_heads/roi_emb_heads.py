@@ -273,11 +273,13 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         nhwc = ops.nchw_to_nhwc(features[0].detach())
         # position-major pixel rows [oh, ow, R, C]: a GEMM tile then holds one tile position of many
         # ROIs, which lets the 3x3 convolutions skip their zero-padding taps
-        x0 = ops.roi_align_nhwc(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio,
-                                self.pooler.aligned, bin_stride=2, pos_major=True)
-        oh, ow, R, C = x0.shape
-        y = self.res5.forward_rows(x0.view(oh * ow * R, C), oh, ow, pos_major=True,
-                                   winograd=self.res5_conv3x3 == "winograd")
+        oh = ow = P // 2
+        R = rois.shape[0]
+        # (ROIAlign writes straight into the operand block 0's K-concatenated conv3 + shortcut GEMM reads)
+        x0 = self.res5.rows_input(oh * ow * R, nhwc.device)
+        ops.roi_align_nhwc(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned,
+                           bin_stride=2, pos_major=True, out=x0)
+        y = self.res5.forward_rows(x0, oh, ow, pos_major=True, winograd=self.res5_conv3x3 == "winograd")
         return y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)      # logical [R, C5, oh, ow]
 
     def _pooled_mean(self, box_features: torch.Tensor) -> torch.Tensor:

@@ -71,3 +71,42 @@ def test_winograd_pack_weight_is_fp64_transform(ops):
 def test_winograd_empty(ops):
     U = ops.winograd_pack_weight(torch.randn(8, 32, 3, 3).cuda())
     assert ops.winograd_conv3x3(torch.empty(0, 32).cuda(), U).shape == (0, 8)
+
+
+def test_row_strided_operands_and_outputs(ops):
+    """The K-concatenation of Res5 block 0 (res5.Res5Stage.rows_input): ROIAlign and the Winograd conv
+    write column blocks of a wider matrix, the GEMM reads a column block as its A operand."""
+    g = torch.Generator().manual_seed(11)
+    R, C, N = 19, 64, 32
+    feat = torch.randn(2, 20, 24, C, generator=g).cuda()
+    rois = torch.tensor([[i % 2, 8.0 + i, 6.0 + 2 * i, 150.0 + 5 * i, 120.0 + 3 * i] for i in range(R)]).cuda()
+    want = ops.roi_align_nhwc(feat, rois, 14, 1.0 / 16, 0, True, bin_stride=2, pos_major=True).view(49 * R, C)
+    buf = torch.full((49 * R, N + C), 7.0, device="cuda")
+    got = ops.roi_align_nhwc(feat, rois, 14, 1.0 / 16, 0, True, bin_stride=2, pos_major=True, out=buf[:, N:])
+    assert got.data_ptr() == buf[:, N:].data_ptr() and torch.equal(buf[:, N:], want) and bool((buf[:, :N] == 7.0).all())
+    w = torch.randn(N, C, 3, 3, generator=g).cuda() * 0.05
+    U = ops.winograd_pack_weight(w)
+    y_want = ops.winograd_conv3x3(want, U, relu=True)
+    ops.winograd_conv3x3(buf[:, N:], U, relu=True, out=buf[:, :N])          # strided input AND output
+    assert torch.equal(buf[:, :N], y_want) and torch.equal(buf[:, N:], want)
+    wl = torch.randn(40, C, generator=g).cuda()
+    assert torch.equal(ops.linear(buf[:, N:], wl), ops.linear(want.contiguous(), wl))
+
+
+def test_block0_k_concatenation_matches_separate_gemms(ops, oracle):
+    from locov_amd.config import get_cfg
+    from locov_amd.res5 import build_res5_block
+    cfg = get_cfg()
+    cfg.MODEL.RESNETS.RES2_OUT_CHANNELS = 32
+    cfg.MODEL.RESNETS.WIDTH_PER_GROUP = 8
+    res5, out_ch = build_res5_block(cfg)
+    res5.load_state_dict(oracle.make_res5_params(3, in_ch=128, mid=64, out_ch=256))
+    res5 = res5.cuda().eval()
+    x = torch.randn(49 * 23, 128, generator=torch.Generator().manual_seed(5)).cuda()
+    plain = res5.forward_rows(x, 7, 7, pos_major=True, winograd=True)
+    x0 = res5.rows_input(49 * 23, x.device)
+    assert x0.stride(0) == 64 + 128
+    x0.copy_(x)
+    fused = res5.forward_rows(x0, 7, 7, pos_major=True, winograd=True)
+    # same arithmetic up to where the FrozenBN scales are applied (weights vs epilogue): rounding-level agreement
+    assert (fused - plain).abs().max().item() <= 1e-5 * plain.abs().max().item()
