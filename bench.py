@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--conv3x3", choices=["winograd", "direct"], default="winograd",
                    help="form of the Res5 3x3 convolutions on the hip backend")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--skip-s1", action="store_true",
+                   help="only the S2 scope (profiling runs: the kernel mix then equals the timed region's)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
     # developer/test knobs: rehearse the multi-process flow on a box with fewer GPUs than ranks
     p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl")
@@ -131,7 +133,7 @@ class Workload:
         return self.head(self.r5_standin)
 
 
-TRAFFIC_FILE = "r01d_pmc_traffic.json"
+TRAFFIC_FILE = "r01e_pmc_traffic.json"
 
 
 def recorded_traffic(args, kernel_key: str):
@@ -261,7 +263,7 @@ def main():
     gemm_plain, gemm_conv = gemm_class(0), gemm_class(1)
     lib.locov_gemm_timing_enable(0)
     dom_ms = float(np.mean([a.elapsed_time(b) for a, b in wl.ev])) if wl.ev else float("nan")
-    dt1 = timed(wl.step_s1, args.steps, args.warmup)
+    dt1 = timed(wl.step_s1, args.steps, args.warmup) if not args.skip_s1 else float("nan")
 
     if rank == 0:
         R_local = args.images * args.proposals
@@ -315,8 +317,8 @@ def main():
                        "res5_backend": args.res5, "res5_conv3x3": args.conv3x3 if args.res5 == "hip" else "miopen",
                        "parallelism": f"image-sharded x{world}, no collective"},
             "scopes": {"S2_full_head_proposals_per_s": props_per_step * args.steps / dt2,
-                       "S1_handwritten_kernels_proposals_per_s": props_per_step * args.steps / dt1,
-                       "S1_ms_per_step": dt1 / args.steps * 1e3},
+                       "S1_handwritten_kernels_proposals_per_s": None if args.skip_s1 else props_per_step * args.steps / dt1,
+                       "S1_ms_per_step": None if args.skip_s1 else dt1 / args.steps * 1e3},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
