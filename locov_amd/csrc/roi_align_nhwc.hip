@@ -12,6 +12,8 @@
 // 14x14 tile, so 3/4 of the pooler's output bytes are never produced.
 #include "common.h"
 
+#include <type_traits>
+
 namespace locov {
 
 struct AxisSampleN {
@@ -213,9 +215,19 @@ __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
     gw = (gw > 0 && valid_b) ? gw : 0;
     const int ny = PH * gh, nx = PW * gw;
     const bool use_lds = ny <= kT2Axis && nx <= kT2Axis;
+    // the tables hold BYTE offsets into the image (row offset for y, pixel offset for x): a tap address is
+    // then two 32-bit adds on top of a wave-uniform buffer descriptor instead of 64-bit multiplies per tap
+    const unsigned ystride = (unsigned)W * C * (unsigned)sizeof(float), xstride = (unsigned)C * (unsigned)sizeof(float);
+    auto as_offsets = [](AxisSampleN a, unsigned stride) {
+        a.lo = (int)((unsigned)a.lo * stride);
+        a.hi = (int)((unsigned)a.hi * stride);
+        return a;
+    };
     if (use_lds) {
-        for (int t = threadIdx.x; t < ny; t += kT2Threads) ytab[t] = axis_sample_n(start_h, bin_h, t / gh, t % gh, gh, H);
-        for (int t = threadIdx.x; t < nx; t += kT2Threads) xtab[t] = axis_sample_n(start_w, bin_w, t / gw, t % gw, gw, W);
+        for (int t = threadIdx.x; t < ny; t += kT2Threads)
+            ytab[t] = as_offsets(axis_sample_n(start_h, bin_h, t / gh, t % gh, gh, H), ystride);
+        for (int t = threadIdx.x; t < nx; t += kT2Threads)
+            xtab[t] = as_offsets(axis_sample_n(start_w, bin_w, t / gw, t % gw, gw, W), xstride);
     }
     __syncthreads();
 
@@ -225,53 +237,85 @@ __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
     const int q = lane % QN, sub = lane / QN;
     const int cq = c0 + 4 * q;
     const bool c_ok = cq < C;                                 // C % 4 == 0: a quad is all-in or all-out
-    const float *img = feat + (int64_t)(valid_b ? b : 0) * H * W * C + (c_ok ? cq : 0);
+    const float *img = feat + (int64_t)(valid_b ? b : 0) * H * W * C;
+    const __amdgpu_buffer_rsrc_t img_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(img), 0, (unsigned)H * ystride, 0x00020000);
+    const unsigned ch_off = (unsigned)(c_ok ? cq : 0) * (unsigned)sizeof(float);
+    auto tap = [&](unsigned off) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(img_rsrc, off, 0, 0));
+    };
     const int ns = gh * gw;                                   // samples per bin
     constexpr int U = 4;                                      // samples in flight per lane (16 x 16-byte loads)
+    const float inv_pw = 1.0f / (float)PW;
+    const int icount = prod > 1 ? prod : 1;
+    const bool count_pow2 = (icount & (icount - 1)) == 0;     // wave-uniform
+    const float inv_count = 1.0f / count;                     // exact when count is a power of two
     for (int g0 = 0; g0 < bins; g0 += 4 * BPW) {
         const int bin = g0 + wave * BPW + sub;
         const bool bin_ok = bin < bins;
-        const int ph = bin_ok ? bin / PW : 0, pw = bin_ok ? bin - (bin / PW) * PW : 0;
+        // bin -> (ph, pw): exact for these small integers, and far cheaper than an integer division
+        const int ph = bin_ok ? (int)(((float)bin + 0.5f) * inv_pw) : 0, pw = bin_ok ? bin - ph * PW : 0;
         float4 acc = {0.f, 0.f, 0.f, 0.f};
         if (bin_ok && c_ok) {
-            // The gather is latency-bound (taps come from L2 / Infinity Cache), so the loads of U
-            // samples are issued back to back before any of them is consumed; the accumulation
-            // below still runs in sample order (iy outer, ix inner), i.e. the oracle's order.
-            for (int s0 = 0; s0 < ns; s0 += U) {
-                float4 v[U][4];
-                float w[U][4];
+            // The gather is latency-bound (taps come from L1 / L2), so the loads of up to U samples are
+            // issued back to back before any of them is consumed; the accumulation still runs in sample
+            // order (iy outer, ix inner), i.e. the oracle's order.  Groups are sized exactly (ns is
+            // uniform per ROI): most ROIs have 1-4 samples per bin and padded groups would spend the
+            // texture-address unit and the vector ALU -- both ~80 % busy here -- on duplicates.
+            int iy = 0, ix = 0;                                  // sample counters (wave-uniform: scalar registers)
+            auto group = [&](auto nu_tag) __attribute__((always_inline)) {
+                constexpr int NU = decltype(nu_tag)::value;
+                float4 v[NU][4];
+                float w[NU][4];
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int sidx = s0 + u < ns ? s0 + u : ns - 1;
-                    const int iy = sidx / gw, ix = sidx - iy * gw;
-                    const AxisSampleN ys = use_lds ? ytab[ph * gh + iy] : axis_sample_n(start_h, bin_h, ph, iy, gh, H);
-                    const AxisSampleN xs = use_lds ? xtab[pw * gw + ix] : axis_sample_n(start_w, bin_w, pw, ix, gw, W);
-                    const float *row_lo = img + (int64_t)ys.lo * W * C, *row_hi = img + (int64_t)ys.hi * W * C;
+                for (int u = 0; u < NU; u++) {
+                    const AxisSampleN ys = use_lds ? ytab[ph * gh + iy]
+                                                   : as_offsets(axis_sample_n(start_h, bin_h, ph, iy, gh, H), ystride);
+                    const AxisSampleN xs = use_lds ? xtab[pw * gw + ix]
+                                                   : as_offsets(axis_sample_n(start_w, bin_w, pw, ix, gw, W), xstride);
+                    const unsigned xlo = (unsigned)xs.lo + ch_off, xhi = (unsigned)xs.hi + ch_off;
                     w[u][0] = ys.wh * xs.wh; w[u][1] = ys.wh * xs.wl; w[u][2] = ys.wl * xs.wh; w[u][3] = ys.wl * xs.wl;
-                    v[u][0] = load4(row_lo + (int64_t)xs.lo * C);
-                    v[u][1] = load4(row_lo + (int64_t)xs.hi * C);
-                    v[u][2] = load4(row_hi + (int64_t)xs.lo * C);
-                    v[u][3] = load4(row_hi + (int64_t)xs.hi * C);
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    if (s0 + u < ns) {
-                        // ((w1*v1 + w2*v2) + w3*v3) + w4*v4, then accumulate -- un-fused (file built
-                        // with -ffp-contract=off)
-                        acc.x = acc.x + (((w[u][0] * v[u][0].x + w[u][1] * v[u][1].x) + w[u][2] * v[u][2].x) + w[u][3] * v[u][3].x);
-                        acc.y = acc.y + (((w[u][0] * v[u][0].y + w[u][1] * v[u][1].y) + w[u][2] * v[u][2].y) + w[u][3] * v[u][3].y);
-                        acc.z = acc.z + (((w[u][0] * v[u][0].z + w[u][1] * v[u][1].z) + w[u][2] * v[u][2].z) + w[u][3] * v[u][3].z);
-                        acc.w = acc.w + (((w[u][0] * v[u][0].w + w[u][1] * v[u][1].w) + w[u][2] * v[u][2].w) + w[u][3] * v[u][3].w);
+                    v[u][0] = tap((unsigned)ys.lo + xlo);
+                    v[u][1] = tap((unsigned)ys.lo + xhi);
+                    v[u][2] = tap((unsigned)ys.hi + xlo);
+                    v[u][3] = tap((unsigned)ys.hi + xhi);
+                    if (++ix == gw) {
+                        ix = 0;
+                        iy++;
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < NU; u++) {
+                    // ((w1*v1 + w2*v2) + w3*v3) + w4*v4, then accumulate -- un-fused (file built
+                    // with -ffp-contract=off)
+                    acc.x = acc.x + (((w[u][0] * v[u][0].x + w[u][1] * v[u][1].x) + w[u][2] * v[u][2].x) + w[u][3] * v[u][3].x);
+                    acc.y = acc.y + (((w[u][0] * v[u][0].y + w[u][1] * v[u][1].y) + w[u][2] * v[u][2].y) + w[u][3] * v[u][3].y);
+                    acc.z = acc.z + (((w[u][0] * v[u][0].z + w[u][1] * v[u][1].z) + w[u][2] * v[u][2].z) + w[u][3] * v[u][3].z);
+                    acc.w = acc.w + (((w[u][0] * v[u][0].w + w[u][1] * v[u][1].w) + w[u][2] * v[u][2].w) + w[u][3] * v[u][3].w);
+                }
+            };
+            int s0 = 0;
+            for (; s0 + U <= ns; s0 += U) group(std::integral_constant<int, U>{});
+            switch (ns - s0) {                                   // wave-uniform remainder, 0..U-1 samples
+            case 3: group(std::integral_constant<int, 3>{}); break;
+            case 2: group(std::integral_constant<int, 2>{}); break;
+            case 1: group(std::integral_constant<int, 1>{}); break;
+            default: break;
             }
         }
         if (bin_ok) {
             float *t = tile + (4 * q) * ts + bin;
-            t[0] = acc.x / count;
-            t[ts] = acc.y / count;
-            t[2 * ts] = acc.z / count;
-            t[3 * ts] = acc.w / count;
+            if (count_pow2) {          // x / 2^k == x * 2^-k bit for bit (both are the correctly rounded quotient)
+                t[0] = acc.x * inv_count;
+                t[ts] = acc.y * inv_count;
+                t[2 * ts] = acc.z * inv_count;
+                t[3 * ts] = acc.w * inv_count;
+            } else {
+                t[0] = acc.x / count;
+                t[ts] = acc.y / count;
+                t[2 * ts] = acc.z / count;
+                t[3 * ts] = acc.w / count;
+            }
         }
     }
     __syncthreads();
