@@ -59,6 +59,18 @@ __device__ __forceinline__ void store4(__bf16 *p, const float4 &v)
     *reinterpret_cast<bf16x4 *>(p) = o;
 }
 
+// one tap = 4 consecutive channels through a raw buffer descriptor (byte offset in a VGPR, base in SGPRs)
+__device__ __forceinline__ float4 tap4(__amdgpu_buffer_rsrc_t r, unsigned off, float *)
+{
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ float4 tap4(__amdgpu_buffer_rsrc_t r, unsigned off, __bf16 *)
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const bf16x4 v = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    return float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
 constexpr int kNhwcThreads = 256;
 constexpr int kMaxAxisN = 1024;
 
@@ -98,36 +110,53 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
     // table of this bin row's y samples and of every (strided) column's x samples
     const int nx = OW * gw;
     const bool use_lds = gh <= kMaxAxisN && nx <= kMaxAxisN;
+    // (the tables hold BYTE offsets into the image -- row offset for y, pixel offset for x -- so that a tap
+    // address is two 32-bit adds on top of a wave-uniform buffer descriptor)
+    const unsigned ystride = (unsigned)W * C * (unsigned)sizeof(TIn), xstride = (unsigned)C * (unsigned)sizeof(TIn);
+    auto as_offsets = [](AxisSampleN a, unsigned stride) {
+        a.lo = (int)((unsigned)a.lo * stride);
+        a.hi = (int)((unsigned)a.hi * stride);
+        return a;
+    };
     if (use_lds) {
-        for (int t = threadIdx.x; t < gh; t += kNhwcThreads) ytab[t] = axis_sample_n(start_h, bin_h, ph, t, gh, H);
+        for (int t = threadIdx.x; t < gh; t += kNhwcThreads)
+            ytab[t] = as_offsets(axis_sample_n(start_h, bin_h, ph, t, gh, H), ystride);
         for (int t = threadIdx.x; t < nx; t += kNhwcThreads)
-            xtab[t] = axis_sample_n(start_w, bin_w, (t / gw) * bin_stride, t % gw, gw, W);
+            xtab[t] = as_offsets(axis_sample_n(start_w, bin_w, (t / gw) * bin_stride, t % gw, gw, W), xstride);
     }
     __syncthreads();
 
     const int c4n = C >> 2;
-    const int total = OW * c4n;
     const bool valid_b = b >= 0 && b < N;
     const TIn *img = feat + (int64_t)(valid_b ? b : 0) * H * W * C;
+    const __amdgpu_buffer_rsrc_t img_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<TIn *>(img), 0, (unsigned)H * ystride, 0x00020000);
     // ROI-major: out[r][oh][ow][c]; position-major: out[oh][ow][r][c] (R = gridDim.x rows per position)
     // (out_ld = elements between consecutive pixel rows, >= C: the rows may be a column block of a wider matrix)
     const int64_t ow_stride = pos_major ? (int64_t)gridDim.x * out_ld : out_ld;
     TOut *orow = pos_major ? out + ((int64_t)oh * OW * gridDim.x + r) * out_ld : out + ((r * OH + oh) * (int64_t)OW) * out_ld;
-    for (int o = threadIdx.x; o < total; o += kNhwcThreads) {
-        const int ow = o / c4n;
-        const int c = (o - ow * c4n) << 2;
+    // (output column, channel quad) of this thread: advanced incrementally, no integer division in the loop
+    int ow = 0, cq = threadIdx.x;
+    while (cq >= c4n) {
+        cq -= c4n;
+        ow++;
+    }
+    for (; ow < OW;) {
+        const int c = cq << 2;
+        const unsigned ch_off = (unsigned)c * (unsigned)sizeof(TIn);
         float4 acc = {0.f, 0.f, 0.f, 0.f};
         if (valid_b) {
             for (int iy = 0; iy < gh; iy++) {
-                const AxisSampleN ys = use_lds ? ytab[iy] : axis_sample_n(start_h, bin_h, ph, iy, gh, H);
-                const TIn *row_lo = img + (int64_t)ys.lo * W * C + c;
-                const TIn *row_hi = img + (int64_t)ys.hi * W * C + c;
+                const AxisSampleN ys = use_lds ? ytab[iy] : as_offsets(axis_sample_n(start_h, bin_h, ph, iy, gh, H), ystride);
+                const unsigned ylo = (unsigned)ys.lo + ch_off, yhi = (unsigned)ys.hi + ch_off;
                 for (int ix = 0; ix < gw; ix++) {
                     const AxisSampleN xs = use_lds ? xtab[ow * gw + ix]
-                                                   : axis_sample_n(start_w, bin_w, ow * bin_stride, ix, gw, W);
+                                                   : as_offsets(axis_sample_n(start_w, bin_w, ow * bin_stride, ix, gw, W), xstride);
                     const float w1 = ys.wh * xs.wh, w2 = ys.wh * xs.wl, w3 = ys.wl * xs.wh, w4 = ys.wl * xs.wl;
-                    const float4 v1 = load4(row_lo + (int64_t)xs.lo * C), v2 = load4(row_lo + (int64_t)xs.hi * C);
-                    const float4 v3 = load4(row_hi + (int64_t)xs.lo * C), v4 = load4(row_hi + (int64_t)xs.hi * C);
+                    const float4 v1 = tap4(img_rsrc, ylo + (unsigned)xs.lo, (TIn *)nullptr);
+                    const float4 v2 = tap4(img_rsrc, ylo + (unsigned)xs.hi, (TIn *)nullptr);
+                    const float4 v3 = tap4(img_rsrc, yhi + (unsigned)xs.lo, (TIn *)nullptr);
+                    const float4 v4 = tap4(img_rsrc, yhi + (unsigned)xs.hi, (TIn *)nullptr);
                     // this file is built with -ffp-contract=off (exact coordinates); the
                     // accumulation asks for FMA explicitly
                     acc.x = fmaf(w4, v4.x, fmaf(w3, v3.x, fmaf(w2, v2.x, fmaf(w1, v1.x, acc.x))));
@@ -139,6 +168,11 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
         }
         acc.x *= inv_count; acc.y *= inv_count; acc.z *= inv_count; acc.w *= inv_count;
         store4(orow + ow * ow_stride + c, acc);
+        cq += kNhwcThreads;
+        while (cq >= c4n) {
+            cq -= c4n;
+            ow++;
+        }
     }
 }
 
@@ -321,8 +355,9 @@ __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
     __syncthreads();
     const int cn = min(kT2Ch, C - c0);
     float *dst = out + (r * C + c0) * (int64_t)bins;
+    const float inv_bins = 1.0f / (float)bins;
     for (int idx = threadIdx.x; idx < cn * bins; idx += kT2Threads) {
-        const int c = idx / bins;
+        const int c = (int)(((float)idx + 0.5f) * inv_bins);       // idx / bins, exact for these sizes (no integer divide)
         dst[idx] = tile[c * ts + (idx - c * bins)];
     }
 }
