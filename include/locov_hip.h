@@ -203,6 +203,22 @@ int locov_gemm_nt_batched_f32(const float *x, int64_t lda, int64_t stride_x, con
                               int64_t stride_w, float *y, int64_t ldc, int64_t stride_y,
                               int64_t M, int N, int K, int batch, locov_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * f-4  Multi-token class scoring of the grounding predictor.  Replaces the part of
+ * GroundingModule.forward after its token_score Linear (box_emb_grounding_head.py:163-225:
+ * per-class padding, masked softmax / hardmax over the tokens, attention-weighted distance).
+ *   sim [R, Ttot]      raw token similarities = emb . token_bank^T (locov_gemm_nt_f32)
+ *   tok_off [K1]       first column of class k in sim;  num_tok [K1] its real token count
+ *                      (0 = no tokens: attention 0, score -0, like the reference's bg row)
+ *   gmin [1]           device scalar: minimum of the reference's padded similarity tensor
+ *   scores [R, K1] = -sum_t att_t * dist_t;   att [R, K1, Tmax] (may be null)
+ *   cosine: dist = (1 - sim)/T with NaN similarities zeroed; else dist = -sim/T.  Tmax <= 32.
+ * ------------------------------------------------------------------------------------- */
+int locov_token_attention_fwd(const float *sim, int64_t R, int Ttot, const int *tok_off,
+                              const int *num_tok, int K1, int Tmax, float temperature,
+                              int cosine, int hardmax, const float *gmin, float *scores,
+                              float *att, locov_stream_t stream);
+
 /* Measurement aid (bench.py's roofline block): while enabled, every GEMM-kernel launch made by
  * this library is bracketed by HIP events on its launch stream.  read() waits for them and
  * returns, for one kernel class, the number of launches, the sum of their durations (ms) and

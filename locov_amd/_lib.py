@@ -59,6 +59,7 @@ SIGNATURES = {
     "locov_nms_sorted": (c_int, [_p, c_int64, c_float, _p, _p, _p, _p]),
     "locov_grounding_fwd": (c_int, [_p, c_int, c_int, c_int, _p, _p, c_float, _p, _p, _p]),
     "locov_grounding_bwd": (c_int, [_p, c_int, c_int, c_int, _p, _p, c_float, _p, _p, _p, _p]),
+    "locov_token_attention_fwd": (c_int, [_p, c_int64, c_int, _p, _p, c_int, c_int, c_float, c_int, c_int, _p, _p, _p, _p]),
     "locov_rownorm_fwd": (c_int, [_p, c_int64, c_int, c_int, c_float, _p, _p]),
     "locov_f32_to_bf16": (c_int, [_p, c_int64, _p, _p]),
     "locov_sim_gemm_bf16": (c_int, [_p, _p, c_int64, c_int, c_int, _p, c_int64, _p]),

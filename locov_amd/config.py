@@ -90,6 +90,15 @@ def get_cfg() -> CfgNode:
                 "SCORE_THRESH_TEST": 0.05,                         # [D2-upstream]
                 "NMS_THRESH_TEST": 0.5,                            # [D2-upstream]
                 "DETACH_CLASS_PREDICTOR": False,                   # config.py:136
+                # read by EmbeddingGroundingFastRCNNOutputLayers.from_config (box_emb_grounding_head.py:355) but
+                # never defined in ovr/config/config.py; defined here so that the predictor can be built
+                "MAX_TOKENS": 8,
+            },
+            "MMSS_HEAD": {
+                "GROUNDING": {                                     # config.py:51-55 (keys the box predictor reads)
+                    "LOCAL_METRIC": "dot", "GLOBAL_METRIC": "aligned_local", "ALIGNMENT": "softmax",
+                    "ALIGNMENT_TEMPERATURE": 10.0,
+                },
             },
             "ROI_BOX_HEAD": {
                 "NAME": "EmbeddingFastRCNNOutputLayers",

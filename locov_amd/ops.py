@@ -523,3 +523,22 @@ def box_head(x: torch.Tensor, emb_w: torch.Tensor, emb_b: torch.Tensor, bbox_w: 
                                              int(norm_mode), int(sim_dtype), _ptr(pooled), _ptr(deltas), _ptr(emb),
                                              _ptr(emb_bf16), _ptr(logits), _stream(x)), "locov_box_head_fwd")
     return pooled, deltas, emb, logits
+
+
+def token_attention(sim: torch.Tensor, tok_off: torch.Tensor, num_tok: torch.Tensor, tmax: int, temperature: float,
+                    gmin: torch.Tensor, cosine: bool = False, hardmax: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Multi-token class scores of the grounding predictor (box_emb_grounding_head.py:163-225).
+    sim [R,Ttot] raw token similarities; tok_off / num_tok [K1] int32; gmin: 1-element device tensor.
+    Returns (scores [R,K1], attention [R,K1,tmax])."""
+    sim = _dev(sim, "sim")
+    tok_off, num_tok = _dev(tok_off, "tok_off", torch.int32), _dev(num_tok, "num_tok", torch.int32)
+    gmin = _dev(gmin.reshape(1), "gmin")
+    R, Ttot = sim.shape
+    K1 = num_tok.numel()
+    scores = torch.empty((R, K1), dtype=torch.float32, device=sim.device)
+    att = torch.empty((R, K1, tmax), dtype=torch.float32, device=sim.device)
+    with torch.cuda.device(sim.device):
+        check(_lib.load().locov_token_attention_fwd(_ptr(sim), R, Ttot, _ptr(tok_off), _ptr(num_tok), K1, int(tmax),
+                                                    float(temperature), int(cosine), int(hardmax), _ptr(gmin),
+                                                    _ptr(scores), _ptr(att), _stream(sim)), "locov_token_attention_fwd")
+    return scores, att

@@ -7,6 +7,7 @@ configs/coco_lsm.yaml then resolves to the MI355X implementation (see INTEGRATIO
 """
 from .box_emb_head import (Box2BoxTransform, EmbeddingFastRCNNOutputLayers, FastRCNNOutputLayers,
                            build_box_predictor, fast_rcnn_inference)
+from .box_emb_grounding_head import EmbeddingGroundingFastRCNNOutputLayers, GroundingModule
 from .roi_emb_heads import (ROI_HEADS_REGISTRY, EmbeddingProposalsRes5ROIHeads, EmbeddingRes5ROIHeads,
                             SampleAllROIHeads, build_roi_heads)
 
@@ -27,6 +28,6 @@ def register_with_detectron2(override: bool = True) -> bool:
     return True
 
 
-__all__ = ["Box2BoxTransform", "EmbeddingFastRCNNOutputLayers", "FastRCNNOutputLayers", "build_box_predictor",
+__all__ = ["Box2BoxTransform", "EmbeddingGroundingFastRCNNOutputLayers", "GroundingModule", "EmbeddingFastRCNNOutputLayers", "FastRCNNOutputLayers", "build_box_predictor",
            "fast_rcnn_inference", "ROI_HEADS_REGISTRY", "EmbeddingProposalsRes5ROIHeads", "EmbeddingRes5ROIHeads",
            "SampleAllROIHeads", "build_roi_heads", "register_with_detectron2"]

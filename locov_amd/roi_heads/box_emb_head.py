@@ -438,9 +438,10 @@ def build_box_predictor(cfg, input_shape):
     predictors = {
         "FastRCNNOutputLayers": FastRCNNOutputLayers,
         "EmbeddingFastRCNNOutputLayers": EmbeddingFastRCNNOutputLayers,
-        # "EmbeddingGroundingFastRCNNOutputLayers": unreachable with the reference's configs
-        # (cfg.MODEL.ROI_HEADS.MAX_TOKENS is never defined)
     }
+    if name == "EmbeddingGroundingFastRCNNOutputLayers":      # SURVEY.md 8f-4 (imported late: it imports this module)
+        from .box_emb_grounding_head import EmbeddingGroundingFastRCNNOutputLayers
+        predictors[name] = EmbeddingGroundingFastRCNNOutputLayers
     if name not in predictors:
         raise KeyError(f"box predictor {name!r} is not part of the LSM ROI-head path")
     return predictors[name](cfg, input_shape)

@@ -17,6 +17,8 @@ which imports Detectron2):
   G4  ovr/modeling/mmss_heads/grounding_head.py  GroundingHead.forward (:92-388)
   G5  ovr/modeling/meta_arch/distill_mmss_gcnn.py  MultiDistillLoss, MultiDistillLossJS,
       MultiDistillLossL2 .forward                                     (:211-433)
+  G6  ovr/modeling/roi_heads/box_emb_grounding_head.py  GroundingModule.set_class_embeddings /
+      .forward (multi-token class scoring)                            (:60-256)
 
 Detectron2 / fvcore are not installed, so import-time names are satisfied with
 inert stand-ins (below).  The ONLY stand-in whose behaviour reaches a golden
@@ -276,6 +278,29 @@ def main():
             case += 1
     g5["num_cases"] = np.int64(case)
     np.savez_compressed(os.path.join(OUT, "g5_distill_losses.npz"), **g5)
+
+    # ---- G6: multi-token grounding predictor ---------------------------------------
+    begh = sys.modules["ovr.modeling.roi_heads.box_emb_grounding_head"]
+    D6, K6, R6 = 48, 9, 37
+    ntok = [1, 3, 2, 5, 1, 4, 2, 1, 3]
+    embs = {k: torch.randn(n, D6, generator=g) * 0.3 for k, n in enumerate(ntok)}
+    img = torch.randn(R6, D6, generator=g)
+    g6 = {"ntok": np.array(ntok, np.int32), "image_emb": img.numpy()}
+    for k, e in embs.items():
+        g6[f"emb{k}"] = e.numpy()
+    for metric, norm in (("dot", False), ("cosine", True)):
+        for align in ("softmax", "hardmax"):
+            for temp in (1.0, 10.0):
+                gm = begh.GroundingModule(D6, K6, 5, local_metric=metric, alignment=align, temperature=temp,
+                                          normalize_emb=norm)
+                gm.set_class_embeddings({k: v.clone() for k, v in embs.items()}, "cpu")
+                x = lm.normalize_vec(img, dim=1) if norm else img       # the predictor normalises before the module (:423-424)
+                scores, att = gm(x)
+                tag = f"{metric}_{align}_t{int(temp)}"
+                g6[tag + "_scores"], g6[tag + "_att"] = scores.detach().numpy(), att.detach().numpy()
+                scores2, _ = gm(x)                                       # second call (num_tok was mutated in place)
+                assert torch.equal(scores, scores2)
+    np.savez_compressed(os.path.join(OUT, "g6_grounding_module.npz"), **g6)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")

@@ -67,3 +67,23 @@ def test_g4_grounding_head(oracle, golden_dir):
             assert abs(losses[str(name)] - float(want)) <= 2e-5, (B, name)
         for name, want in zip(g[p + "info_names"], g[p + "info"]):
             assert info[str(name)] == float(want), (B, name)
+
+
+def _g6_cases():
+    return [(m, a, t) for m in ("dot", "cosine") for a in ("softmax", "hardmax") for t in (1, 10)]
+
+
+def test_g6_grounding_module(oracle, golden_dir):
+    """GroundingModule.forward restatement vs the reference's own outputs (multi-token classes, both
+    metrics and alignments, token-less background row)."""
+    g = _load(golden_dir, "g6_grounding_module.npz")
+    embs = [g[f"emb{k}"] for k in range(len(g["ntok"]))]
+    for metric, align, temp in _g6_cases():
+        cos = metric == "cosine"
+        x = oracle.normalize_vec(g["image_emb"]) if cos else g["image_emb"]
+        toks = [oracle.normalize_vec(e) for e in embs] if cos else embs
+        scores, att = oracle.grounding_module_forward(x, toks, float(temp), cosine=cos, hardmax=align == "hardmax")
+        tag = f"{metric}_{align}_t{temp}"
+        np.testing.assert_allclose(scores, g[tag + "_scores"], atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(att, g[tag + "_att"], atol=2e-6)
+        assert np.all(scores[:, -1] == 0) and np.all(att[:, -1] == 0)        # background row
