@@ -90,8 +90,14 @@ def test_heads_build_from_config_with_reference_surface(lsm_cfg):
     assert bp.num_classes == 65 and tuple(bp.cls_score.weight.shape) == (66, 768)
     assert not bp.cls_score.weight.requires_grad and torch.all(bp.cls_score.bias == 0)
     assert "box_predictor.cls_score.weight" in heads.state_dict()
+    # the multi-token predictor (box_emb_grounding_head.py:259) is built through the same name lookup
+    lsm_cfg.MODEL.ROI_BOX_HEAD.NAME = "EmbeddingGroundingFastRCNNOutputLayers"
+    gp = beh.build_box_predictor(lsm_cfg, 2048)
+    assert type(gp).__name__ == "EmbeddingGroundingFastRCNNOutputLayers" and gp.num_classes is None
+    assert type(gp.cls_score).__name__ == "GroundingModule" and gp.cls_score.temperature == 10.0
+    assert tuple(gp.emb_pred.weight.shape) == (768, 2048) and gp.loss_weight["loss_cls"] == 0.0
     with pytest.raises(KeyError):
-        lsm_cfg.MODEL.ROI_BOX_HEAD.NAME = "EmbeddingGroundingFastRCNNOutputLayers"
+        lsm_cfg.MODEL.ROI_BOX_HEAD.NAME = "NoSuchOutputLayers"
         beh.build_box_predictor(lsm_cfg, 2048)
 
 
