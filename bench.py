@@ -48,6 +48,8 @@ def parse():
     p.add_argument("--res5", choices=["miopen", "hip"], default="hip")
     p.add_argument("--conv3x3", choices=["winograd", "direct"], default="winograd",
                    help="form of the Res5 3x3 convolutions on the hip backend")
+    p.add_argument("--block0", choices=["map", "pooled"], default="map",
+                   help="run Res5 block 0's 1x1 convolutions on the map (before ROIAlign) or on the pooled rows")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--skip-s1", action="store_true",
                    help="only the S2 scope (profiling runs: the kernel mix then equals the timed region's)")
@@ -111,9 +113,14 @@ class Workload:
             nhwc = ops.nchw_to_nhwc(self.feat)
             # (position-major pixel rows [7,7,R,C]: the 3x3 convs skip their zero-padding taps)
             R = self.rois.shape[0]
-            x0 = self.res5.rows_input(49 * R, self.device)
-            ops.roi_align_nhwc(nhwc, self.rois, 14, 1.0 / 16, 0, True, bin_stride=2, pos_major=True, out=x0)
-            y = self.res5.forward_rows(x0, 7, 7, pos_major=True, winograd=self.args.conv3x3 == "winograd")
+            wino = self.args.conv3x3 == "winograd"
+            if self.args.block0 == "map" and self.res5.map_path_pays(R, nhwc.shape[0] * 50 * 84):
+                # block 0's 1x1 convolutions on the map, ROIAlign pools their outputs (Res5Stage.forward_from_map)
+                y = self.res5.forward_from_map(nhwc, self.rois, 14, 1.0 / 16, 0, True, winograd=wino)
+            else:
+                x0 = self.res5.rows_input(49 * R, self.device)
+                ops.roi_align_nhwc(nhwc, self.rois, 14, 1.0 / 16, 0, True, bin_stride=2, pos_major=True, out=x0)
+                y = self.res5.forward_rows(x0, 7, 7, pos_major=True, winograd=wino)
             out = self.head(y.view(7, 7, R, 2048), channels_last=2)
         else:
             if timed:
@@ -315,6 +322,7 @@ def main():
                        "scope": "S2 (full ROI head incl. Res5)", "images_per_gpu": args.images,
                        "proposals_per_image": args.proposals, "classes": args.classes, "emb_dim": args.dim,
                        "res5_backend": args.res5, "res5_conv3x3": args.conv3x3 if args.res5 == "hip" else "miopen",
+                       "res5_block0": args.block0 if args.res5 == "hip" else "miopen",
                        "parallelism": f"image-sharded x{world}, no collective"},
             "scopes": {"S2_full_head_proposals_per_s": props_per_step * args.steps / dt2,
                        "S1_handwritten_kernels_proposals_per_s": None if args.skip_s1 else props_per_step * args.steps / dt1,

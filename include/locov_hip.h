@@ -131,6 +131,22 @@ int locov_roi_align_nhwc_ld_fwd(const void *feat, int feat_dtype, int N, int H, 
                                 int bin_stride, int pos_major, void *out, int64_t out_ld,
                                 int out_dtype, locov_stream_t stream);
 
+/* Same again, for pooling a map that already went through a 1x1 convolution.  ROIAlign is linear, so
+ * W . ROIAlign(F) == ROIAlign(W . F): Res5 block 0's conv1 and projection shortcut (both 1x1, stride 2 ==
+ * the even bins; roi_emb_heads.py:217-241) are applied to the res4 MAP -- once per pixel instead of once
+ * per ROI bin, 12x fewer rows at 1000 proposals per image -- and pooled here.
+ *   feat_ld : elements between consecutive pixels of feat (>= C; the C channels pooled by this call may be
+ *             a column block of a wider per-pixel vector, e.g. [conv1 | shortcut] outputs)
+ *   ch_scale, ch_shift [C] (either may be null), relu: per-channel affine (FrozenBN) + ReLU applied to the
+ *             pooled value, i.e. AFTER the pooling, exactly where the reference applies them. */
+int locov_roi_align_nhwc_affine_fwd(const void *feat, int feat_dtype, int N, int H, int W, int C,
+                                    int64_t feat_ld, const float *rois, int64_t R, int pooled_h,
+                                    int pooled_w, float spatial_scale, int sampling_ratio,
+                                    int aligned, int bin_stride, int pos_major,
+                                    const float *ch_scale, const float *ch_shift, int relu,
+                                    void *out, int64_t out_ld, int out_dtype,
+                                    locov_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * a-4  spatial mean.  Replaces box_features.mean(dim=[2,3])
  * (roi_emb_heads.py:262,344,356).  x [R,C,HW] -> out [R,C].

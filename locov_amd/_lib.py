@@ -40,6 +40,8 @@ SIGNATURES = {
                                          c_float, c_int, c_int, c_int, c_int, _p, c_int, _p]),
     "locov_roi_align_nhwc_ld_fwd": (c_int, [_p, c_int, c_int, c_int, c_int, c_int, _p, c_int64, c_int, c_int,
                                             c_float, c_int, c_int, c_int, c_int, _p, c_int64, c_int, _p]),
+    "locov_roi_align_nhwc_affine_fwd": (c_int, [_p, c_int, c_int, c_int, c_int, c_int, c_int64, _p, c_int64, c_int, c_int,
+                                                c_float, c_int, c_int, c_int, c_int, _p, _p, c_int, _p, c_int64, c_int, _p]),
     "locov_roi_align_from_nhwc_fwd": (c_int, [_p, c_int, c_int, c_int, c_int, _p, c_int64, c_int, c_int, c_float,
                                               c_int, c_int, _p, _p]),
     "locov_spatial_mean_fwd": (c_int, [_p, c_int64, c_int, c_int, c_int, _p, _p]),

@@ -79,8 +79,13 @@ template <typename TIn, typename TOut>
 __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
     const TIn *__restrict__ feat, int N, int H, int W, int C, const float *__restrict__ rois, int PH, int PW,
     float scale, int sampling_ratio, int aligned, int bin_stride, int OH, int OW, int pos_major,
-    TOut *__restrict__ out, int64_t out_ld)
+    TOut *__restrict__ out, int64_t out_ld, int64_t feat_ld, const float *__restrict__ ch_scale,
+    const float *__restrict__ ch_shift, int relu)
 {
+    // feat_ld = elements between consecutive pixels of the map (>= C: the C channels may be a column block
+    // of a wider per-pixel vector).  ch_scale / ch_shift / relu: optional per-channel affine + ReLU applied to
+    // the pooled value -- ROIAlign is linear, so a 1x1 convolution can run on the MAP (once per pixel instead
+    // of once per ROI bin) and its FrozenBN + ReLU are applied here, after the pooling.
     __shared__ AxisSampleN ytab[kMaxAxisN];
     __shared__ AxisSampleN xtab[kMaxAxisN];
 
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
     const bool use_lds = gh <= kMaxAxisN && nx <= kMaxAxisN;
     // (the tables hold BYTE offsets into the image -- row offset for y, pixel offset for x -- so that a tap
     // address is two 32-bit adds on top of a wave-uniform buffer descriptor)
-    const unsigned ystride = (unsigned)W * C * (unsigned)sizeof(TIn), xstride = (unsigned)C * (unsigned)sizeof(TIn);
+    const unsigned xstride = (unsigned)feat_ld * (unsigned)sizeof(TIn), ystride = (unsigned)W * xstride;
     auto as_offsets = [](AxisSampleN a, unsigned stride) {
         a.lo = (int)((unsigned)a.lo * stride);
         a.hi = (int)((unsigned)a.hi * stride);
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
 
     const int c4n = C >> 2;
     const bool valid_b = b >= 0 && b < N;
-    const TIn *img = feat + (int64_t)(valid_b ? b : 0) * H * W * C;
+    const TIn *img = feat + (int64_t)(valid_b ? b : 0) * H * W * feat_ld;
     const __amdgpu_buffer_rsrc_t img_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<TIn *>(img), 0, (unsigned)H * ystride, 0x00020000);
     // ROI-major: out[r][oh][ow][c]; position-major: out[oh][ow][r][c] (R = gridDim.x rows per position)
@@ -167,6 +172,17 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
             }
         }
         acc.x *= inv_count; acc.y *= inv_count; acc.z *= inv_count; acc.w *= inv_count;
+        if (ch_scale) {
+            const float4 sc = *reinterpret_cast<const float4 *>(ch_scale + c);
+            acc.x *= sc.x; acc.y *= sc.y; acc.z *= sc.z; acc.w *= sc.w;
+        }
+        if (ch_shift) {
+            const float4 sh = *reinterpret_cast<const float4 *>(ch_shift + c);
+            acc.x += sh.x; acc.y += sh.y; acc.z += sh.z; acc.w += sh.w;
+        }
+        if (relu) {
+            acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        }
         store4(orow + ow * ow_stride + c, acc);
         cq += kNhwcThreads;
         while (cq >= c4n) {
@@ -421,7 +437,20 @@ int locov_roi_align_nhwc_ld_fwd(const void *feat, int feat_dtype, int N, int H, 
                                 int aligned, int bin_stride, int pos_major, void *out, int64_t out_ld, int out_dtype,
                                 locov_stream_t stream)
 {
+    return locov_roi_align_nhwc_affine_fwd(feat, feat_dtype, N, H, W, C, (int64_t)C, rois, R, pooled_h, pooled_w,
+                                           spatial_scale, sampling_ratio, aligned, bin_stride, pos_major, nullptr, nullptr, 0,
+                                           out, out_ld, out_dtype, stream);
+}
+
+int locov_roi_align_nhwc_affine_fwd(const void *feat, int feat_dtype, int N, int H, int W, int C, int64_t feat_ld,
+                                    const float *rois, int64_t R, int pooled_h, int pooled_w, float spatial_scale,
+                                    int sampling_ratio, int aligned, int bin_stride, int pos_major, const float *ch_scale,
+                                    const float *ch_shift, int relu, void *out, int64_t out_ld, int out_dtype,
+                                    locov_stream_t stream)
+{
     LOCOV_REQUIRE(out_ld >= C && out_ld % 4 == 0, "locov_roi_align_nhwc_fwd: out_ld must be >= C and a multiple of 4");
+    LOCOV_REQUIRE(feat_ld >= C && feat_ld % 4 == 0, "locov_roi_align_nhwc_fwd: feat_ld must be >= C and a multiple of 4");
+    LOCOV_REQUIRE((int64_t)H * W * feat_ld * 4 < 0xffffffffLL, "locov_roi_align_nhwc_fwd: one image must stay below 4 GiB");
     LOCOV_REQUIRE(R >= 0, "locov_roi_align_nhwc_fwd: R < 0");
     LOCOV_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "locov_roi_align_nhwc_fwd: bad feature shape");
     LOCOV_REQUIRE(pooled_h > 0 && pooled_w > 0, "locov_roi_align_nhwc_fwd: bad pooled size");
@@ -438,7 +467,8 @@ int locov_roi_align_nhwc_ld_fwd(const void *feat, int feat_dtype, int N, int H, 
     hipStream_t s = as_stream(stream);
 #define LOCOV_LAUNCH_NHWC(TI, TO)                                                                                   \
     hipLaunchKernelGGL((roi_align_nhwc_kernel<TI, TO>), grid, dim3(kNhwcThreads), 0, s, (const TI *)feat, N, H, W, C, \
-                       rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, bin_stride, OH, OW, pos_major, (TO *)out, out_ld)
+                       rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, bin_stride, OH, OW, pos_major, (TO *)out, out_ld, \
+                       feat_ld, ch_scale, ch_shift, relu)
     if (feat_dtype == LOCOV_F32 && out_dtype == LOCOV_F32) LOCOV_LAUNCH_NHWC(float, float);
     else if (feat_dtype == LOCOV_F32 && out_dtype == LOCOV_BF16) LOCOV_LAUNCH_NHWC(float, __bf16);
     else if (feat_dtype == LOCOV_BF16 && out_dtype == LOCOV_F32) LOCOV_LAUNCH_NHWC(__bf16, float);

@@ -167,14 +167,27 @@ def nchw_to_nhwc(feat: torch.Tensor, dtype: torch.dtype = torch.float32) -> torc
 def roi_align_nhwc(feat: torch.Tensor, rois: torch.Tensor, output_size: int, spatial_scale: float,
                    sampling_ratio: int = 0, aligned: bool = True, bin_stride: int = 1,
                    out_dtype: torch.dtype = torch.float32, pos_major: bool = False,
-                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   out: Optional[torch.Tensor] = None, ch_scale: Optional[torch.Tensor] = None,
+                   ch_shift: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
     """feat [N,H,W,C] (fp32|bf16) -> [R, o, o, C] with o = ceil(P/bin_stride), or, with pos_major,
     [o, o, R, C] (position-major pixel rows, the fast layout of the Res5 GEMMs).
+    feat may be a channel slice of a wider channels-last map (pixel stride > C).
     out: optional destination given as the pixel-row matrix [o*o*R, C]; its rows may be a column block
-    of a wider matrix (row stride >= C)."""
-    feat = _dev(feat, "feat", None)
-    rois = _dev(rois, "rois")
+    of a wider matrix (row stride >= C).
+    ch_scale / ch_shift [C], relu: per-channel affine + ReLU applied to the pooled values."""
+    if not isinstance(feat, torch.Tensor) or feat.dim() != 4:
+        raise ValueError("roi_align_nhwc: feat must be [N,H,W,C]")
     N, H, W, C = feat.shape
+    fld = C
+    if (feat.is_cuda and feat.stride(3) == 1 and feat.stride(2) > C and feat.stride(2) % 4 == 0
+            and feat.stride(1) == W * feat.stride(2) and feat.stride(0) == H * W * feat.stride(2)
+            and feat.data_ptr() % 16 == 0):
+        fld = feat.stride(2)                       # channel slice of a wider map: no copy
+    else:
+        feat = _dev(feat, "feat", None)
+    rois = _dev(rois, "rois")
+    ch_scale = _dev(ch_scale, "ch_scale") if ch_scale is not None else None
+    ch_shift = _dev(ch_shift, "ch_shift") if ch_shift is not None else None
     R = rois.shape[0]
     o = (output_size + bin_stride - 1) // bin_stride
     ld = C
@@ -186,12 +199,12 @@ def roi_align_nhwc(feat: torch.Tensor, rois: torch.Tensor, output_size: int, spa
             raise ValueError("roi_align_nhwc: out must be a [o*o*R, C] device matrix with unit column stride")
         ld = out.stride(0) if R else C
     with torch.cuda.device(feat.device):
-        check(_lib.load().locov_roi_align_nhwc_ld_fwd(_ptr(feat), _dtype_code(feat.dtype), N, H, W, C, _ptr(rois), R,
-                                                      output_size, output_size, float(spatial_scale),
-                                                      int(sampling_ratio), int(aligned), int(bin_stride),
-                                                      int(pos_major), _ptr(out), ld, _dtype_code(out_dtype),
-                                                      _stream(feat)),
-              "locov_roi_align_nhwc_ld_fwd")
+        check(_lib.load().locov_roi_align_nhwc_affine_fwd(_ptr(feat), _dtype_code(feat.dtype), N, H, W, C, fld, _ptr(rois), R,
+                                                          output_size, output_size, float(spatial_scale),
+                                                          int(sampling_ratio), int(aligned), int(bin_stride),
+                                                          int(pos_major), _ptr(ch_scale), _ptr(ch_shift), int(relu),
+                                                          _ptr(out), ld, _dtype_code(out_dtype), _stream(feat)),
+              "locov_roi_align_nhwc_affine_fwd")
     return out
 
 

@@ -275,6 +275,12 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         # ROIs, which lets the 3x3 convolutions skip their zero-padding taps
         oh = ow = P // 2
         R = rois.shape[0]
+        wino = self.res5_conv3x3 == "winograd"
+        if P == 14 and self.res5.map_path_pays(R, nhwc.shape[0] * nhwc.shape[1] * nhwc.shape[2]):
+            # many proposals per image: block 0's 1x1 convolutions run on the map, ROIAlign pools their outputs
+            y = self.res5.forward_from_map(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio,
+                                           self.pooler.aligned, winograd=wino)
+            return y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)
         # (ROIAlign writes straight into the operand block 0's K-concatenated conv3 + shortcut GEMM reads)
         x0 = self.res5.rows_input(oh * ow * R, nhwc.device)
         ops.roi_align_nhwc(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned,
