@@ -29,7 +29,8 @@ json.dump(bench, open(dst("bench.json"), "w"), indent=1)
 shutil.copy(os.path.join(SRC, "stats", "s_kernel_stats.csv"), dst("bench_kernel_stats.csv"))
 cfg = bench["config"]
 workload = {"images": cfg["images_per_gpu"], "proposals": cfg["proposals_per_image"], "classes": cfg["classes"],
-            "dim": cfg["emb_dim"], "res5": cfg["res5_backend"], "conv3x3": cfg["res5_conv3x3"]}
+            "dim": cfg["emb_dim"], "res5": cfg["res5_backend"], "conv3x3": cfg["res5_conv3x3"],
+            "block0": cfg.get("res5_block0", "pooled")}
 
 fetch, write = counters("pmc_fetch"), counters("pmc_write")
 traffic = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and a separate --pmc WRITE_SIZE pass over `python3 bench.py "
