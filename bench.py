@@ -40,7 +40,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--images", type=int, default=4, help="images per GPU per step")
+    p.add_argument("--images", type=int, default=8, help="images per GPU per step (SURVEY.md 8d: N = 8 / GPU)")
     p.add_argument("--proposals", type=int, default=1000)
     p.add_argument("--classes", type=int, default=1203)
     p.add_argument("--dim", type=int, default=768)
@@ -140,7 +140,7 @@ class Workload:
         return self.head(self.r5_standin)
 
 
-TRAFFIC_FILE = "r01f_pmc_traffic.json"
+TRAFFIC_FILE = "r01g_pmc_traffic.json"
 
 
 def recorded_traffic(args, kernel_key: str):
