@@ -72,7 +72,7 @@ __device__ __forceinline__ float4 tap4(__amdgpu_buffer_rsrc_t r, unsigned off, _
 }
 
 constexpr int kNhwcThreads = 256;
-constexpr int kMaxAxisN = 1024;
+constexpr int kMaxAxisN = 192;     // per-axis LDS table entries (7 x up to 27 samples; larger grids are computed on the fly): keeps the kernel at 6+ workgroups per CU
 
 // grid = (R, OH): one workgroup = one ROI x one output row of bins.
 template <typename TIn, typename TOut>
