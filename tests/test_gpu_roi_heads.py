@@ -212,6 +212,36 @@ def test_roi_heads_reference_config_vs_oracle(pkg, oracle, conv3x3):
     assert np.all(scores.cpu().numpy()[:, -1] == 0)          # zero background row
 
 
+def test_heads_take_the_map_path_with_many_proposals(pkg, oracle):
+    """Many proposals per image (49 R >= 3 N H W): EmbeddingProposalsRes5ROIHeads runs block 0's 1x1 convolutions
+    on the map (Res5Stage.forward_from_map); logits gate 1e-4 against the oracle, which pools first."""
+    from locov_amd.structures import Boxes, Instances
+    cfg = _small_cfg(pkg)
+    heads, params, h = _make_heads(pkg, oracle, cfg, 80, 31)
+    rng = np.random.default_rng(31)
+    feat = rng.standard_normal((2, 128, 20, 30)).astype(np.float32)              # a 480 x 320 image at stride 16
+    boxes = [oracle.synth_boxes(rng, 300, 480.0, 320.0), oracle.synth_boxes(rng, 260, 480.0, 320.0)]
+    assert heads.res5.map_path_pays(560, 2 * 20 * 30)
+    calls = []
+    orig = heads.res5.forward_from_map
+    heads.res5.forward_from_map = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    props = []
+    for b in boxes:
+        inst = Instances((320, 480))
+        inst.proposal_boxes = Boxes(torch.from_numpy(b).cuda())
+        inst.objectness_logits = torch.zeros(len(b), device="cuda")
+        props.append(inst)
+    want = oracle.roi_head_forward(feat, boxes, params, h)
+    with torch.no_grad():
+        bf = heads._shared_roi_transform([dev(feat)], [p.proposal_boxes for p in props])
+        scores, deltas = heads.box_predictor(heads._pooled_mean(bf))
+    assert calls, "the map path was not taken"
+    assert tuple(bf.shape) == (560, 256, 7, 7)
+    assert np.abs(bf.cpu().numpy() - want["res5"]).max() <= 2e-5 * np.abs(want["res5"]).max()
+    assert np.abs(scores.cpu().numpy() - want["scores"]).max() <= 1e-4
+    np.testing.assert_allclose(deltas.cpu().numpy(), want["deltas"], atol=1e-5)
+
+
 def test_training_forward_contract(pkg, oracle):
     """EmbeddingProposalsRes5ROIHeads.forward with targets: 4-tuple, sampled proposals with
     gt_classes / fg_proposal, losses with loss_cls weight 0 under DETACH_CLASS_PREDICTOR
