@@ -242,6 +242,46 @@ def test_heads_take_the_map_path_with_many_proposals(pkg, oracle):
     np.testing.assert_allclose(deltas.cpu().numpy(), want["deltas"], atol=1e-5)
 
 
+def test_full_size_head_properties(pkg, oracle):
+    """BASELINE.json's full size (1333x800 map, 4 x 1000 proposals, Res5 1024 -> 2048, 1203-class bank) is beyond the
+    CPU oracle's reach in a test, so the size-independent properties of the path are checked instead:
+    image sharding (what bench.py --gpus N does) and proposal permutation leave every row bit-identical, the three
+    Res5 forms agree within the logits gate, the background column is exactly zero."""
+    cfg = pkg.config.get_cfg()
+    cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
+    cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED = True
+    cfg.MODEL.ROI_HEADS.NAME = "EmbeddingProposalsRes5ROIHeads"
+    heads, params, h = _make_heads(pkg, oracle, cfg, 1203, 5)
+    rng = np.random.default_rng(77)
+    feat = dev(rng.standard_normal((4, 1024, 50, 84)).astype(np.float32))
+    props, boxes = _proposals(pkg, oracle, rng, 4, 1000)
+
+    def logits(f, pr):
+        with torch.no_grad():
+            bf = heads._shared_roi_transform([f], [p.proposal_boxes for p in pr])
+            return heads.box_predictor(heads._pooled_mean(bf))[0]
+
+    assert heads.res5.map_path_pays(4000, 4 * 50 * 84)
+    full = logits(feat, props)
+    assert tuple(full.shape) == (4000, 1204) and torch.isfinite(full).all() and torch.all(full[:, -1] == 0)
+    # sharding by image: ranks see disjoint image subsets, results must not depend on the split
+    a, b = logits(feat[:2], props[:2]), logits(feat[2:], props[2:])
+    assert torch.equal(torch.cat([a, b]), full)
+    # permuting the proposals of an image permutes its rows
+    perm = torch.from_numpy(rng.permutation(1000)).cuda()
+    from locov_amd.structures import Boxes, Instances
+    p0 = Instances((800, 1333))
+    p0.proposal_boxes = Boxes(props[0].proposal_boxes.tensor[perm])
+    p0.objectness_logits = props[0].objectness_logits[perm]
+    assert torch.equal(logits(feat[:1], [p0]), full[:1000][perm])
+    # the pooled-rows form (K-concatenated block 0) and the direct 3x3 form agree within the gate
+    heads.res5.map_path_pays = lambda *a, **k: False
+    pooled = logits(feat, props)
+    heads.res5_conv3x3 = "direct"
+    direct = logits(feat, props)
+    assert (pooled - full).abs().max().item() <= 1e-4 and (direct - full).abs().max().item() <= 1e-4
+
+
 def test_training_forward_contract(pkg, oracle):
     """EmbeddingProposalsRes5ROIHeads.forward with targets: 4-tuple, sampled proposals with
     gt_classes / fg_proposal, losses with loss_cls weight 0 under DETACH_CLASS_PREDICTOR
