@@ -299,7 +299,8 @@ def pack_conv3x3_weight(w: torch.Tensor, dtype: torch.dtype = torch.float32) -> 
     return out
 
 
-_WINO_WS = {}      # device -> cached transform-domain workspace (grows to the largest request)
+_WINO_WS = {}      # (device, stream) -> cached transform-domain workspace (grows to the largest request);
+                   # per stream, because calls enqueued on different streams may run concurrently
 
 
 def winograd_pack_weight(w: torch.Tensor) -> torch.Tensor:
@@ -337,11 +338,12 @@ def winograd_conv3x3(x: torch.Tensor, U: torch.Tensor, *, scale=None, shift=None
     ldy = y.stride(0) if M else N
     lib = _lib.load()
     need = int(lib.locov_winograd_workspace_bytes(R, Cin, N))
-    ws = _WINO_WS.get(x.device)
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _WINO_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = None
-        _WINO_WS.pop(x.device, None)
-        ws = _WINO_WS[x.device] = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+        _WINO_WS.pop(key, None)
+        ws = _WINO_WS[key] = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         check(lib.locov_winograd_conv3x3_f32(_ptr(x), R, Cin, _ptr(U), _ptr(scale), _ptr(shift), _ptr(y), ldy, N,
                                              _lib.EPI_RELU if relu else 0, _ptr(ws), ws.numel(), _stream(x)),

@@ -110,3 +110,22 @@ def test_block0_k_concatenation_matches_separate_gemms(ops, oracle):
     fused = res5.forward_rows(x0, 7, 7, pos_major=True, winograd=True)
     # same arithmetic up to where the FrozenBN scales are applied (weights vs epilogue): rounding-level agreement
     assert (fused - plain).abs().max().item() <= 1e-5 * plain.abs().max().item()
+
+
+def test_concurrent_streams_do_not_share_the_workspace(ops):
+    """Two Winograd convolutions enqueued on two HIP streams may run concurrently: each stream owns its
+    transform-domain workspace (ops._WINO_WS is keyed by device and stream)."""
+    g = torch.Generator().manual_seed(2)
+    xs = [torch.randn(49 * 600, 128, generator=g).cuda() for _ in range(2)]
+    U = ops.winograd_pack_weight((torch.randn(128, 128, 3, 3, generator=g) * 0.05).cuda())
+    want = [ops.winograd_conv3x3(x, U, relu=True) for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for _ in range(5):
+        got = []
+        for st, x in zip(streams, xs):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                got.append(ops.winograd_conv3x3(x, U, relu=True))
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
