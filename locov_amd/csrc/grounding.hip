@@ -183,9 +183,10 @@ int locov_grounding_fwd(const float *S, int B, int T, int NR, const float *capti
     if (rc) return rc;
     LOCOV_REQUIRE(S && caption_mask && region_mask && cost_w2r && cost_r2w, "locov_grounding_fwd: null pointer");
     LOCOV_REQUIRE(temperature > 0.f, "locov_grounding_fwd: temperature must be > 0");
-    if (lds > 64 * 1024)
+    if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(grounding_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return set_error(LOCOV_ERR_LAUNCH, "locov_grounding_fwd: cannot raise the dynamic LDS limit to %zu bytes", (size_t)lds);
     hipLaunchKernelGGL(grounding_kernel<false>, dim3((unsigned)(B * B)), dim3(kGroundThreads), lds, as_stream(stream), S,
                        B, T, NR, caption_mask, region_mask, 1.f / temperature, cost_w2r, cost_r2w, nullptr, nullptr,
                        nullptr);
@@ -201,9 +202,10 @@ int locov_grounding_bwd(const float *S, int B, int T, int NR, const float *capti
     if (rc) return rc;
     LOCOV_REQUIRE(S && caption_mask && region_mask && grad_w2r && grad_r2w && grad_S, "locov_grounding_bwd: null pointer");
     LOCOV_REQUIRE(temperature > 0.f, "locov_grounding_bwd: temperature must be > 0");
-    if (lds > 64 * 1024)
+    if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(grounding_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return set_error(LOCOV_ERR_LAUNCH, "locov_grounding_bwd: cannot raise the dynamic LDS limit to %zu bytes", (size_t)lds);
     hipLaunchKernelGGL(grounding_kernel<true>, dim3((unsigned)(B * B)), dim3(kGroundThreads), lds, as_stream(stream), S,
                        B, T, NR, caption_mask, region_mask, 1.f / temperature, nullptr, nullptr, grad_w2r, grad_r2w,
                        grad_S);

@@ -66,7 +66,6 @@ __device__ __forceinline__ float4 tap4(__amdgpu_buffer_rsrc_t r, unsigned off, f
 }
 __device__ __forceinline__ float4 tap4(__amdgpu_buffer_rsrc_t r, unsigned off, __bf16 *)
 {
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const bf16x4 v = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
     return float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
@@ -486,9 +485,10 @@ int locov_roi_align_from_nhwc_fwd(const float *feat_nhwc, int N, int H, int W, i
     const size_t lds = ((size_t)kT2Ch * ts + 4) * sizeof(float) + 2 * kT2Axis * sizeof(AxisSampleN);
     LOCOV_REQUIRE(lds <= 150 * 1024, "locov_roi_align_from_nhwc_fwd: pooled size %dx%d too large for the LDS tile", pooled_h,
                   pooled_w);
-    if (lds > 64 * 1024)
+    if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(roi_align_nhwc2nchw_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return set_error(LOCOV_ERR_LAUNCH, "locov_roi_align_from_nhwc_fwd: cannot raise the dynamic LDS limit to %zu bytes", (size_t)lds);
     dim3 grid((unsigned)R, (unsigned)ceil_div(C, kT2Ch));
     hipLaunchKernelGGL(roi_align_nhwc2nchw_kernel, grid, dim3(kT2Threads), lds, as_stream(stream), feat_nhwc, N, H, W, C,
                        rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, out);
