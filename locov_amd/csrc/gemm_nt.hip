@@ -161,8 +161,30 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
         B += b * bt.sb;
         Cout += b * bt.sc;
     }
-    int64_t m0 = (int64_t)(tile / tiles_n) * BM;
-    int n0 = (tile % tiles_n) * BN;
+    // Plain GEMM tile order: the N tiles are taken in groups of NG columns-of-tiles; inside a group M-tile outer,
+    // N-tile inner.  The workgroups resident on an XCD then stream a B slice of NG*BN rows (2 MB at K = 512 / 1 MB
+    // per 128 columns at K = 2048) that stays in the 4 MB L2 next to the A panels, instead of the whole weight
+    // matrix (4 MB for the Res5 1x1 convolutions), which would be re-fetched from the Infinity Cache by every
+    // M-tile group; the price is reading A once per group.
+    int64_t m0;
+    int n0;
+    {
+        const int NG = (int64_t)K_ * (int)sizeof(T) * BN * 8 <= (2 << 20) ? 8 : 4;      // <= 2 MB of B per group
+        const int tiles_m = (int)((bt.count > 1 ? nwg / bt.count : nwg) / tiles_n);
+        const int full = (tiles_n / NG) * NG, per_group = tiles_m * NG;
+        if (tiles_n <= NG) {
+            m0 = (int64_t)(tile / tiles_n) * BM;
+            n0 = (tile % tiles_n) * BN;
+        } else if (tile < tiles_m * full) {
+            const int g = tile / per_group, rem = tile - g * per_group;
+            m0 = (int64_t)(rem / NG) * BM;
+            n0 = (g * NG + rem % NG) * BN;
+        } else {                                            // ragged last group
+            const int gs = tiles_n - full, rem = tile - tiles_m * full;
+            m0 = (int64_t)(rem / gs) * BM;
+            n0 = (full + rem % gs) * BN;
+        }
+    }
     int64_t M = M_;
     int K = K_;
     unsigned long long taps = 0;          // CONVP: valid tap ids, 4 bits each, in ascending order
