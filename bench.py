@@ -140,7 +140,7 @@ class Workload:
         return self.head(self.r5_standin)
 
 
-TRAFFIC_FILE = "r01g_pmc_traffic.json"
+TRAFFIC_FILE = "r01h_pmc_traffic.json"
 
 
 def recorded_traffic(args, kernel_key: str):
