@@ -39,6 +39,10 @@
 #include <mutex>
 #include <vector>
 
+#ifndef LOCOV_RES_PREFETCH
+#define LOCOV_RES_PREFETCH 4     // residual row groups (of 16 per wave sub-tile) requested before the last K-tile
+#endif
+
 namespace locov {
 
 // Optional per-launch timing of the GEMM kernels (locov_gemm_timing_*): HIP events recorded on the
@@ -547,10 +551,33 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
         tile_step(0, k0);
         tile_step(1, k0 + BK);
     }
+    // Residual prefetch: the residual rows of the first NPRE row groups are requested BEFORE the last K-tile, into
+    // the registers the (now idle) staging stream used, so that their HBM latency sits under that tile's MFMAs
+    // instead of at the head of the epilogue.
+    constexpr int NPRE = LOCOV_RES_PREFETCH;
+    constexpr int P_LPR = TN / 4, P_RPI = 64 / P_LPR;
+    f32x4 res_pre[NPRE > 0 ? NPRE : 1];
+    const bool pre_ok = NPRE > 0 && sizeof(TOut) == 4 && epi.residual && !(epi.flags & 0x800u) && (N % 4 == 0) &&
+                        (ldc % 4 == 0) && ((uintptr_t)Cout % 16 == 0) && ((uintptr_t)epi.residual % 16 == 0);
+    auto prefetch_residual = [&]() __attribute__((always_inline)) {
+        if (!pre_ok) return;
+        const int pc4 = (lane % P_LPR) * 4, prr = lane / P_LPR, pn = n0 + wn + pc4;
+        if (pn >= N) return;
+        const int64_t rows_here = M - m0 < BM ? M - m0 : BM;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(epi.residual) + m0 * ldc, 0, (unsigned)(rows_here * ldc * (int64_t)sizeof(float)), 0x00020000);
+        const unsigned pvoff = (unsigned)(((int64_t)(wm + prr) * ldc + pn) * (int64_t)sizeof(float));
+        const unsigned pvstep = (unsigned)(P_RPI * ldc * (int64_t)sizeof(float));
+#pragma unroll
+        for (int it = 0; it < NPRE; it++)
+            res_pre[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, pvoff + it * pvstep, 0, 0));
+    };
     if (k0 < k_last) {
         tile_step(0, k0);
+        prefetch_residual();
         last_tile(1);
     } else {
+        prefetch_residual();
         last_tile(0);
     }
 
@@ -599,9 +626,14 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
             f32x4 res[NIT];
             if (epi.residual && n_ok) {
 #pragma unroll
-                for (int it = 0; it < NIT; it++)
-                    res[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                            r_res, FULL ? voff : voff + it * vstep, FULL ? it * vstep : 0u, 0));
+                for (int it = 0; it < NIT; it++) {
+                    if (it < NPRE && NPRE > 0) {
+                        res[it] = res_pre[it];                 // requested before the last K-tile (pre_ok holds here)
+                    } else {
+                        res[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                r_res, FULL ? voff : voff + it * vstep, FULL ? it * vstep : 0u, 0));
+                    }
+                }
             }
             __syncthreads();                              // every wave is done reading the last stage
 #pragma unroll
