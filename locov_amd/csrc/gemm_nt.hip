@@ -635,6 +635,10 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
                     }
                 }
             }
+            // (scale / shift of this lane's four columns: requested here, consumed after the re-layout)
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (n_ok && epi.scale) sc = *reinterpret_cast<const f32x4 *>(epi.scale + n);
+            if (n_ok && epi.shift) sh = *reinterpret_cast<const f32x4 *>(epi.shift + n);
             __syncthreads();                              // every wave is done reading the last stage
 #pragma unroll
             for (int i = 0; i < MI; i++)
@@ -645,9 +649,6 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
                         ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPS + j * 32 + (lane & 31)] = acc[i][j][r];
             __syncthreads();
             if (n_ok) {
-                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-                if (epi.scale) sc = *reinterpret_cast<const f32x4 *>(epi.scale + n);
-                if (epi.shift) sh = *reinterpret_cast<const f32x4 *>(epi.shift + n);
 #pragma unroll
                 for (int it = 0; it < NIT; it++) {
                     f32x4 v = *reinterpret_cast<const f32x4 *>(ep + (it * RPI + rr) * EPS + c4);
