@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # f32-input MFMA peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA peak (only used by the opt-in --res5-dtype bf16 run)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
@@ -50,6 +51,8 @@ def parse():
                    help="form of the Res5 3x3 convolutions on the hip backend")
     p.add_argument("--block0", choices=["map", "pooled"], default="map",
                    help="run Res5 block 0's 1x1 convolutions on the map (before ROIAlign) or on the pooled rows")
+    p.add_argument("--res5-dtype", choices=["fp32", "bf16"], default="fp32",
+                   help="bf16 = opt-in reduced-precision Res5 GEMM operands (NOT the headline configuration)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--skip-s1", action="store_true",
                    help="only the S2 scope (profiling runs: the kernel mix then equals the timed region's)")
@@ -114,7 +117,9 @@ class Workload:
             # (position-major pixel rows [7,7,R,C]: the 3x3 convs skip their zero-padding taps)
             R = self.rois.shape[0]
             wino = self.args.conv3x3 == "winograd"
-            if self.args.block0 == "map" and self.res5.map_path_pays(R, nhwc.shape[0] * 50 * 84):
+            if self.args.res5_dtype == "bf16":
+                y = self.res5.forward_from_map(nhwc, self.rois, 14, 1.0 / 16, 0, True, bf16=True)
+            elif self.args.block0 == "map" and self.res5.map_path_pays(R, nhwc.shape[0] * 50 * 84):
                 # block 0's 1x1 convolutions on the map, ROIAlign pools their outputs (Res5Stage.forward_from_map)
                 y = self.res5.forward_from_map(nhwc, self.rois, 14, 1.0 / 16, 0, True, winograd=wino)
             else:
@@ -268,6 +273,7 @@ def main():
         _lib.check(lib.locov_gemm_timing_read(cls, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)))
         return n.value, ms.value, fl.value
     gemm_plain, gemm_conv = gemm_class(0), gemm_class(1)
+    gemm_plain_bf16, gemm_conv_bf16 = gemm_class(3), gemm_class(4)
     lib.locov_gemm_timing_enable(0)
     dom_ms = float(np.mean([a.elapsed_time(b) for a, b in wl.ev])) if wl.ev else float("nan")
     dt1 = timed(wl.step_s1, args.steps, args.warmup) if not args.skip_s1 else float("nan")
@@ -300,6 +306,22 @@ def main():
             if n1:
                 roof["direct_conv3x3"] = {"launches_per_step": n1 / args.steps, "avg_launch_ms": ms1 / n1,
                                           "executed_tflops": fl1 / (ms1 * 1e-3) / 1e12}
+            if args.res5_dtype == "bf16":
+                # opt-in reduced-precision run: the dominant kernel is the bf16-operand instance of the same
+                # template, priced against the dense bf16 MFMA peak; no PMC traffic pass is recorded for it
+                nb, msb, flb = gemm_plain_bf16
+                nc, msc, flc = gemm_conv_bf16
+                ach = flb / (msb * 1e-3) / 1e12 if msb > 0 else float("nan")
+                roof = {"kernel": "gemm_nt_kernel<__bf16,float,128,128,...> (Res5 1x1 convs with bf16 operands)",
+                        "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                        "launches_per_step": nb / args.steps, "avg_launch_ms": msb / max(nb, 1),
+                        "share_of_step_time": msb * 1e-3 / dt2,
+                        "direct_conv3x3_bf16": {"launches_per_step": nc / args.steps, "avg_launch_ms": msc / max(nc, 1),
+                                                "executed_tflops": flc / (msc * 1e-3) / 1e12 if msc > 0 else None,
+                                                "share_of_step_time": msc * 1e-3 / dt2},
+                        "f32_gemms": {"launches_per_step": n0 / args.steps, "share_of_step_time": ms0 * 1e-3 / dt2,
+                                      "executed_tflops": achieved}}
         else:
             alg_bytes = args.images * 1024 * 50 * 84 * 4 + R_local * 5 * 4 + R_local * 1024 * 14 * 14 * 4
             achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
@@ -314,7 +336,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt2 / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.sim_dtype == "fp32" else "f32 (bf16 similarity operands)",
+            "dtype": ("bf16 operands / f32 accumulate in Res5 (opt-in reduced precision, not the parity configuration)"
+                      if args.res5_dtype == "bf16" else
+                      "f32" if args.sim_dtype == "fp32" else "f32 (bf16 similarity operands)"),
             "data": "synthetic",
             "config": {"workload": f"{args.images} img/GPU x {args.proposals} proposals, res4 [B,1024,50,84] fp32, "
                                    f"ROIAlign 14x14 -> Res5({args.res5}) -> mean -> bbox_pred/emb_pred(2048->{args.dim}) -> "
@@ -323,6 +347,7 @@ def main():
                        "proposals_per_image": args.proposals, "classes": args.classes, "emb_dim": args.dim,
                        "res5_backend": args.res5, "res5_conv3x3": args.conv3x3 if args.res5 == "hip" else "miopen",
                        "res5_block0": args.block0 if args.res5 == "hip" else "miopen",
+                       "res5_dtype": args.res5_dtype,
                        "parallelism": f"image-sharded x{world}, no collective"},
             "scopes": {"S2_full_head_proposals_per_s": props_per_step * args.steps / dt2,
                        "S1_handwritten_kernels_proposals_per_s": None if args.skip_s1 else props_per_step * args.steps / dt1,

@@ -235,11 +235,28 @@ int locov_token_attention_fwd(const float *sim, int64_t R, int Ttot, const int *
                               int cosine, int hardmax, const float *gmin, float *scores,
                               float *att, locov_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Opt-in reduced-precision form of the Res5 GEMMs (MODEL.ROI_BOX_HEAD.RES5_DTYPE: "bf16"; the default
+ * and the parity path are fp32): bf16 operands on the bf16 MFMA pipe, fp32 accumulate, fp32 epilogue
+ * (scale / shift / residual / ReLU as in locov_gemm_nt_f32) and fp32 output.  x / W / w_packed hold
+ * bf16 bit patterns (locov_f32_to_bf16, locov_pack_conv3x3_weight(out_dtype = LOCOV_BF16)).
+ * K % 8 == 0 (GEMM), Cin % 64 == 0 (conv).
+ * ------------------------------------------------------------------------------------- */
+int locov_gemm_nt_bf16(const uint16_t *x, int64_t lda, const uint16_t *W, const float *scale,
+                       const float *shift, const float *residual, float *y, int64_t ldc,
+                       int64_t M, int N, int K, unsigned flags, locov_stream_t stream);
+
+int locov_conv3x3_nhwc_bf16(const uint16_t *x, int64_t R, int H, int W, int Cin, int pos_major,
+                            const uint16_t *w_packed, const float *scale, const float *shift,
+                            const float *residual, float *y, int N, unsigned flags,
+                            locov_stream_t stream);
+
 /* Measurement aid (bench.py's roofline block): while enabled, every GEMM-kernel launch made by
  * this library is bracketed by HIP events on its launch stream.  read() waits for them and
  * returns, for one kernel class, the number of launches, the sum of their durations (ms) and
  * the FLOPs they executed.  cls: 0 = gemm_nt_kernel<128x128, plain / batched> (1x1 convs, FCs,
- * Winograd-domain GEMMs), 1 = the position-major direct 3x3 conv, 2 = the other tile shapes.
+ * Winograd-domain GEMMs), 1 = the position-major direct 3x3 conv, 2 = the other tile shapes,
+ * 3 / 4 = classes 0 / 1 launched with bf16 operands.
  * enable(on) clears what was recorded. */
 int locov_gemm_timing_enable(int on);
 int locov_gemm_timing_read(int cls, int64_t *launches, double *ms, double *flops);

@@ -120,6 +120,8 @@ def get_cfg() -> CfgNode:
                 # extension: "hip" = hand-written channels-last MFMA GEMM Res5, "miopen" = torch conv2d
                 "RES5_BACKEND": "hip",
                 "RES5_CONV3X3": "winograd",
+                # extension: "bf16" = bf16 GEMM operands / fp32 accumulate in Res5 (opt-in; the parity path is "fp32")
+                "RES5_DTYPE": "fp32",
             },
             "RESNETS": {
                 "NUM_GROUPS": 1, "WIDTH_PER_GROUP": 64, "RES2_OUT_CHANNELS": 256,

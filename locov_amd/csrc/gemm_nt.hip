@@ -720,9 +720,11 @@ static int launch_cfg(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C,
     if (bt.count > 1 && (cg.H > 0 || epi.residual))
         return set_error(LOCOV_ERR_UNSUPPORTED, "%s: batched launches are plain GEMMs without residual", what);
     if (tiles > 0x7fffffffLL) return set_error(LOCOV_ERR_INVALID_ARG, "%s: problem too large", what);
-    // timing class: 0 = the 128x128 plain / batched GEMM, 1 = position-major 3x3 conv, 2 = everything else;
+    // timing class: 0 = the 128x128 plain / batched GEMM, 1 = position-major 3x3 conv, 2 = everything else,
+    // 3 / 4 = classes 0 / 1 with bf16 operands;
     // FLOPs = what the kernel executes (the position-major conv skips its padding taps)
-    const int tcls = posm ? 1 : (cg.H == 0 && BM == 128 && BN == 128 ? 0 : 2);
+    const int tcls0 = posm ? 1 : (cg.H == 0 && BM == 128 && BN == 128 ? 0 : 2);
+    const int tcls = (sizeof(T) == 2 && tcls0 < 2) ? tcls0 + 3 : tcls0;
     const double tflops = posm ? 2.0 * cg.R * (3.0 * cg.H - 2) * (3.0 * cg.W - 2) * cg.Cin * N
                                : 2.0 * (double)M * N * K * (bt.count > 1 ? bt.count : 1);
     const int trec = timing_begin(s, tcls, tflops);
@@ -904,6 +906,39 @@ int locov_frozen_bn_fold(const float *weight, const float *bias, const float *ru
     hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, as_stream(stream), weight, bias,
                        running_mean, running_var, eps, C, scale, shift);
     return check_launch("locov_frozen_bn_fold");
+}
+
+int locov_gemm_nt_bf16(const uint16_t *x, int64_t lda, const uint16_t *W, const float *scale, const float *shift,
+                       const float *residual, float *y, int64_t ldc, int64_t M, int N, int K, unsigned flags,
+                       locov_stream_t stream)
+{
+    LOCOV_REQUIRE(M >= 0 && N > 0 && K > 0, "locov_gemm_nt_bf16: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    if (M == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(x && W && y, "locov_gemm_nt_bf16: null pointer");
+    LOCOV_REQUIRE(K % 8 == 0 && lda % 8 == 0, "locov_gemm_nt_bf16: K and lda must be multiples of 8 (got %d, %lld)", K,
+                  (long long)lda);
+    LOCOV_REQUIRE(lda >= K && ldc >= N, "locov_gemm_nt_bf16: lda < K or ldc < N");
+    LOCOV_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)W % 16 == 0, "locov_gemm_nt_bf16: x / W must be 16-byte aligned");
+    Epilogue epi{scale, shift, residual, flags};
+    return launch_gemm_nt<__bf16, float>(reinterpret_cast<const __bf16 *>(x), lda, reinterpret_cast<const __bf16 *>(W),
+                                         (int64_t)K, y, ldc, M, N, K, epi, as_stream(stream), "locov_gemm_nt_bf16");
+}
+
+int locov_conv3x3_nhwc_bf16(const uint16_t *x, int64_t R, int H, int W, int Cin, int pos_major, const uint16_t *w_packed,
+                            const float *scale, const float *shift, const float *residual, float *y, int N,
+                            unsigned flags, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(R >= 0 && H > 0 && W > 0 && Cin > 0 && N > 0, "locov_conv3x3_nhwc_bf16: bad shape");
+    if (R == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(x && w_packed && y, "locov_conv3x3_nhwc_bf16: null pointer");
+    LOCOV_REQUIRE(Cin % 64 == 0, "locov_conv3x3_nhwc_bf16: Cin must be a multiple of 64 (got %d)", Cin);
+    LOCOV_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w_packed % 16 == 0, "locov_conv3x3_nhwc_bf16: misaligned pointer");
+    LOCOV_REQUIRE(R <= 0x7fffffffLL / (H * W), "locov_conv3x3_nhwc_bf16: R too large");
+    Epilogue epi{scale, shift, residual, flags};
+    ConvGeom cg{H, W, Cin, pos_major ? (int)R : 0, 0};
+    return launch_gemm_nt<__bf16, float>(reinterpret_cast<const __bf16 *>(x), (int64_t)Cin,
+                                         reinterpret_cast<const __bf16 *>(w_packed), (int64_t)9 * Cin, y, (int64_t)N,
+                                         R * H * W, N, 9 * Cin, epi, as_stream(stream), "locov_conv3x3_nhwc_bf16", cg);
 }
 
 int locov_sim_gemm_bf16(const uint16_t *emb, const uint16_t *bank, int64_t R, int D, int K1, float *logits,

@@ -490,6 +490,47 @@ def to_bf16(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+                scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                relu: bool = False) -> torch.Tensor:
+    """y = epi(x . weight^T) with bf16 operands on the bf16 MFMA pipe, fp32 accumulate, fp32 epilogue and
+    output (the opt-in reduced-precision form of the Res5 GEMMs).  x [M,K] bf16, weight [N,K] bf16."""
+    x = _dev(x, "x", torch.bfloat16)
+    weight = _dev(weight, "weight", torch.bfloat16)
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K or K % 8:
+        raise ValueError(f"linear_bf16: x {tuple(x.shape)} weight {tuple(weight.shape)} (K must be a multiple of 8)")
+    bias = _dev(bias, "bias") if bias is not None else None
+    scale = _dev(scale, "scale") if scale is not None else None
+    residual = _dev(residual, "residual") if residual is not None else None
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_gemm_nt_bf16(_ptr(x), K, _ptr(weight), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(y), N,
+                                             M, N, K, _lib.EPI_RELU if relu else 0, _stream(x)), "locov_gemm_nt_bf16")
+    return y
+
+
+def conv3x3_nhwc_bf16(x: torch.Tensor, w_packed: torch.Tensor, H: int, W: int, *, scale=None, shift=None,
+                      residual=None, relu: bool = False, pos_major: bool = False) -> torch.Tensor:
+    """conv3x3_nhwc with bf16 operands (x [R*H*W, Cin] bf16, w_packed [N, 9*Cin] bf16), fp32 output."""
+    x = _dev(x, "x", torch.bfloat16)
+    w_packed = _dev(w_packed, "w_packed", torch.bfloat16)
+    M, Cin = x.shape
+    N = w_packed.shape[0]
+    if w_packed.shape[1] != 9 * Cin or M % (H * W) != 0:
+        raise ValueError("conv3x3_nhwc_bf16: inconsistent shapes")
+    scale = _dev(scale, "scale") if scale is not None else None
+    shift = _dev(shift, "shift") if shift is not None else None
+    residual = _dev(residual, "residual") if residual is not None else None
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_conv3x3_nhwc_bf16(_ptr(x), M // (H * W), H, W, Cin, int(pos_major), _ptr(w_packed),
+                                                  _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), N,
+                                                  _lib.EPI_RELU if relu else 0, _stream(x)), "locov_conv3x3_nhwc_bf16")
+    return y
+
+
 def sim_gemm_bf16(emb: torch.Tensor, bank: torch.Tensor) -> torch.Tensor:
     """logits[R,K1] = emb[R,D] . bank[K1,D]^T, bf16 operands, fp32 accumulate / output."""
     emb = _dev(emb, "emb", torch.bfloat16)

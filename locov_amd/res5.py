@@ -169,6 +169,16 @@ class Res5Stage(nn.Sequential):
         x0._locov_cat = buf
         return x0
 
+    def _bf16(self, t: torch.Tensor) -> torch.Tensor:
+        """bf16 copy of a packed fp32 weight (cached per tensor object; the packed tensors are themselves cached)."""
+        from . import ops
+        hit = self._cache.get(("bf16", id(t)))
+        if hit is not None and hit[0] is t:
+            return hit[1]
+        out = ops.to_bf16(t.contiguous())
+        self._cache[("bf16", id(t))] = (t, out)
+        return out
+
     def _packed_block0_on_map(self):
         """Weights for running block 0's two 1x1 stride-2 convolutions on the feature MAP (see
         forward_from_map): Wmap = [W1 ; ss*Ws]  ([mid + Cout, Cin]; the shortcut's FrozenBN scale is folded into
@@ -194,7 +204,8 @@ class Res5Stage(nn.Sequential):
 
     @torch.no_grad()
     def forward_from_map(self, nhwc: torch.Tensor, rois: torch.Tensor, pooler_resolution: int, spatial_scale: float,
-                         sampling_ratio: int = 0, aligned: bool = True, winograd: bool = True) -> torch.Tensor:
+                         sampling_ratio: int = 0, aligned: bool = True, winograd: bool = True,
+                         bf16: bool = False) -> torch.Tensor:
         """The whole stage from the channels-last res4 map [N,H,W,Cin] and the rois [R,5] -> position-major
         rows [49*R, Cout], with block 0's conv1 and projection shortcut moved IN FRONT of the pooler:
 
@@ -211,7 +222,10 @@ class Res5Stage(nn.Sequential):
         mid = b0.conv1.out_channels
         N, H, W, cin = nhwc.shape
         wmap, s1, b1, shift_tail = self._packed_block0_on_map()
-        g = ops.linear(nhwc.reshape(N * H * W, cin), wmap).view(N, H, W, wmap.shape[0])
+        if bf16:
+            g = ops.linear_bf16(ops.to_bf16(nhwc.reshape(N * H * W, cin)), self._bf16(wmap)).view(N, H, W, wmap.shape[0])
+        else:
+            g = ops.linear(nhwc.reshape(N * H * W, cin), wmap).view(N, H, W, wmap.shape[0])
         y = ops.roi_align_nhwc(g[..., :mid], rois, 14, spatial_scale, sampling_ratio, aligned, bin_stride=2,
                                pos_major=True, ch_scale=s1, ch_shift=b1, relu=True)          # conv1 + FBN + ReLU, pooled
         sc = ops.roi_align_nhwc(g[..., mid:], rois, 14, spatial_scale, sampling_ratio, aligned, bin_stride=2,
@@ -219,19 +233,24 @@ class Res5Stage(nn.Sequential):
         R = rois.shape[0]
         y, sc = y.view(49 * R, mid), sc.view(49 * R, -1)
         c2 = b0.conv2
+        w3, s3, _ = self._packed(b0.conv3)
+        if bf16:
+            w2, s2, b2 = self._packed(c2)
+            y = ops.conv3x3_nhwc_bf16(ops.to_bf16(y), self._bf16(w2), 7, 7, scale=s2, shift=b2, relu=True, pos_major=True)
+            x = ops.linear_bf16(ops.to_bf16(y), self._bf16(w3), shift_tail, scale=s3, residual=sc, relu=True)
+            return self.forward_rows(x, 7, 7, pos_major=True, start_block=1, bf16=True)
         if winograd and c2.in_channels % 32 == 0 and c2.out_channels % 4 == 0:
             u2, s2, b2 = self._packed(c2, winograd=True)
             y = ops.winograd_conv3x3(y, u2, scale=s2, shift=b2, relu=True)
         else:
             w2, s2, b2 = self._packed(c2)
             y = ops.conv3x3_nhwc(y, w2, 7, 7, scale=s2, shift=b2, relu=True, pos_major=True)
-        w3, s3, _ = self._packed(b0.conv3)
         x = ops.linear(y, w3, shift_tail, scale=s3, residual=sc, relu=True)                  # conv3 + FBN + add + ReLU
         return self.forward_rows(x, 7, 7, pos_major=True, winograd=winograd, start_block=1)
 
     @torch.no_grad()
     def forward_rows(self, x0: torch.Tensor, H: int, W: int, pos_major: bool = False,
-                     winograd: bool = True, start_block: int = 0) -> torch.Tensor:
+                     winograd: bool = True, start_block: int = 0, bf16: bool = False) -> torch.Tensor:
         """Rows are ROI-major (r*H*W + pos) or position-major (pos*R + r); the 1x1 convolutions do not
         care.  The 3x3 one runs, on 7x7 position-major tiles, in the Winograd domain (121 instead of 361
         products per tile and channel pair; `winograd=False` keeps the direct implicit GEMM, which skips
@@ -246,6 +265,20 @@ class Res5Stage(nn.Sequential):
             w1, s1, b1 = self._packed(blk.conv1)
             w3, s3, b3 = self._packed(blk.conv3)
             c2 = blk.conv2
+            if bf16:
+                # opt-in reduced precision: bf16 GEMM operands (direct tap-skipping 3x3), fp32 accumulate, fp32
+                # FrozenBN / ReLU / residual and an fp32 residual stream
+                w2, s2, b2 = self._packed(c2)
+                y = ops.linear_bf16(ops.to_bf16(x.contiguous()), self._bf16(w1), b1, scale=s1, relu=True)
+                y = ops.conv3x3_nhwc_bf16(ops.to_bf16(y), self._bf16(w2), H, W, scale=s2, shift=b2, relu=True,
+                                          pos_major=pos_major)
+                if blk.shortcut is not None:
+                    ws, ss, bs = self._packed(blk.shortcut)
+                    sc = ops.linear_bf16(ops.to_bf16(x.contiguous()), self._bf16(ws), bs, scale=ss)
+                else:
+                    sc = x
+                x = ops.linear_bf16(ops.to_bf16(y), self._bf16(w3), b3, scale=s3, residual=sc, relu=True)
+                continue
             y = ops.linear(x, w1, b1, scale=s1, relu=True)                        # 1x1 (+stride via x0) + FBN + ReLU
             use_wino = winograd and pos_major and H == 7 and W == 7 and c2.in_channels % 32 == 0 and c2.out_channels % 4 == 0
             if use_wino and bi == 0 and cat is not None and blk.shortcut is not None:

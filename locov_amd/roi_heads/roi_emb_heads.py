@@ -205,9 +205,10 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
     @configurable
     def __init__(self, *, in_features: List[str], pooler: ROIPooler, res5: nn.Module, box_predictor: nn.Module,
                  mask_head: Optional[nn.Module] = None, output_shape: Optional[int] = 0,
-                 res5_backend: str = "hip", res5_conv3x3: str = "winograd", **kwargs):
+                 res5_backend: str = "hip", res5_conv3x3: str = "winograd", res5_dtype: str = "fp32", **kwargs):
         super().__init__(**kwargs)
-        assert res5_backend in ("hip", "miopen") and res5_conv3x3 in ("winograd", "direct")
+        assert res5_backend in ("hip", "miopen") and res5_conv3x3 in ("winograd", "direct") and res5_dtype in ("fp32", "bf16")
+        self.res5_dtype = res5_dtype          # extension: "bf16" = opt-in reduced-precision GEMM operands (not the parity path)
         self.res5_backend = res5_backend      # extension: how the Res5 convolutions run (see res5.py)
         self.res5_conv3x3 = res5_conv3x3      # extension: form of the 3x3 convolutions on the hip backend
         self.in_features = in_features
@@ -241,6 +242,7 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         box_head = cfg.MODEL.ROI_BOX_HEAD
         ret["res5_backend"] = box_head.get("RES5_BACKEND", "hip") if hasattr(box_head, "get") else "hip"
         ret["res5_conv3x3"] = box_head.get("RES5_CONV3X3", "winograd") if hasattr(box_head, "get") else "winograd"
+        ret["res5_dtype"] = box_head.get("RES5_DTYPE", "fp32") if hasattr(box_head, "get") else "fp32"
         return ret
 
     @classmethod
@@ -276,6 +278,16 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         oh = ow = P // 2
         R = rois.shape[0]
         wino = self.res5_conv3x3 == "winograd"
+        if self.res5_dtype == "bf16":
+            x0 = torch.empty((oh * ow * R, nhwc.shape[3]), dtype=torch.float32, device=nhwc.device)
+            if P == 14 and self.res5[0].shortcut is not None:
+                y = self.res5.forward_from_map(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio,
+                                               self.pooler.aligned, bf16=True)
+            else:
+                ops.roi_align_nhwc(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned,
+                                   bin_stride=2, pos_major=True, out=x0)
+                y = self.res5.forward_rows(x0, oh, ow, pos_major=True, bf16=True)
+            return y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)
         if P == 14 and self.res5.map_path_pays(R, nhwc.shape[0] * nhwc.shape[1] * nhwc.shape[2]):
             # many proposals per image: block 0's 1x1 convolutions run on the map, ROIAlign pools their outputs
             y = self.res5.forward_from_map(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio,

@@ -242,6 +242,33 @@ def test_heads_take_the_map_path_with_many_proposals(pkg, oracle):
     np.testing.assert_allclose(deltas.cpu().numpy(), want["deltas"], atol=1e-5)
 
 
+@pytest.mark.parametrize("many", [False, True])
+def test_opt_in_bf16_res5_is_bounded_against_the_fp32_path(pkg, oracle, many):
+    """MODEL.ROI_BOX_HEAD.RES5_DTYPE = "bf16" (extension, default "fp32"): bf16 GEMM operands, fp32 accumulate and
+    epilogues. It is NOT the parity configuration - this test only bounds its deviation (relative to the feature
+    magnitude: bf16 has 8 mantissa bits, ~4e-3 per operand) and checks that the default stays the fp32 path."""
+    cfg = _small_cfg(pkg)
+    assert cfg.MODEL.ROI_BOX_HEAD.RES5_DTYPE == "fp32"
+    cfg.MODEL.ROI_BOX_HEAD.RES5_DTYPE = "bf16"
+    heads, params, h = _make_heads(pkg, oracle, cfg, 80, 5)
+    rng = np.random.default_rng(5)
+    if many:
+        feat = rng.standard_normal((2, 128, 20, 30)).astype(np.float32)
+        boxes = [oracle.synth_boxes(rng, 300, 480.0, 320.0), oracle.synth_boxes(rng, 260, 480.0, 320.0)]
+    else:
+        feat = rng.standard_normal((2, 128, 50, 84)).astype(np.float32)
+        boxes = [oracle.synth_boxes(rng, 40), oracle.synth_boxes(rng, 33)]
+    want = oracle.roi_head_forward(feat, boxes, params, h)
+    from locov_amd.structures import Boxes
+    with torch.no_grad():
+        bf = heads._shared_roi_transform([dev(feat)], [Boxes(torch.from_numpy(b).cuda()) for b in boxes])
+        scores, deltas = heads.box_predictor(heads._pooled_mean(bf))
+    rel = np.abs(bf.cpu().numpy() - want["res5"]).max() / np.abs(want["res5"]).max()
+    assert 0 < rel <= 2e-2, rel                               # > 0: the bf16 path really ran
+    srel = np.abs(scores.cpu().numpy() - want["scores"]).max() / np.abs(want["scores"]).max()
+    assert srel <= 2e-2, srel
+
+
 def test_full_size_head_properties(pkg, oracle):
     """BASELINE.json's full size (1333x800 map, 4 x 1000 proposals, Res5 1024 -> 2048, 1203-class bank) is beyond the
     CPU oracle's reach in a test, so the size-independent properties of the path are checked instead:
