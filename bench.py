@@ -51,7 +51,7 @@ def parse():
                    help="form of the Res5 3x3 convolutions on the hip backend")
     p.add_argument("--block0", choices=["map", "pooled"], default="map",
                    help="run Res5 block 0's 1x1 convolutions on the map (before ROIAlign) or on the pooled rows")
-    p.add_argument("--res5-dtype", choices=["fp32", "bf16"], default="fp32",
+    p.add_argument("--res5-dtype", choices=["fp32", "f16x2", "bf16"], default="fp32",
                    help="bf16 = opt-in reduced-precision Res5 GEMM operands (NOT the headline configuration)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--skip-s1", action="store_true",
@@ -121,11 +121,12 @@ class Workload:
                 y = self.res5.forward_from_map(nhwc, self.rois, 14, 1.0 / 16, 0, True, bf16=True)
             elif self.args.block0 == "map" and self.res5.map_path_pays(R, nhwc.shape[0] * 50 * 84):
                 # block 0's 1x1 convolutions on the map, ROIAlign pools their outputs (Res5Stage.forward_from_map)
-                y = self.res5.forward_from_map(nhwc, self.rois, 14, 1.0 / 16, 0, True, winograd=wino)
+                y = self.res5.forward_from_map(nhwc, self.rois, 14, 1.0 / 16, 0, True, winograd=wino,
+                                               split=self.args.res5_dtype == "f16x2")
             else:
                 x0 = self.res5.rows_input(49 * R, self.device)
                 ops.roi_align_nhwc(nhwc, self.rois, 14, 1.0 / 16, 0, True, bin_stride=2, pos_major=True, out=x0)
-                y = self.res5.forward_rows(x0, 7, 7, pos_major=True, winograd=wino)
+                y = self.res5.forward_rows(x0, 7, 7, pos_major=True, winograd=wino, split=self.args.res5_dtype == "f16x2")
             out = self.head(y.view(7, 7, R, 2048), channels_last=2)
         else:
             if timed:

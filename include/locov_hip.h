@@ -215,6 +215,14 @@ int locov_winograd_conv3x3_f32(const float *x, int64_t R, int Cin, const float *
                                int N, unsigned flags, void *workspace, int64_t workspace_bytes,
                                locov_stream_t stream);
 
+/* The same convolution with the 121 transform-domain GEMMs in split-operand arithmetic (see
+ * locov_gemm_nt_f32_split below): U_split = locov_split_f16x2_pack of the [121*N, Cin] matrix U with
+ * w_scale = u_scale; the transformed input is scaled by v_scale before its split. */
+int locov_winograd_conv3x3_f32_split(const float *x, int64_t R, int Cin, const void *U_split,
+                                     float u_scale, float v_scale, const float *scale,
+                                     const float *shift, float *y, int64_t ldy, int N, unsigned flags,
+                                     void *workspace, int64_t workspace_bytes, locov_stream_t stream);
+
 int locov_gemm_nt_batched_f32(const float *x, int64_t lda, int64_t stride_x, const float *W,
                               int64_t stride_w, float *y, int64_t ldc, int64_t stride_y,
                               int64_t M, int N, int K, int batch, locov_stream_t stream);
@@ -251,12 +259,38 @@ int locov_conv3x3_nhwc_bf16(const uint16_t *x, int64_t R, int H, int W, int Cin,
                             const float *residual, float *y, int N, unsigned flags,
                             locov_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Opt-in split-operand form of the fp32 Res5 GEMMs (MODEL.ROI_BOX_HEAD.RES5_DTYPE: "f16x2"; replaces the
+ * same reference convolutions as locov_gemm_nt_f32, roi_emb_heads.py:217-245).  Every fp32 operand value v,
+ * scaled by a power of two s that places the data in fp16's range, is represented as hi + lo with
+ * hi = fp16(s v), lo = fp16(s v - hi) (22 significant bits; absolute floor 2^-25 / s), and x . W^T is formed
+ * on the f16 matrix pipe as (hi.hi + hi.lo + lo.hi) / (s_x s_w) with fp32 accumulation: fp32 in, fp32 out,
+ * a result within about two fp32 roundings per operand of the fp32-MFMA GEMM.  |s_x x| and |s_w w| must stay
+ * below 65504 (x_scale = 64 covers |x| < 1023; choose w_scale from max |w|).  x is split on the fly; W is
+ * split once by locov_split_f16x2_pack into `out`, a buffer of the SAME size as the fp32 matrix
+ * (rows * K * 4 bytes; per row and group of 8 columns: 8 hi halves, then 8 lo halves).
+ * K % 32 == 0; N, lda, ldc % 4 == 0; 16-byte aligned pointers.  Epilogue as locov_gemm_nt_f32.
+ * ------------------------------------------------------------------------------------- */
+int locov_split_f16x2_pack(const float *w, int64_t rows, int K, int64_t ld, float w_scale, void *out,
+                           locov_stream_t stream);
+
+int locov_gemm_nt_f32_split(const float *x, int64_t lda, const void *W_split, const float *scale,
+                            const float *shift, const float *residual, float *y, int64_t ldc,
+                            int64_t M, int N, int K, unsigned flags, float x_scale, float w_scale,
+                            locov_stream_t stream);
+
+/* `batch` independent problems (strides in fp32 elements; W_split problem b starts stride_w * 4 bytes * b in) */
+int locov_gemm_nt_batched_f32_split(const float *x, int64_t lda, int64_t stride_x, const void *W_split,
+                                    int64_t stride_w, float *y, int64_t ldc, int64_t stride_y,
+                                    int64_t M, int N, int K, int batch, float x_scale, float w_scale,
+                                    locov_stream_t stream);
+
 /* Measurement aid (bench.py's roofline block): while enabled, every GEMM-kernel launch made by
  * this library is bracketed by HIP events on its launch stream.  read() waits for them and
  * returns, for one kernel class, the number of launches, the sum of their durations (ms) and
  * the FLOPs they executed.  cls: 0 = gemm_nt_kernel<128x128, plain / batched> (1x1 convs, FCs,
  * Winograd-domain GEMMs), 1 = the position-major direct 3x3 conv, 2 = the other tile shapes,
- * 3 / 4 = classes 0 / 1 launched with bf16 operands.
+ * 3 / 4 = classes 0 / 1 launched with bf16 operands, 5 = the split-operand GEMM.
  * enable(on) clears what was recorded. */
 int locov_gemm_timing_enable(int on);
 int locov_gemm_timing_read(int cls, int64_t *launches, double *ms, double *flops);

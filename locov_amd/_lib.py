@@ -52,6 +52,8 @@ SIGNATURES = {
     "locov_winograd_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
     "locov_winograd_pack_weight": (c_int, [_p, c_int, c_int, _p, _p]),
     "locov_winograd_conv3x3_f32": (c_int, [_p, c_int64, c_int, _p, _p, _p, _p, c_int64, c_int, c_uint, _p, c_int64, _p]),
+    "locov_winograd_conv3x3_f32_split": (c_int, [_p, c_int64, c_int, _p, c_float, c_float, _p, _p, _p, c_int64, c_int, c_uint,
+                                                 _p, c_int64, _p]),
     "locov_gemm_nt_batched_f32": (c_int, [_p, c_int64, c_int64, _p, c_int64, _p, c_int64, c_int64, c_int64, c_int,
                                           c_int, c_int, _p]),
     "locov_gemm_timing_enable": (c_int, [c_int]),
@@ -66,6 +68,11 @@ SIGNATURES = {
     "locov_f32_to_bf16": (c_int, [_p, c_int64, _p, _p]),
     "locov_gemm_nt_bf16": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, _p]),
     "locov_conv3x3_nhwc_bf16": (c_int, [_p, c_int64, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, c_int, c_uint, _p]),
+    "locov_split_f16x2_pack": (c_int, [_p, c_int64, c_int, c_int64, c_float, _p, _p]),
+    "locov_gemm_nt_f32_split": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, c_float,
+                                        c_float, _p]),
+    "locov_gemm_nt_batched_f32_split": (c_int, [_p, c_int64, c_int64, _p, c_int64, _p, c_int64, c_int64, c_int64, c_int,
+                                                c_int, c_int, c_float, c_float, _p]),
     "locov_sim_gemm_bf16": (c_int, [_p, _p, c_int64, c_int, c_int, _p, c_int64, _p]),
     "locov_box_head_fwd": (c_int, [_p, c_int64, c_int, c_int, c_int, _p, _p, _p, _p, _p, _p, c_int, c_int,
                                    c_int, c_int, _p, _p, _p, _p, _p, _p]),

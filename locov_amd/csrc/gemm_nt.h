@@ -32,4 +32,15 @@ int launch_gemm_nt(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C, in
                    const Epilogue &epi, hipStream_t s, const char *what, const ConvGeom &cg = ConvGeom{0, 0, 0, 0, 0},
                    const Batch &bt = Batch{1, 0, 0, 0});
 
+// Per-launch timing hooks of locov_gemm_timing_* (gemm_nt.hip): begin() returns a record index or -1 when timing is
+// off; cls = kernel class (include/locov_hip.h), flops = what the launch executes.
+int timing_begin(hipStream_t s, int cls, double flops);
+void timing_end(int idx, hipStream_t s);
+
+// y[M,N] = epi(A[M,K] . W[N,K]^T) with fp32 A split on the fly (scaled by a_scale) and W pre-split into f16 (hi, lo)
+// pairs of w_scale * W (gemm_split.hip); same Epilogue / Batch meaning as launch_gemm_nt.
+int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C, int64_t ldc, int64_t M, int N, int K,
+                      const Epilogue &epi, float a_scale, float w_scale, hipStream_t s, const char *what,
+                      const Batch &bt = Batch{1, 0, 0, 0});
+
 }  // namespace locov

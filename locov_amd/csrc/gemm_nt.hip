@@ -57,7 +57,7 @@ static std::mutex g_timing_mutex;
 static bool g_timing_on = false;
 static std::vector<TimingRec> g_timing;
 
-static int timing_begin(hipStream_t s, int cls, double flops)
+int timing_begin(hipStream_t s, int cls, double flops)
 {
     std::lock_guard<std::mutex> lock(g_timing_mutex);
     if (!g_timing_on) return -1;
@@ -67,7 +67,7 @@ static int timing_begin(hipStream_t s, int cls, double flops)
     g_timing.push_back(r);
     return (int)g_timing.size() - 1;
 }
-static void timing_end(int idx, hipStream_t s)
+void timing_end(int idx, hipStream_t s)
 {
     if (idx < 0) return;
     std::lock_guard<std::mutex> lock(g_timing_mutex);

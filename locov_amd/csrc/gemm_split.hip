@@ -1,0 +1,415 @@
+// fp32 NT GEMM  y[M,N] = epi(x[M,K] . W[N,K]^T)  on the gfx950 16-bit matrix pipe with SPLIT operands
+// (opt-in "f16x2" arithmetic of the Res5 GEMMs, roi_emb_heads.py:217-245 of the reference as GEMMs):
+//
+//     s x = hi + lo,      hi = fp16(s x) (round to nearest),   lo = fp16(s x - hi)        (s = a power of two)
+//     a.b ~= (hi_a.hi_b + hi_a.lo_b + lo_a.hi_b) / (s_a s_b)
+//
+// hi + lo carries 22 significant bits of x (s x - hi is exact in fp32; lo is an fp16 NORMAL number, i.e. keeps
+// its 11 bits, for every |s x| >= 2^-3, and below that its absolute error is <= 2^-25 -- a fixed-point floor far
+// under the rounding of the larger entries of the same row).  The operand scales s_a, s_w exist to place the
+// data in fp16's range: s_w is chosen per weight matrix at pack time (max |s_w w| ~ 2^13), s_a is a launch
+// parameter (2^6 for activations: exact up to |x| < 1024; 1 for Winograd-domain data).  The dropped lo.lo term is
+// 2^-24 relative; all three products are accumulated in fp32 by v_mfma_f32_32x32x16_f16 into ONE accumulator.
+// The result differs from an fp32-MFMA GEMM by about two fp32 roundings per operand -- the order of the fp32
+// accumulation error itself at K >= 512 -- while the matrix pipe runs 3 f16 MFMAs per 32x32x16 block instead of
+// 8 f32 ones at 1/16 of the rate (5.3x fewer matrix-pipe cycles).
+//
+// Data movement is the fp32 kernel's (gemm_nt.hip), byte for byte: A is read as fp32 (16-byte buffer loads, two
+// tiles ahead) and split in registers on its way into LDS; W is split ONCE (locov_split_f16x2_pack) into a layout
+// with the same size and row pitch as the fp32 matrix -- per row and per group of 8 columns: 8 hi halves, then 8 lo
+// halves -- so a tile row is 128 B in global memory and in LDS for both operands; LDS rows are padded to 144 B,
+// every fragment read is a conflict-free ds_read_b128 (lane l: row l&31, k = 8*(l>>5) .. +7 of a 16-wide k-step)
+// and so are the 8-byte hi / lo stores of the A staging (two rows x eight 4-column chunks per 16-lane group).
+// 128x128 tile, 4 waves (2x2, 64x64 each = 2x2 MFMA blocks x {main, correction} accumulators), two LDS stages, one
+// barrier per K-tile, two workgroups per CU; tile order, epilogue (LDS re-layout, 16-byte buffer stores, residual
+// prefetch) and the batched form are those of gemm_nt.hip.
+#include "gemm_nt.h"
+
+#include <type_traits>
+
+#ifndef LOCOV_RES_PREFETCH
+#define LOCOV_RES_PREFETCH 4
+#endif
+
+namespace locov {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, WM = 2, WN = 2, NT = 256;
+constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+constexpr int BK = 32;                      // fp32 columns per K-tile = two 16-wide MFMA k-steps
+constexpr int ROWB = 144;                   // LDS row pitch: 4 x (16 B hi + 16 B lo) + 16 B pad
+constexpr int STAGEB = (BM + BN) * ROWB;    // bytes per stage
+constexpr int CH = 4;                       // 16-byte chunks per thread, operand and tile
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+// four fp32 values -> four hi halves and four lo halves of s*x
+__device__ __forceinline__ void split4(const f32x4 &x, float s, u32x2 &hi, u32x2 &lo)
+{
+    const f32x4 xs = x * s;                                  // exact (power of two)
+    const f16x4 h = __builtin_convertvector(xs, f16x4);
+    const f32x4 hf = __builtin_convertvector(h, f32x4);
+    const f32x4 r = xs - hf;                                 // exact: <= 13 significant bits
+    const f16x4 l = __builtin_convertvector(r, f16x4);
+    hi = __builtin_bit_cast(u32x2, h);
+    lo = __builtin_bit_cast(u32x2, l);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restrict__ A, int64_t lda,
+                                                           const float *__restrict__ B, float *__restrict__ Cout,
+                                                           int64_t ldc, int64_t M, int N, int K, Epilogue epi, Batch bt,
+                                                           float a_scale, float out_scale)
+{
+    __shared__ u32x4 lds[2 * STAGEB / 16];
+    char *const ldsb = reinterpret_cast<char *>(lds);
+
+    __builtin_amdgcn_s_setprio(3);
+    const int tiles_n = (N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int tile = xcd_remap(blockIdx.x, nwg);
+    if (bt.count > 1) {
+        const int per = nwg / bt.count, b = tile / per;
+        tile -= b * per;
+        A += b * bt.sa;
+        B += b * bt.sb;
+        Cout += b * bt.sc;
+    }
+    // tile order of gemm_nt.hip: N tiles in groups of NG, inside a group M-tile outer / N-tile inner, so that the
+    // workgroups resident on an XCD stream a W slice that stays in its L2
+    int64_t m0;
+    int n0;
+    {
+        const int NG = (int64_t)K * 4 * BN * 8 <= (2 << 20) ? 8 : 4;
+        const int tiles_m = (int)((bt.count > 1 ? nwg / bt.count : nwg) / tiles_n);
+        const int full = (tiles_n / NG) * NG, per_group = tiles_m * NG;
+        if (tiles_n <= NG) {
+            m0 = (int64_t)(tile / tiles_n) * BM;
+            n0 = (tile % tiles_n) * BN;
+        } else if (tile < tiles_m * full) {
+            const int g = tile / per_group, rem = tile - g * per_group;
+            m0 = (int64_t)(rem / NG) * BM;
+            n0 = (g * NG + rem % NG) * BN;
+        } else {
+            const int gs = tiles_n - full, rem = tile - tiles_m * full;
+            m0 = (int64_t)(rem / gs) * BM;
+            n0 = (full + rem % gs) * BN;
+        }
+    }
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave / WN) * TM, wn = (wave % WN) * TN;
+
+    // staging: chunk i of a thread = row (tid + i*NT) / 8, 16-byte chunk (tid + i*NT) % 8 of the tile row; rows past
+    // M / N read a clamped in-bounds row (they only feed outputs that are never stored)
+    const char *a_base = reinterpret_cast<const char *>(A + m0 * lda);
+    const char *b_base = reinterpret_cast<const char *>(B + (int64_t)n0 * K);
+    unsigned a_off[CH], b_off[CH];
+    int a_lds[CH], b_lds[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+        const int idx = tid + i * NT, row = idx >> 3, ch = idx & 7;
+        const int64_t gm = m0 + row;
+        a_off[i] = (unsigned)((((gm < M ? gm : M - 1) - m0) * lda + ch * 4) * 4);
+        const int gn = n0 + row;
+        b_off[i] = (unsigned)(((int64_t)((gn < N ? gn : N - 1) - n0) * K + ch * 4) * 4);
+        a_lds[i] = row * ROWB + (ch >> 1) * 32 + (ch & 1) * 8;   // hi halves of k-group ch/2; its lo halves 16 B further
+        b_lds[i] = BM * ROWB + row * ROWB + ch * 16;  // W tile rows are stored as they come
+    }
+    auto ld_a = [&](int i) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a_base), 0, 0xffffffff, 0x00020000);
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, a_off[i], 0, 0));
+    };
+    auto ld_b = [&](int i) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b_base), 0, 0xffffffff, 0x00020000);
+        return __builtin_amdgcn_raw_buffer_load_b128(r, b_off[i], 0, 0);
+    };
+    f32x4 ra[CH];
+    u32x4 rb[CH];
+    auto st_a = [&](int i, int stage) {
+        u32x2 hi, lo;
+        split4(ra[i], a_scale, hi, lo);
+        char *p = ldsb + stage * STAGEB + a_lds[i];
+        *reinterpret_cast<u32x2 *>(p) = hi;
+        *reinterpret_cast<u32x2 *>(p + 16) = lo;
+    };
+    auto st_b = [&](int i, int stage) { *reinterpret_cast<u32x4 *>(ldsb + stage * STAGEB + b_lds[i]) = rb[i]; };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NI; j++) acc[i][j] = f32x16{};
+
+    // fragments of the two k-steps of a tile: [step][block][0 = hi, 1 = lo]
+    f16x8 fa[2][MI][2], fb[2][NI][2];
+    const int frow = lane & 31, fch = lane >> 5;
+    auto read_frags = [&](int stage, int q) {
+        const char *As = ldsb + stage * STAGEB + (2 * q + fch) * 32, *Bs = As + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < MI; i++) {
+            fa[q][i][0] = *reinterpret_cast<const f16x8 *>(As + (wm + i * 32 + frow) * ROWB);
+            fa[q][i][1] = *reinterpret_cast<const f16x8 *>(As + (wm + i * 32 + frow) * ROWB + 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            fb[q][j][0] = *reinterpret_cast<const f16x8 *>(Bs + (wn + j * 32 + frow) * ROWB);
+            fb[q][j][1] = *reinterpret_cast<const f16x8 *>(Bs + (wn + j * 32 + frow) * ROWB + 16);
+        }
+    };
+    // MFMAs p0..p1-1 of k-step q: per accumulator block hi.hi, hi.lo, lo.hi
+    constexpr int NMFMA = MI * NI * 3;
+    auto mma_range = [&](int q, int p0, int p1) {
+#pragma unroll
+        for (int p = 0; p < NMFMA; p++) {
+            if (p < p0 || p >= p1) continue;
+            const int t = p / 3, i = t / NI, j = t % NI, w = p % 3;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[q][i][w == 2 ? 1 : 0], fb[q][j][w == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int k_last = K - BK;                              // k0 of the last K-tile (K % BK == 0)
+    // prologue: tile 0 -> LDS stage 0, tile 1 -> staging registers, fragments of k-step 0
+#pragma unroll
+    for (int i = 0; i < CH; i++) ra[i] = ld_a(i);
+#pragma unroll
+    for (int i = 0; i < CH; i++) rb[i] = ld_b(i);
+#pragma unroll
+    for (int i = 0; i < CH; i++) st_a(i, 0);
+#pragma unroll
+    for (int i = 0; i < CH; i++) st_b(i, 0);
+    int k_ptr = BK < k_last ? BK : k_last;                  // the tile the bases address
+    a_base += (int64_t)k_ptr * 4;
+    b_base += (int64_t)k_ptr * 4;
+#pragma unroll
+    for (int i = 0; i < CH; i++) ra[i] = ld_a(i);
+#pragma unroll
+    for (int i = 0; i < CH; i++) rb[i] = ld_b(i);
+    __syncthreads();
+    read_frags(0, 0);
+    __builtin_amdgcn_s_setprio(0);
+
+    // One K-tile that has a successor, computing from LDS stage s: k-step 0's MFMAs carry the staging of tile t+1
+    // (registers -> the other stage; A is split here) and the refill loads of tile t+2; the barrier sits in the
+    // middle of k-step 1's MFMAs.
+    auto tile_step = [&](const int s, const int k0) __attribute__((always_inline)) {
+        const int kn = k0 + 2 * BK < k_last ? k0 + 2 * BK : k_last;
+        a_base += (int64_t)(kn - k_ptr) * 4;
+        b_base += (int64_t)(kn - k_ptr) * 4;
+        k_ptr = kn;
+        read_frags(s, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 2 * CH; g++) {
+            if (g < CH) {
+                st_a(g, s ^ 1);
+                ra[g] = ld_a(g);
+            } else {
+                st_b(g - CH, s ^ 1);
+                rb[g - CH] = ld_b(g - CH);
+            }
+            mma_range(0, g * NMFMA / (2 * CH), (g + 1) * NMFMA / (2 * CH));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mma_range(1, 0, NMFMA / 2);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        read_frags(s ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_range(1, NMFMA / 2, NMFMA);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto last_tile = [&](const int s) __attribute__((always_inline)) {
+        read_frags(s, 1);
+        mma_range(0, 0, NMFMA);
+        mma_range(1, 0, NMFMA);
+    };
+    int k0 = 0;
+    for (; k0 + BK < k_last; k0 += 2 * BK) {
+        tile_step(0, k0);
+        tile_step(1, k0 + BK);
+    }
+    // residual rows of the first NPRE row groups are requested before the last K-tile (gemm_nt.hip)
+    constexpr int NPRE = LOCOV_RES_PREFETCH;
+    constexpr int LPR = TN / 4, RPI = 64 / LPR, NIT = TM / RPI;
+    f32x4 res_pre[NPRE > 0 ? NPRE : 1];
+    const int c4 = (lane % LPR) * 4, rr = lane / LPR;
+    const int n = n0 + wn + c4;
+    const bool n_ok = n < N;
+    const int64_t rows_here = M - m0 < BM ? M - m0 : BM;
+    const unsigned nrec = (unsigned)(rows_here * ldc * 4);
+    const unsigned voff = (unsigned)(((int64_t)(wm + rr) * ldc + n) * 4);
+    const unsigned vstep = (unsigned)(RPI * ldc * 4);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(Cout + m0 * ldc, 0, nrec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(epi.residual ? epi.residual + m0 * ldc : Cout + m0 * ldc), 0, nrec, 0x00020000);
+    auto prefetch_residual = [&]() __attribute__((always_inline)) {
+        if (NPRE == 0 || !epi.residual || !n_ok) return;
+#pragma unroll
+        for (int it = 0; it < NPRE; it++)
+            res_pre[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, voff + it * vstep, 0, 0));
+    };
+    if (k0 < k_last) {
+        tile_step(0, k0);
+        prefetch_residual();
+        last_tile(1);
+    } else {
+        prefetch_residual();
+        last_tile(0);
+    }
+
+    __builtin_amdgcn_s_setprio(3);
+    // Epilogue (C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)): fold the
+    // correction in, re-lay the wave's sub-tile out through LDS, 16 bytes per lane and row-contiguous from there.
+    const bool relu = (epi.flags & LOCOV_EPI_RELU) != 0;
+    constexpr int EPS = TN + 4;
+    static_assert(WM * WN * TM * EPS * 4 <= 2 * STAGEB, "epilogue staging must fit the K-loop LDS");
+    float *ep = reinterpret_cast<float *>(lds) + wave * (TM * EPS);
+    auto tail = [&](auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        f32x4 res[NIT];
+        if (epi.residual && n_ok) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                if (it < NPRE && NPRE > 0)
+                    res[it] = res_pre[it];
+                else
+                    res[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                            r_res, FULL ? voff : voff + it * vstep, FULL ? it * vstep : 0u, 0));
+            }
+        }
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (n_ok && epi.scale) sc = *reinterpret_cast<const f32x4 *>(epi.scale + n);
+        sc *= out_scale;                                  // undo the operand scales
+        if (n_ok && epi.shift) sh = *reinterpret_cast<const f32x4 *>(epi.shift + n);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MI; i++)
+#pragma unroll
+            for (int j = 0; j < NI; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPS + j * 32 + (lane & 31)] =
+                        acc[i][j][r];
+        __syncthreads();
+        if (n_ok) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                f32x4 v = *reinterpret_cast<const f32x4 *>(ep + (it * RPI + rr) * EPS + c4);
+                v = v * sc + sh;
+                if (epi.residual) v += res[it];
+                if (relu) {
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, FULL ? voff : voff + it * vstep,
+                                                       FULL ? it * vstep : 0u, 0);
+            }
+        }
+    };
+    if (rows_here == BM)
+        tail(std::true_type{});
+    else
+        tail(std::false_type{});
+}
+
+// W [rows, K] fp32 (row pitch ld) -> the split layout of s*W: per row and group of 8 columns, 8 hi halves then 8 lo halves
+__global__ __launch_bounds__(256) void split_pack_kernel(const float *__restrict__ w, int64_t rows, int K, int64_t ld,
+                                                         float s, _Float16 *__restrict__ out)
+{
+    const int64_t total = rows * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / K;
+        const int k = (int)(i - r * K), t = k >> 5, e = k & 31;
+        const float x = w[r * ld + k] * s;
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        _Float16 *o = out + r * 2 * K + t * 64 + (e >> 3) * 16 + (e & 7);
+        o[0] = h;
+        o[8] = l;
+    }
+}
+
+int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C, int64_t ldc, int64_t M, int N, int K,
+                      const Epilogue &epi, float a_scale, float w_scale, hipStream_t s, const char *what, const Batch &bt)
+{
+    if (!(a_scale > 0.f) || !(w_scale > 0.f)) return set_error(LOCOV_ERR_INVALID_ARG, "%s: operand scales must be positive", what);
+    if (K % BK != 0 || K < BK) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: K must be a positive multiple of %d", what, BK);
+    if (N % 4 != 0 || ldc % 4 != 0 || lda % 4 != 0 || (uintptr_t)A % 16 != 0 || (uintptr_t)Wsplit % 16 != 0 ||
+        (uintptr_t)C % 16 != 0 || (epi.residual && (uintptr_t)epi.residual % 16 != 0) ||
+        (epi.scale && (uintptr_t)epi.scale % 16 != 0) || (epi.shift && (uintptr_t)epi.shift % 16 != 0))
+        return set_error(LOCOV_ERR_UNSUPPORTED, "%s: N, lda, ldc must be multiples of 4 and every pointer 16-byte aligned", what);
+    if (bt.count > 1 && epi.residual) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: batched launches take no residual", what);
+    const int count = bt.count > 1 ? bt.count : 1;
+    const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN) * count;
+    if (tiles > 0x7fffffffLL) return set_error(LOCOV_ERR_INVALID_ARG, "%s: problem too large", what);
+    if ((int64_t)BM * (lda > ldc ? lda : ldc) * 4 > 0x7fffffffLL)
+        return set_error(LOCOV_ERR_INVALID_ARG, "%s: row pitch too large for 32-bit tile offsets", what);
+    const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K * count);     // class 5: split-operand GEMM
+    hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)tiles), dim3(NT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
+                       C, ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale));
+    timing_end(trec, s);
+    return check_launch(what);
+}
+
+}  // namespace locov
+
+using namespace locov;
+
+extern "C" {
+
+int locov_split_f16x2_pack(const float *w, int64_t rows, int K, int64_t ld, float w_scale, void *out, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(w_scale > 0.f, "locov_split_f16x2_pack: w_scale must be positive");
+    LOCOV_REQUIRE(rows >= 0 && K > 0 && K % BK == 0 && ld >= K, "locov_split_f16x2_pack: K must be a multiple of %d, ld >= K", BK);
+    if (rows == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(w && out, "locov_split_f16x2_pack: null pointer");
+    const int64_t total = rows * K;
+    const unsigned blocks = (unsigned)(ceil_div(total, 256) < 65536 ? ceil_div(total, 256) : 65536);
+    hipLaunchKernelGGL(split_pack_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, rows, K, ld, w_scale,
+                       reinterpret_cast<_Float16 *>(out));
+    return check_launch("locov_split_f16x2_pack");
+}
+
+int locov_gemm_nt_f32_split(const float *x, int64_t lda, const void *W_split, const float *scale, const float *shift,
+                            const float *residual, float *y, int64_t ldc, int64_t M, int N, int K, unsigned flags,
+                            float x_scale, float w_scale, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(M >= 0 && N > 0 && K > 0, "locov_gemm_nt_f32_split: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    if (M == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(x && W_split && y, "locov_gemm_nt_f32_split: null pointer");
+    LOCOV_REQUIRE(lda >= K && ldc >= N, "locov_gemm_nt_f32_split: lda < K or ldc < N");
+    Epilogue epi{scale, shift, residual, flags};
+    return launch_gemm_split(x, lda, W_split, y, ldc, M, N, K, epi, x_scale, w_scale, as_stream(stream),
+                             "locov_gemm_nt_f32_split");
+}
+
+int locov_gemm_nt_batched_f32_split(const float *x, int64_t lda, int64_t stride_x, const void *W_split, int64_t stride_w,
+                                    float *y, int64_t ldc, int64_t stride_y, int64_t M, int N, int K, int batch,
+                                    float x_scale, float w_scale, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(M >= 0 && N > 0 && K > 0 && batch > 0, "locov_gemm_nt_batched_f32_split: bad shape");
+    if (M == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(x && W_split && y, "locov_gemm_nt_batched_f32_split: null pointer");
+    LOCOV_REQUIRE(lda >= K && ldc >= N && stride_x % 4 == 0 && stride_w % 4 == 0 && stride_y % 4 == 0,
+                  "locov_gemm_nt_batched_f32_split: lda < K, ldc < N or a stride that is not a multiple of 4");
+    Epilogue epi{nullptr, nullptr, nullptr, 0u};
+    return launch_gemm_split(x, lda, W_split, y, ldc, M, N, K, epi, x_scale, w_scale, as_stream(stream),
+                             "locov_gemm_nt_batched_f32_split", Batch{batch, stride_x, stride_w, stride_y});
+}
+
+}  // extern "C"

@@ -187,9 +187,31 @@ int locov_winograd_pack_weight(const float *w, int N, int Cin, float *U, locov_s
     return check_launch("locov_winograd_pack_weight");
 }
 
+// u_scale > 0: U is the split-operand packing of u_scale * U (locov_split_f16x2_pack) and the 121 GEMMs run on the
+// f16 matrix pipe with V scaled by v_scale (gemm_split.hip); u_scale == 0: fp32 U, fp32 MFMA.
+static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
+                            const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
+                            void *workspace, int64_t workspace_bytes, locov_stream_t stream);
+
 int locov_winograd_conv3x3_f32(const float *x, int64_t R, int Cin, const float *U, const float *scale,
                                const float *shift, float *y, int64_t ldy, int N, unsigned flags, void *workspace,
                                int64_t workspace_bytes, locov_stream_t stream)
+{
+    return winograd_conv3x3(x, R, Cin, U, 0.f, 0.f, scale, shift, y, ldy, N, flags, workspace, workspace_bytes, stream);
+}
+
+int locov_winograd_conv3x3_f32_split(const float *x, int64_t R, int Cin, const void *U_split, float u_scale, float v_scale,
+                                     const float *scale, const float *shift, float *y, int64_t ldy, int N,
+                                     unsigned flags, void *workspace, int64_t workspace_bytes, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(u_scale > 0.f && v_scale > 0.f, "locov_winograd_conv3x3_f32_split: operand scales must be positive");
+    return winograd_conv3x3(x, R, Cin, static_cast<const float *>(U_split), u_scale, v_scale, scale, shift, y, ldy, N, flags,
+                            workspace, workspace_bytes, stream);
+}
+
+static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
+                            const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
+                            void *workspace, int64_t workspace_bytes, locov_stream_t stream)
 {
     LOCOV_REQUIRE(ldy >= N && ldy % 2 == 0, "locov_winograd_conv3x3_f32: ldy must be >= N and even");
     LOCOV_REQUIRE(R >= 0 && Cin > 0 && N > 0, "locov_winograd_conv3x3_f32: bad shape");
@@ -213,9 +235,14 @@ int locov_winograd_conv3x3_f32(const float *x, int64_t R, int Cin, const float *
         int rcode = check_launch("locov_winograd_conv3x3_f32 (input transform)");
         if (rcode) return rcode;
         Epilogue epi{nullptr, nullptr, nullptr, 0u};
-        rcode = launch_gemm_nt<float, float>(V, (int64_t)Cin, U, (int64_t)Cin, Mv, (int64_t)N, rc, N, Cin, epi, s,
-                                             "locov_winograd_conv3x3_f32 (batched GEMM)", ConvGeom{0, 0, 0, 0, 0},
-                                             Batch{NF * NF, rc * Cin, (int64_t)N * Cin, rc * N});
+        if (u_scale > 0.f)
+            rcode = launch_gemm_split(V, (int64_t)Cin, U, Mv, (int64_t)N, rc, N, Cin, epi, v_scale, u_scale, s,
+                                      "locov_winograd_conv3x3_f32_split (batched GEMM)",
+                                      Batch{NF * NF, rc * Cin, (int64_t)N * Cin, rc * N});
+        else
+            rcode = launch_gemm_nt<float, float>(V, (int64_t)Cin, U, (int64_t)Cin, Mv, (int64_t)N, rc, N, Cin, epi, s,
+                                                 "locov_winograd_conv3x3_f32 (batched GEMM)", ConvGeom{0, 0, 0, 0, 0},
+                                                 Batch{NF * NF, rc * Cin, (int64_t)N * Cin, rc * N});
         if (rcode) return rcode;
         hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)ceil_div(tout, 256)), dim3(256), 0, s, Mv, R, rc, N, scale, shift,
                            (flags & LOCOV_EPI_RELU) ? 1 : 0, y + r0 * ldy, ldy);

@@ -8,7 +8,8 @@ CPU path: tensors must live on a ROCm device.
 from __future__ import annotations
 
 import ctypes
-from typing import Optional, Sequence, Tuple
+import math
+from typing import NamedTuple, Optional, Sequence, Tuple
 
 import torch
 
@@ -315,13 +316,16 @@ def winograd_pack_weight(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def winograd_conv3x3(x: torch.Tensor, U: torch.Tensor, *, scale=None, shift=None, relu: bool = False,
-                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool = False,
+                     out: Optional[torch.Tensor] = None, v_scale: float = 1.0) -> torch.Tensor:
     """3x3 / pad 1 / stride 1 convolution of 7x7 position-major tiles in the Winograd domain.
     x [49*R, Cin] (row = pos*R + r), U [121, N, Cin] (winograd_pack_weight) -> [49*R, N].
-    out: optional [49*R, N] destination whose rows may be a column block of a wider matrix."""
+    out: optional [49*R, N] destination whose rows may be a column block of a wider matrix.
+    U may be a SplitWeight (split_pack(winograd_pack_weight(w))): the 121 transform-domain GEMMs then run with
+    split operands on the f16 matrix pipe, the transformed input scaled by v_scale."""
     x = _dev(x, "x")
-    U = _dev(U, "U")
+    split = U if isinstance(U, SplitWeight) else None
+    U = _dev(split.data if split is not None else U, "U")
     M, Cin = x.shape
     if U.dim() != 3 or U.shape[0] != 121 or U.shape[2] != Cin or M % 49 != 0:
         raise ValueError("winograd_conv3x3: inconsistent shapes")
@@ -345,9 +349,14 @@ def winograd_conv3x3(x: torch.Tensor, U: torch.Tensor, *, scale=None, shift=None
         _WINO_WS.pop(key, None)
         ws = _WINO_WS[key] = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        check(lib.locov_winograd_conv3x3_f32(_ptr(x), R, Cin, _ptr(U), _ptr(scale), _ptr(shift), _ptr(y), ldy, N,
-                                             _lib.EPI_RELU if relu else 0, _ptr(ws), ws.numel(), _stream(x)),
-              "locov_winograd_conv3x3_f32")
+        if split is not None:
+            check(lib.locov_winograd_conv3x3_f32_split(_ptr(x), R, Cin, _ptr(U), split.scale, float(v_scale), _ptr(scale),
+                                                       _ptr(shift), _ptr(y), ldy, N, _lib.EPI_RELU if relu else 0, _ptr(ws),
+                                                       ws.numel(), _stream(x)), "locov_winograd_conv3x3_f32_split")
+        else:
+            check(lib.locov_winograd_conv3x3_f32(_ptr(x), R, Cin, _ptr(U), _ptr(scale), _ptr(shift), _ptr(y), ldy, N,
+                                                 _lib.EPI_RELU if relu else 0, _ptr(ws), ws.numel(), _stream(x)),
+                  "locov_winograd_conv3x3_f32")
     return y
 
 
@@ -363,6 +372,74 @@ def gemm_nt_batched(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(x.device):
         check(_lib.load().locov_gemm_nt_batched_f32(_ptr(x), K, M * K, _ptr(w), N * K, _ptr(y), N, M * N, M, N, K, B,
                                                     _stream(x)), "locov_gemm_nt_batched_f32")
+    return y
+
+
+class SplitWeight(NamedTuple):
+    """A weight matrix in the split-operand layout (split_pack) and the power-of-two scale it was packed with."""
+    data: torch.Tensor
+    scale: float
+
+
+def split_pack(w: torch.Tensor, scale: Optional[float] = None) -> SplitWeight:
+    """fp32 [..., K] (K % 32 == 0) -> the split-operand layout of locov_split_f16x2_pack: a float32-typed tensor of
+    the same shape whose bytes hold, per row and group of 8 columns, 8 fp16 hi halves then 8 fp16 lo halves of
+    scale * w (scale * w = hi + lo).  scale defaults to the power of two that puts max |scale * w| in [2^12, 2^13).
+    Only meaningful as the `weight` of linear_split / gemm_nt_batched_split."""
+    w = _dev(w, "w")
+    K = w.shape[-1]
+    if K % 32:
+        raise ValueError(f"split_pack: K = {K} must be a multiple of 32")
+    if scale is None:
+        amax = float(w.abs().max()) if w.numel() else 1.0
+        scale = 2.0 ** (12 - math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
+        scale = min(max(scale, 2.0 ** -100), 2.0 ** 100)
+    out = torch.empty_like(w)
+    rows = w.numel() // K
+    with torch.cuda.device(w.device):
+        check(_lib.load().locov_split_f16x2_pack(_ptr(w), rows, K, K, float(scale), _ptr(out), _stream(w)),
+              "locov_split_f16x2_pack")
+    return SplitWeight(out, float(scale))
+
+
+def linear_split(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tensor] = None, *,
+                 scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                 relu: bool = False, x_scale: float = 64.0) -> torch.Tensor:
+    """y = epi(x . W^T), fp32 in / fp32 out, products on the f16 matrix pipe with split operands (opt-in "f16x2"
+    arithmetic).  x [M,K] fp32 (rows may be strided), weight = split_pack(W [N,K]); x_scale = the power of two x is
+    multiplied by before the split (|x_scale * x| must stay below 65504)."""
+    x = _rows(x, "x")
+    wd = _dev(weight.data, "weight")
+    M, K = x.shape
+    N = wd.shape[0]
+    if wd.shape[1] != K or K % 32 or N % 4:
+        raise ValueError(f"linear_split: x {tuple(x.shape)} weight {tuple(wd.shape)} (K % 32 == 0, N % 4 == 0)")
+    bias = _dev(bias, "bias") if bias is not None else None
+    scale = _dev(scale, "scale") if scale is not None else None
+    residual = _dev(residual, "residual") if residual is not None else None
+    if residual is not None and tuple(residual.shape) != (M, N):
+        raise ValueError("residual must be [M,N]")
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_gemm_nt_f32_split(_ptr(x), x.stride(0) if M else K, _ptr(wd), _ptr(scale), _ptr(bias),
+                                                  _ptr(residual), _ptr(y), N, M, N, K, _lib.EPI_RELU if relu else 0,
+                                                  float(x_scale), weight.scale, _stream(x)), "locov_gemm_nt_f32_split")
+    return y
+
+
+def gemm_nt_batched_split(x: torch.Tensor, w: SplitWeight, x_scale: float = 1.0) -> torch.Tensor:
+    """x [B,M,K] fp32, w = split_pack(w [B,N,K]) -> [B,M,N] fp32 (one launch, split-operand arithmetic)."""
+    x = _dev(x, "x")
+    wd = _dev(w.data, "w")
+    B, M, K = x.shape
+    if wd.shape[0] != B or wd.shape[2] != K or K % 32:
+        raise ValueError("gemm_nt_batched_split: inconsistent shapes")
+    N = wd.shape[1]
+    y = torch.empty((B, M, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_gemm_nt_batched_f32_split(_ptr(x), K, M * K, _ptr(wd), N * K, _ptr(y), N, M * N, M, N, K,
+                                                          B, float(x_scale), w.scale, _stream(x)),
+              "locov_gemm_nt_batched_f32_split")
     return y
 
 

@@ -179,6 +179,23 @@ class Res5Stage(nn.Sequential):
         self._cache[("bf16", id(t))] = (t, out)
         return out
 
+    def _split(self, t: torch.Tensor):
+        """Split-operand packing (ops.split_pack) of a packed fp32 weight, cached per tensor object."""
+        from . import ops
+        hit = self._cache.get(("split", id(t)))
+        if hit is not None and hit[0] is t:
+            return hit[1]
+        out = ops.split_pack(t.contiguous())
+        self._cache[("split", id(t))] = (t, out)
+        return out
+
+    def _linear(self, split: bool, x, w, bias=None, **kw):
+        """One 1x1 convolution / FC as a GEMM: fp32 MFMA, or (split) split-operand f16 MFMA when the shape allows."""
+        from . import ops
+        if split and w.shape[1] % 32 == 0 and w.shape[0] % 4 == 0:
+            return ops.linear_split(x, self._split(w), bias, **kw)
+        return ops.linear(x, w, bias, **kw)
+
     def _packed_block0_on_map(self):
         """Weights for running block 0's two 1x1 stride-2 convolutions on the feature MAP (see
         forward_from_map): Wmap = [W1 ; ss*Ws]  ([mid + Cout, Cin]; the shortcut's FrozenBN scale is folded into
@@ -205,7 +222,7 @@ class Res5Stage(nn.Sequential):
     @torch.no_grad()
     def forward_from_map(self, nhwc: torch.Tensor, rois: torch.Tensor, pooler_resolution: int, spatial_scale: float,
                          sampling_ratio: int = 0, aligned: bool = True, winograd: bool = True,
-                         bf16: bool = False) -> torch.Tensor:
+                         bf16: bool = False, split: bool = False) -> torch.Tensor:
         """The whole stage from the channels-last res4 map [N,H,W,Cin] and the rois [R,5] -> position-major
         rows [49*R, Cout], with block 0's conv1 and projection shortcut moved IN FRONT of the pooler:
 
@@ -225,7 +242,7 @@ class Res5Stage(nn.Sequential):
         if bf16:
             g = ops.linear_bf16(ops.to_bf16(nhwc.reshape(N * H * W, cin)), self._bf16(wmap)).view(N, H, W, wmap.shape[0])
         else:
-            g = ops.linear(nhwc.reshape(N * H * W, cin), wmap).view(N, H, W, wmap.shape[0])
+            g = self._linear(split, nhwc.reshape(N * H * W, cin), wmap).view(N, H, W, wmap.shape[0])
         y = ops.roi_align_nhwc(g[..., :mid], rois, 14, spatial_scale, sampling_ratio, aligned, bin_stride=2,
                                pos_major=True, ch_scale=s1, ch_shift=b1, relu=True)          # conv1 + FBN + ReLU, pooled
         sc = ops.roi_align_nhwc(g[..., mid:], rois, 14, spatial_scale, sampling_ratio, aligned, bin_stride=2,
@@ -241,16 +258,16 @@ class Res5Stage(nn.Sequential):
             return self.forward_rows(x, 7, 7, pos_major=True, start_block=1, bf16=True)
         if winograd and c2.in_channels % 32 == 0 and c2.out_channels % 4 == 0:
             u2, s2, b2 = self._packed(c2, winograd=True)
-            y = ops.winograd_conv3x3(y, u2, scale=s2, shift=b2, relu=True)
+            y = ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True)
         else:
             w2, s2, b2 = self._packed(c2)
             y = ops.conv3x3_nhwc(y, w2, 7, 7, scale=s2, shift=b2, relu=True, pos_major=True)
-        x = ops.linear(y, w3, shift_tail, scale=s3, residual=sc, relu=True)                  # conv3 + FBN + add + ReLU
-        return self.forward_rows(x, 7, 7, pos_major=True, winograd=winograd, start_block=1)
+        x = self._linear(split, y, w3, shift_tail, scale=s3, residual=sc, relu=True)         # conv3 + FBN + add + ReLU
+        return self.forward_rows(x, 7, 7, pos_major=True, winograd=winograd, start_block=1, split=split)
 
     @torch.no_grad()
     def forward_rows(self, x0: torch.Tensor, H: int, W: int, pos_major: bool = False,
-                     winograd: bool = True, start_block: int = 0, bf16: bool = False) -> torch.Tensor:
+                     winograd: bool = True, start_block: int = 0, bf16: bool = False, split: bool = False) -> torch.Tensor:
         """Rows are ROI-major (r*H*W + pos) or position-major (pos*R + r); the 1x1 convolutions do not
         care.  The 3x3 one runs, on 7x7 position-major tiles, in the Winograd domain (121 instead of 361
         products per tile and channel pair; `winograd=False` keeps the direct implicit GEMM, which skips
@@ -279,26 +296,27 @@ class Res5Stage(nn.Sequential):
                     sc = x
                 x = ops.linear_bf16(ops.to_bf16(y), self._bf16(w3), b3, scale=s3, residual=sc, relu=True)
                 continue
-            y = ops.linear(x, w1, b1, scale=s1, relu=True)                        # 1x1 (+stride via x0) + FBN + ReLU
+            y = self._linear(split, x, w1, b1, scale=s1, relu=True)               # 1x1 (+stride via x0) + FBN + ReLU
             use_wino = winograd and pos_major and H == 7 and W == 7 and c2.in_channels % 32 == 0 and c2.out_channels % 4 == 0
             if use_wino and bi == 0 and cat is not None and blk.shortcut is not None:
                 u2, s2, b2 = self._packed(c2, winograd=True)
-                ops.winograd_conv3x3(y, u2, scale=s2, shift=b2, relu=True, out=cat[:, :c2.out_channels])
+                ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True,
+                                     out=cat[:, :c2.out_channels])
                 wcat, bcat = self._packed_block0_tail()
-                x = ops.linear(cat, wcat, bcat, relu=True)                        # conv3 + shortcut + add + ReLU, K-concatenated
+                x = self._linear(split, cat, wcat, bcat, relu=True)               # conv3 + shortcut + add + ReLU, K-concatenated
                 continue
             if use_wino:
                 u2, s2, b2 = self._packed(c2, winograd=True)
-                y = ops.winograd_conv3x3(y, u2, scale=s2, shift=b2, relu=True)    # 3x3 + FBN + ReLU
+                y = ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True)   # 3x3 + FBN + ReLU
             else:
                 w2, s2, b2 = self._packed(c2)
                 y = ops.conv3x3_nhwc(y, w2, H, W, scale=s2, shift=b2, relu=True, pos_major=pos_major)
             if blk.shortcut is not None:
                 ws, ss, bs = self._packed(blk.shortcut)
-                sc = ops.linear(x, ws, bs, scale=ss)                              # 1x1 shortcut + FBN
+                sc = self._linear(split, x, ws, bs, scale=ss)                     # 1x1 shortcut + FBN
             else:
                 sc = x
-            x = ops.linear(y, w3, b3, scale=s3, residual=sc, relu=True)           # 1x1 + FBN + add + ReLU
+            x = self._linear(split, y, w3, b3, scale=s3, residual=sc, relu=True)  # 1x1 + FBN + add + ReLU
         return x
 
 

@@ -207,8 +207,10 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
                  mask_head: Optional[nn.Module] = None, output_shape: Optional[int] = 0,
                  res5_backend: str = "hip", res5_conv3x3: str = "winograd", res5_dtype: str = "fp32", **kwargs):
         super().__init__(**kwargs)
-        assert res5_backend in ("hip", "miopen") and res5_conv3x3 in ("winograd", "direct") and res5_dtype in ("fp32", "bf16")
-        self.res5_dtype = res5_dtype          # extension: "bf16" = opt-in reduced-precision GEMM operands (not the parity path)
+        assert res5_backend in ("hip", "miopen") and res5_conv3x3 in ("winograd", "direct") and res5_dtype in ("fp32", "f16x2", "bf16")
+        # extension: "f16x2" = fp32 GEMMs formed from split f16 operand pairs on the f16 matrix pipe (fp32-level
+        # accuracy, see csrc/gemm_split.hip); "bf16" = reduced-precision GEMM operands (not a parity configuration)
+        self.res5_dtype = res5_dtype
         self.res5_backend = res5_backend      # extension: how the Res5 convolutions run (see res5.py)
         self.res5_conv3x3 = res5_conv3x3      # extension: form of the 3x3 convolutions on the hip backend
         self.in_features = in_features
@@ -278,6 +280,7 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         oh = ow = P // 2
         R = rois.shape[0]
         wino = self.res5_conv3x3 == "winograd"
+        split = self.res5_dtype == "f16x2"
         if self.res5_dtype == "bf16":
             x0 = torch.empty((oh * ow * R, nhwc.shape[3]), dtype=torch.float32, device=nhwc.device)
             if P == 14 and self.res5[0].shortcut is not None:
@@ -291,13 +294,13 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         if P == 14 and self.res5.map_path_pays(R, nhwc.shape[0] * nhwc.shape[1] * nhwc.shape[2]):
             # many proposals per image: block 0's 1x1 convolutions run on the map, ROIAlign pools their outputs
             y = self.res5.forward_from_map(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio,
-                                           self.pooler.aligned, winograd=wino)
+                                           self.pooler.aligned, winograd=wino, split=split)
             return y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)
         # (ROIAlign writes straight into the operand block 0's K-concatenated conv3 + shortcut GEMM reads)
         x0 = self.res5.rows_input(oh * ow * R, nhwc.device)
         ops.roi_align_nhwc(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned,
                            bin_stride=2, pos_major=True, out=x0)
-        y = self.res5.forward_rows(x0, oh, ow, pos_major=True, winograd=self.res5_conv3x3 == "winograd")
+        y = self.res5.forward_rows(x0, oh, ow, pos_major=True, winograd=wino, split=split)
         return y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)      # logical [R, C5, oh, ow]
 
     def _pooled_mean(self, box_features: torch.Tensor) -> torch.Tensor:

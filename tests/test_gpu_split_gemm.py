@@ -1,0 +1,174 @@
+"""Split-operand fp32 GEMM (locov_gemm_nt_f32_split / _batched_ / locov_winograd_conv3x3_f32_split; csrc/gemm_split.hip):
+fp32 in, fp32 out, products formed on the f16 matrix pipe from (hi, lo) fp16 pairs.  It stands in for the same
+reference convolutions as the fp32-MFMA GEMM (Res5, roi_emb_heads.py:217-245), so the bar is the fp32 one: its error
+against an fp64 product must be of the order of the fp32-MFMA kernel's on the same inputs, over the whole range of
+magnitudes the operand scales are meant to cover, and the head's logits must stay inside the 1e-4 gate."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device")
+    from locov_amd import _lib, ops
+    _lib.load()
+    return ops
+
+
+def _rel(y, ref):
+    return float((y.double() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4, 32), (127, 128, 64), (128, 132, 96), (1000, 512, 2048), (777, 2048, 512),
+                                   (333, 2560, 1024), (4097, 388, 1536)])
+@pytest.mark.parametrize("mag", [1.0, 0.05, 10.0])
+def test_split_gemm_is_as_accurate_as_the_fp32_mfma_gemm(ops, M, N, K, mag):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = (torch.randn(M, K, generator=g) * mag).relu_()
+    x[::7, ::5] *= 1e-4                                       # small entries next to large ones
+    w = torch.randn(N, K, generator=g) * 0.02
+    ref = x.double() @ w.double().t()
+    xd, wd = x.cuda(), w.cuda()
+    e32 = _rel(ops.linear(xd, wd).cpu(), ref)
+    es = _rel(ops.linear_split(xd, ops.split_pack(wd)).cpu(), ref)       # default x_scale = 64: |x| < 1023
+    # 22-bit operands: ~2.4e-7 per operand on top of the accumulation error both kernels share
+    assert es <= 3e-6, es
+    assert es <= 1.5 * e32 + 6e-7, (es, e32)
+
+
+def test_split_gemm_operand_scale_covers_other_magnitudes(ops):
+    """x_scale places the activations in fp16's range: 2^-6-scaled for values up to 4e6, 2^12-scaled for 1e-5-sized
+    ones -- same accuracy as at unit scale."""
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(256, 512, generator=g) * 0.02).cuda()
+    for mag, xs in ((1e-5, 2.0 ** 22), (3e4, 2.0 ** -6)):
+        x = (torch.randn(500, 512, generator=g) * mag).relu_().cuda()
+        ref = x.double() @ w.double().t()
+        es = _rel(ops.linear_split(x, ops.split_pack(w), x_scale=xs), ref)
+        assert es <= 2e-6, (mag, es)
+
+
+def test_split_pack_layout_and_scale(ops):
+    """scale * w == hi + lo to 22 bits; per group of 8 columns the packed row holds 8 hi halves, then 8 lo halves."""
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(5, 64, generator=g) * 0.03
+    sw = ops.split_pack(w.cuda())
+    assert sw.data.shape == w.shape and sw.data.dtype == torch.float32
+    amax = float(w.abs().max()) * sw.scale
+    assert 2.0 ** 12 <= amax < 2.0 ** 13 and np.log2(sw.scale) == int(np.log2(sw.scale))
+    halves = sw.data.cpu().view(torch.float16).view(5, 8, 2, 8).float()      # [row, group, hi/lo, 8]
+    back = (halves[:, :, 0] + halves[:, :, 1]).reshape(5, 64) / sw.scale
+    assert (back - w).abs().max().item() <= 2.0 ** -21 * float(w.abs().max())
+    np.testing.assert_array_equal(halves[:, :, 0].reshape(5, 64).numpy(), (w * sw.scale).half().float().numpy())
+
+
+def test_split_gemm_epilogue_and_strided_rows(ops):
+    """scale / shift / residual / ReLU, x as a column block of a wider matrix, ragged M and N tiles."""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 901, 516, 160
+    wide = torch.randn(M, K + 64, generator=g).cuda()
+    x = wide[:, 32:32 + K]
+    w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    sc, sh, res = (torch.rand(N, generator=g) + 0.5).cuda(), torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    ref = torch.relu((x.double() @ w.double().t()) * sc.double() + sh.double() + res.double())
+    got = ops.linear_split(x, ops.split_pack(w), sh, scale=sc, residual=res, relu=True)
+    assert (got.double() - ref).abs().max().item() <= 5e-6
+    plain = ops.linear_split(x, ops.split_pack(w))
+    assert (plain.double() - x.double() @ w.double().t()).abs().max().item() <= 5e-6
+
+
+def test_split_gemm_rejects_what_it_cannot_run(ops):
+    from locov_amd._lib import LocovError
+    x = torch.randn(8, 48).cuda()
+    with pytest.raises(ValueError):
+        ops.split_pack(x)                                     # K % 32
+    w = ops.split_pack(torch.randn(6, 64).cuda())
+    with pytest.raises(ValueError):
+        ops.linear_split(torch.randn(8, 64).cuda(), w)        # N % 4
+    with pytest.raises((LocovError, TypeError)):
+        ops.linear_split(torch.randn(8, 64), w)               # host tensor: no CPU path
+
+
+@pytest.mark.parametrize("B,M,N,K", [(3, 70, 48, 64), (121, 130, 128, 32), (5, 700, 512, 512)])
+def test_split_batched_gemm(ops, B, M, N, K):
+    g = torch.Generator().manual_seed(B * 1000 + M)
+    x = torch.randn(B, M, K, generator=g) * 10
+    w = torch.randn(B, N, K, generator=g) * 0.05
+    ref = torch.bmm(x.double(), w.double().transpose(1, 2))
+    got = ops.gemm_nt_batched_split(x.cuda(), ops.split_pack(w.cuda())).cpu()
+    e32 = _rel(ops.gemm_nt_batched(x.cuda(), w.cuda()).cpu(), ref)
+    es = _rel(got, ref)
+    assert es <= 3e-6 and es <= 1.5 * e32 + 2e-7, (es, e32)
+
+
+@pytest.mark.parametrize("R,Cin,N", [(37, 64, 48), (129, 512, 512)])
+def test_split_winograd_conv_vs_direct(ops, R, Cin, N):
+    g = torch.Generator().manual_seed(R)
+    x = torch.randn(R, Cin, 7, 7, generator=g).relu_()
+    w = torch.randn(N, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    sc, sh = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1
+    ref = torch.relu(F.conv2d(x.double(), w.double(), padding=1) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    rows = x.permute(2, 3, 0, 1).reshape(49 * R, Cin).contiguous().cuda()
+    U = ops.winograd_pack_weight(w.cuda())
+    y32 = ops.winograd_conv3x3(rows, U, scale=sc.cuda(), shift=sh.cuda(), relu=True)
+    ys = ops.winograd_conv3x3(rows, ops.split_pack(U), scale=sc.cuda(), shift=sh.cuda(), relu=True)
+    unrows = lambda y: y.reshape(7, 7, R, -1).permute(2, 3, 0, 1).cpu()
+    e32, es = _rel(unrows(y32), ref), _rel(unrows(ys), ref)
+    assert es <= 2e-5 and es <= 1.5 * e32 + 1e-6, (es, e32)
+
+
+@pytest.mark.parametrize("many", [False, True])
+def test_heads_with_split_res5_pass_the_logit_gate(many):
+    """MODEL.ROI_BOX_HEAD.RES5_DTYPE = "f16x2": the whole head against the CPU oracle, same gates as the fp32 path
+    (logits 1e-4, box deltas 1e-5), on the pooled-rows path and on the map path."""
+    import locov_amd as pkg
+    from oracle import lsm_oracle as oracle
+    import test_gpu_roi_heads as T
+    oracle.build()
+    cfg = T._small_cfg(pkg)
+    cfg.MODEL.ROI_BOX_HEAD.RES5_DTYPE = "f16x2"
+    heads, params, h = T._make_heads(pkg, oracle, cfg, 80, 23)
+    rng = np.random.default_rng(23)
+    if many:
+        feat = rng.standard_normal((2, 128, 20, 30)).astype(np.float32)
+        boxes = [oracle.synth_boxes(rng, 300, 480.0, 320.0), oracle.synth_boxes(rng, 260, 480.0, 320.0)]
+    else:
+        feat = rng.standard_normal((2, 128, 50, 84)).astype(np.float32)
+        boxes = [oracle.synth_boxes(rng, 40), oracle.synth_boxes(rng, 33)]
+    want = oracle.roi_head_forward(feat, boxes, params, h)
+    from locov_amd.structures import Boxes
+    with torch.no_grad():
+        bf = heads._shared_roi_transform([T.dev(feat)], [Boxes(torch.from_numpy(b).cuda()) for b in boxes])
+        scores, deltas = heads.box_predictor(heads._pooled_mean(bf))
+    assert np.abs(bf.cpu().numpy() - want["res5"]).max() <= 2e-5 * np.abs(want["res5"]).max()
+    assert np.abs(scores.cpu().numpy() - want["scores"]).max() <= 1e-4
+    np.testing.assert_allclose(deltas.cpu().numpy(), want["deltas"], atol=1e-5)
+
+
+def test_reference_config_heads_with_split_res5():
+    """configs/coco_lsm.yaml shapes (Res5 1024 -> 2048, D = 768, 80-class bank): logits within 1e-4 of the oracle."""
+    import locov_amd as pkg
+    from oracle import lsm_oracle as oracle
+    import test_gpu_roi_heads as T
+    oracle.build()
+    cfg = pkg.config.get_cfg()
+    cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
+    cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED = True
+    cfg.MODEL.ROI_HEADS.NAME = "EmbeddingProposalsRes5ROIHeads"
+    cfg.MODEL.ROI_BOX_HEAD.RES5_DTYPE = "f16x2"
+    heads, params, h = T._make_heads(pkg, oracle, cfg, 80, 1992)
+    rng = np.random.default_rng(1992)
+    feat = rng.standard_normal((2, 1024, 50, 84)).astype(np.float32)
+    props, boxes = T._proposals(pkg, oracle, rng, 2, 40)
+    want = oracle.roi_head_forward(feat, boxes, params, h)
+    with torch.no_grad():
+        bf = heads._shared_roi_transform([T.dev(feat)], [p.proposal_boxes for p in props])
+        scores, deltas = heads.box_predictor(heads._pooled_mean(bf))
+    err = np.abs(scores.cpu().numpy() - want["scores"]).max()
+    assert err <= 1e-4, err
+    np.testing.assert_allclose(deltas.cpu().numpy(), want["deltas"], atol=1e-5)
