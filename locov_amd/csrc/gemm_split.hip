@@ -46,7 +46,8 @@ constexpr int BM = 128, BN = 128, WM = 2, WN = 2, NT = 256;
 constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
 constexpr int BK = 32;                      // fp32 columns per K-tile = two 16-wide MFMA k-steps
 constexpr int ROWB = 144;                   // LDS row pitch: 4 x (16 B hi + 16 B lo) + 16 B pad
-constexpr int STAGEB = (BM + BN) * ROWB;    // bytes per stage
+constexpr int WROWB = 128;                  // W tile rows in LDS: unpadded (LDS DMA writes 1 KB runs), XOR-swizzled
+constexpr int STAGEB = BM * ROWB + BN * WROWB;   // bytes per stage
 constexpr int CH = 4;                       // 16-byte chunks per thread, operand and tile
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg)
@@ -114,32 +115,43 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave / WN) * TM, wn = (wave % WN) * TN;
 
-    // staging: chunk i of a thread = row (tid + i*NT) / 8, 16-byte chunk (tid + i*NT) % 8 of the tile row; rows past
-    // M / N read a clamped in-bounds row (they only feed outputs that are never stored)
+    // A staging: chunk i of a thread = row (tid + i*NT) / 8, 16-byte chunk (tid + i*NT) % 8 of the tile row; rows past
+    // M read a clamped in-bounds row (they only feed outputs that are never stored)
     const char *a_base = reinterpret_cast<const char *>(A + m0 * lda);
     const char *b_base = reinterpret_cast<const char *>(B + (int64_t)n0 * K);
-    unsigned a_off[CH], b_off[CH];
-    int a_lds[CH], b_lds[CH];
+    unsigned a_off[CH];
+    int a_lds[CH];
 #pragma unroll
     for (int i = 0; i < CH; i++) {
         const int idx = tid + i * NT, row = idx >> 3, ch = idx & 7;
         const int64_t gm = m0 + row;
         a_off[i] = (unsigned)((((gm < M ? gm : M - 1) - m0) * lda + ch * 4) * 4);
-        const int gn = n0 + row;
-        b_off[i] = (unsigned)(((int64_t)((gn < N ? gn : N - 1) - n0) * K + ch * 4) * 4);
         a_lds[i] = row * ROWB + (ch >> 1) * 32 + (ch & 1) * 8;   // hi halves of k-group ch/2; its lo halves 16 B further
-        b_lds[i] = BM * ROWB + row * ROWB + ch * 16;  // W tile rows are stored as they come
     }
     auto ld_a = [&](int i) {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a_base), 0, 0xffffffff, 0x00020000);
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, a_off[i], 0, 0));
     };
-    auto ld_b = [&](int i) {
+    // W staging needs no conversion, so it bypasses the registers: `buffer_load_dwordx4 ... lds` (LDS DMA) writes the 64
+    // lanes' 16 bytes to 1 KB of consecutive LDS = 8 tile rows of 128 B.  Instruction i of wave w brings rows
+    // (4w + i)*8 .. +7; lane l supplies row l/8 and fetches the GLOBAL chunk (l%8) ^ x(row), x = (row/2) % 8, so that
+    // chunk c of row r sits at slot c ^ x(r): the fragment reads below (32 consecutive rows, same c) then touch all
+    // 16 sixteen-byte slots of the 256-byte bank window exactly once per 16-lane group.
+    unsigned b_voff[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+        const int row = (wave * CH + i) * 8 + (lane >> 3), gn = n0 + row;
+        b_voff[i] = (unsigned)(((int64_t)((gn < N ? gn : N - 1) - n0) * K * 4) + (((lane & 7) ^ ((row >> 1) & 7)) * 16));
+    }
+    auto dma_b = [&](int stage) {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b_base), 0, 0xffffffff, 0x00020000);
-        return __builtin_amdgcn_raw_buffer_load_b128(r, b_off[i], 0, 0);
+#pragma unroll
+        for (int i = 0; i < CH; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                r, (__attribute__((address_space(3))) void *)(ldsb + stage * STAGEB + BM * ROWB + (wave * CH + i) * 8 * WROWB), 16,
+                b_voff[i], 0, 0, 0);
     };
     f32x4 ra[CH];
-    u32x4 rb[CH];
     auto st_a = [&](int i, int stage) {
         u32x2 hi, lo;
         split4(ra[i], a_scale, hi, lo);
@@ -147,7 +159,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
         *reinterpret_cast<u32x2 *>(p) = hi;
         *reinterpret_cast<u32x2 *>(p + 16) = lo;
     };
-    auto st_b = [&](int i, int stage) { *reinterpret_cast<u32x4 *>(ldsb + stage * STAGEB + b_lds[i]) = rb[i]; };
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -158,8 +169,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
     // fragments of the two k-steps of a tile: [step][block][0 = hi, 1 = lo]
     f16x8 fa[2][MI][2], fb[2][NI][2];
     const int frow = lane & 31, fch = lane >> 5;
+    int bfo[2][2];                                         // W fragment offsets [k-step][hi/lo] inside a 32-row block
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int hl = 0; hl < 2; hl++) bfo[q][hl] = frow * WROWB + (((4 * q + 2 * fch + hl) ^ ((frow >> 1) & 7)) * 16);
     auto read_frags = [&](int stage, int q) {
-        const char *As = ldsb + stage * STAGEB + (2 * q + fch) * 32, *Bs = As + BM * ROWB;
+        const char *As = ldsb + stage * STAGEB + (2 * q + fch) * 32, *Bs = ldsb + stage * STAGEB + BM * ROWB;
 #pragma unroll
         for (int i = 0; i < MI; i++) {
             fa[q][i][0] = *reinterpret_cast<const f16x8 *>(As + (wm + i * 32 + frow) * ROWB);
@@ -167,8 +183,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
         }
 #pragma unroll
         for (int j = 0; j < NI; j++) {
-            fb[q][j][0] = *reinterpret_cast<const f16x8 *>(Bs + (wn + j * 32 + frow) * ROWB);
-            fb[q][j][1] = *reinterpret_cast<const f16x8 *>(Bs + (wn + j * 32 + frow) * ROWB + 16);
+            fb[q][j][0] = *reinterpret_cast<const f16x8 *>(Bs + (wn + j * 32) * WROWB + bfo[q][0]);
+            fb[q][j][1] = *reinterpret_cast<const f16x8 *>(Bs + (wn + j * 32) * WROWB + bfo[q][1]);
         }
     };
     // MFMAs p0..p1-1 of k-step q: per accumulator block hi.hi, hi.lo, lo.hi
@@ -183,50 +199,44 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
     };
 
     const int k_last = K - BK;                              // k0 of the last K-tile (K % BK == 0)
-    // prologue: tile 0 -> LDS stage 0, tile 1 -> staging registers, fragments of k-step 0
+    // prologue: tile 0 -> LDS stage 0 (W by DMA), A tile 1 -> staging registers, fragments of k-step 0
+    dma_b(0);
+    b_base += BK * 4;                                       // W is fetched ONE tile ahead: b_base addresses tile t+1
 #pragma unroll
     for (int i = 0; i < CH; i++) ra[i] = ld_a(i);
-#pragma unroll
-    for (int i = 0; i < CH; i++) rb[i] = ld_b(i);
 #pragma unroll
     for (int i = 0; i < CH; i++) st_a(i, 0);
-#pragma unroll
-    for (int i = 0; i < CH; i++) st_b(i, 0);
-    int k_ptr = BK < k_last ? BK : k_last;                  // the tile the bases address
+    int k_ptr = BK < k_last ? BK : k_last;                  // the A tile a_base addresses (two ahead in the loop)
     a_base += (int64_t)k_ptr * 4;
-    b_base += (int64_t)k_ptr * 4;
 #pragma unroll
     for (int i = 0; i < CH; i++) ra[i] = ld_a(i);
-#pragma unroll
-    for (int i = 0; i < CH; i++) rb[i] = ld_b(i);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | CH);                // vmcnt(CH): everything but the A loads just issued has landed
     __syncthreads();
     read_frags(0, 0);
     __builtin_amdgcn_s_setprio(0);
 
-    // One K-tile that has a successor, computing from LDS stage s: k-step 0's MFMAs carry the staging of tile t+1
-    // (registers -> the other stage; A is split here) and the refill loads of tile t+2; the barrier sits in the
-    // middle of k-step 1's MFMAs.
+    // One K-tile that has a successor, computing from LDS stage s: the W rows of tile t+1 are requested first (DMA into
+    // the other stage), k-step 0's MFMAs carry the A staging of tile t+1 (registers -> the other stage, split here) and
+    // the A refill loads of tile t+2; the barrier sits in the middle of k-step 1's MFMAs, behind a wait for the DMA.
     auto tile_step = [&](const int s, const int k0) __attribute__((always_inline)) {
         const int kn = k0 + 2 * BK < k_last ? k0 + 2 * BK : k_last;
         a_base += (int64_t)(kn - k_ptr) * 4;
-        b_base += (int64_t)(kn - k_ptr) * 4;
         k_ptr = kn;
         read_frags(s, 1);
         __builtin_amdgcn_sched_barrier(0);
+        dma_b(s ^ 1);
+        b_base += BK * 4;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < 2 * CH; g++) {
-            if (g < CH) {
-                st_a(g, s ^ 1);
-                ra[g] = ld_a(g);
-            } else {
-                st_b(g - CH, s ^ 1);
-                rb[g - CH] = ld_b(g - CH);
-            }
-            mma_range(0, g * NMFMA / (2 * CH), (g + 1) * NMFMA / (2 * CH));
+        for (int g = 0; g < CH; g++) {
+            st_a(g, s ^ 1);
+            ra[g] = ld_a(g);
+            mma_range(0, g * NMFMA / CH, (g + 1) * NMFMA / CH);
             __builtin_amdgcn_sched_barrier(0);
         }
         mma_range(1, 0, NMFMA / 2);
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70 | CH);            // vmcnt(CH): the DMA is older than the CH A loads
         __syncthreads();
         read_frags(s ^ 1, 0);
         __builtin_amdgcn_sched_barrier(0);

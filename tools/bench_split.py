@@ -14,8 +14,9 @@ def t(fn, n=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
 
+SPEED_ONLY = len(sys.argv) > 1 and sys.argv[1] == "speed"
 # accuracy on a small problem incl. tiny / large magnitudes and a ragged M
-for (M, N, K, mag) in [(1000, 512, 2048, 1.0), (777, 2048, 512, 1.0), (300, 512, 512, 1e-3), (300, 512, 512, 300.0)]:
+for (M, N, K, mag) in [] if SPEED_ONLY else [(1000, 512, 2048, 1.0), (777, 2048, 512, 1.0), (300, 512, 512, 1e-3), (300, 512, 512, 300.0)]:
     x = (torch.randn(M, K, device=dev) * mag).relu_()
     x[::7, ::5] *= 1e-4
     w = torch.randn(N, K, device=dev) * 0.02
@@ -26,6 +27,16 @@ for (M, N, K, mag) in [(1000, 512, 2048, 1.0), (777, 2048, 512, 1.0), (300, 512,
     print(f"M={M} N={N} K={K} mag={mag}: fp32-mfma max err {float((y32 - ref).abs().max() / den):.2e}   "
           f"split max err {float((ys - ref).abs().max() / den):.2e}   (relative to max |y|)")
 # epilogue: scale / shift / residual / relu
+if SPEED_ONLY:
+    R = 8000
+    for (M, N, K, res) in [(49 * R, 512, 2048, False), (49 * R, 2048, 512, True)]:
+        x = torch.randn(M, K, device=dev).relu_(); w = torch.randn(N, K, device=dev) * 0.02
+        ws = ops.split_pack(w)
+        r = torch.randn(M, N, device=dev) if res else None
+        f = 2.0 * M * N * K
+        ts = t(lambda: ops.linear_split(x, ws, residual=r, relu=True))
+        print(f"M={M} N={N} K={K} res={res}: split {ts:.3f} ms ({f / ts / 1e9:.0f} TF-equivalent)")
+    sys.exit(0)
 M, N, K = 1000, 512, 1024
 x = torch.randn(M, K, device=dev).relu_(); w = torch.randn(N, K, device=dev) * 0.02
 sc, sh, res = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev), torch.randn(M, N, device=dev)

@@ -1,0 +1,35 @@
+"""DIAGNOSTIC builds of gemm_split.hip (tools/liblocov_splitv<N>.so, never the product; results are WRONG on purpose):
+ablations that remove one cost at a time from the K-loop, to see what bounds the kernel.  Run with
+LOCOV_HIP_LIB=tools/liblocov_splitv<N>.so python tools/bench_split.py speed
+  1: no fp32 -> (hi, lo) conversion (raw bits stored)     2: no refill loads in the K-loop
+  3: no staging at all (no loads, no LDS writes)          4: no fragment reads either (MFMA-only loop)"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = open(os.path.join(ROOT, "locov_amd/csrc/gemm_split.hip")).read().replace('#include "gemm_nt.h"', '#include "%s/locov_amd/csrc/gemm_nt.h"' % ROOT)
+def variant(n):
+    s = SRC
+    def rep(a, b):
+        nonlocal s
+        assert s.count(a) == 1, a
+        s = s.replace(a, b)
+    if n == 1:
+        rep("        split4(ra[i], a_scale, hi, lo);", "        hi = u32x2{__builtin_bit_cast(unsigned, ra[i][0]), __builtin_bit_cast(unsigned, ra[i][1])}; lo = u32x2{__builtin_bit_cast(unsigned, ra[i][2]), __builtin_bit_cast(unsigned, ra[i][3])};")
+    if n >= 2:
+        rep("                ra[g] = ld_a(g);\n", "")
+        rep("                rb[g - CH] = ld_b(g - CH);\n", "")
+    if n >= 3:
+        rep("                st_a(g, s ^ 1);\n", "")
+        rep("                st_b(g - CH, s ^ 1);\n", "")
+    if n >= 4:
+        rep("        read_frags(s, 1);\n        __builtin_amdgcn_sched_barrier(0);\n#pragma unroll\n        for (int g = 0; g < 2 * CH; g++) {", "        __builtin_amdgcn_sched_barrier(0);\n#pragma unroll\n        for (int g = 0; g < 2 * CH; g++) {")
+        rep("        __syncthreads();\n        read_frags(s ^ 1, 0);\n        __builtin_amdgcn_sched_barrier(0);\n        mma_range(1, NMFMA / 2, NMFMA);", "        __syncthreads();\n        __builtin_amdgcn_sched_barrier(0);\n        mma_range(1, NMFMA / 2, NMFMA);")
+        rep("    read_frags(0, 0);\n    __builtin_amdgcn_s_setprio(0);", "    read_frags(0, 0); read_frags(0, 1);\n    __builtin_amdgcn_s_setprio(0);")
+    return s
+cs = os.path.join(ROOT, "locov_amd/csrc")
+others = [os.path.join(cs, "build", f) for f in sorted(os.listdir(os.path.join(cs, "build"))) if f.endswith(".o") and f != "gemm_split.o"]
+for n in [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]:
+    open("/tmp/gemm_splitv.hip", "w").write(variant(n))
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-w", "-I" + os.path.join(ROOT, "include"), "-I" + cs, "-c", "/tmp/gemm_splitv.hip", "-o", "/tmp/gemm_splitv.o"])
+    out = os.path.join(ROOT, "tools/liblocov_splitv%d.so" % n)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-o", out, "/tmp/gemm_splitv.o"] + others)
+    print("built", out)
