@@ -51,9 +51,13 @@ def parse():
                    help="form of the Res5 3x3 convolutions on the hip backend")
     p.add_argument("--block0", choices=["map", "pooled"], default="map",
                    help="run Res5 block 0's 1x1 convolutions on the map (before ROIAlign) or on the pooled rows")
-    p.add_argument("--res5-dtype", choices=["fp32", "f16x2", "bf16"], default="fp32",
-                   help="bf16 = opt-in reduced-precision Res5 GEMM operands (NOT the headline configuration)")
+    p.add_argument("--res5-dtype", choices=["fp32", "f16x2", "bf16"], default="f16x2",
+                   help="arithmetic of the Res5 GEMMs: f16x2 = fp32 in / fp32 out with the products formed from split "
+                        "(hi, lo) f16 operand pairs on the f16 matrix pipe, fp32 accumulate (fp32-level accuracy, "
+                        "csrc/gemm_split.hip); fp32 = the f32 MFMA; bf16 = reduced-precision operands (never a headline)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--skip-f32-reference", action="store_true",
+                   help="do not also time the f32-MFMA form of the Res5 GEMMs (profile runs)")
     p.add_argument("--skip-s1", action="store_true",
                    help="only the S2 scope (profiling runs: the kernel mix then equals the timed region's)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
@@ -275,7 +279,14 @@ def main():
         return n.value, ms.value, fl.value
     gemm_plain, gemm_conv = gemm_class(0), gemm_class(1)
     gemm_plain_bf16, gemm_conv_bf16 = gemm_class(3), gemm_class(4)
+    gemm_split = gemm_class(5)
     lib.locov_gemm_timing_enable(0)
+    # the same job with the Res5 GEMMs on the f32 MFMA (reported beside the headline when that is the split path)
+    dt2_f32 = None
+    if args.res5 == "hip" and args.res5_dtype == "f16x2" and not args.skip_f32_reference:
+        args.res5_dtype = "fp32"
+        dt2_f32 = timed(wl.step_s2, args.steps, args.warmup, timed=True)
+        args.res5_dtype = "f16x2"
     dom_ms = float(np.mean([a.elapsed_time(b) for a, b in wl.ev])) if wl.ev else float("nan")
     dt1 = timed(wl.step_s1, args.steps, args.warmup) if not args.skip_s1 else float("nan")
 
@@ -307,6 +318,28 @@ def main():
             if n1:
                 roof["direct_conv3x3"] = {"launches_per_step": n1 / args.steps, "avg_launch_ms": ms1 / n1,
                                           "executed_tflops": fl1 / (ms1 * 1e-3) / 1e12}
+            if args.res5_dtype == "f16x2":
+                # Dominant kernel = the split-operand GEMM (csrc/gemm_split.hip): Res5's 1x1 convolutions and the
+                # Winograd-domain batched GEMMs.  It executes three f16 MFMAs per fp32 product block, so it is priced
+                # against the dense f16 MFMA peak on the f16 FLOPs it executes (3 x 2MNK); the fp32-equivalent rate
+                # (2MNK / time) is reported next to it.
+                ns, mss, fls = gemm_split
+                ach = 3.0 * fls / (mss * 1e-3) / 1e12 if mss > 0 else float("nan")
+                roof = {"kernel": "gemm_split_kernel (Res5 1x1 convs, Winograd-domain batched GEMMs; fp32 in/out, f16x2 split "
+                                  "operands on the f16 matrix pipe)",
+                        "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                        "traffic": recorded_traffic(args, "gemm_split_kernel"),
+                        "traffic_unit": f"HBM-side bytes per launch, averaged over this kernel's launches (PMC, profiles/{TRAFFIC_FILE})",
+                        "launches_per_step": ns / args.steps, "avg_launch_ms": mss / max(ns, 1),
+                        "share_of_step_time": mss * 1e-3 / dt2,
+                        "executed_f16_flops_per_step": 3.0 * fls / args.steps,
+                        "fp32_equivalent_tflops": fls / (mss * 1e-3) / 1e12 if mss > 0 else None,
+                        "fp32_equivalent_vs_f32_mfma_peak": fls / (mss * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if mss > 0 else None,
+                        "f32_mfma_gemms": {"launches_per_step": n0 / args.steps, "share_of_step_time": ms0 * 1e-3 / dt2,
+                                           "executed_tflops": achieved},
+                        "note": "achieved counts the f16 MFMA FLOPs the kernel executes (three products per fp32 product); "
+                                "peak is the dense f16/bf16 MFMA peak"}
             if args.res5_dtype == "bf16":
                 # opt-in reduced-precision run: the dominant kernel is the bf16-operand instance of the same
                 # template, priced against the dense bf16 MFMA peak; no PMC traffic pass is recorded for it
@@ -339,7 +372,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16 operands / f32 accumulate in Res5 (opt-in reduced precision, not the parity configuration)"
                       if args.res5_dtype == "bf16" else
-                      "f32" if args.sim_dtype == "fp32" else "f32 (bf16 similarity operands)"),
+                      ("f32 (Res5 GEMM products formed from f16x2 split operands on the f16 matrix pipe, f32 accumulate; error "
+                       "vs f64 <= the f32-MFMA path's, tests/test_gpu_split_gemm.py)" if args.res5_dtype == "f16x2" and args.res5 == "hip"
+                       else "f32") + ("" if args.sim_dtype == "fp32" else " (bf16 similarity operands)")),
             "data": "synthetic",
             "config": {"workload": f"{args.images} img/GPU x {args.proposals} proposals, res4 [B,1024,50,84] fp32, "
                                    f"ROIAlign 14x14 -> Res5({args.res5}) -> mean -> bbox_pred/emb_pred(2048->{args.dim}) -> "
@@ -355,6 +390,10 @@ def main():
                        "S1_ms_per_step": None if args.skip_s1 else dt1 / args.steps * 1e3},
             "roofline": roof,
         }
+        if dt2_f32 is not None:
+            out["f32_mfma_reference"] = {"value": props_per_step * args.steps / dt2_f32, "unit": "proposals/s",
+                                         "ms_per_step": dt2_f32 / args.steps * 1e3,
+                                         "what": "the same job, same run, with --res5-dtype fp32 (Res5 GEMMs on v_mfma_f32_32x32x2_f32)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out))

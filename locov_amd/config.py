@@ -120,8 +120,11 @@ def get_cfg() -> CfgNode:
                 # extension: "hip" = hand-written channels-last MFMA GEMM Res5, "miopen" = torch conv2d
                 "RES5_BACKEND": "hip",
                 "RES5_CONV3X3": "winograd",
-                # extension: "bf16" = bf16 GEMM operands / fp32 accumulate in Res5 (opt-in; the parity path is "fp32")
-                "RES5_DTYPE": "fp32",
+                # extension: arithmetic of the Res5 GEMMs on the HIP backend.  "f16x2": fp32 in / fp32 out, products formed
+                # from split (hi, lo) f16 operand pairs on the f16 matrix pipe, fp32 accumulate -- error vs fp64 no larger
+                # than the f32 MFMA's, ~2x its speed (activations must stay below 4094 in magnitude); "fp32": the f32 MFMA;
+                # "bf16": bf16 operands (reduced precision, opt-in, not a parity configuration)
+                "RES5_DTYPE": "f16x2",
             },
             "RESNETS": {
                 "NUM_GROUPS": 1, "WIDTH_PER_GROUP": 64, "RES2_OUT_CHANNELS": 256,

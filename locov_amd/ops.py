@@ -404,10 +404,10 @@ def split_pack(w: torch.Tensor, scale: Optional[float] = None) -> SplitWeight:
 
 def linear_split(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tensor] = None, *,
                  scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                 relu: bool = False, x_scale: float = 64.0) -> torch.Tensor:
+                 relu: bool = False, x_scale: float = 16.0) -> torch.Tensor:
     """y = epi(x . W^T), fp32 in / fp32 out, products on the f16 matrix pipe with split operands (opt-in "f16x2"
     arithmetic).  x [M,K] fp32 (rows may be strided), weight = split_pack(W [N,K]); x_scale = the power of two x is
-    multiplied by before the split (|x_scale * x| must stay below 65504)."""
+    multiplied by before the split (|x_scale * x| must stay below 65504: |x| < 4094 at the default)."""
     x = _rows(x, "x")
     wd = _dev(weight.data, "weight")
     M, K = x.shape

@@ -205,7 +205,7 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
     @configurable
     def __init__(self, *, in_features: List[str], pooler: ROIPooler, res5: nn.Module, box_predictor: nn.Module,
                  mask_head: Optional[nn.Module] = None, output_shape: Optional[int] = 0,
-                 res5_backend: str = "hip", res5_conv3x3: str = "winograd", res5_dtype: str = "fp32", **kwargs):
+                 res5_backend: str = "hip", res5_conv3x3: str = "winograd", res5_dtype: str = "f16x2", **kwargs):
         super().__init__(**kwargs)
         assert res5_backend in ("hip", "miopen") and res5_conv3x3 in ("winograd", "direct") and res5_dtype in ("fp32", "f16x2", "bf16")
         # extension: "f16x2" = fp32 GEMMs formed from split f16 operand pairs on the f16 matrix pipe (fp32-level
@@ -244,7 +244,7 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         box_head = cfg.MODEL.ROI_BOX_HEAD
         ret["res5_backend"] = box_head.get("RES5_BACKEND", "hip") if hasattr(box_head, "get") else "hip"
         ret["res5_conv3x3"] = box_head.get("RES5_CONV3X3", "winograd") if hasattr(box_head, "get") else "winograd"
-        ret["res5_dtype"] = box_head.get("RES5_DTYPE", "fp32") if hasattr(box_head, "get") else "fp32"
+        ret["res5_dtype"] = box_head.get("RES5_DTYPE", "f16x2") if hasattr(box_head, "get") else "f16x2"
         return ret
 
     @classmethod

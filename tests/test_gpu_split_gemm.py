@@ -35,7 +35,7 @@ def test_split_gemm_is_as_accurate_as_the_fp32_mfma_gemm(ops, M, N, K, mag):
     ref = x.double() @ w.double().t()
     xd, wd = x.cuda(), w.cuda()
     e32 = _rel(ops.linear(xd, wd).cpu(), ref)
-    es = _rel(ops.linear_split(xd, ops.split_pack(wd)).cpu(), ref)       # default x_scale = 64: |x| < 1023
+    es = _rel(ops.linear_split(xd, ops.split_pack(wd)).cpu(), ref)       # default x_scale = 16: |x| < 4094
     # 22-bit operands: ~2.4e-7 per operand on top of the accumulation error both kernels share
     assert es <= 3e-6, es
     assert es <= 1.5 * e32 + 6e-7, (es, e32)
@@ -122,16 +122,18 @@ def test_split_winograd_conv_vs_direct(ops, R, Cin, N):
     assert es <= 2e-5 and es <= 1.5 * e32 + 1e-6, (es, e32)
 
 
+@pytest.mark.parametrize("dtype", ["f16x2", "fp32"])
 @pytest.mark.parametrize("many", [False, True])
-def test_heads_with_split_res5_pass_the_logit_gate(many):
-    """MODEL.ROI_BOX_HEAD.RES5_DTYPE = "f16x2": the whole head against the CPU oracle, same gates as the fp32 path
-    (logits 1e-4, box deltas 1e-5), on the pooled-rows path and on the map path."""
+def test_heads_pass_the_logit_gate_with_either_res5_arithmetic(many, dtype):
+    """MODEL.ROI_BOX_HEAD.RES5_DTYPE = "f16x2" (default) and "fp32": the whole head against the CPU oracle, the same
+    gates for both (logits 1e-4, box deltas 1e-5), on the pooled-rows path and on the map path."""
     import locov_amd as pkg
     from oracle import lsm_oracle as oracle
     import test_gpu_roi_heads as T
     oracle.build()
     cfg = T._small_cfg(pkg)
-    cfg.MODEL.ROI_BOX_HEAD.RES5_DTYPE = "f16x2"
+    assert cfg.MODEL.ROI_BOX_HEAD.RES5_DTYPE == "f16x2"
+    cfg.MODEL.ROI_BOX_HEAD.RES5_DTYPE = dtype
     heads, params, h = T._make_heads(pkg, oracle, cfg, 80, 23)
     rng = np.random.default_rng(23)
     if many:
@@ -150,7 +152,8 @@ def test_heads_with_split_res5_pass_the_logit_gate(many):
     np.testing.assert_allclose(deltas.cpu().numpy(), want["deltas"], atol=1e-5)
 
 
-def test_reference_config_heads_with_split_res5():
+@pytest.mark.parametrize("dtype", ["f16x2", "fp32"])
+def test_reference_config_heads_with_either_res5_arithmetic(dtype):
     """configs/coco_lsm.yaml shapes (Res5 1024 -> 2048, D = 768, 80-class bank): logits within 1e-4 of the oracle."""
     import locov_amd as pkg
     from oracle import lsm_oracle as oracle
@@ -160,7 +163,7 @@ def test_reference_config_heads_with_split_res5():
     cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
     cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED = True
     cfg.MODEL.ROI_HEADS.NAME = "EmbeddingProposalsRes5ROIHeads"
-    cfg.MODEL.ROI_BOX_HEAD.RES5_DTYPE = "f16x2"
+    cfg.MODEL.ROI_BOX_HEAD.RES5_DTYPE = dtype
     heads, params, h = T._make_heads(pkg, oracle, cfg, 80, 1992)
     rng = np.random.default_rng(1992)
     feat = rng.standard_normal((2, 1024, 50, 84)).astype(np.float32)

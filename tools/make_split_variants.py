@@ -1,8 +1,9 @@
 """DIAGNOSTIC builds of gemm_split.hip (tools/liblocov_splitv<N>.so, never the product; results are WRONG on purpose):
 ablations that remove one cost at a time from the K-loop, to see what bounds the kernel.  Run with
 LOCOV_HIP_LIB=tools/liblocov_splitv<N>.so python tools/bench_split.py speed
-  1: no fp32 -> (hi, lo) conversion (raw bits stored)     2: no refill loads in the K-loop
-  3: no staging at all (no loads, no LDS writes)          4: no fragment reads either (MFMA-only loop)"""
+  1: no fp32 -> (hi, lo) conversion (raw bits stored)     2: no A refill loads in the K-loop
+  3: no staging at all (no loads, no LDS writes, no DMA)  4: no fragment reads either (MFMA-only loop)
+  5: as 3 but the W DMA stays                              6: as 3 but the A LDS stores stay"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = open(os.path.join(ROOT, "locov_amd/csrc/gemm_split.hip")).read().replace('#include "gemm_nt.h"', '#include "%s/locov_amd/csrc/gemm_nt.h"' % ROOT)
@@ -15,13 +16,13 @@ def variant(n):
     if n == 1:
         rep("        split4(ra[i], a_scale, hi, lo);", "        hi = u32x2{__builtin_bit_cast(unsigned, ra[i][0]), __builtin_bit_cast(unsigned, ra[i][1])}; lo = u32x2{__builtin_bit_cast(unsigned, ra[i][2]), __builtin_bit_cast(unsigned, ra[i][3])};")
     if n >= 2:
-        rep("                ra[g] = ld_a(g);\n", "")
-        rep("                rb[g - CH] = ld_b(g - CH);\n", "")
-    if n >= 3:
-        rep("                st_a(g, s ^ 1);\n", "")
-        rep("                st_b(g - CH, s ^ 1);\n", "")
-    if n >= 4:
-        rep("        read_frags(s, 1);\n        __builtin_amdgcn_sched_barrier(0);\n#pragma unroll\n        for (int g = 0; g < 2 * CH; g++) {", "        __builtin_amdgcn_sched_barrier(0);\n#pragma unroll\n        for (int g = 0; g < 2 * CH; g++) {")
+        rep("            ra[g] = ld_a(g);\n", "")
+    if n >= 3 and n != 6:
+        rep("            st_a(g, s ^ 1);\n", "")
+    if n >= 3 and n != 5:
+        rep("        dma_b(s ^ 1);\n", "")
+    if n == 4:
+        rep("        read_frags(s, 1);\n        __builtin_amdgcn_sched_barrier(0);\n", "        __builtin_amdgcn_sched_barrier(0);\n")
         rep("        __syncthreads();\n        read_frags(s ^ 1, 0);\n        __builtin_amdgcn_sched_barrier(0);\n        mma_range(1, NMFMA / 2, NMFMA);", "        __syncthreads();\n        __builtin_amdgcn_sched_barrier(0);\n        mma_range(1, NMFMA / 2, NMFMA);")
         rep("    read_frags(0, 0);\n    __builtin_amdgcn_s_setprio(0);", "    read_frags(0, 0); read_frags(0, 1);\n    __builtin_amdgcn_s_setprio(0);")
     return s
