@@ -150,7 +150,7 @@ class Workload:
         return self.head(self.r5_standin)
 
 
-TRAFFIC_FILE = "r01h_pmc_traffic.json"
+TRAFFIC_FILE = "r01i_pmc_traffic.json"
 
 
 def recorded_traffic(args, kernel_key: str):
@@ -162,7 +162,7 @@ def recorded_traffic(args, kernel_key: str):
         with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
             rec = json.load(f)
         wl = rec["workload"]
-        if any(wl[k] != getattr(args, k) for k in ("images", "proposals", "classes", "dim", "res5", "conv3x3", "block0")):
+        if any(wl[k] != getattr(args, k) for k in ("images", "proposals", "classes", "dim", "res5", "conv3x3", "block0", "res5_dtype")):
             return None
         for name, v in rec["kernels"].items():
             if kernel_key in name:

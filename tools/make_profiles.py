@@ -30,7 +30,7 @@ shutil.copy(os.path.join(SRC, "stats", "s_kernel_stats.csv"), dst("bench_kernel_
 cfg = bench["config"]
 workload = {"images": cfg["images_per_gpu"], "proposals": cfg["proposals_per_image"], "classes": cfg["classes"],
             "dim": cfg["emb_dim"], "res5": cfg["res5_backend"], "conv3x3": cfg["res5_conv3x3"],
-            "block0": cfg.get("res5_block0", "pooled")}
+            "block0": cfg.get("res5_block0", "pooled"), "res5_dtype": cfg.get("res5_dtype", "fp32")}
 
 fetch, write = counters("pmc_fetch"), counters("pmc_write")
 traffic = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and a separate --pmc WRITE_SIZE pass over `python3 bench.py "
