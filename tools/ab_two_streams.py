@@ -3,7 +3,7 @@ import sys, os, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from locov_amd import ops
-args = types.SimpleNamespace(images=8, proposals=1000, classes=1203, dim=768, sim_dtype="fp32", res5="hip", conv3x3="winograd", block0="map")
+args = types.SimpleNamespace(images=8, proposals=1000, classes=1203, dim=768, sim_dtype="fp32", res5="hip", conv3x3="winograd", block0="map", res5_dtype="f16x2")
 dev = torch.device("cuda")
 wl = bench.Workload(args, dev)
 nh = ops.nchw_to_nhwc(wl.feat)
@@ -11,7 +11,7 @@ halves = [wl.rois[:4000].contiguous(), wl.rois[4000:].contiguous()]
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 
 def part(rois):
-    y = wl.res5.forward_from_map(nh, rois, 14, 1.0 / 16, 0, True, winograd=True)
+    y = wl.res5.forward_from_map(nh, rois, 14, 1.0 / 16, 0, True, winograd=True, split=True)
     return wl.head(y.view(7, 7, rois.shape[0], 2048), channels_last=2)
 
 def one():

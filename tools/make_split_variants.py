@@ -3,7 +3,9 @@ ablations that remove one cost at a time from the K-loop, to see what bounds the
 LOCOV_HIP_LIB=tools/liblocov_splitv<N>.so python tools/bench_split.py speed
   1: no fp32 -> (hi, lo) conversion (raw bits stored)     2: no A refill loads in the K-loop
   3: no staging at all (no loads, no LDS writes, no DMA)  4: no fragment reads either (MFMA-only loop)
-  5: as 3 but the W DMA stays                              6: as 3 but the A LDS stores stay"""
+  5: as 3 but the W DMA stays                              6: as 3 but the A LDS stores stay
+  7: A taken as ALREADY split and staged by LDS DMA like W (what the kernel would do if the producers wrote the
+     activations in split format): timing only"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = open(os.path.join(ROOT, "locov_amd/csrc/gemm_split.hip")).read().replace('#include "gemm_nt.h"', '#include "%s/locov_amd/csrc/gemm_nt.h"' % ROOT)
@@ -15,6 +17,32 @@ def variant(n):
         s = s.replace(a, b)
     if n == 1:
         rep("        split4(ra[i], a_scale, hi, lo);", "        hi = u32x2{__builtin_bit_cast(unsigned, ra[i][0]), __builtin_bit_cast(unsigned, ra[i][1])}; lo = u32x2{__builtin_bit_cast(unsigned, ra[i][2]), __builtin_bit_cast(unsigned, ra[i][3])};")
+    if n == 7:
+        rep("    f32x4 ra[CH];\n", """    f32x4 ra[CH];
+    unsigned a_voff[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+        const int row = (wave * CH + i) * 8 + (lane >> 3);
+        const int64_t gm = m0 + row;
+        a_voff[i] = (unsigned)((((gm < M ? gm : M - 1) - m0) * lda * 4) + (((lane & 7) ^ ((row >> 1) & 7)) * 16));
+    }
+    const char *a_dbase = reinterpret_cast<const char *>(A + m0 * lda);
+    auto dma_a = [&](int stage) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a_dbase), 0, 0xffffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < CH; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                r, (__attribute__((address_space(3))) void *)(ldsb + stage * STAGEB + (wave * CH + i) * 8 * WROWB), 16, a_voff[i], 0, 0, 0);
+    };
+""")
+        rep("            fa[q][i][0] = *reinterpret_cast<const f16x8 *>(As + (wm + i * 32 + frow) * ROWB);\n            fa[q][i][1] = *reinterpret_cast<const f16x8 *>(As + (wm + i * 32 + frow) * ROWB + 16);",
+            "            fa[q][i][0] = *reinterpret_cast<const f16x8 *>(ldsb + stage * STAGEB + (wm + i * 32) * WROWB + bfo[q][0]);\n            fa[q][i][1] = *reinterpret_cast<const f16x8 *>(ldsb + stage * STAGEB + (wm + i * 32) * WROWB + bfo[q][1]);")
+        rep("#pragma unroll\n    for (int i = 0; i < CH; i++) ra[i] = ld_a(i);\n#pragma unroll\n    for (int i = 0; i < CH; i++) st_a(i, 0);\n", "    dma_a(0);\n    a_dbase += BK * 4;\n")
+        rep("#pragma unroll\n    for (int i = 0; i < CH; i++) ra[i] = ld_a(i);\n    __builtin_amdgcn_s_waitcnt(0x0F70 | CH);", "    __builtin_amdgcn_s_waitcnt(0x0F70);")
+        rep("        dma_b(s ^ 1);\n        b_base += BK * 4;\n", "        dma_b(s ^ 1);\n        b_base += BK * 4;\n        dma_a(s ^ 1);\n        a_dbase += BK * 4;\n")
+        rep("            st_a(g, s ^ 1);\n            ra[g] = ld_a(g);\n", "")
+        rep("        __builtin_amdgcn_s_waitcnt(0x0F70 | CH);            // vmcnt(CH): the DMA is older than the CH A loads", "        __builtin_amdgcn_s_waitcnt(0x0F70);")
+        return s
     if n >= 2:
         rep("            ra[g] = ld_a(g);\n", "")
     if n >= 3 and n != 6:
