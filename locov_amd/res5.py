@@ -186,6 +186,10 @@ class Res5Stage(nn.Sequential):
         if hit is not None and hit[0] is t:
             return hit[1]
         out = ops.split_pack(t.contiguous())
+        stale = [k for k in self._cache if isinstance(k, tuple) and k and k[0] == "split"]
+        if len(stale) >= 64:                     # weights that keep changing (training + eval): drop superseded packings
+            for k in stale:
+                del self._cache[k]
         self._cache[("split", id(t))] = (t, out)
         return out
 

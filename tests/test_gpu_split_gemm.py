@@ -175,3 +175,28 @@ def test_reference_config_heads_with_either_res5_arithmetic(dtype):
     err = np.abs(scores.cpu().numpy() - want["scores"]).max()
     assert err <= 1e-4, err
     np.testing.assert_allclose(deltas.cpu().numpy(), want["deltas"], atol=1e-5)
+
+
+@pytest.mark.parametrize("fscale", [30.0, 0.03])
+def test_split_res5_tracks_the_f32_mfma_path_across_input_magnitudes(fscale):
+    """Heavy-tailed post-ReLU features scaled by 30 (Res5 activations up to ~1.4e3) and by 0.03: the split-operand head's
+    error against the oracle stays at the f32-MFMA head's (relative to the logit range, which scales with the input)."""
+    import locov_amd as pkg
+    from oracle import lsm_oracle as oracle
+    import test_gpu_roi_heads as T
+    oracle.build()
+    errs = {}
+    for dtype in ("fp32", "f16x2"):
+        cfg = T._small_cfg(pkg)
+        cfg.MODEL.ROI_BOX_HEAD.RES5_DTYPE = dtype
+        heads, params, h = T._make_heads(pkg, oracle, cfg, 80, 1992)
+        rng = np.random.default_rng(1992)
+        feat = (np.maximum(rng.standard_normal((2, 128, 50, 84)), 0) * fscale).astype(np.float32)
+        feat[:, :, ::9, ::7] *= 8.0
+        props, boxes = T._proposals(pkg, oracle, rng, 2, 60)
+        want = oracle.roi_head_forward(feat, boxes, params, h)
+        with torch.no_grad():
+            bf = heads._shared_roi_transform([T.dev(feat)], [p.proposal_boxes for p in props])
+            scores, _ = heads.box_predictor(heads._pooled_mean(bf))
+        errs[dtype] = np.abs(scores.cpu().numpy() - want["scores"]).max() / np.abs(want["scores"]).max()
+    assert errs["f16x2"] <= 5e-6 and errs["f16x2"] <= 2 * errs["fp32"] + 5e-7, errs
