@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
         if (NPRE == 0 || !epi.residual || !n_ok) return;
 #pragma unroll
         for (int it = 0; it < NPRE; it++)
-            res_pre[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, voff + it * vstep, 0, 0));
+            res_pre[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, voff + it * vstep, 0, 2));
     };
     if (k0 < k_last) {
         tile_step(0, k0);
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
                     res[it] = res_pre[it];
                 else
                     res[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                            r_res, FULL ? voff : voff + it * vstep, FULL ? it * vstep : 0u, 0));
+                                                            r_res, FULL ? voff : voff + it * vstep, FULL ? it * vstep : 0u, 2));
             }
         }
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
                     v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, FULL ? voff : voff + it * vstep,
-                                                       FULL ? it * vstep : 0u, 0);
+                                                       FULL ? it * vstep : 0u, 2);      // aux 2 = nt: streamed once
             }
         }
     };

@@ -5,7 +5,8 @@ LOCOV_HIP_LIB=tools/liblocov_splitv<N>.so python tools/bench_split.py speed
   3: no staging at all (no loads, no LDS writes, no DMA)  4: no fragment reads either (MFMA-only loop)
   5: as 3 but the W DMA stays                              6: as 3 but the A LDS stores stay
   7: A taken as ALREADY split and staged by LDS DMA like W (what the kernel would do if the producers wrote the
-     activations in split format): timing only"""
+     activations in split format): timing only
+  8: no epilogue traffic (no residual loads, no output stores)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = open(os.path.join(ROOT, "locov_amd/csrc/gemm_split.hip")).read().replace('#include "gemm_nt.h"', '#include "%s/locov_amd/csrc/gemm_nt.h"' % ROOT)
@@ -17,6 +18,12 @@ def variant(n):
         s = s.replace(a, b)
     if n == 1:
         rep("        split4(ra[i], a_scale, hi, lo);", "        hi = u32x2{__builtin_bit_cast(unsigned, ra[i][0]), __builtin_bit_cast(unsigned, ra[i][1])}; lo = u32x2{__builtin_bit_cast(unsigned, ra[i][2]), __builtin_bit_cast(unsigned, ra[i][3])};")
+    if n == 8:       # no epilogue traffic: neither residual loads nor output stores (K-loop + LDS re-layout only)
+        rep("        if (epi.residual && n_ok) {\n#pragma unroll\n            for (int it = 0; it < NIT; it++) {\n                if (it < NPRE", "        if (false) {\n#pragma unroll\n            for (int it = 0; it < NIT; it++) {\n                if (it < NPRE")
+        rep("        if (NPRE == 0 || !epi.residual || !n_ok) return;", "        return;")
+        rep("                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out,", "                if (v[0] == 123.456f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out,")
+        rep("                if (epi.residual) v += res[it];\n", "")
+        return s
     if n == 7:
         rep("    f32x4 ra[CH];\n", """    f32x4 ra[CH];
     unsigned a_voff[CH];
