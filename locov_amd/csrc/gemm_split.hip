@@ -1,5 +1,5 @@
 // fp32 NT GEMM  y[M,N] = epi(x[M,K] . W[N,K]^T)  on the gfx950 16-bit matrix pipe with SPLIT operands
-// (opt-in "f16x2" arithmetic of the Res5 GEMMs, roi_emb_heads.py:217-245 of the reference as GEMMs):
+// ("f16x2" arithmetic of the Res5 GEMMs -- the default; roi_emb_heads.py:217-245 of the reference as GEMMs):
 //
 //     s x = hi + lo,      hi = fp16(s x) (round to nearest),   lo = fp16(s x - hi)        (s = a power of two)
 //     a.b ~= (hi_a.hi_b + hi_a.lo_b + lo_a.hi_b) / (s_a s_b)
@@ -8,21 +8,24 @@
 // its 11 bits, for every |s x| >= 2^-3, and below that its absolute error is <= 2^-25 -- a fixed-point floor far
 // under the rounding of the larger entries of the same row).  The operand scales s_a, s_w exist to place the
 // data in fp16's range: s_w is chosen per weight matrix at pack time (max |s_w w| ~ 2^13), s_a is a launch
-// parameter (2^6 for activations: exact up to |x| < 1024; 1 for Winograd-domain data).  The dropped lo.lo term is
-// 2^-24 relative; all three products are accumulated in fp32 by v_mfma_f32_32x32x16_f16 into ONE accumulator.
+// parameter (2^4 for activations: exact up to |x| < 4094; 1 for Winograd-domain data).  The dropped lo.lo term is
+// 2^-24 relative; all three products are accumulated in fp32 by v_mfma_f32_16x16x32_f16 into ONE accumulator.
 // The result differs from an fp32-MFMA GEMM by about two fp32 roundings per operand -- the order of the fp32
-// accumulation error itself at K >= 512 -- while the matrix pipe runs 3 f16 MFMAs per 32x32x16 block instead of
-// 8 f32 ones at 1/16 of the rate (5.3x fewer matrix-pipe cycles).
+// accumulation error itself at K >= 512, and measured at or below it -- while the matrix pipe runs 3 f16 MFMAs
+// (48 cycles) per 16x16x32 block instead of 16 f32 16x16x4 ones (256 cycles): 5.3x fewer matrix-pipe cycles.
 //
-// Data movement is the fp32 kernel's (gemm_nt.hip), byte for byte: A is read as fp32 (16-byte buffer loads, two
-// tiles ahead) and split in registers on its way into LDS; W is split ONCE (locov_split_f16x2_pack) into a layout
-// with the same size and row pitch as the fp32 matrix -- per row and per group of 8 columns: 8 hi halves, then 8 lo
-// halves -- so a tile row is 128 B in global memory and in LDS for both operands; LDS rows are padded to 144 B,
-// every fragment read is a conflict-free ds_read_b128 (lane l: row l&31, k = 8*(l>>5) .. +7 of a 16-wide k-step)
-// and so are the 8-byte hi / lo stores of the A staging (two rows x eight 4-column chunks per 16-lane group).
-// 128x128 tile, 4 waves (2x2, 64x64 each = 2x2 MFMA blocks x {main, correction} accumulators), two LDS stages, one
-// barrier per K-tile, two workgroups per CU; tile order, epilogue (LDS re-layout, 16-byte buffer stores, residual
-// prefetch) and the batched form are those of gemm_nt.hip.
+// Data movement is the fp32 kernel's (gemm_nt.hip), byte for byte: 128x128 tile, BK = 32 fp32 columns, 4 waves
+// (2x2, 64x64 each = 4x4 MFMA blocks of 16x16), two LDS stages, one barrier per K-tile, two workgroups per CU; tile
+// order, epilogue (LDS re-layout, 16-byte buffer stores, residual prefetch) and the batched form are gemm_nt.hip's.
+//   A is read as fp32 (16-byte buffer loads, two tiles ahead) and split in registers on its way into LDS: rows of
+//     160 B = 8 data slots of 16 B + 2 pad, k-group c (8 columns) with its hi halves in slot {0,1,4,5}[c] and its lo
+//     halves two slots further.  Even k-groups in even slots, odd ones in odd slots, pitch 10 slots: the 16x16x32
+//     fragment read (lane l: row l%16, k-group l/16) and the 8-byte hi / lo staging stores (two rows x eight
+//     4-column chunks per 16-lane group) are both bank-conflict-free.
+//   W is split ONCE (locov_split_f16x2_pack) into a buffer with the size and row pitch of the fp32 matrix -- per
+//     group of 8 columns: 8 hi halves, then 8 lo halves -- and needs no conversion, so it bypasses the registers:
+//     `buffer_load_dwordx4 ... lds` (LDS DMA), one tile ahead, into unpadded 128-byte rows whose eight chunks are
+//     XOR-permuted per row (wswz) for conflict-free fragment reads.
 #include "gemm_nt.h"
 
 #include <type_traits>
@@ -43,12 +46,17 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int BM = 128, BN = 128, WM = 2, WN = 2, NT = 256;
-constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 16, NB = TN / 16;   // a wave's 64x64 sub-tile = 4x4 blocks of 16x16
 constexpr int BK = 32;                      // fp32 columns per K-tile = two 16-wide MFMA k-steps
-constexpr int ROWB = 144;                   // LDS row pitch: 4 x (16 B hi + 16 B lo) + 16 B pad
+constexpr int ROWB = 160;                   // LDS pitch of an A row: 8 data slots of 16 B + 2 pad (layout below)
 constexpr int WROWB = 128;                  // W tile rows in LDS: unpadded (LDS DMA writes 1 KB runs), XOR-swizzled
 constexpr int STAGEB = BM * ROWB + BN * WROWB;   // bytes per stage
 constexpr int CH = 4;                       // 16-byte chunks per thread, operand and tile
+
+// W rows sit unpadded in LDS with their eight 16-byte chunks XOR-permuted by wswz(row) (a function of (row/2)%8):
+// chosen so that the 16x16x32 fragment reads -- lane l: row l%16, k-group l/16 -- hit 16 distinct 16-byte slots of the
+// 256-byte bank window in every 16-lane group the LDS serves at once ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32).
+__device__ __forceinline__ int wswz(int row) { return (int)((0x75642031u >> (4 * ((row >> 1) & 7))) & 7u); }
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 {
@@ -126,7 +134,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
         const int idx = tid + i * NT, row = idx >> 3, ch = idx & 7;
         const int64_t gm = m0 + row;
         a_off[i] = (unsigned)((((gm < M ? gm : M - 1) - m0) * lda + ch * 4) * 4);
-        a_lds[i] = row * ROWB + (ch >> 1) * 32 + (ch & 1) * 8;   // hi halves of k-group ch/2; its lo halves 16 B further
+        // k-group c = ch/2 (8 columns): hi halves in 16-byte slot {0,1,4,5}[c], lo halves two slots further
+        a_lds[i] = row * ROWB + (((ch >> 2) * 4 + ((ch >> 1) & 1)) * 16) + (ch & 1) * 8;
     }
     auto ld_a = [&](int i) {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a_base), 0, 0xffffffff, 0x00020000);
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
 #pragma unroll
     for (int i = 0; i < CH; i++) {
         const int row = (wave * CH + i) * 8 + (lane >> 3), gn = n0 + row;
-        b_voff[i] = (unsigned)(((int64_t)((gn < N ? gn : N - 1) - n0) * K * 4) + (((lane & 7) ^ ((row >> 1) & 7)) * 16));
+        b_voff[i] = (unsigned)(((int64_t)((gn < N ? gn : N - 1) - n0) * K * 4) + (((lane & 7) ^ wswz(row)) * 16));
     }
     auto dma_b = [&](int stage) {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b_base), 0, 0xffffffff, 0x00020000);
@@ -157,44 +166,50 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
         split4(ra[i], a_scale, hi, lo);
         char *p = ldsb + stage * STAGEB + a_lds[i];
         *reinterpret_cast<u32x2 *>(p) = hi;
-        *reinterpret_cast<u32x2 *>(p + 16) = lo;
+        *reinterpret_cast<u32x2 *>(p + 32) = lo;
     };
 
-    f32x16 acc[MI][NI];
+    f32x4 acc[MB][NB];
 #pragma unroll
-    for (int i = 0; i < MI; i++)
+    for (int i = 0; i < MB; i++)
 #pragma unroll
-        for (int j = 0; j < NI; j++) acc[i][j] = f32x16{};
+        for (int j = 0; j < NB; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // fragments of the two k-steps of a tile: [step][block][0 = hi, 1 = lo]
-    f16x8 fa[2][MI][2], fb[2][NI][2];
-    const int frow = lane & 31, fch = lane >> 5;
-    int bfo[2][2];                                         // W fragment offsets [k-step][hi/lo] inside a 32-row block
+    // v_mfma_f32_16x16x32_f16 (it runs ~15 % faster than the 32x32x16 form under the chip's power limit): lane l holds
+    // row l%16 and the 8 halves of k-group l/16 of a 16-row block, for the WHOLE 32-wide K-tile.  One register set of
+    // fragments, in four groups: GA0 / GA1 = A row blocks {0,1} / {2,3}, GB0 / GB1 = W column blocks {0,1} / {2,3}
+    // (each [block][0 = hi, 1 = lo]).  A K-tile is four quarters of 12 MFMAs, one (GA, GB) pair each, visited so that
+    // a group is free for the next tile's data as early as possible (see tile_step).
+    f16x8 fa[MB][2], fb[NB][2];
+    const int l16 = lane & 15, kg = lane >> 4;
+    const int afo = l16 * ROWB + ((kg >> 1) * 4 + (kg & 1)) * 16;                   // A: hi; lo 32 B further
+    int bfo[2];                                                                      // W: [hi / lo]
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int hl = 0; hl < 2; hl++) bfo[hl] = l16 * WROWB + (((2 * kg + hl) ^ wswz(l16)) * 16);
+    auto rd_a = [&](int stage, int ga) {
+        const char *As = ldsb + stage * STAGEB + (wm + ga * 32) * ROWB + afo;
 #pragma unroll
-        for (int hl = 0; hl < 2; hl++) bfo[q][hl] = frow * WROWB + (((4 * q + 2 * fch + hl) ^ ((frow >> 1) & 7)) * 16);
-    auto read_frags = [&](int stage, int q) {
-        const char *As = ldsb + stage * STAGEB + (2 * q + fch) * 32, *Bs = ldsb + stage * STAGEB + BM * ROWB;
-#pragma unroll
-        for (int i = 0; i < MI; i++) {
-            fa[q][i][0] = *reinterpret_cast<const f16x8 *>(As + (wm + i * 32 + frow) * ROWB);
-            fa[q][i][1] = *reinterpret_cast<const f16x8 *>(As + (wm + i * 32 + frow) * ROWB + 16);
-        }
-#pragma unroll
-        for (int j = 0; j < NI; j++) {
-            fb[q][j][0] = *reinterpret_cast<const f16x8 *>(Bs + (wn + j * 32) * WROWB + bfo[q][0]);
-            fb[q][j][1] = *reinterpret_cast<const f16x8 *>(Bs + (wn + j * 32) * WROWB + bfo[q][1]);
+        for (int i = 0; i < 2; i++) {
+            fa[2 * ga + i][0] = *reinterpret_cast<const f16x8 *>(As + i * 16 * ROWB);
+            fa[2 * ga + i][1] = *reinterpret_cast<const f16x8 *>(As + i * 16 * ROWB + 32);
         }
     };
-    // MFMAs p0..p1-1 of k-step q: per accumulator block hi.hi, hi.lo, lo.hi
-    constexpr int NMFMA = MI * NI * 3;
-    auto mma_range = [&](int q, int p0, int p1) {
+    auto rd_b = [&](int stage, int gb) {
+        const char *Bs = ldsb + stage * STAGEB + BM * ROWB + (wn + gb * 32) * WROWB;
 #pragma unroll
-        for (int p = 0; p < NMFMA; p++) {
+        for (int j = 0; j < 2; j++) {
+            fb[2 * gb + j][0] = *reinterpret_cast<const f16x8 *>(Bs + j * 16 * WROWB + bfo[0]);
+            fb[2 * gb + j][1] = *reinterpret_cast<const f16x8 *>(Bs + j * 16 * WROWB + bfo[1]);
+        }
+    };
+    // MFMAs p0..p1-1 of the quarter (GA ga, GB gb): per 16x16 block hi.hi, hi.lo, lo.hi
+    constexpr int NQM = 12;
+    auto quarter = [&](int ga, int gb, int p0, int p1) {
+#pragma unroll
+        for (int p = 0; p < NQM; p++) {
             if (p < p0 || p >= p1) continue;
-            const int t = p / 3, i = t / NI, j = t % NI, w = p % 3;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[q][i][w == 2 ? 1 : 0], fb[q][j][w == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
+            const int t = p / 3, i = 2 * ga + t / 2, j = 2 * gb + t % 2, w = p % 3;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][w == 2 ? 1 : 0], fb[j][w == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -212,17 +227,22 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
     for (int i = 0; i < CH; i++) ra[i] = ld_a(i);
     __builtin_amdgcn_s_waitcnt(0x0F70 | CH);                // vmcnt(CH): everything but the A loads just issued has landed
     __syncthreads();
-    read_frags(0, 0);
+    rd_a(0, 0);
+    rd_b(0, 0);
     __builtin_amdgcn_s_setprio(0);
 
-    // One K-tile that has a successor, computing from LDS stage s: the W rows of tile t+1 are requested first (DMA into
-    // the other stage), k-step 0's MFMAs carry the A staging of tile t+1 (registers -> the other stage, split here) and
-    // the A refill loads of tile t+2; the barrier sits in the middle of k-step 1's MFMAs, behind a wait for the DMA.
+    // One K-tile that has a successor, computing from LDS stage s (= the tile's parity).  Quarters: (GA0,GBx) (GA0,GBy)
+    // | barrier | (GA1,GBy) (GA1,GBx) with x = s, y = 1 - s: the tile ends on GBx, so GA0 and GBy are free from its
+    // middle on and receive the next tile's data behind the barrier -- and the next tile (parity 1 - s) starts on exactly
+    // (GA0, GBy).  The first half also carries the staging: the W rows of tile t+1 by DMA, the A chunks of tile t+1 from
+    // registers (split here) with the refill loads of tile t+2.
     auto tile_step = [&](const int s, const int k0) __attribute__((always_inline)) {
         const int kn = k0 + 2 * BK < k_last ? k0 + 2 * BK : k_last;
         a_base += (int64_t)(kn - k_ptr) * 4;
         k_ptr = kn;
-        read_frags(s, 1);
+        const int x = s, y = s ^ 1;
+        rd_b(s, y);
+        rd_a(s, 1);
         __builtin_amdgcn_sched_barrier(0);
         dma_b(s ^ 1);
         b_base += BK * 4;
@@ -231,22 +251,31 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
         for (int g = 0; g < CH; g++) {
             st_a(g, s ^ 1);
             ra[g] = ld_a(g);
-            mma_range(0, g * NMFMA / CH, (g + 1) * NMFMA / CH);
+            if (g < CH / 2)
+                quarter(0, x, g * 2 * NQM / CH, (g + 1) * 2 * NQM / CH);
+            else
+                quarter(0, y, (g - CH / 2) * 2 * NQM / CH, (g - CH / 2 + 1) * 2 * NQM / CH);
             __builtin_amdgcn_sched_barrier(0);
         }
-        mma_range(1, 0, NMFMA / 2);
-        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0x0F70 | CH);            // vmcnt(CH): the DMA is older than the CH A loads
         __syncthreads();
-        read_frags(s ^ 1, 0);
+        rd_a(s ^ 1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        mma_range(1, NMFMA / 2, NMFMA);
+        quarter(1, y, 0, NQM);
+        __builtin_amdgcn_sched_barrier(0);
+        rd_b(s ^ 1, y);
+        __builtin_amdgcn_sched_barrier(0);
+        quarter(1, x, 0, NQM);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto last_tile = [&](const int s) __attribute__((always_inline)) {
-        read_frags(s, 1);
-        mma_range(0, 0, NMFMA);
-        mma_range(1, 0, NMFMA);
+        const int x = s, y = s ^ 1;
+        rd_b(s, y);
+        rd_a(s, 1);
+        quarter(0, x, 0, NQM);
+        quarter(0, y, 0, NQM);
+        quarter(1, y, 0, NQM);
+        quarter(1, x, 0, NQM);
     };
     int k0 = 0;
     for (; k0 + BK < k_last; k0 += 2 * BK) {
@@ -283,8 +312,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
     }
 
     __builtin_amdgcn_s_setprio(3);
-    // Epilogue (C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)): fold the
-    // correction in, re-lay the wave's sub-tile out through LDS, 16 bytes per lane and row-contiguous from there.
+    // Epilogue (C/D layout of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg): re-lay the wave's sub-tile out
+    // through LDS, 16 bytes per lane and row-contiguous from there.
     const bool relu = (epi.flags & LOCOV_EPI_RELU) != 0;
     constexpr int EPS = TN + 4;
     static_assert(WM * WN * TM * EPS * 4 <= 2 * STAGEB, "epilogue staging must fit the K-loop LDS");
@@ -308,13 +337,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
         if (n_ok && epi.shift) sh = *reinterpret_cast<const f32x4 *>(epi.shift + n);
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < MI; i++)
+        for (int i = 0; i < MB; i++)
 #pragma unroll
-            for (int j = 0; j < NI; j++)
+            for (int j = 0; j < NB; j++)
 #pragma unroll
-                for (int r = 0; r < 16; r++)
-                    ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPS + j * 32 + (lane & 31)] =
-                        acc[i][j][r];
+                for (int r = 0; r < 4; r++) ep[(i * 16 + 4 * kg + r) * EPS + j * 16 + l16] = acc[i][j][r];
         __syncthreads();
         if (n_ok) {
 #pragma unroll

@@ -6,7 +6,8 @@ LOCOV_HIP_LIB=tools/liblocov_splitv<N>.so python tools/bench_split.py speed
   5: as 3 but the W DMA stays                              6: as 3 but the A LDS stores stay
   7: A taken as ALREADY split and staged by LDS DMA like W (what the kernel would do if the producers wrote the
      activations in split format): timing only
-  8: no epilogue traffic (no residual loads, no output stores)"""
+  8: no epilogue traffic (no residual loads, no output stores)
+  9 / 10: variant 4 / the full kernel with 2 x v_mfma_f32_16x16x32_f16 in place of each 32x32x16 (timing only)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = open(os.path.join(ROOT, "locov_amd/csrc/gemm_split.hip")).read().replace('#include "gemm_nt.h"', '#include "%s/locov_amd/csrc/gemm_nt.h"' % ROOT)
@@ -18,6 +19,18 @@ def variant(n):
         s = s.replace(a, b)
     if n == 1:
         rep("        split4(ra[i], a_scale, hi, lo);", "        hi = u32x2{__builtin_bit_cast(unsigned, ra[i][0]), __builtin_bit_cast(unsigned, ra[i][1])}; lo = u32x2{__builtin_bit_cast(unsigned, ra[i][2]), __builtin_bit_cast(unsigned, ra[i][3])};")
+    if n in (9, 10):  # 9: variant 4 (MFMA-only loop), 10: the full kernel -- with each 32x32x16 MFMA replaced by two 16x16x32 ones
+        rep("            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[q][i][w == 2 ? 1 : 0], fb[q][j][w == 1 ? 1 : 0], acc[i][j], 0, 0, 0);",
+            """            {
+                f32x4 c0 = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]}, c1 = {acc[i][j][4], acc[i][j][5], acc[i][j][6], acc[i][j][7]};
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[q][i][w == 2 ? 1 : 0], fb[q][j][w == 1 ? 1 : 0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[q][i][w == 2 ? 1 : 0], fb[q][j][w == 1 ? 1 : 0], c1, 0, 0, 0);
+                acc[i][j][0] = c0[0]; acc[i][j][1] = c0[1]; acc[i][j][2] = c0[2]; acc[i][j][3] = c0[3];
+                acc[i][j][4] = c1[0]; acc[i][j][5] = c1[1]; acc[i][j][6] = c1[2]; acc[i][j][7] = c1[3];
+            }""")
+        if n == 10:
+            return s
+        n = 4
     if n == 8:       # no epilogue traffic: neither residual loads nor output stores (K-loop + LDS re-layout only)
         rep("        if (epi.residual && n_ok) {\n#pragma unroll\n            for (int it = 0; it < NIT; it++) {\n                if (it < NPRE", "        if (false) {\n#pragma unroll\n            for (int it = 0; it < NIT; it++) {\n                if (it < NPRE")
         rep("        if (NPRE == 0 || !epi.residual || !n_ok) return;", "        return;")
