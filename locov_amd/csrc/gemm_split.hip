@@ -65,16 +65,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return base + (bid >> 3);
 }
 
-// four fp32 values -> four hi halves and four lo halves of s*x
+// four fp32 values -> four hi halves and four lo halves of s*x, one vector-ALU instruction per half produced:
+// v_fma_mix{lo,hi}_f16 forms a*b+c in fp32 from fp32 / f16 sources and rounds once to f16, so  hi = f16(x*s)  and
+// lo = f16(x*s - hi)  (x*s and the difference are exact) take 8 instructions per chunk instead of the 14 the
+// convert / multiply / subtract sequence compiles to -- the staging's vector-ALU work shares the SIMD's issue with the MFMAs.
 __device__ __forceinline__ void split4(const f32x4 &x, float s, u32x2 &hi, u32x2 &lo)
 {
-    const f32x4 xs = x * s;                                  // exact (power of two)
-    const f16x4 h = __builtin_convertvector(xs, f16x4);
-    const f32x4 hf = __builtin_convertvector(h, f32x4);
-    const f32x4 r = xs - hf;                                 // exact: <= 13 significant bits
-    const f16x4 l = __builtin_convertvector(r, f16x4);
-    hi = __builtin_bit_cast(u32x2, h);
-    lo = __builtin_bit_cast(u32x2, l);
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        unsigned h, l;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x[2 * e]), "s"(s));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x[2 * e + 1]), "s"(s));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x[2 * e]), "s"(s), "v"(h));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x[2 * e + 1]), "s"(s), "v"(h));
+        hi[e] = h;
+        lo[e] = l;
+    }
 }
 
 }  // namespace
