@@ -125,13 +125,16 @@ class Workload:
                 y = self.res5.forward_from_map(nhwc, self.rois, 14, 1.0 / 16, 0, True, bf16=True)
             elif self.args.block0 == "map" and self.res5.map_path_pays(R, nhwc.shape[0] * 50 * 84):
                 # block 0's 1x1 convolutions on the map, ROIAlign pools their outputs (Res5Stage.forward_from_map)
+                # (pooled: the stage returns the spatial mean the box head consumes; in split arithmetic it is fused into
+                # the last 1x1 convolution)
                 y = self.res5.forward_from_map(nhwc, self.rois, 14, 1.0 / 16, 0, True, winograd=wino,
-                                               split=self.args.res5_dtype == "f16x2")
+                                               split=self.args.res5_dtype == "f16x2", pooled=True)
             else:
                 x0 = self.res5.rows_input(49 * R, self.device)
                 ops.roi_align_nhwc(nhwc, self.rois, 14, 1.0 / 16, 0, True, bin_stride=2, pos_major=True, out=x0)
-                y = self.res5.forward_rows(x0, 7, 7, pos_major=True, winograd=wino, split=self.args.res5_dtype == "f16x2")
-            out = self.head(y.view(7, 7, R, 2048), channels_last=2)
+                y = self.res5.forward_rows(x0, 7, 7, pos_major=True, winograd=wino, split=self.args.res5_dtype == "f16x2",
+                                           pooled=True)
+            out = self.head(y) if y.shape[0] == R else self.head(y.view(7, 7, R, 2048), channels_last=2)
         else:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

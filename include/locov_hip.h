@@ -47,6 +47,9 @@ extern "C" {
 
 /* epilogue flags of the GEMM entry points */
 #define LOCOV_EPI_RELU 1u
+/* locov_winograd_conv3x3_f32{,_split}: write the output rows ROI-major (row = roi * 49 + position) instead of
+ * position-major (row = position * R + roi) -- the order locov_gemm_nt_f32_split_segmean consumes */
+#define LOCOV_WINO_OUT_ROI_MAJOR 0x100u
 
 typedef void *locov_stream_t;
 
@@ -278,6 +281,19 @@ int locov_gemm_nt_f32_split(const float *x, int64_t lda, const void *W_split, co
                             const float *shift, const float *residual, float *y, int64_t ldc,
                             int64_t M, int N, int K, unsigned flags, float x_scale, float w_scale,
                             locov_stream_t stream);
+
+/* The last 1x1 convolution of Res5 fused with the spatial mean behind it (roi_emb_heads.py:245 -> :262,:344,:356):
+ *   out[q, n] = mean over p < seg of relu?( scale[n] * (x[q*seg + p, :] . W[n, :]) + shift[n] + residual[p*R + q, n] )
+ * with R = M / seg ROIs: x rows are ROI-major (LOCOV_WINO_OUT_ROI_MAJOR), the residual is the POSITION-major [M, N]
+ * tensor of the previous block, the [M, N] result is never written.  Per M-tile and ROI the kernel leaves column
+ * sums in `workspace` (locov_gemm_segmean_workspace_bytes), a second small kernel adds the one or two partials of
+ * each ROI in a fixed order (deterministic).  seg <= 128, M % seg == 0, M * N * 4 < 2^32, otherwise as
+ * locov_gemm_nt_f32_split. */
+int64_t locov_gemm_segmean_workspace_bytes(int64_t M, int N);
+int locov_gemm_nt_f32_split_segmean(const float *x, int64_t lda, const void *W_split, const float *scale,
+                                    const float *shift, const float *residual, float *out, int64_t M,
+                                    int N, int K, int seg, unsigned flags, float x_scale, float w_scale,
+                                    void *workspace, int64_t workspace_bytes, locov_stream_t stream);
 
 /* `batch` independent problems (strides in fp32 elements; W_split problem b starts stride_w * 4 bytes * b in) */
 int locov_gemm_nt_batched_f32_split(const float *x, int64_t lda, int64_t stride_x, const void *W_split,

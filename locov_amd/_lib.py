@@ -17,6 +17,7 @@ OK = 0
 F32, BF16 = 0, 1
 NORM_NONE, NORM_L2, NORM_STANDARDIZE = 0, 1, 2
 EPI_RELU = 1
+WINO_OUT_ROI_MAJOR = 0x100
 MAX_LEVELS = 8
 ABI_VERSION = 1
 
@@ -71,6 +72,9 @@ SIGNATURES = {
     "locov_split_f16x2_pack": (c_int, [_p, c_int64, c_int, c_int64, c_float, _p, _p]),
     "locov_gemm_nt_f32_split": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, c_float,
                                         c_float, _p]),
+    "locov_gemm_segmean_workspace_bytes": (c_int64, [c_int64, c_int]),
+    "locov_gemm_nt_f32_split_segmean": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int, c_int, c_int, c_uint, c_float,
+                                                c_float, _p, c_int64, _p]),
     "locov_gemm_nt_batched_f32_split": (c_int, [_p, c_int64, c_int64, _p, c_int64, _p, c_int64, c_int64, c_int64, c_int,
                                                 c_int, c_int, c_float, c_float, _p]),
     "locov_sim_gemm_bf16": (c_int, [_p, _p, c_int64, c_int, c_int, _p, c_int64, _p]),

@@ -85,10 +85,22 @@ __device__ __forceinline__ void split4(const f32x4 &x, float s, u32x2 &hi, u32x2
 
 }  // namespace
 
+// SEGSUM form (the last 1x1 convolution of Res5 + the spatial mean that follows it, roi_emb_heads.py:262,344,356): the
+// rows are ROI-major (m = roi * seg + position, seg = 49), the residual is gathered from the position-major tensor
+// (row position * R + roi), and instead of the [M,N] output the kernel leaves, per M-tile and per ROI the tile touches
+// (at most four), the column sums of the finished values: partial[(tile_m * 4 + slot) * N + n].  segsum_finish_kernel
+// adds the one or two partials of each ROI in a fixed order -- the [M,N] tensor is never written or re-read.
+struct SegSum {
+    int seg;
+    int64_t R;
+    float *partial;
+};
+
+template <bool SEGSUM>
 __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restrict__ A, int64_t lda,
                                                            const float *__restrict__ B, float *__restrict__ Cout,
                                                            int64_t ldc, int64_t M, int N, int K, Epilogue epi, Batch bt,
-                                                           float a_scale, float out_scale)
+                                                           float a_scale, float out_scale, SegSum ss)
 {
     __shared__ u32x4 lds[2 * STAGEB / 16];
     char *const ldsb = reinterpret_cast<char *>(lds);
@@ -299,11 +311,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
     const unsigned nrec = (unsigned)(rows_here * ldc * 4);
     const unsigned voff = (unsigned)(((int64_t)(wm + rr) * ldc + n) * 4);
     const unsigned vstep = (unsigned)(RPI * ldc * 4);
-    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(Cout + m0 * ldc, 0, nrec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out =
+        __builtin_amdgcn_make_buffer_rsrc(SEGSUM ? const_cast<float *>(epi.residual) : Cout + m0 * ldc, 0, nrec, 0x00020000);
+    // (SEGSUM: the residual descriptor spans the whole position-major tensor, rows are gathered by a computed offset)
     const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(epi.residual ? epi.residual + m0 * ldc : Cout + m0 * ldc), 0, nrec, 0x00020000);
+        const_cast<float *>(SEGSUM ? epi.residual : epi.residual ? epi.residual + m0 * ldc : Cout + m0 * ldc), 0,
+        SEGSUM ? (unsigned)(M * ldc * 4) : nrec, 0x00020000);
     auto prefetch_residual = [&]() __attribute__((always_inline)) {
-        if (NPRE == 0 || !epi.residual || !n_ok) return;
+        if (SEGSUM || NPRE == 0 || !epi.residual || !n_ok) return;
 #pragma unroll
         for (int it = 0; it < NPRE; it++)
             res_pre[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, voff + it * vstep, 0, 2));
@@ -324,13 +339,24 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
     constexpr int EPS = TN + 4;
     static_assert(WM * WN * TM * EPS * 4 <= 2 * STAGEB, "epilogue staging must fit the K-loop LDS");
     float *ep = reinterpret_cast<float *>(lds) + wave * (TM * EPS);
+    const int64_t seg_q0 = SEGSUM ? m0 / ss.seg : 0;                 // first ROI of the tile, and the position its first row holds
+    const int seg_r0 = SEGSUM ? (int)(m0 - seg_q0 * ss.seg) : 0;
+    const float seg_inv = SEGSUM ? 1.0f / (float)ss.seg : 0.f;
     auto tail = [&](auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
         f32x4 res[NIT];
         if (epi.residual && n_ok) {
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
-                if (it < NPRE && NPRE > 0)
+                if (SEGSUM) {
+                    // row m = m0 + t of the tile is (ROI q, position pos): small-integer division by a float reciprocal
+                    // (t + m0 % seg < 256, exact), 32-bit offsets (M * N * 4 < 2^32 is checked by the launcher)
+                    const int u = seg_r0 + wm + it * RPI + rr;
+                    const int dq = (int)(((float)u + 0.5f) * seg_inv), pos = u - dq * ss.seg;
+                    const unsigned row = (unsigned)pos * (unsigned)ss.R + (unsigned)(seg_q0 + dq);
+                    const unsigned off = wm + it * RPI + rr < rows_here ? (row * (unsigned)ldc + (unsigned)n) * 4u : 0xffffffffu;
+                    res[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off, 0, 2));
+                } else if (it < NPRE && NPRE > 0)
                     res[it] = res_pre[it];
                 else
                     res[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -359,8 +385,36 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
                     v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
                     v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, FULL ? voff : voff + it * vstep,
-                                                       FULL ? it * vstep : 0u, 2);      // aux 2 = nt: streamed once
+                if (SEGSUM)
+                    *reinterpret_cast<f32x4 *>(ep + (it * RPI + rr) * EPS + c4) = v;    // finished value back in place
+                else
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, FULL ? voff : voff + it * vstep,
+                                                           FULL ? it * vstep : 0u, 2);  // aux 2 = nt: streamed once
+            }
+        }
+        if (SEGSUM) {
+            // column sums per ROI: thread t owns column t % 128 and the ROI slots {t / 128, t / 128 + 2} of this tile
+            __syncthreads();
+            const float *base = reinterpret_cast<const float *>(lds);
+            const int col = tid & (BN - 1), cw = (col >> 6) * (TM * EPS) + (col & 63);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int slot = (tid >> 7) + 2 * k;
+                int lo = slot * ss.seg - seg_r0, hi = lo + ss.seg;            // tile rows of ROI q0 + slot
+                lo = lo > 0 ? lo : 0;
+                hi = hi < (int)rows_here ? hi : (int)rows_here;
+                // eight independent partial sums (fixed order): the LDS reads of a pass are all in flight together
+                float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int row = lo; row < hi; row += 8) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int rw = row + e < hi ? row + e : lo;                  // in range; masked below
+                        const float v = base[(rw >> 6) * (WN * TM * EPS) + (rw & 63) * EPS + cw];
+                        ps[e] += row + e < hi ? v : 0.f;
+                    }
+                }
+                const float acc_s = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+                if (n0 + col < N) ss.partial[((m0 / BM) * 4 + slot) * (int64_t)N + n0 + col] = acc_s;
             }
         }
     };
@@ -387,6 +441,24 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float *__restrict
     }
 }
 
+// out[q, n] = (sum over the one or two M-tiles ROI q's rows fall into of its partial) * inv_seg
+__global__ __launch_bounds__(256) void segsum_finish_kernel(const float *__restrict__ partial, int64_t R, int N, int seg,
+                                                            float inv_seg, float *__restrict__ out)
+{
+    const int64_t total = R * (N / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = i / (N / 4);
+        const int n = (int)(i - q * (N / 4)) * 4;
+        const int64_t t0 = (q * seg) / BM, t1 = (q * seg + seg - 1) / BM;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t t = t0; t <= t1; t++) {
+            const int64_t slot = q - (t * BM) / seg;
+            a += *reinterpret_cast<const f32x4 *>(partial + (t * 4 + slot) * N + n);
+        }
+        *reinterpret_cast<f32x4 *>(out + q * N + n) = a * inv_seg;
+    }
+}
+
 int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C, int64_t ldc, int64_t M, int N, int K,
                       const Epilogue &epi, float a_scale, float w_scale, hipStream_t s, const char *what, const Batch &bt)
 {
@@ -403,9 +475,38 @@ int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C,
     if ((int64_t)BM * (lda > ldc ? lda : ldc) * 4 > 0x7fffffffLL)
         return set_error(LOCOV_ERR_INVALID_ARG, "%s: row pitch too large for 32-bit tile offsets", what);
     const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K * count);     // class 5: split-operand GEMM
-    hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)tiles), dim3(NT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
-                       C, ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale));
+    hipLaunchKernelGGL(gemm_split_kernel<false>, dim3((unsigned)tiles), dim3(NT), 0, s, A, lda,
+                       reinterpret_cast<const float *>(Wsplit), C, ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale),
+                       SegSum{0, 0, nullptr});
     timing_end(trec, s);
+    return check_launch(what);
+}
+
+// The SEGSUM form + its finishing pass: mean over the `seg` rows of every ROI of relu(scale * (x . W^T) + shift + residual)
+int launch_gemm_split_segmean(const float *A, int64_t lda, const void *Wsplit, int64_t M, int N, int K, const Epilogue &epi,
+                              int seg, float a_scale, float w_scale, float *partial, float *out, hipStream_t s, const char *what)
+{
+    if (!(a_scale > 0.f) || !(w_scale > 0.f)) return set_error(LOCOV_ERR_INVALID_ARG, "%s: operand scales must be positive", what);
+    if (K % BK != 0 || K < BK) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: K must be a positive multiple of %d", what, BK);
+    if (seg <= 0 || seg > BM || M % seg != 0) return set_error(LOCOV_ERR_INVALID_ARG, "%s: M must be a multiple of seg (1..%d)", what, BM);
+    if (N % 4 != 0 || lda % 4 != 0 || (uintptr_t)A % 16 != 0 || (uintptr_t)Wsplit % 16 != 0 || (uintptr_t)partial % 16 != 0 ||
+        (uintptr_t)out % 16 != 0 || (epi.residual && (uintptr_t)epi.residual % 16 != 0) ||
+        (epi.scale && (uintptr_t)epi.scale % 16 != 0) || (epi.shift && (uintptr_t)epi.shift % 16 != 0))
+        return set_error(LOCOV_ERR_UNSUPPORTED, "%s: N, lda must be multiples of 4 and every pointer 16-byte aligned", what);
+    if (!epi.residual) return set_error(LOCOV_ERR_INVALID_ARG, "%s: the residual is required", what);
+    const int64_t tiles_m = ceil_div(M, BM), tiles = tiles_m * ceil_div(N, BN);
+    if (tiles > 0x7fffffffLL || (double)M * N * 4 > 4294967295.0 || (int64_t)BM * lda * 4 > 0x7fffffffLL)
+        return set_error(LOCOV_ERR_INVALID_ARG, "%s: problem too large for 32-bit residual offsets", what);
+    const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K);
+    hipLaunchKernelGGL(gemm_split_kernel<true>, dim3((unsigned)tiles), dim3(NT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
+                       static_cast<float *>(nullptr), (int64_t)N, M, N, K, epi, Batch{1, 0, 0, 0}, a_scale, 1.f / (a_scale * w_scale),
+                       SegSum{seg, M / seg, partial});
+    timing_end(trec, s);
+    int rc = check_launch(what);
+    if (rc) return rc;
+    const int64_t R = M / seg, total = R * (N / 4);
+    const unsigned blocks = (unsigned)(ceil_div(total, 256) < 65536 ? ceil_div(total, 256) : 65536);
+    hipLaunchKernelGGL(segsum_finish_kernel, dim3(blocks), dim3(256), 0, s, partial, R, N, seg, 1.f / (float)seg, out);
     return check_launch(what);
 }
 
@@ -439,6 +540,29 @@ int locov_gemm_nt_f32_split(const float *x, int64_t lda, const void *W_split, co
     Epilogue epi{scale, shift, residual, flags};
     return launch_gemm_split(x, lda, W_split, y, ldc, M, N, K, epi, x_scale, w_scale, as_stream(stream),
                              "locov_gemm_nt_f32_split");
+}
+
+int64_t locov_gemm_segmean_workspace_bytes(int64_t M, int N)
+{
+    if (M <= 0 || N <= 0) return 0;
+    return ceil_div(M, BM) * 4 * (int64_t)N * (int64_t)sizeof(float);
+}
+
+int locov_gemm_nt_f32_split_segmean(const float *x, int64_t lda, const void *W_split, const float *scale, const float *shift,
+                                    const float *residual, float *out, int64_t M, int N, int K, int seg, unsigned flags,
+                                    float x_scale, float w_scale, void *workspace, int64_t workspace_bytes,
+                                    locov_stream_t stream)
+{
+    LOCOV_REQUIRE(M >= 0 && N > 0 && K > 0, "locov_gemm_nt_f32_split_segmean: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    if (M == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(x && W_split && residual && out && workspace, "locov_gemm_nt_f32_split_segmean: null pointer");
+    LOCOV_REQUIRE(lda >= K, "locov_gemm_nt_f32_split_segmean: lda < K");
+    LOCOV_REQUIRE(!(flags & ~(unsigned)LOCOV_EPI_RELU), "locov_gemm_nt_f32_split_segmean: unsupported flags 0x%x", flags);
+    LOCOV_REQUIRE(workspace_bytes >= locov_gemm_segmean_workspace_bytes(M, N),
+                  "locov_gemm_nt_f32_split_segmean: workspace too small (%lld bytes)", (long long)workspace_bytes);
+    Epilogue epi{scale, shift, residual, flags};
+    return launch_gemm_split_segmean(x, lda, W_split, M, N, K, epi, seg, x_scale, w_scale, static_cast<float *>(workspace), out,
+                                     as_stream(stream), "locov_gemm_nt_f32_split_segmean");
 }
 
 int locov_gemm_nt_batched_f32_split(const float *x, int64_t lda, int64_t stride_x, const void *W_split, int64_t stride_w,

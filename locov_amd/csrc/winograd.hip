@@ -93,8 +93,9 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
     }
 }
 
-// M [NF*NF][Rc][N]  ->  y rows [(y*7+x)*ld_pos + r0 + r] (ldy elements apart) = relu?(acc * scale[n] + shift[n])
-__global__ __launch_bounds__(256) void wino_output_kernel(const float *__restrict__ Mv, int64_t ld_pos, int64_t Rc, int N,
+// M [NF*NF][Rc][N]  ->  y rows [(y*7+x)*ld_pos + r*ld_roi] (ldy elements apart) = relu?(acc * scale[n] + shift[n]);
+// position-major output: ld_pos = R, ld_roi = 1; ROI-major output (row = roi*49 + position): ld_pos = 1, ld_roi = 49
+__global__ __launch_bounds__(256) void wino_output_kernel(const float *__restrict__ Mv, int64_t ld_pos, int64_t ld_roi, int64_t Rc, int N,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, int relu,
                                                           float *__restrict__ y, int64_t ldy)
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
     f32x2 sc = {1.f, 1.f}, sh = {0.f, 0.f};
     if (scale) sc = *reinterpret_cast<const f32x2 *>(scale + n);
     if (shift) sh = *reinterpret_cast<const f32x2 *>(shift + n);
-    float *dst = y + r * ldy + n;
+    float *dst = y + r * ld_roi * ldy + n;
 #pragma unroll
     for (int yy = 0; yy < 7; yy++)
 #pragma unroll
@@ -221,7 +222,8 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
                   Cin, N);
     LOCOV_REQUIRE(((uintptr_t)x | (uintptr_t)U | (uintptr_t)y | (uintptr_t)workspace) % 16 == 0,
                   "locov_winograd_conv3x3_f32: misaligned pointer");
-    LOCOV_REQUIRE(!(flags & ~(unsigned)LOCOV_EPI_RELU), "locov_winograd_conv3x3_f32: unsupported flags 0x%x", flags);
+    LOCOV_REQUIRE(!(flags & ~(unsigned)(LOCOV_EPI_RELU | LOCOV_WINO_OUT_ROI_MAJOR)), "locov_winograd_conv3x3_f32: unsupported flags 0x%x",
+                  flags);
     LOCOV_REQUIRE(workspace_bytes >= locov_winograd_workspace_bytes(R, Cin, N),
                   "locov_winograd_conv3x3_f32: workspace too small (%lld bytes)", (long long)workspace_bytes);
     const int64_t chunk = chunk_rois(R, Cin, N);
@@ -244,8 +246,10 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
                                                  "locov_winograd_conv3x3_f32 (batched GEMM)", ConvGeom{0, 0, 0, 0, 0},
                                                  Batch{NF * NF, rc * Cin, (int64_t)N * Cin, rc * N});
         if (rcode) return rcode;
-        hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)ceil_div(tout, 256)), dim3(256), 0, s, Mv, R, rc, N, scale, shift,
-                           (flags & LOCOV_EPI_RELU) ? 1 : 0, y + r0 * ldy, ldy);
+        const bool roi_major = (flags & LOCOV_WINO_OUT_ROI_MAJOR) != 0;
+        hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)ceil_div(tout, 256)), dim3(256), 0, s, Mv, roi_major ? (int64_t)1 : R,
+                           roi_major ? (int64_t)49 : (int64_t)1, rc, N, scale, shift, (flags & LOCOV_EPI_RELU) ? 1 : 0,
+                           y + r0 * (roi_major ? 49 : 1) * ldy, ldy);
         rcode = check_launch("locov_winograd_conv3x3_f32 (output transform)");
         if (rcode) return rcode;
     }

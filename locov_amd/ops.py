@@ -317,12 +317,13 @@ def winograd_pack_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool = False,
-                     out: Optional[torch.Tensor] = None, v_scale: float = 1.0) -> torch.Tensor:
+                     out: Optional[torch.Tensor] = None, v_scale: float = 1.0, roi_major: bool = False) -> torch.Tensor:
     """3x3 / pad 1 / stride 1 convolution of 7x7 position-major tiles in the Winograd domain.
     x [49*R, Cin] (row = pos*R + r), U [121, N, Cin] (winograd_pack_weight) -> [49*R, N].
     out: optional [49*R, N] destination whose rows may be a column block of a wider matrix.
     U may be a SplitWeight (split_pack(winograd_pack_weight(w))): the 121 transform-domain GEMMs then run with
-    split operands on the f16 matrix pipe, the transformed input scaled by v_scale."""
+    split operands on the f16 matrix pipe, the transformed input scaled by v_scale.
+    roi_major: write the output rows ROI-major (row = r*49 + pos), the order linear_split_segmean reads."""
     x = _dev(x, "x")
     split = U if isinstance(U, SplitWeight) else None
     U = _dev(split.data if split is not None else U, "U")
@@ -348,14 +349,15 @@ def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool =
         ws = None
         _WINO_WS.pop(key, None)
         ws = _WINO_WS[key] = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+    wflags = (_lib.EPI_RELU if relu else 0) | (_lib.WINO_OUT_ROI_MAJOR if roi_major else 0)
     with torch.cuda.device(x.device):
         if split is not None:
             check(lib.locov_winograd_conv3x3_f32_split(_ptr(x), R, Cin, _ptr(U), split.scale, float(v_scale), _ptr(scale),
-                                                       _ptr(shift), _ptr(y), ldy, N, _lib.EPI_RELU if relu else 0, _ptr(ws),
+                                                       _ptr(shift), _ptr(y), ldy, N, wflags, _ptr(ws),
                                                        ws.numel(), _stream(x)), "locov_winograd_conv3x3_f32_split")
         else:
             check(lib.locov_winograd_conv3x3_f32(_ptr(x), R, Cin, _ptr(U), _ptr(scale), _ptr(shift), _ptr(y), ldy, N,
-                                                 _lib.EPI_RELU if relu else 0, _ptr(ws), ws.numel(), _stream(x)),
+                                                 wflags, _ptr(ws), ws.numel(), _stream(x)),
                   "locov_winograd_conv3x3_f32")
     return y
 
@@ -425,6 +427,40 @@ def linear_split(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tens
                                                   _ptr(residual), _ptr(y), N, M, N, K, _lib.EPI_RELU if relu else 0,
                                                   float(x_scale), weight.scale, _stream(x)), "locov_gemm_nt_f32_split")
     return y
+
+
+_SEGMEAN_WS = {}
+
+
+def linear_split_segmean(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tensor], residual: torch.Tensor, seg: int, *,
+                         scale: Optional[torch.Tensor] = None, relu: bool = True, x_scale: float = 16.0) -> torch.Tensor:
+    """Res5's last 1x1 convolution fused with the spatial mean behind it:
+        out[q, :] = mean_{p < seg} relu(scale * (x[q*seg + p, :] . W^T) + bias + residual[p*R + q, :]),   R = M // seg
+    x [M,K] with ROI-major rows, residual [M,N] with POSITION-major rows (the previous block's output), -> [R,N].
+    The [M,N] tensor is neither written nor re-read; deterministic (fixed summation order)."""
+    x = _rows(x, "x")
+    wd = _dev(weight.data, "weight")
+    residual = _dev(residual, "residual")
+    M, K = x.shape
+    N = wd.shape[0]
+    if wd.shape[1] != K or K % 32 or N % 4 or seg <= 0 or M % seg or tuple(residual.shape) != (M, N):
+        raise ValueError(f"linear_split_segmean: x {tuple(x.shape)} weight {tuple(wd.shape)} residual {tuple(residual.shape)} seg {seg}")
+    bias = _dev(bias, "bias") if bias is not None else None
+    scale = _dev(scale, "scale") if scale is not None else None
+    out = torch.empty((M // seg, N), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    need = int(lib.locov_gemm_segmean_workspace_bytes(M, N))
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _SEGMEAN_WS.get(key)
+    if ws is None or ws.numel() < need:
+        _SEGMEAN_WS.pop(key, None)
+        ws = _SEGMEAN_WS[key] = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.locov_gemm_nt_f32_split_segmean(_ptr(x), x.stride(0) if M else K, _ptr(wd), _ptr(scale), _ptr(bias),
+                                                  _ptr(residual), _ptr(out), M, N, K, int(seg), _lib.EPI_RELU if relu else 0,
+                                                  float(x_scale), weight.scale, _ptr(ws), ws.numel(), _stream(x)),
+              "locov_gemm_nt_f32_split_segmean")
+    return out
 
 
 def gemm_nt_batched_split(x: torch.Tensor, w: SplitWeight, x_scale: float = 1.0) -> torch.Tensor:

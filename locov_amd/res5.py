@@ -226,7 +226,7 @@ class Res5Stage(nn.Sequential):
     @torch.no_grad()
     def forward_from_map(self, nhwc: torch.Tensor, rois: torch.Tensor, pooler_resolution: int, spatial_scale: float,
                          sampling_ratio: int = 0, aligned: bool = True, winograd: bool = True,
-                         bf16: bool = False, split: bool = False) -> torch.Tensor:
+                         bf16: bool = False, split: bool = False, pooled: bool = False) -> torch.Tensor:
         """The whole stage from the channels-last res4 map [N,H,W,Cin] and the rois [R,5] -> position-major
         rows [49*R, Cout], with block 0's conv1 and projection shortcut moved IN FRONT of the pooler:
 
@@ -267,15 +267,19 @@ class Res5Stage(nn.Sequential):
             w2, s2, b2 = self._packed(c2)
             y = ops.conv3x3_nhwc(y, w2, 7, 7, scale=s2, shift=b2, relu=True, pos_major=True)
         x = self._linear(split, y, w3, shift_tail, scale=s3, residual=sc, relu=True)         # conv3 + FBN + add + ReLU
-        return self.forward_rows(x, 7, 7, pos_major=True, winograd=winograd, start_block=1, split=split)
+        return self.forward_rows(x, 7, 7, pos_major=True, winograd=winograd, start_block=1, split=split, pooled=pooled)
 
     @torch.no_grad()
     def forward_rows(self, x0: torch.Tensor, H: int, W: int, pos_major: bool = False,
-                     winograd: bool = True, start_block: int = 0, bf16: bool = False, split: bool = False) -> torch.Tensor:
+                     winograd: bool = True, start_block: int = 0, bf16: bool = False, split: bool = False,
+                     pooled: bool = False) -> torch.Tensor:
         """Rows are ROI-major (r*H*W + pos) or position-major (pos*R + r); the 1x1 convolutions do not
         care.  The 3x3 one runs, on 7x7 position-major tiles, in the Winograd domain (121 instead of 361
         products per tile and channel pair; `winograd=False` keeps the direct implicit GEMM, which skips
-        the zero-padding taps in the position-major order)."""
+        the zero-padding taps in the position-major order).
+        pooled: return the spatial mean [R, Cout] of the stage output instead of its rows (what the box head consumes,
+        roi_emb_heads.py:262,344,356).  With split arithmetic on the Winograd path the mean is fused into the last 1x1
+        convolution (ops.linear_split_segmean: the [49*R, Cout] output is neither written nor re-read)."""
         from . import ops
         assert self.supports_rows_path(), "forward_rows needs FrozenBN, STRIDE_IN_1X1 and ungrouped convs"
         x = x0
@@ -309,6 +313,12 @@ class Res5Stage(nn.Sequential):
                 wcat, bcat = self._packed_block0_tail()
                 x = self._linear(split, cat, wcat, bcat, relu=True)               # conv3 + shortcut + add + ReLU, K-concatenated
                 continue
+            last = bi == len(self) - 1
+            if (use_wino and pooled and last and split and blk.shortcut is None and w3.shape[1] % 32 == 0 and w3.shape[0] % 4 == 0
+                    and x.shape[0] * w3.shape[0] * 4 < 2 ** 32):
+                u2, s2, b2 = self._packed(c2, winograd=True)
+                y = ops.winograd_conv3x3(y, self._split(u2), scale=s2, shift=b2, relu=True, roi_major=True)
+                return ops.linear_split_segmean(y, self._split(w3), b3, x, H * W, scale=s3, relu=True)
             if use_wino:
                 u2, s2, b2 = self._packed(c2, winograd=True)
                 y = ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True)   # 3x3 + FBN + ReLU
@@ -321,6 +331,10 @@ class Res5Stage(nn.Sequential):
             else:
                 sc = x
             x = self._linear(split, y, w3, b3, scale=s3, residual=sc, relu=True)  # 1x1 + FBN + add + ReLU
+        if pooled:
+            R = x.shape[0] // (H * W)
+            return ops.spatial_mean(x.view(H, W, R, x.shape[1]), channels_last=2) if pos_major else \
+                ops.spatial_mean(x.view(R, H, W, x.shape[1]), channels_last=1)
         return x
 
 

@@ -262,15 +262,18 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         return (hasattr(self.res5, "forward_rows") and self.res5.supports_rows_path() and self.res5[0].stride == 2
                 and ph == pw and ph % 2 == 0 and features[0].shape[1] % 32 == 0)
 
-    def _shared_roi_transform(self, features: List[torch.Tensor], boxes: List[Boxes]):
-        """roi_emb_heads.py:243-245: res5(pooler(features, boxes)) -> [R, C5, P/2, P/2].
+    def _shared_roi_transform(self, features: List[torch.Tensor], boxes: List[Boxes], pooled: bool = False):
+        """roi_emb_heads.py:243-245: res5(pooler(features, boxes)) -> [R, C5, P/2, P/2]; with `pooled` the spatial
+        mean of that tensor, [R, C5] (:262,:344,:356), which on the hand-written path in split arithmetic comes fused
+        out of Res5's last 1x1 convolution.
 
         MI355X path: ROIAlign is evaluated on a channels-last copy of the map and only at the even
         bins the stride-2 1x1 convs of block 0 read; Res5 then runs as MFMA GEMMs over pixel rows.
         The result is returned as a logical NCHW tensor in channels-last memory."""
         if not self._fused_path_ok(features):
             x = self.pooler(features, boxes)                 # :244
-            return self.res5(x)                              # :245
+            x = self.res5(x)                                 # :245
+            return self._pooled_mean(x) if pooled else x
         assert len(boxes) == features[0].shape[0]
         rois = convert_boxes_to_pooler_format(boxes)
         P = self.pooler.output_size[0]
@@ -290,18 +293,19 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
                 ops.roi_align_nhwc(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned,
                                    bin_stride=2, pos_major=True, out=x0)
                 y = self.res5.forward_rows(x0, oh, ow, pos_major=True, bf16=True)
-            return y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)
+            y = y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)
+            return self._pooled_mean(y) if pooled else y
         if P == 14 and self.res5.map_path_pays(R, nhwc.shape[0] * nhwc.shape[1] * nhwc.shape[2]):
             # many proposals per image: block 0's 1x1 convolutions run on the map, ROIAlign pools their outputs
             y = self.res5.forward_from_map(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio,
-                                           self.pooler.aligned, winograd=wino, split=split)
-            return y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)
+                                           self.pooler.aligned, winograd=wino, split=split, pooled=pooled)
+            return y if pooled else y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)
         # (ROIAlign writes straight into the operand block 0's K-concatenated conv3 + shortcut GEMM reads)
         x0 = self.res5.rows_input(oh * ow * R, nhwc.device)
         ops.roi_align_nhwc(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned,
                            bin_stride=2, pos_major=True, out=x0)
-        y = self.res5.forward_rows(x0, oh, ow, pos_major=True, winograd=wino, split=split)
-        return y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)      # logical [R, C5, oh, ow]
+        y = self.res5.forward_rows(x0, oh, ow, pos_major=True, winograd=wino, split=split, pooled=pooled)
+        return y if pooled else y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)      # logical [R, C5, oh, ow]
 
     def _pooled_mean(self, box_features: torch.Tensor) -> torch.Tensor:
         """box_features.mean(dim=[2,3]) (:262,:344,:356) on the HIP kernel."""
@@ -322,8 +326,8 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
             proposals = self.label_and_sample_proposals(proposals, targets)
         del targets
         proposal_boxes = [x.proposal_boxes for x in proposals]
-        box_features = self._shared_roi_transform([features[f] for f in self.in_features], proposal_boxes)
-        predictions = self.box_predictor(self._pooled_mean(box_features))
+        box_features = self._shared_roi_transform([features[f] for f in self.in_features], proposal_boxes, pooled=True)
+        predictions = self.box_predictor(box_features)       # (:261-262: the mean is all the predictor sees)
         if self.training:
             del features
             losses = self.box_predictor.losses(predictions, proposals)
@@ -353,10 +357,9 @@ class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
         visual_grid_features = self.res5(features[self.in_features[0]])          # :323
         proposal_boxes = [x.proposal_boxes for x in proposals]
         boxes_per_image = [len(x) for x in proposals]
-        box_features = self._shared_roi_transform([features[f] for f in self.in_features], proposal_boxes)
+        box_features = self._shared_roi_transform([features[f] for f in self.in_features], proposal_boxes, pooled=True)   # :343-344
         del features
         losses = {}
-        box_features = self._pooled_mean(box_features)                           # :344
         predictions = self.box_predictor(box_features)                           # :345
         box_features = list(box_features.split(boxes_per_image, dim=0))          # :346
         losses.update(self.box_predictor.losses(predictions, proposals))         # :347
@@ -365,8 +368,8 @@ class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
     def inference_detection(self, features, proposals):
         """roi_emb_heads.py:351-360."""
         proposal_boxes = [x.proposal_boxes for x in proposals]
-        box_features = self._shared_roi_transform([features[f] for f in self.in_features], proposal_boxes)
-        predictions = self.box_predictor(self._pooled_mean(box_features))
+        box_features = self._shared_roi_transform([features[f] for f in self.in_features], proposal_boxes, pooled=True)   # :355-356
+        predictions = self.box_predictor(box_features)
         pred_instances, _ = self.box_predictor.inference(predictions, proposals)
         pred_instances = self.forward_with_given_boxes(features, pred_instances)
         return pred_instances, {}

@@ -200,3 +200,66 @@ def test_split_res5_tracks_the_f32_mfma_path_across_input_magnitudes(fscale):
             scores, _ = heads.box_predictor(heads._pooled_mean(bf))
         errs[dtype] = np.abs(scores.cpu().numpy() - want["scores"]).max() / np.abs(want["scores"]).max()
     assert errs["f16x2"] <= 5e-6 and errs["f16x2"] <= 2 * errs["fp32"] + 5e-7, errs
+
+
+@pytest.mark.parametrize("R,N,K", [(1, 4, 32), (5, 128, 64), (300, 516, 160), (131, 2048, 512)])
+def test_segmean_matches_the_unfused_gemm_plus_mean(ops, R, N, K):
+    """locov_gemm_nt_f32_split_segmean: ROI-major x rows, POSITION-major residual -> mean over the 49 positions of the
+    finished values; against the unfused split GEMM + mean and an fp64 evaluation; bit-identical from run to run."""
+    seg, M = 49, 49 * R
+    g = torch.Generator().manual_seed(R + N)
+    x = torch.randn(M, K, generator=g).relu_().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    res_pm = torch.randn(M, N, generator=g).cuda()
+    sc, sh = (torch.rand(N, generator=g) + 0.5).cuda(), torch.randn(N, generator=g).cuda()
+    res_rm = res_pm.view(seg, R, N).permute(1, 0, 2).reshape(M, N).contiguous()
+    ws = ops.split_pack(w)
+    want = ops.linear_split(x, ws, sh, scale=sc, residual=res_rm, relu=True).view(R, seg, N).double().mean(dim=1)
+    ref = torch.relu((x.double() @ w.double().t()) * sc.double() + sh.double() + res_rm.double()).view(R, seg, N).mean(dim=1)
+    got = ops.linear_split_segmean(x, ws, sh, res_pm, seg, scale=sc, relu=True)
+    assert tuple(got.shape) == (R, N)
+    assert (got.double() - want).abs().max().item() <= 2e-6
+    assert (got.double() - ref).abs().max().item() <= 3e-6
+    assert torch.equal(got, ops.linear_split_segmean(x, ws, sh, res_pm, seg, scale=sc, relu=True))
+
+
+def test_winograd_roi_major_output(ops):
+    g = torch.Generator().manual_seed(9)
+    R, Cin, N = 37, 64, 48
+    rows = torch.randn(49 * R, Cin, generator=g).cuda()
+    U = ops.winograd_pack_weight((torch.randn(N, Cin, 3, 3, generator=g) * 0.1).cuda())
+    for u in (U, ops.split_pack(U)):
+        pm = ops.winograd_conv3x3(rows, u, relu=True)
+        rm = ops.winograd_conv3x3(rows, u, relu=True, roi_major=True)
+        assert torch.equal(rm.view(R, 49, N), pm.view(49, R, N).permute(1, 0, 2))
+
+
+@pytest.mark.parametrize("many", [False, True])
+def test_pooled_stage_output_equals_the_mean_of_the_unpooled_one(many):
+    """Res5Stage.forward_rows / forward_from_map(pooled=True) (fused mean in split arithmetic) against the mean of the
+    rows the same call returns without `pooled`, and the heads' pooled path against the oracle."""
+    import locov_amd as pkg
+    from oracle import lsm_oracle as oracle
+    import test_gpu_roi_heads as T
+    oracle.build()
+    cfg = T._small_cfg(pkg)
+    heads, params, h = T._make_heads(pkg, oracle, cfg, 80, 41)
+    rng = np.random.default_rng(41)
+    if many:
+        feat = rng.standard_normal((2, 128, 20, 30)).astype(np.float32)
+        boxes = [oracle.synth_boxes(rng, 300, 480.0, 320.0), oracle.synth_boxes(rng, 260, 480.0, 320.0)]
+    else:
+        feat = rng.standard_normal((2, 128, 50, 84)).astype(np.float32)
+        boxes = [oracle.synth_boxes(rng, 40), oracle.synth_boxes(rng, 33)]
+    want = oracle.roi_head_forward(feat, boxes, params, h)
+    from locov_amd.structures import Boxes
+    bl = [Boxes(torch.from_numpy(b).cuda()) for b in boxes]
+    with torch.no_grad():
+        full = heads._shared_roi_transform([T.dev(feat)], bl)
+        pooled = heads._shared_roi_transform([T.dev(feat)], bl, pooled=True)
+        scores, deltas = heads.box_predictor(pooled)
+    assert tuple(pooled.shape) == (full.shape[0], full.shape[1])
+    assert (pooled - heads._pooled_mean(full)).abs().max().item() <= 2e-6 * float(full.abs().max())
+    np.testing.assert_allclose(pooled.cpu().numpy(), want["box_features"], atol=2e-5 * np.abs(want["res5"]).max(), rtol=1e-4)
+    assert np.abs(scores.cpu().numpy() - want["scores"]).max() <= 1e-4
+    np.testing.assert_allclose(deltas.cpu().numpy(), want["deltas"], atol=1e-5)
