@@ -403,17 +403,24 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
                 int lo = slot * ss.seg - seg_r0, hi = lo + ss.seg;            // tile rows of ROI q0 + slot
                 lo = lo > 0 ? lo : 0;
                 hi = hi < (int)rows_here ? hi : (int)rows_here;
-                // eight independent partial sums (fixed order): the LDS reads of a pass are all in flight together
-                float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int row = lo; row < hi; row += 8) {
+                // rows lo..hi-1 of column `col`: the part in each 64-row half of the tile is a fixed-stride walk through that
+                // half's staging area; four independent partial sums (fixed order) keep the LDS reads in flight
+                float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const int rw = row + e < hi ? row + e : lo;                  // in range; masked below
-                        const float v = base[(rw >> 6) * (WN * TM * EPS) + (rw & 63) * EPS + cw];
-                        ps[e] += row + e < hi ? v : 0.f;
+                for (int half = 0; half < 2; half++) {
+                    const int a = lo > half * 64 ? lo : half * 64, b = hi < half * 64 + 64 ? hi : half * 64 + 64;
+                    if (a >= b) continue;
+                    const float *p = base + half * (WN * TM * EPS) + (a & 63) * EPS + cw;
+                    int r = a;
+                    for (; r + 4 <= b; r += 4, p += 4 * EPS) {
+                        ps[0] += p[0];
+                        ps[1] += p[EPS];
+                        ps[2] += p[2 * EPS];
+                        ps[3] += p[3 * EPS];
                     }
+                    for (; r < b; r++, p += EPS) ps[r & 3] += p[0];
                 }
-                const float acc_s = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+                const float acc_s = (ps[0] + ps[1]) + (ps[2] + ps[3]);
                 if (n0 + col < N) ss.partial[((m0 / BM) * 4 + slot) * (int64_t)N + n0 + col] = acc_s;
             }
         }
