@@ -47,7 +47,7 @@ namespace {
 
 constexpr int BM = 128, BN = 128, WM = 2, WN = 2, NT = 256;
 constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 16, NB = TN / 16;   // a wave's 64x64 sub-tile = 4x4 blocks of 16x16
-constexpr int BK = 32;                      // fp32 columns per K-tile = two 16-wide MFMA k-steps
+constexpr int BK = 32;                      // fp32 columns per K-tile = the k of one v_mfma_f32_16x16x32_f16
 constexpr int ROWB = 160;                   // LDS pitch of an A row: 8 data slots of 16 B + 2 pad (layout below)
 constexpr int WROWB = 128;                  // W tile rows in LDS: unpadded (LDS DMA writes 1 KB runs), XOR-swizzled
 constexpr int STAGEB = BM * ROWB + BN * WROWB;   // bytes per stage
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
     };
 
     const int k_last = K - BK;                              // k0 of the last K-tile (K % BK == 0)
-    // prologue: tile 0 -> LDS stage 0 (W by DMA), A tile 1 -> staging registers, fragments of k-step 0
+    // prologue: tile 0 -> LDS stage 0 (W by DMA), A tile 1 -> staging registers, fragments of the first quarter
     dma_b(0);
     b_base += BK * 4;                                       // W is fetched ONE tile ahead: b_base addresses tile t+1
 #pragma unroll
