@@ -263,3 +263,15 @@ def test_pooled_stage_output_equals_the_mean_of_the_unpooled_one(many):
     np.testing.assert_allclose(pooled.cpu().numpy(), want["box_features"], atol=2e-5 * np.abs(want["res5"]).max(), rtol=1e-4)
     assert np.abs(scores.cpu().numpy() - want["scores"]).max() <= 1e-4
     np.testing.assert_allclose(deltas.cpu().numpy(), want["deltas"], atol=1e-5)
+
+
+def test_split_gemm_overflow_is_loud(ops):
+    """Outside the range the operand scale covers (|x_scale * x| >= 65504) the split GEMM does not return a plausible
+    wrong answer: the affected outputs are inf / NaN.  The same data is fine with a smaller x_scale."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(64, 64, generator=g).cuda()
+    x[3, 5] = 1.0e5                                            # 16 * 1e5 > 65504
+    w = ops.split_pack((torch.randn(32, 64, generator=g) * 0.1).cuda())
+    y = ops.linear_split(x, w)                                 # default x_scale = 16
+    assert not torch.isfinite(y[3]).all() and torch.isfinite(y[:3]).all() and torch.isfinite(y[4:]).all()
+    assert torch.isfinite(ops.linear_split(x, w, x_scale=0.25)).all()
