@@ -269,7 +269,7 @@ int locov_conv3x3_nhwc_bf16(const uint16_t *x, int64_t R, int H, int W, int Cin,
  * hi = fp16(s v), lo = fp16(s v - hi) (22 significant bits; absolute floor 2^-25 / s), and x . W^T is formed
  * on the f16 matrix pipe as (hi.hi + hi.lo + lo.hi) / (s_x s_w) with fp32 accumulation: fp32 in, fp32 out,
  * a result within about two fp32 roundings per operand of the fp32-MFMA GEMM.  |s_x x| and |s_w w| must stay
- * below 65504 (x_scale = 64 covers |x| < 1023; choose w_scale from max |w|).  x is split on the fly; W is
+ * below 65504 (x_scale = 16 covers |x| < 4094; choose w_scale from max |w|).  x is split on the fly; W is
  * split once by locov_split_f16x2_pack into `out`, a buffer of the SAME size as the fp32 matrix
  * (rows * K * 4 bytes; per row and group of 8 columns: 8 hi halves, then 8 lo halves).
  * K % 32 == 0; N, lda, ldc % 4 == 0; 16-byte aligned pointers.  Epilogue as locov_gemm_nt_f32.

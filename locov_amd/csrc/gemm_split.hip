@@ -8,7 +8,7 @@
 // its 11 bits, for every |s x| >= 2^-3, and below that its absolute error is <= 2^-25 -- a fixed-point floor far
 // under the rounding of the larger entries of the same row).  The operand scales s_a, s_w exist to place the
 // data in fp16's range: s_w is chosen per weight matrix at pack time (max |s_w w| ~ 2^13), s_a is a launch
-// parameter (2^4 for activations: exact up to |x| < 4094; 1 for Winograd-domain data).  The dropped lo.lo term is
+// parameter (2^4 for activations: exact up to |x| < 4094; 2^-2 for Winograd-domain data).  The dropped lo.lo term is
 // 2^-24 relative; all three products are accumulated in fp32 by v_mfma_f32_16x16x32_f16 into ONE accumulator.
 // The result differs from an fp32-MFMA GEMM by about two fp32 roundings per operand -- the order of the fp32
 // accumulation error itself at K >= 512, and measured at or below it -- while the matrix pipe runs 3 f16 MFMAs

@@ -317,12 +317,13 @@ def winograd_pack_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool = False,
-                     out: Optional[torch.Tensor] = None, v_scale: float = 1.0, roi_major: bool = False) -> torch.Tensor:
+                     out: Optional[torch.Tensor] = None, v_scale: float = 0.25, roi_major: bool = False) -> torch.Tensor:
     """3x3 / pad 1 / stride 1 convolution of 7x7 position-major tiles in the Winograd domain.
     x [49*R, Cin] (row = pos*R + r), U [121, N, Cin] (winograd_pack_weight) -> [49*R, N].
     out: optional [49*R, N] destination whose rows may be a column block of a wider matrix.
     U may be a SplitWeight (split_pack(winograd_pack_weight(w))): the 121 transform-domain GEMMs then run with
-    split operands on the f16 matrix pipe, the transformed input scaled by v_scale.
+    split operands on the f16 matrix pipe, the transformed input scaled by v_scale (the input transform amplifies
+    non-negative data by up to 64x, any data by up to 100x: 0.25 keeps |x| < 4094 in fp16's range, as for the 1x1s).
     roi_major: write the output rows ROI-major (row = r*49 + pos), the order linear_split_segmean reads."""
     x = _dev(x, "x")
     split = U if isinstance(U, SplitWeight) else None
