@@ -128,7 +128,7 @@ class Workload:
                 # (pooled: the stage returns the spatial mean the box head consumes; in split arithmetic it is fused into
                 # the last 1x1 convolution)
                 y = self.res5.forward_from_map(nhwc, self.rois, 14, 1.0 / 16, 0, True, winograd=wino,
-                                               split=self.args.res5_dtype == "f16x2", pooled=True)
+                                               split=self.args.res5_dtype == "f16x2", pooled=True, roi_major=wino)
             else:
                 x0 = self.res5.rows_input(49 * R, self.device)
                 ops.roi_align_nhwc(nhwc, self.rois, 14, 1.0 / 16, 0, True, bin_stride=2, pos_major=True, out=x0)

@@ -47,9 +47,12 @@ extern "C" {
 
 /* epilogue flags of the GEMM entry points */
 #define LOCOV_EPI_RELU 1u
+#define LOCOV_SEGMEAN_RES_ROI_MAJOR 0x400u   /* locov_gemm_nt_f32_split_segmean: the residual rows are ROI-major */
 /* locov_winograd_conv3x3_f32{,_split}: write the output rows ROI-major (row = roi * 49 + position) instead of
  * position-major (row = position * R + roi) -- the order locov_gemm_nt_f32_split_segmean consumes */
 #define LOCOV_WINO_OUT_ROI_MAJOR 0x100u
+/* ... and READ the input rows in that order */
+#define LOCOV_WINO_IN_ROI_MAJOR 0x200u
 
 typedef void *locov_stream_t;
 
@@ -285,7 +288,8 @@ int locov_gemm_nt_f32_split(const float *x, int64_t lda, const void *W_split, co
 /* The last 1x1 convolution of Res5 fused with the spatial mean behind it (roi_emb_heads.py:245 -> :262,:344,:356):
  *   out[q, n] = mean over p < seg of relu?( scale[n] * (x[q*seg + p, :] . W[n, :]) + shift[n] + residual[p*R + q, n] )
  * with R = M / seg ROIs: x rows are ROI-major (LOCOV_WINO_OUT_ROI_MAJOR), the residual is the POSITION-major [M, N]
- * tensor of the previous block, the [M, N] result is never written.  Per M-tile and ROI the kernel leaves column
+ * tensor of the previous block -- or, with LOCOV_SEGMEAN_RES_ROI_MAJOR in `flags`, a ROI-major one (row q*seg + p) --
+ * and the [M, N] result is never written.  Per M-tile and ROI the kernel leaves column
  * sums in `workspace` (locov_gemm_segmean_workspace_bytes), a second small kernel adds the one or two partials of
  * each ROI in a fixed order (deterministic).  seg <= 128, M % seg == 0, M * N * 4 < 2^32, otherwise as
  * locov_gemm_nt_f32_split. */

@@ -18,6 +18,8 @@ F32, BF16 = 0, 1
 NORM_NONE, NORM_L2, NORM_STANDARDIZE = 0, 1, 2
 EPI_RELU = 1
 WINO_OUT_ROI_MAJOR = 0x100
+WINO_IN_ROI_MAJOR = 0x200
+SEGMEAN_RES_ROI_MAJOR = 0x400
 MAX_LEVELS = 8
 ABI_VERSION = 1
 

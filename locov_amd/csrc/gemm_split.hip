@@ -353,7 +353,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
                     // (t + m0 % seg < 256, exact), 32-bit offsets (M * N * 4 < 2^32 is checked by the launcher)
                     const int u = seg_r0 + wm + it * RPI + rr;
                     const int dq = (int)(((float)u + 0.5f) * seg_inv), pos = u - dq * ss.seg;
-                    const unsigned row = (unsigned)pos * (unsigned)ss.R + (unsigned)(seg_q0 + dq);
+                    const unsigned row = ss.R ? (unsigned)pos * (unsigned)ss.R + (unsigned)(seg_q0 + dq)     // position-major residual
+                                              : (unsigned)(m0 + wm + it * RPI + rr);                        // ROI-major residual
                     const unsigned off = wm + it * RPI + rr < rows_here ? (row * (unsigned)ldc + (unsigned)n) * 4u : 0xffffffffu;
                     res[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, off, 0, 2));
                 } else if (it < NPRE && NPRE > 0)
@@ -507,7 +508,7 @@ int launch_gemm_split_segmean(const float *A, int64_t lda, const void *Wsplit, i
     const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K);
     hipLaunchKernelGGL(gemm_split_kernel<true>, dim3((unsigned)tiles), dim3(NT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
                        static_cast<float *>(nullptr), (int64_t)N, M, N, K, epi, Batch{1, 0, 0, 0}, a_scale, 1.f / (a_scale * w_scale),
-                       SegSum{seg, M / seg, partial});
+                       SegSum{seg, (epi.flags & LOCOV_SEGMEAN_RES_ROI_MAJOR) ? (int64_t)0 : M / seg, partial});
     timing_end(trec, s);
     int rc = check_launch(what);
     if (rc) return rc;
@@ -564,7 +565,8 @@ int locov_gemm_nt_f32_split_segmean(const float *x, int64_t lda, const void *W_s
     if (M == 0) return LOCOV_OK;
     LOCOV_REQUIRE(x && W_split && residual && out && workspace, "locov_gemm_nt_f32_split_segmean: null pointer");
     LOCOV_REQUIRE(lda >= K, "locov_gemm_nt_f32_split_segmean: lda < K");
-    LOCOV_REQUIRE(!(flags & ~(unsigned)LOCOV_EPI_RELU), "locov_gemm_nt_f32_split_segmean: unsupported flags 0x%x", flags);
+    LOCOV_REQUIRE(!(flags & ~(unsigned)(LOCOV_EPI_RELU | LOCOV_SEGMEAN_RES_ROI_MAJOR)),
+                  "locov_gemm_nt_f32_split_segmean: unsupported flags 0x%x", flags);
     LOCOV_REQUIRE(workspace_bytes >= locov_gemm_segmean_workspace_bytes(M, N),
                   "locov_gemm_nt_f32_split_segmean: workspace too small (%lld bytes)", (long long)workspace_bytes);
     Epilogue epi{scale, shift, residual, flags};

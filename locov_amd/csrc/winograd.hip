@@ -53,8 +53,9 @@ __global__ __launch_bounds__(256) void wino_pack_weight_kernel(const float *__re
     }
 }
 
-// x rows [(y*7+x)*ld_pos + r0 + r][C]  ->  V [NF*NF][Rc][C]
-__global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, int64_t ld_pos, int64_t Rc, int C,
+// x rows [(y*7+x)*ld_pos + r*ld_roi][C]  ->  V [NF*NF][Rc][C]   (position-major input: ld_pos = R, ld_roi = 1;
+// ROI-major input, row = roi*49 + position: ld_pos = 1, ld_roi = 49)
+__global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, int64_t ld_pos, int64_t ld_roi, int64_t Rc, int C,
                                                          float *__restrict__ V)
 {
     const int c2 = C >> 1;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
     if (t >= Rc * c2) return;
     const int64_t r = t / c2;
     const int c = (int)(t - r * c2) * 2;
-    const float *src = x + r * C + c;
+    const float *src = x + r * ld_roi * C + c;
     f32x2 d[7][7];
 #pragma unroll
     for (int y = 0; y < 7; y++)
@@ -222,7 +223,8 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
                   Cin, N);
     LOCOV_REQUIRE(((uintptr_t)x | (uintptr_t)U | (uintptr_t)y | (uintptr_t)workspace) % 16 == 0,
                   "locov_winograd_conv3x3_f32: misaligned pointer");
-    LOCOV_REQUIRE(!(flags & ~(unsigned)(LOCOV_EPI_RELU | LOCOV_WINO_OUT_ROI_MAJOR)), "locov_winograd_conv3x3_f32: unsupported flags 0x%x",
+    LOCOV_REQUIRE(!(flags & ~(unsigned)(LOCOV_EPI_RELU | LOCOV_WINO_OUT_ROI_MAJOR | LOCOV_WINO_IN_ROI_MAJOR)),
+                  "locov_winograd_conv3x3_f32: unsupported flags 0x%x",
                   flags);
     LOCOV_REQUIRE(workspace_bytes >= locov_winograd_workspace_bytes(R, Cin, N),
                   "locov_winograd_conv3x3_f32: workspace too small (%lld bytes)", (long long)workspace_bytes);
@@ -233,7 +235,10 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
     for (int64_t r0 = 0; r0 < R; r0 += chunk) {
         const int64_t rc = R - r0 < chunk ? R - r0 : chunk;
         const int64_t tin = rc * (Cin / 2), tout = rc * (N / 2);
-        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(tin, 256)), dim3(256), 0, s, x + r0 * Cin, R, rc, Cin, V);
+        const bool in_roi_major = (flags & LOCOV_WINO_IN_ROI_MAJOR) != 0;
+        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(tin, 256)), dim3(256), 0, s,
+                           x + r0 * (in_roi_major ? 49 : 1) * Cin, in_roi_major ? (int64_t)1 : R, in_roi_major ? (int64_t)49 : (int64_t)1,
+                           rc, Cin, V);
         int rcode = check_launch("locov_winograd_conv3x3_f32 (input transform)");
         if (rcode) return rcode;
         Epilogue epi{nullptr, nullptr, nullptr, 0u};

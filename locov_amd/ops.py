@@ -317,14 +317,16 @@ def winograd_pack_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool = False,
-                     out: Optional[torch.Tensor] = None, v_scale: float = 0.25, roi_major: bool = False) -> torch.Tensor:
+                     out: Optional[torch.Tensor] = None, v_scale: float = 0.25, roi_major: bool = False,
+                     in_roi_major: bool = False) -> torch.Tensor:
     """3x3 / pad 1 / stride 1 convolution of 7x7 position-major tiles in the Winograd domain.
     x [49*R, Cin] (row = pos*R + r), U [121, N, Cin] (winograd_pack_weight) -> [49*R, N].
     out: optional [49*R, N] destination whose rows may be a column block of a wider matrix.
     U may be a SplitWeight (split_pack(winograd_pack_weight(w))): the 121 transform-domain GEMMs then run with
     split operands on the f16 matrix pipe, the transformed input scaled by v_scale (the input transform amplifies
     non-negative data by up to 64x, any data by up to 100x: 0.25 keeps |x| < 4094 in fp16's range, as for the 1x1s).
-    roi_major: write the output rows ROI-major (row = r*49 + pos), the order linear_split_segmean reads."""
+    roi_major: write the output rows ROI-major (row = r*49 + pos), the order linear_split_segmean reads;
+    in_roi_major: x is given in that order."""
     x = _dev(x, "x")
     split = U if isinstance(U, SplitWeight) else None
     U = _dev(split.data if split is not None else U, "U")
@@ -350,7 +352,8 @@ def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool =
         ws = None
         _WINO_WS.pop(key, None)
         ws = _WINO_WS[key] = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
-    wflags = (_lib.EPI_RELU if relu else 0) | (_lib.WINO_OUT_ROI_MAJOR if roi_major else 0)
+    wflags = ((_lib.EPI_RELU if relu else 0) | (_lib.WINO_OUT_ROI_MAJOR if roi_major else 0)
+              | (_lib.WINO_IN_ROI_MAJOR if in_roi_major else 0))
     with torch.cuda.device(x.device):
         if split is not None:
             check(lib.locov_winograd_conv3x3_f32_split(_ptr(x), R, Cin, _ptr(U), split.scale, float(v_scale), _ptr(scale),
@@ -434,10 +437,12 @@ _SEGMEAN_WS = {}
 
 
 def linear_split_segmean(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tensor], residual: torch.Tensor, seg: int, *,
-                         scale: Optional[torch.Tensor] = None, relu: bool = True, x_scale: float = 16.0) -> torch.Tensor:
+                         scale: Optional[torch.Tensor] = None, relu: bool = True, x_scale: float = 16.0,
+                         residual_roi_major: bool = False) -> torch.Tensor:
     """Res5's last 1x1 convolution fused with the spatial mean behind it:
         out[q, :] = mean_{p < seg} relu(scale * (x[q*seg + p, :] . W^T) + bias + residual[p*R + q, :]),   R = M // seg
-    x [M,K] with ROI-major rows, residual [M,N] with POSITION-major rows (the previous block's output), -> [R,N].
+    x [M,K] with ROI-major rows, residual [M,N] with POSITION-major rows (the previous block's output; ROI-major rows
+    q*seg + p with residual_roi_major), -> [R,N].
     The [M,N] tensor is neither written nor re-read; deterministic (fixed summation order)."""
     x = _rows(x, "x")
     wd = _dev(weight.data, "weight")
@@ -458,7 +463,8 @@ def linear_split_segmean(x: torch.Tensor, weight: SplitWeight, bias: Optional[to
         ws = _SEGMEAN_WS[key] = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         check(lib.locov_gemm_nt_f32_split_segmean(_ptr(x), x.stride(0) if M else K, _ptr(wd), _ptr(scale), _ptr(bias),
-                                                  _ptr(residual), _ptr(out), M, N, K, int(seg), _lib.EPI_RELU if relu else 0,
+                                                  _ptr(residual), _ptr(out), M, N, K, int(seg),
+                                                  (_lib.EPI_RELU if relu else 0) | (_lib.SEGMEAN_RES_ROI_MAJOR if residual_roi_major else 0),
                                                   float(x_scale), weight.scale, _ptr(ws), ws.numel(), _stream(x)),
               "locov_gemm_nt_f32_split_segmean")
     return out

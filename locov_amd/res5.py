@@ -226,7 +226,7 @@ class Res5Stage(nn.Sequential):
     @torch.no_grad()
     def forward_from_map(self, nhwc: torch.Tensor, rois: torch.Tensor, pooler_resolution: int, spatial_scale: float,
                          sampling_ratio: int = 0, aligned: bool = True, winograd: bool = True,
-                         bf16: bool = False, split: bool = False, pooled: bool = False) -> torch.Tensor:
+                         bf16: bool = False, split: bool = False, pooled: bool = False, roi_major: bool = False) -> torch.Tensor:
         """The whole stage from the channels-last res4 map [N,H,W,Cin] and the rois [R,5] -> position-major
         rows [49*R, Cout], with block 0's conv1 and projection shortcut moved IN FRONT of the pooler:
 
@@ -247,10 +247,14 @@ class Res5Stage(nn.Sequential):
             g = ops.linear_bf16(ops.to_bf16(nhwc.reshape(N * H * W, cin)), self._bf16(wmap)).view(N, H, W, wmap.shape[0])
         else:
             g = self._linear(split, nhwc.reshape(N * H * W, cin), wmap).view(N, H, W, wmap.shape[0])
+        # row order of every [49*R, C] tensor from here on: position-major (pos*R + r; what the direct 3x3 convolution's
+        # tap skipping needs) or, with roi_major, ROI-major (r*49 + pos: a ROI's 49 rows are adjacent in memory, which
+        # the Winograd transforms and the mean-fused last convolution prefer)
+        pm = not (roi_major and not bf16)
         y = ops.roi_align_nhwc(g[..., :mid], rois, 14, spatial_scale, sampling_ratio, aligned, bin_stride=2,
-                               pos_major=True, ch_scale=s1, ch_shift=b1, relu=True)          # conv1 + FBN + ReLU, pooled
+                               pos_major=pm, ch_scale=s1, ch_shift=b1, relu=True)            # conv1 + FBN + ReLU, pooled
         sc = ops.roi_align_nhwc(g[..., mid:], rois, 14, spatial_scale, sampling_ratio, aligned, bin_stride=2,
-                                pos_major=True)                                              # ss * shortcut, pooled
+                                pos_major=pm)                                                # ss * shortcut, pooled
         R = rois.shape[0]
         y, sc = y.view(49 * R, mid), sc.view(49 * R, -1)
         c2 = b0.conv2
@@ -262,12 +266,13 @@ class Res5Stage(nn.Sequential):
             return self.forward_rows(x, 7, 7, pos_major=True, start_block=1, bf16=True)
         if winograd and c2.in_channels % 32 == 0 and c2.out_channels % 4 == 0:
             u2, s2, b2 = self._packed(c2, winograd=True)
-            y = ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True)
+            y = ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True,
+                                     roi_major=not pm, in_roi_major=not pm)
         else:
             w2, s2, b2 = self._packed(c2)
-            y = ops.conv3x3_nhwc(y, w2, 7, 7, scale=s2, shift=b2, relu=True, pos_major=True)
+            y = ops.conv3x3_nhwc(y, w2, 7, 7, scale=s2, shift=b2, relu=True, pos_major=pm)
         x = self._linear(split, y, w3, shift_tail, scale=s3, residual=sc, relu=True)         # conv3 + FBN + add + ReLU
-        return self.forward_rows(x, 7, 7, pos_major=True, winograd=winograd, start_block=1, split=split, pooled=pooled)
+        return self.forward_rows(x, 7, 7, pos_major=pm, winograd=winograd, start_block=1, split=split, pooled=pooled)
 
     @torch.no_grad()
     def forward_rows(self, x0: torch.Tensor, H: int, W: int, pos_major: bool = False,
@@ -305,11 +310,12 @@ class Res5Stage(nn.Sequential):
                 x = ops.linear_bf16(ops.to_bf16(y), self._bf16(w3), b3, scale=s3, residual=sc, relu=True)
                 continue
             y = self._linear(split, x, w1, b1, scale=s1, relu=True)               # 1x1 (+stride via x0) + FBN + ReLU
-            use_wino = winograd and pos_major and H == 7 and W == 7 and c2.in_channels % 32 == 0 and c2.out_channels % 4 == 0
+            use_wino = winograd and H == 7 and W == 7 and c2.in_channels % 32 == 0 and c2.out_channels % 4 == 0
+            rm = not pos_major                     # the Winograd transforms read / write either row order
             if use_wino and bi == 0 and cat is not None and blk.shortcut is not None:
                 u2, s2, b2 = self._packed(c2, winograd=True)
                 ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True,
-                                     out=cat[:, :c2.out_channels])
+                                     out=cat[:, :c2.out_channels], roi_major=rm, in_roi_major=rm)
                 wcat, bcat = self._packed_block0_tail()
                 x = self._linear(split, cat, wcat, bcat, relu=True)               # conv3 + shortcut + add + ReLU, K-concatenated
                 continue
@@ -317,11 +323,12 @@ class Res5Stage(nn.Sequential):
             if (use_wino and pooled and last and split and blk.shortcut is None and w3.shape[1] % 32 == 0 and w3.shape[0] % 4 == 0
                     and x.shape[0] * w3.shape[0] * 4 < 2 ** 32):
                 u2, s2, b2 = self._packed(c2, winograd=True)
-                y = ops.winograd_conv3x3(y, self._split(u2), scale=s2, shift=b2, relu=True, roi_major=True)
-                return ops.linear_split_segmean(y, self._split(w3), b3, x, H * W, scale=s3, relu=True)
+                y = ops.winograd_conv3x3(y, self._split(u2), scale=s2, shift=b2, relu=True, roi_major=True, in_roi_major=rm)
+                return ops.linear_split_segmean(y, self._split(w3), b3, x, H * W, scale=s3, relu=True, residual_roi_major=rm)
             if use_wino:
                 u2, s2, b2 = self._packed(c2, winograd=True)
-                y = ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True)   # 3x3 + FBN + ReLU
+                y = ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True,
+                                         roi_major=rm, in_roi_major=rm)                                      # 3x3 + FBN + ReLU
             else:
                 w2, s2, b2 = self._packed(c2)
                 y = ops.conv3x3_nhwc(y, w2, H, W, scale=s2, shift=b2, relu=True, pos_major=pos_major)

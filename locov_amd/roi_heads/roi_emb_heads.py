@@ -297,9 +297,13 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
             return self._pooled_mean(y) if pooled else y
         if P == 14 and self.res5.map_path_pays(R, nhwc.shape[0] * nhwc.shape[1] * nhwc.shape[2]):
             # many proposals per image: block 0's 1x1 convolutions run on the map, ROIAlign pools their outputs
+            # (ROI-major rows with the Winograd form: its transforms and the mean-fused last convolution prefer a ROI's
+            # 49 rows adjacent; the direct 3x3 form needs position-major rows for its tap skipping)
             y = self.res5.forward_from_map(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio,
-                                           self.pooler.aligned, winograd=wino, split=split, pooled=pooled)
-            return y if pooled else y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)
+                                           self.pooler.aligned, winograd=wino, split=split, pooled=pooled, roi_major=wino)
+            if pooled:
+                return y
+            return y.view(R, oh, ow, y.shape[1]).permute(0, 3, 1, 2) if wino else y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)
         # (ROIAlign writes straight into the operand block 0's K-concatenated conv3 + shortcut GEMM reads)
         x0 = self.res5.rows_input(oh * ow * R, nhwc.device)
         ops.roi_align_nhwc(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned,

@@ -76,8 +76,11 @@ def test_res5_rows_path_vs_oracle(pkg, oracle):
     np.testing.assert_allclose(got_m, want, atol=2e-4, rtol=1e-4)
     # hand-written rows path on the even positions
     x0 = x[:, :, ::2, ::2].permute(0, 2, 3, 1).reshape(21 * 49, 128).contiguous().cuda()
-    got = res5.forward_rows(x0, 7, 7).view(21, 7, 7, out_ch).permute(0, 3, 1, 2).cpu().numpy()
+    got = res5.forward_rows(x0, 7, 7, winograd=False).view(21, 7, 7, out_ch).permute(0, 3, 1, 2).cpu().numpy()
     np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5)
+    # (ROI-major rows also go through the Winograd form, the default: bounded relative to the activation range)
+    got = res5.forward_rows(x0, 7, 7).view(21, 7, 7, out_ch).permute(0, 3, 1, 2).cpu().numpy()
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
     # same, position-major rows
     x0p = x[:, :, ::2, ::2].permute(2, 3, 0, 1).reshape(49 * 21, 128).contiguous().cuda()
     got = res5.forward_rows(x0p, 7, 7, pos_major=True, winograd=False).view(7, 7, 21, out_ch).permute(2, 3, 0, 1)

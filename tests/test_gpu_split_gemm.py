@@ -275,3 +275,32 @@ def test_split_gemm_overflow_is_loud(ops):
     y = ops.linear_split(x, w)                                 # default x_scale = 16
     assert not torch.isfinite(y[3]).all() and torch.isfinite(y[:3]).all() and torch.isfinite(y[4:]).all()
     assert torch.isfinite(ops.linear_split(x, w, x_scale=0.25)).all()
+
+
+@pytest.mark.parametrize("split", [True, False])
+def test_roi_major_stage_equals_the_position_major_one(split):
+    """Res5Stage.forward_from_map(roi_major=True): ROIAlign, the Winograd transforms and the mean-fused last convolution
+    all in ROI-major row order -- same values as the position-major pipeline, rows permuted; pooled outputs equal."""
+    import locov_amd as pkg
+    from locov_amd import ops
+    from locov_amd.res5 import build_res5_block
+    from oracle import lsm_oracle as oracle
+    import test_gpu_roi_heads as T
+    oracle.build()
+    res5, out_ch = build_res5_block(T._small_cfg(pkg))
+    res5.load_state_dict(oracle.make_res5_params(13, in_ch=128, mid=64, out_ch=256))
+    res5 = res5.cuda().eval()
+    rng = np.random.default_rng(3)
+    feat = rng.standard_normal((2, 128, 50, 84)).astype(np.float32)
+    rois = T.dev(oracle.boxes_to_pooler_format([oracle.synth_boxes(rng, 90), oracle.synth_boxes(rng, 75)]))
+    R = rois.shape[0]
+    with torch.no_grad():
+        nhwc = ops.nchw_to_nhwc(T.dev(feat))
+        pm = res5.forward_from_map(nhwc, rois, 14, 1.0 / 16, 0, True, split=split)
+        rm = res5.forward_from_map(nhwc, rois, 14, 1.0 / 16, 0, True, split=split, roi_major=True)
+        scale = float(pm.abs().max())
+        assert (rm.view(R, 49, out_ch) - pm.view(49, R, out_ch).permute(1, 0, 2)).abs().max().item() <= 2e-6 * scale
+        pp = res5.forward_from_map(nhwc, rois, 14, 1.0 / 16, 0, True, split=split, pooled=True)
+        rp = res5.forward_from_map(nhwc, rois, 14, 1.0 / 16, 0, True, split=split, pooled=True, roi_major=True)
+        assert tuple(rp.shape) == (R, out_ch) and (rp - pp).abs().max().item() <= 2e-6 * scale
+        assert (rp - rm.view(R, 49, out_ch).mean(dim=1)).abs().max().item() <= 2e-6 * scale
