@@ -153,7 +153,7 @@ class Workload:
         return self.head(self.r5_standin)
 
 
-TRAFFIC_FILE = "r01k_pmc_traffic.json"
+TRAFFIC_FILE = "r01l_pmc_traffic.json"
 
 
 def recorded_traffic(args, kernel_key: str):
