@@ -131,8 +131,8 @@ class Workload:
                                                split=self.args.res5_dtype == "f16x2", pooled=True, roi_major=wino)
             else:
                 x0 = self.res5.rows_input(49 * R, self.device)
-                ops.roi_align_nhwc(nhwc, self.rois, 14, 1.0 / 16, 0, True, bin_stride=2, pos_major=True, out=x0)
-                y = self.res5.forward_rows(x0, 7, 7, pos_major=True, winograd=wino, split=self.args.res5_dtype == "f16x2",
+                ops.roi_align_nhwc(nhwc, self.rois, 14, 1.0 / 16, 0, True, bin_stride=2, pos_major=not wino, out=x0)
+                y = self.res5.forward_rows(x0, 7, 7, pos_major=not wino, winograd=wino, split=self.args.res5_dtype == "f16x2",
                                            pooled=True)
             out = self.head(y) if y.shape[0] == R else self.head(y.view(7, 7, R, 2048), channels_last=2)
         else:

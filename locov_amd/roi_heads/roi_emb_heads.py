@@ -306,10 +306,14 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
             return y.view(R, oh, ow, y.shape[1]).permute(0, 3, 1, 2) if wino else y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)
         # (ROIAlign writes straight into the operand block 0's K-concatenated conv3 + shortcut GEMM reads)
         x0 = self.res5.rows_input(oh * ow * R, nhwc.device)
+        pm = not (wino and oh == 7)                      # ROI-major rows with the Winograd form, as on the map path
         ops.roi_align_nhwc(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned,
-                           bin_stride=2, pos_major=True, out=x0)
-        y = self.res5.forward_rows(x0, oh, ow, pos_major=True, winograd=wino, split=split, pooled=pooled)
-        return y if pooled else y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1)      # logical [R, C5, oh, ow]
+                           bin_stride=2, pos_major=pm, out=x0)
+        y = self.res5.forward_rows(x0, oh, ow, pos_major=pm, winograd=wino, split=split, pooled=pooled)
+        if pooled:
+            return y
+        # logical [R, C5, oh, ow]
+        return y.view(oh, ow, R, y.shape[1]).permute(2, 3, 0, 1) if pm else y.view(R, oh, ow, y.shape[1]).permute(0, 3, 1, 2)
 
     def _pooled_mean(self, box_features: torch.Tensor) -> torch.Tensor:
         """box_features.mean(dim=[2,3]) (:262,:344,:356) on the HIP kernel."""
