@@ -304,3 +304,31 @@ def test_roi_major_stage_equals_the_position_major_one(split):
         rp = res5.forward_from_map(nhwc, rois, 14, 1.0 / 16, 0, True, split=split, pooled=True, roi_major=True)
         assert tuple(rp.shape) == (R, out_ch) and (rp - pp).abs().max().item() <= 2e-6 * scale
         assert (rp - rm.view(R, 49, out_ch).mean(dim=1)).abs().max().item() <= 2e-6 * scale
+
+
+def test_split_gemm_random_shapes(ops):
+    """40 random (M, N, K, strided lda, epilogue) combinations against fp64: ragged M / N tiles, one to many K-tiles."""
+    rng = np.random.default_rng(2024)
+    for _ in range(40):
+        M = int(rng.integers(1, 700))
+        N = 4 * int(rng.integers(1, 130))
+        K = 32 * int(rng.integers(1, 9))
+        pad = 4 * int(rng.integers(0, 5))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        wide = torch.randn(M, K + pad, generator=g).cuda()
+        x = wide[:, :K] if pad else wide
+        w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+        use_res, use_aff, relu = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+        res = torch.randn(M, N, generator=g).cuda() if use_res else None
+        sc = (torch.rand(N, generator=g) + 0.5).cuda() if use_aff else None
+        sh = torch.randn(N, generator=g).cuda() if use_aff else None
+        ref = x.double() @ w.double().t()
+        if use_aff:
+            ref = ref * sc.double() + sh.double()
+        if use_res:
+            ref = ref + res.double()
+        if relu:
+            ref = torch.relu(ref)
+        got = ops.linear_split(x, ops.split_pack(w), sh, scale=sc, residual=res, relu=relu)
+        err = (got.double() - ref).abs().max().item()
+        assert err <= 4e-6 * max(1.0, float(ref.abs().max())), (M, N, K, pad, use_res, use_aff, relu, err)
