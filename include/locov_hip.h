@@ -291,7 +291,8 @@ int locov_gemm_nt_f32_split(const float *x, int64_t lda, const void *W_split, co
  * tensor of the previous block -- or, with LOCOV_SEGMEAN_RES_ROI_MAJOR in `flags`, a ROI-major one (row q*seg + p) --
  * and the [M, N] result is never written.  Per M-tile and ROI the kernel leaves column
  * sums in `workspace` (locov_gemm_segmean_workspace_bytes), a second small kernel adds the one or two partials of
- * each ROI in a fixed order (deterministic).  seg <= 128, M % seg == 0, M * N * 4 < 2^32, otherwise as
+ * each ROI in a fixed order (deterministic).  43 <= seg <= 128 (a 128-row tile holds at most four ROIs; Res5's 7x7
+ * positions give 49), M % seg == 0, M * N * 4 < 2^32, otherwise as
  * locov_gemm_nt_f32_split. */
 int64_t locov_gemm_segmean_workspace_bytes(int64_t M, int N);
 int locov_gemm_nt_f32_split_segmean(const float *x, int64_t lda, const void *W_split, const float *scale,

@@ -496,7 +496,9 @@ int launch_gemm_split_segmean(const float *A, int64_t lda, const void *Wsplit, i
 {
     if (!(a_scale > 0.f) || !(w_scale > 0.f)) return set_error(LOCOV_ERR_INVALID_ARG, "%s: operand scales must be positive", what);
     if (K % BK != 0 || K < BK) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: K must be a positive multiple of %d", what, BK);
-    if (seg <= 0 || seg > BM || M % seg != 0) return set_error(LOCOV_ERR_INVALID_ARG, "%s: M must be a multiple of seg (1..%d)", what, BM);
+    // (a 128-row tile may touch at most the four ROIs its partial slots provide for: seg >= 43)
+    if (seg < 43 || seg > BM || M % seg != 0)
+        return set_error(LOCOV_ERR_UNSUPPORTED, "%s: M must be a multiple of seg, 43 <= seg <= %d (got %d)", what, BM, seg);
     if (N % 4 != 0 || lda % 4 != 0 || (uintptr_t)A % 16 != 0 || (uintptr_t)Wsplit % 16 != 0 || (uintptr_t)partial % 16 != 0 ||
         (uintptr_t)out % 16 != 0 || (epi.residual && (uintptr_t)epi.residual % 16 != 0) ||
         (epi.scale && (uintptr_t)epi.scale % 16 != 0) || (epi.shift && (uintptr_t)epi.shift % 16 != 0))

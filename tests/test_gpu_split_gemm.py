@@ -332,3 +332,28 @@ def test_split_gemm_random_shapes(ops):
         got = ops.linear_split(x, ops.split_pack(w), sh, scale=sc, residual=res, relu=relu)
         err = (got.double() - ref).abs().max().item()
         assert err <= 4e-6 * max(1.0, float(ref.abs().max())), (M, N, K, pad, use_res, use_aff, relu, err)
+
+
+def test_segmean_random_shapes_both_residual_orders(ops):
+    rng = np.random.default_rng(77)
+    for _ in range(16):
+        R, seg = int(rng.integers(1, 90)), int(rng.choice([49, 49, 43, 64, 100, 128]))
+        N, K = 4 * int(rng.integers(1, 80)), 32 * int(rng.integers(1, 6))
+        M = R * seg
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        x = torch.randn(M, K, generator=g).relu_().cuda()
+        w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+        res_rm = torch.randn(M, N, generator=g).cuda()                                  # ROI-major rows q*seg + p
+        res_pm = res_rm.view(R, seg, N).permute(1, 0, 2).reshape(M, N).contiguous()     # position-major rows p*R + q
+        sh = torch.randn(N, generator=g).cuda()
+        ref = torch.relu(x.double() @ w.double().t() + sh.double() + res_rm.double()).view(R, seg, N).mean(dim=1)
+        ws = ops.split_pack(w)
+        a = ops.linear_split_segmean(x, ws, sh, res_pm, seg)
+        b = ops.linear_split_segmean(x, ws, sh, res_rm, seg, residual_roi_major=True)
+        for got in (a, b):
+            assert (got.double() - ref).abs().max().item() <= 4e-6 * max(1.0, float(ref.abs().max())), (R, seg, N, K)
+        assert torch.equal(a, b)
+    from locov_amd._lib import LocovError
+    with pytest.raises(LocovError):                           # fewer than 43 rows per ROI: more than four ROIs per tile
+        ops.linear_split_segmean(torch.randn(42, 32).cuda(), ops.split_pack(torch.randn(8, 32).cuda()), None,
+                                 torch.randn(42, 8).cuda(), 7)
