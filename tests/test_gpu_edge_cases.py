@@ -175,3 +175,33 @@ def test_whole_head_replays_from_a_hip_graph(pkg, oracle):
         torch.cuda.synchronize()
     assert not torch.equal(eager[3], want2[3])
     assert all(torch.equal(a, b) for a, b in zip(out, want2))        # pooled, deltas, embeddings, logits
+
+
+def test_f32_gemm_random_shapes(pkg):
+    """40 random (M, N, K, strided lda, epilogue) combinations of the f32-MFMA NT GEMM against fp64 (ragged tiles, K not a
+    multiple of the K-tile, every tile configuration the dispatcher picks)."""
+    ops = pkg.ops
+    rng = np.random.default_rng(4242)
+    for _ in range(40):
+        M = int(rng.integers(1, 700))
+        N = int(rng.integers(1, 400))
+        K = 4 * int(rng.integers(1, 80))
+        pad = 4 * int(rng.integers(0, 5))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        wide = torch.randn(M, K + pad, generator=g).cuda()
+        x = wide[:, :K] if pad else wide
+        w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+        use_res, use_aff, relu = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+        res = torch.randn(M, N, generator=g).cuda() if use_res else None
+        sc = (torch.rand(N, generator=g) + 0.5).cuda() if use_aff else None
+        sh = torch.randn(N, generator=g).cuda() if use_aff else None
+        ref = x.double() @ w.double().t()
+        if use_aff:
+            ref = ref * sc.double() + sh.double()
+        if use_res:
+            ref = ref + res.double()
+        if relu:
+            ref = torch.relu(ref)
+        got = ops.linear(x, w, sh, scale=sc, residual=res, relu=relu)
+        err = (got.double() - ref).abs().max().item()
+        assert err <= 4e-6 * max(1.0, float(ref.abs().max())), (M, N, K, pad, use_res, use_aff, relu, err)
