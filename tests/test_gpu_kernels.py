@@ -325,3 +325,25 @@ def test_batched_nms_and_inference_on_device(ops, oracle):
     np.testing.assert_allclose(inst.pred_boxes.tensor.cpu().numpy(), wb, atol=1e-4)
     np.testing.assert_allclose(inst.scores.cpu().numpy(), ws, atol=1e-6)
     np.testing.assert_array_equal(inst.pred_classes.cpu().numpy(), wc)
+
+
+def test_roi_align_nhwc_random_configurations(ops, oracle):
+    """Random sweeps of the even-grid channels-last kernel against the oracle: sampling ratio 0 / 1 / 2 / 3, aligned or
+    not, several channel counts, map sizes, scales and output sizes, wild boxes (outside the map, degenerate, huge)."""
+    rng = np.random.default_rng(909)
+    for _ in range(12):
+        N, C = int(rng.integers(1, 4)), 4 * int(rng.integers(1, 40))
+        H, W = int(rng.integers(5, 40)), int(rng.integers(5, 60))
+        P = int(rng.choice([14, 7, 8]))
+        scale = float(rng.choice([1 / 16, 1 / 8, 1 / 32]))
+        ratio, aligned = int(rng.choice([0, 0, 1, 2, 3])), bool(rng.integers(2))
+        stride = int(rng.choice([1, 2])) if P % 2 == 0 else 1
+        feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        rois = _rois(oracle, rng, N, 23, W, H, wild=5)
+        rois[:, 1:] *= (1 / 16) / scale                            # _rois draws boxes for a stride-16 map
+        want = oracle.roi_align(feat, rois, (P, P), scale, ratio, aligned)[:, :, ::stride, ::stride]
+        got = ops.roi_align_nhwc(ops.nchw_to_nhwc(dev(feat)), dev(rois), P, scale, ratio, aligned, stride)
+        got_p = ops.roi_align_nhwc(ops.nchw_to_nhwc(dev(feat)), dev(rois), P, scale, ratio, aligned, stride, pos_major=True)
+        assert torch.equal(got_p.permute(2, 0, 1, 3), got)
+        np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want, atol=2e-5,
+                                   err_msg=str((N, C, H, W, P, scale, ratio, aligned, stride)))
