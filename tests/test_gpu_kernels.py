@@ -347,3 +347,20 @@ def test_roi_align_nhwc_random_configurations(ops, oracle):
         assert torch.equal(got_p.permute(2, 0, 1, 3), got)
         np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want, atol=2e-5,
                                    err_msg=str((N, C, H, W, P, scale, ratio, aligned, stride)))
+
+
+def test_roi_align_nchw_bit_exact_random_configurations(ops, oracle):
+    """Bit-exactness of the contract kernel over random configurations (both gather kernels: C % 4 == 0 or not)."""
+    rng = np.random.default_rng(515)
+    for _ in range(14):
+        N, C = int(rng.integers(1, 4)), int(rng.integers(1, 70))
+        H, W = int(rng.integers(4, 40)), int(rng.integers(4, 60))
+        P = int(rng.choice([14, 7, 5, 3]))
+        scale = float(rng.choice([1 / 16, 1 / 8, 1 / 4]))
+        ratio, aligned = int(rng.choice([0, 0, 1, 2, 4])), bool(rng.integers(2))
+        feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        rois = _rois(oracle, rng, N, 19, W, H, wild=5)
+        rois[:, 1:] *= (1 / 16) / scale
+        want = oracle.roi_align(feat, rois, (P, P), scale, ratio, aligned)
+        got = ops.roi_align(dev(feat), dev(rois), P, scale, ratio, aligned).cpu().numpy()
+        np.testing.assert_array_equal(got, want, err_msg=str((N, C, H, W, P, scale, ratio, aligned)))
