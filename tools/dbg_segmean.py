@@ -26,5 +26,6 @@ def t(fn, n=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
 ws = ops.split_pack(w)
+print("fused, ROI-major residual %.3f ms" % t(lambda: ops.linear_split_segmean(x, ws, sh, res_pm, seg, scale=sc, residual_roi_major=True)))
 print("fused %.3f ms   unfused GEMM %.3f ms + mean %.3f ms" % (t(lambda: ops.linear_split_segmean(x, ws, sh, res_pm, seg, scale=sc)),
       t(lambda: ops.linear_split(x, ws, sh, scale=sc, residual=res_pm, relu=True)), t(lambda: ops.spatial_mean(full.view(seg, R, N), channels_last=2) if hasattr(ops, "spatial_mean") else None)))
