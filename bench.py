@@ -1,18 +1,27 @@
 #!/usr/bin/env python
 """bench.py -- proposals/sec through the LSM ROI head on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: starts N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path over one batch of synthetic input resident in HBM:
-`--images` res4 feature maps [B,1024,50,84] (1333x800 images, stride 16) x `--proposals`
-boxes each -> ROIAlign 14x14 -> Res5 -> spatial mean -> bbox_pred / emb_pred -> (norm) ->
-similarity GEMM against a (`--classes`+1) x `--dim` text bank.  Images shard over
-ranks with no data-path collective (inference needs none): weak scaling.
+A step = one pass of the hot path over one batch of synthetic input resident in HBM, THROUGH THE PLUGIN SURFACE the
+reference defines the metric on: `--images` res4 feature maps [B,1024,50,84] (1333x800 images, stride 16)
+and `--proposals` boxes per image as Detectron2-style `Instances` / `Boxes` ->
 
-`value` is scope S2 = the full head as the reference executes it (Res5 included).  Scope S1 =
-the north-star kernel list only (ROIAlign + mean/FCs/similarity on a stand-in for the Res5
-output) is reported beside it in "scopes".  One JSON line on rank 0.
+    EmbeddingProposalsRes5ROIHeads._shared_roi_transform(features, boxes)      roi_emb_heads.py:243-245  (ROIAlign + Res5)
+        .mean(dim=[2,3])                                                         :356  (fused into the call: pooled=True)
+    EmbeddingFastRCNNOutputLayers.forward(box_features)                        box_emb_head.py:179-212 (bbox_pred, emb_pred,
+                                                                                 (norm), similarity GEMM x (classes+1) x dim bank)
+
+Images shard over ranks with no data-path collective (inference needs none): weak scaling.
+`value` is scope S2 = the full head as the reference executes it (Res5 included).  Scope S1 = the north-star kernel list only
+(ROIAlign + mean/FCs/similarity on a stand-in for the Res5 output) and the 1024-d bank variants are reported in "scopes".
+
+--mode train adds a `train` object: one LSM training step of the path per iteration (configs/coco_lsm.yaml: 4 images per GPU,
+200 sampled proposals per image) -- EmbeddingProposalsRes5ROIHeads.forward with targets (roi_emb_heads.py:311-349: labelling /
+sampling, whole-grid Res5, ROIAlign + Res5 + mean, box predictor, losses) + GroundingHead on the box branch
+(grounding_head.py:92-388) + backward + SGD step, on the hand-written kernels and, beside it, with RES5_BACKEND miopen.
+One JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -20,27 +29,28 @@ import argparse
 import json
 import os
 import platform
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3   # f32-input MFMA peak
-MFMA_BF16_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA peak (only used by the opt-in --res5-dtype bf16 run)
-MFMA_BF16_PEAK_TFLOPS = 2500.0
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3    # f32-input MFMA peak
+MFMA_16BIT_PEAK_TFLOPS = 2500.0 # dense f16 / bf16 MFMA peak
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--mode", choices=["infer", "train"], default="infer",
+                   help="train: additionally time one LSM training step of the path (forward + backward + SGD)")
     p.add_argument("--images", type=int, default=8, help="images per GPU per step (SURVEY.md 8d: N = 8 / GPU)")
     p.add_argument("--proposals", type=int, default=1000)
     p.add_argument("--classes", type=int, default=1203)
@@ -55,105 +65,213 @@ def parse():
                    help="arithmetic of the Res5 GEMMs: f16x2 = fp32 in / fp32 out with the products formed from split "
                         "(hi, lo) f16 operand pairs on the f16 matrix pipe, fp32 accumulate (fp32-level accuracy, "
                         "csrc/gemm_split.hip); fp32 = the f32 MFMA; bf16 = reduced-precision operands (never a headline)")
+    p.add_argument("--train-images", type=int, default=4, help="--mode train: images per GPU (IMS_PER_BATCH 32 / 8 GPUs)")
+    p.add_argument("--train-samples", type=int, default=200, help="--mode train: ROI_HEADS.BATCH_SIZE_PER_IMAGE (coco_lsm.yaml:32)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--skip-f32-reference", action="store_true",
                    help="do not also time the f32-MFMA form of the Res5 GEMMs (profile runs)")
     p.add_argument("--skip-s1", action="store_true",
                    help="only the S2 scope (profiling runs: the kernel mix then equals the timed region's)")
+    p.add_argument("--skip-variants", action="store_true", help="do not time the 1024-d bank variants (profile runs)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
     # developer/test knobs: rehearse the multi-process flow on a box with fewer GPUs than ranks
     p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl")
     p.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (needs --dist-backend gloo)")
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
-def synth_rois(gen: torch.Generator, n_img: int, r: int, device) -> torch.Tensor:
-    """SURVEY.md 8d boxes: centre uniform, log2(side) U[4, log2 800], aspect U[0.5,2], clipped."""
-    n = n_img * r
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `torch.distributed.run` (nothing in this
+    process has touched the GPU yet, and it never will), relay rank 0's JSON line and the child's exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if r.returncode != 0 or line is None:
+        sys.stderr.write(r.stdout[-4000:])
+        sys.stderr.write(f"\nbench.py: the {args.gpus}-rank child exited with code {r.returncode}\n")
+        return r.returncode or 1
+    print(line)
+    return 0
+
+
+def synth_boxes(gen, n: int):
+    """SURVEY.md 8d boxes: centre uniform, log2(side) U[4, log2 800], aspect U[0.5,2], clipped; XYXY fp32 [n,4]."""
+    import torch
     cx = torch.rand(n, generator=gen) * 1333.0
     cy = torch.rand(n, generator=gen) * 800.0
     side = 2.0 ** (4.0 + torch.rand(n, generator=gen) * (np.log2(800.0) - 4.0))
     aspect = 0.5 + 1.5 * torch.rand(n, generator=gen)
     w, h = side * aspect.sqrt(), side / aspect.sqrt()
-    b = torch.stack([(cx - w / 2).clamp(0, 1333), (cy - h / 2).clamp(0, 800),
-                     (cx + w / 2).clamp(0, 1333), (cy + h / 2).clamp(0, 800)], dim=1)
-    idx = torch.arange(n_img, dtype=torch.float32).repeat_interleave(r)[:, None]
-    return torch.cat([idx, b], dim=1).to(torch.float32).to(device)
+    return torch.stack([(cx - w / 2).clamp(0, 1333), (cy - h / 2).clamp(0, 800),
+                        (cx + w / 2).clamp(0, 1333), (cy + h / 2).clamp(0, 800)], dim=1).to(torch.float32)
+
+
+def build_heads(args, device, *, dim=None, sim_dtype=None, res5=None, res5_dtype=None, train=False, seed=1992):
+    """The plugin exactly as train_ovnet.py gets it: cfg -> build_roi_heads (roi_emb_heads.py:168-214) -> load_embeddings'
+    set_class_embeddings (trainer.py:365-396).  Random-init weights (He-init Res5, FrozenBN identity, emb_pred N(0, 0.01))."""
+    import torch
+    import locov_amd
+    from locov_amd.structures import ShapeSpec
+    cfg = locov_amd.config.get_cfg()
+    cfg.MODEL.ROI_HEADS.NAME = "EmbeddingProposalsRes5ROIHeads"
+    cfg.MODEL.ROI_HEADS.NUM_CLASSES = args.classes
+    cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = args.train_samples          # coco_lsm.yaml:32
+    cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION = 1.0                            # coco_lsm.yaml:30
+    cfg.MODEL.ROI_HEADS.DETACH_CLASS_PREDICTOR = True                      # coco_lsm.yaml:31
+    cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
+    cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED = True
+    cfg.MODEL.ROI_BOX_HEAD.FREEZE_EMB_PRED = False
+    cfg.MODEL.ROI_BOX_HEAD.EMB_DIM = dim or args.dim
+    cfg.MODEL.ROI_BOX_HEAD.SIM_GEMM_DTYPE = sim_dtype or args.sim_dtype
+    cfg.MODEL.ROI_BOX_HEAD.RES5_BACKEND = res5 or args.res5
+    cfg.MODEL.ROI_BOX_HEAD.RES5_CONV3X3 = args.conv3x3
+    cfg.MODEL.ROI_BOX_HEAD.RES5_DTYPE = res5_dtype or args.res5_dtype
+    torch.manual_seed(seed)                                                # configs/coco_lsm.yaml:126
+    heads = locov_amd.build_roi_heads(cfg, {"res4": ShapeSpec(channels=1024, stride=16)}).to(device)
+    heads.train(train)
+    gen = torch.Generator().manual_seed(seed + 1)
+    bank = torch.randn(args.classes + 1, cfg.MODEL.ROI_BOX_HEAD.EMB_DIM, generator=gen) * 0.05
+    bank[-1] = 0
+    heads.box_predictor.set_class_embeddings(bank)
+    heads.num_classes = heads.box_predictor.num_classes
+    if args.block0 == "pooled":                                            # bench-only knob: never take the map path
+        heads.res5.map_path_pays = lambda *a, **k: False
+    return heads, cfg
 
 
 class Workload:
     def __init__(self, args, device):
+        import torch
         from locov_amd import ops
-        from locov_amd.config import get_cfg
-        from locov_amd.res5 import build_res5_block
+        from locov_amd.structures import Boxes, Instances
         self.ops, self.args, self.device = ops, args, device
-        gen = torch.Generator().manual_seed(1992)          # configs/coco_lsm.yaml:126
-        B, R, K, D = args.images, args.proposals, args.classes, args.dim
-        self.feat = torch.randn(B, 1024, 50, 84, generator=gen).to(device)
-        self.rois = synth_rois(gen, B, R, device)
-        res5, _ = build_res5_block(get_cfg())
-        self.res5 = res5.to(device).eval()
-        self.emb_w = (torch.randn(D, 2048, generator=gen) * 0.01).to(device)
-        self.emb_b = torch.zeros(D, device=device)
-        self.bbox_w = (torch.randn(4, 2048, generator=gen) * 0.001).to(device)
-        self.bbox_b = torch.zeros(4, device=device)
-        bank = torch.randn(K + 1, D, generator=gen) * 0.05
-        bank[-1] = 0
-        self.bank = bank.to(device)
-        self.bank16 = ops.to_bf16(self.bank) if args.sim_dtype == "bf16" else None
-        self.sim = ops.BF16 if args.sim_dtype == "bf16" else ops.F32
+        gen = torch.Generator().manual_seed(1992)
+        B, R = args.images, args.proposals
+        self.features = {"res4": torch.randn(B, 1024, 50, 84, generator=gen).to(device)}
+        self.proposals = []
+        for _ in range(B):
+            inst = Instances((800, 1333))
+            inst.proposal_boxes = Boxes(synth_boxes(gen, R).to(device))
+            inst.objectness_logits = torch.zeros(R, device=device)
+            self.proposals.append(inst)
+        self.boxes = [p.proposal_boxes for p in self.proposals]
+        self.heads, _ = build_heads(args, device)
         self.r5_standin = torch.randn(B * R, 2048, 7, 7, generator=gen).clamp_(min=0).to(device)
-        self.ev = []        # (start, end) HIP events around the dominant kernel (miopen mode: ROIAlign)
-        self.timing = False
+        rois = torch.cat([torch.cat([torch.full((R, 1), float(i)), p.proposal_boxes.tensor.cpu()], 1)
+                          for i, p in enumerate(self.proposals)]).to(device)
+        self.rois = rois
+        self.ev = []        # (start, end) events around the dominant hand-written kernel in miopen mode (ROIAlign)
 
-    def head(self, x, channels_last=False):
-        ops = self.ops
-        return ops.box_head(x, self.emb_w, self.emb_b, self.bbox_w, self.bbox_b, self.bank, self.bank16,
-                            ops.NORM_NONE, self.sim, channels_last=channels_last)
-
-    @torch.no_grad()
-    def step_s2(self, timed=False):
-        ops = self.ops
-        self.timing = timed
-        if self.args.res5 == "hip":
-            # channels-last pipeline: even-grid ROIAlign -> Res5 as MFMA GEMMs on pixel rows
-            nhwc = ops.nchw_to_nhwc(self.feat)
-            # (position-major pixel rows [7,7,R,C]: the 3x3 convs skip their zero-padding taps)
-            R = self.rois.shape[0]
-            wino = self.args.conv3x3 == "winograd"
-            if self.args.res5_dtype == "bf16":
-                y = self.res5.forward_from_map(nhwc, self.rois, 14, 1.0 / 16, 0, True, bf16=True)
-            elif self.args.block0 == "map" and self.res5.map_path_pays(R, nhwc.shape[0] * 50 * 84):
-                # block 0's 1x1 convolutions on the map, ROIAlign pools their outputs (Res5Stage.forward_from_map)
-                # (pooled: the stage returns the spatial mean the box head consumes; in split arithmetic it is fused into
-                # the last 1x1 convolution)
-                y = self.res5.forward_from_map(nhwc, self.rois, 14, 1.0 / 16, 0, True, winograd=wino,
-                                               split=self.args.res5_dtype == "f16x2", pooled=True, roi_major=wino)
-            else:
-                x0 = self.res5.rows_input(49 * R, self.device)
-                ops.roi_align_nhwc(nhwc, self.rois, 14, 1.0 / 16, 0, True, bin_stride=2, pos_major=not wino, out=x0)
-                y = self.res5.forward_rows(x0, 7, 7, pos_major=not wino, winograd=wino, split=self.args.res5_dtype == "f16x2",
-                                           pooled=True)
-            out = self.head(y) if y.shape[0] == R else self.head(y.view(7, 7, R, 2048), channels_last=2)
-        else:
-            if timed:
+    def step_s2(self, heads=None, timed=False):
+        """_shared_roi_transform -> mean -> box_predictor.forward, through the plugin."""
+        import torch
+        heads = heads or self.heads
+        with torch.no_grad():
+            feats = [self.features[f] for f in heads.in_features]
+            if timed and heads.res5_backend != "hip":
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            pooled = ops.roi_align(self.feat, self.rois, 14, 1.0 / 16, 0, True)
-            if timed:
+                x = heads.pooler(feats, self.boxes)
                 e1.record()
                 self.ev.append((e0, e1))
-            out = self.head(self.res5(pooled))
-        self.timing = False
-        return out
+                box_features = heads._pooled_mean(heads.res5(x))
+            else:
+                box_features = heads._shared_roi_transform(feats, self.boxes, pooled=True)      # :355-356
+            return heads.box_predictor(box_features)                                             # :357 (scores, deltas)
 
-    @torch.no_grad()
     def step_s1(self):
-        self.ops.roi_align(self.feat, self.rois, 14, 1.0 / 16, 0, True)
-        return self.head(self.r5_standin)
+        import torch
+        with torch.no_grad():
+            self.ops.roi_align(self.features["res4"], self.rois, 14, 1.0 / 16, 0, True)
+            return self.heads.box_predictor(self.heads._pooled_mean(self.r5_standin))
 
 
-TRAFFIC_FILE = "r01l_pmc_traffic.json"
+class TrainWorkload:
+    """One LSM training step of the path (see the module docstring)."""
+
+    def __init__(self, args, device, backend, world):
+        import torch
+        import locov_amd
+        from locov_amd.grounding_head import GroundingHead
+        from locov_amd.structures import Boxes, Instances
+        self.args, self.device = args, device
+        gen = torch.Generator().manual_seed(1992)
+        B, R = args.train_images, args.proposals
+        self.features = torch.randn(B, 1024, 50, 84, generator=gen).to(device)
+        self.proposals, self.targets = [], []
+        for _ in range(B):
+            gt = synth_boxes(gen, 7)
+            b = synth_boxes(gen, R)
+            b[:7] = (gt + torch.rand(7, 4, generator=gen) * 8 - 4).clamp(min=0)
+            b[:, 2:] = torch.maximum(b[:, 2:], b[:, :2] + 1.0)
+            p = Instances((800, 1333))
+            p.proposal_boxes = Boxes(b.to(device))
+            p.objectness_logits = torch.zeros(R, device=device)
+            t = Instances((800, 1333))
+            t.gt_boxes = Boxes(gt.to(device))
+            t.gt_classes = torch.randint(0, args.classes, (7,), generator=gen).to(device)
+            self.proposals.append(p)
+            self.targets.append(t)
+        self.heads, cfg = build_heads(args, device, res5=backend, train=True)
+        cfg.MODEL.MMSS_HEAD.DISTILLATION_LOSS = False
+        cfg.MODEL.MMSS_HEAD.GROUNDING.LOSS = "cross_entropy"
+        cfg.MODEL.MMSS_HEAD.GROUNDING.ALIGN_WORDS_TO_REGIONS = True
+        cfg.MODEL.MMSS_HEAD.GROUNDING.ALIGN_REGIONS_TO_WORDS = True
+        self.grounding = GroundingHead(cfg, 2048, args.dim).to(device)
+        # weight tying of distill_prop_mmss_gcnn.py:117-125: emb_pred IS the grounding head's v2l_projection
+        self.heads.box_predictor.emb_pred.weight = self.grounding.v2l_projection.weight
+        self.heads.box_predictor.emb_pred.bias = self.grounding.v2l_projection.bias
+        self.caption = {"input_embeddings": torch.randn(B, 70, args.dim, generator=gen).to(device),
+                        "attention_mask": torch.ones(B, 70, device=device),
+                        "special_tokens_mask": torch.zeros(B, 70, device=device)}
+        self.caption["special_tokens_mask"][:, 0] = 1
+        n_regions = 100                                                                  # MMSS_HEAD.SPATIAL_DROPOUT
+        heads, grounding, dev_ = self.heads, self.grounding, device
+
+        class LSMStep(torch.nn.Module):
+            """forward of one training step of the path -> (loss, sampled proposals): what DDP wraps."""
+
+            def __init__(self):
+                super().__init__()
+                self.heads, self.grounding = heads, grounding
+
+            def forward(self, feat, proposals, targets, caption):
+                grid, box_feats, sampled, losses = self.heads(None, {"res4": feat}, proposals, targets)
+                n = min(n_regions, min(f.shape[0] for f in box_feats))
+                regions = torch.stack([f[:n] for f in box_feats])           # [B, n, 2048]  (distill_prop_mmss_gcnn.py:348-417)
+                image = {"region_features": regions, "region_mask": torch.ones(regions.shape[:2], device=dev_)}
+                _, g_losses = self.grounding(image, caption)
+                # (the whole-grid features feed the grid grounding branch in the reference; a mean keeps their backward in the step)
+                return sum(losses.values()) + sum(g_losses.values()) + grid.mean(), sum(len(s) for s in sampled)
+
+        self.module = LSMStep()
+        self.run = self.module
+        if world > 1:       # the gradient exchange of the path: DDP's bucketed all-reduce (RCCL over xGMI), overlapped with backward
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            self.run = DDP(self.module, device_ids=None if args.share_gpu else [device.index], broadcast_buffers=False)
+        params = [p for p in self.module.parameters() if p.requires_grad]
+        self.opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=1e-4)   # coco_lsm.yaml:104-105
+
+    def step(self):
+        feat = self.features.detach().requires_grad_(True)          # the backbone trains (FREEZE_AT 0): res4 needs its gradient
+        loss, n_sampled = self.run(feat, self.proposals, self.targets, self.caption)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        self.opt.step()
+        return n_sampled
+
+
+TRAFFIC_FILE = "r02a_pmc_traffic.json"
 
 
 def recorded_traffic(args, kernel_key: str):
@@ -198,6 +316,7 @@ def usable_cores() -> int:
 def cpu_baseline(args, seconds: float):
     """The oracle (a port: the reference's Python cannot run here) timed on this
     host's cores over a bounded sample of the same workload."""
+    import torch
     from oracle import lsm_oracle as oracle
     oracle.build()
     ncores = usable_cores()
@@ -227,11 +346,14 @@ def cpu_baseline(args, seconds: float):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))            # before anything initialises the GPU in this process
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the hot path has no CPU fallback)")
@@ -239,14 +361,21 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    rccl_ranks = 1
     if world > 1:
-        if args.dist_backend == "nccl":       # RCCL over xGMI; only the timing max-reduce and barriers use it
+        if args.dist_backend == "nccl":       # RCCL over xGMI
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group("gloo")
+        ones = torch.ones(1, device=device if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(ones)                 # the collective the training step relies on, exercised explicitly
+        rccl_ranks = int(ones.item())
+        if rccl_ranks != world:
+            raise SystemExit(f"all_reduce over {world} ranks returned {rccl_ranks}")
 
     from locov_amd import _lib
-    _lib.load()
+    from locov_amd.sharding import max_over_ranks
+    lib = _lib.load()
     wl = Workload(args, device)
 
     def barrier():
@@ -265,12 +394,10 @@ def main():
             fn(**kw)
         barrier()
         dt = time.perf_counter() - t0
-        from locov_amd.sharding import max_over_ranks
         # the slowest rank defines the job's time
         return max_over_ranks(dt, device if args.dist_backend == "nccl" else None)
 
     props_per_step = args.images * args.proposals * world
-    lib = _lib.load()
     # dominant kernel: the library brackets each of its GEMM-kernel launches with HIP events on the
     # launch stream while this is enabled (include/locov_hip.h, locov_gemm_timing_*)
     dt2 = timed(wl.step_s2, args.steps, args.warmup, on_start=lambda: lib.locov_gemm_timing_enable(1), timed=True)
@@ -287,20 +414,45 @@ def main():
     # the same job with the Res5 GEMMs on the f32 MFMA (reported beside the headline when that is the split path)
     dt2_f32 = None
     if args.res5 == "hip" and args.res5_dtype == "f16x2" and not args.skip_f32_reference:
-        args.res5_dtype = "fp32"
-        dt2_f32 = timed(wl.step_s2, args.steps, args.warmup, timed=True)
-        args.res5_dtype = "f16x2"
+        wl.heads.res5_dtype = "fp32"
+        dt2_f32 = timed(wl.step_s2, args.steps, args.warmup)
+        wl.heads.res5_dtype = "f16x2"
     dom_ms = float(np.mean([a.elapsed_time(b) for a, b in wl.ev])) if wl.ev else float("nan")
     dt1 = timed(wl.step_s1, args.steps, args.warmup) if not args.skip_s1 else float("nan")
+    # north_star's 1024-d bank, fp32 and bf16 similarity GEMM (config 3): the same job with another predictor / bank
+    variants = {}
+    if not args.skip_variants:
+        for key, (dim, simdt) in {"dim1024_fp32": (1024, "fp32"), "dim1024_bf16sim": (1024, "bf16")}.items():
+            h2, _ = build_heads(args, device, dim=dim, sim_dtype=simdt)
+            h2.res5 = wl.heads.res5                           # same Res5 weights (and packed operands)
+            dtv = timed(lambda: wl.step_s2(heads=h2), max(args.steps // 2, 3), 2)
+            variants[key + "_proposals_per_s"] = props_per_step * max(args.steps // 2, 3) / dtv
+            del h2
+
+    train = None
+    if args.mode == "train":
+        train = {}
+        for backend in ("hip", "miopen"):
+            tw = TrainWorkload(args, device, backend, world)
+            n_sampled = tw.step()
+            steps = max(args.steps // 2, 3)
+            dtt = timed(tw.step, steps, 2)
+            train[backend] = {"sampled_proposals_per_s": n_sampled * world * steps / dtt, "ms_per_step": dtt / steps * 1e3,
+                              "sampled_proposals_per_step_per_gpu": n_sampled}
+            del tw
+            torch.cuda.empty_cache()
+        train["speedup_vs_miopen"] = train["hip"]["sampled_proposals_per_s"] / train["miopen"]["sampled_proposals_per_s"]
+        train["what"] = (f"one LSM training step of the path per iteration: {args.train_images} img/GPU x {args.proposals} proposals -> "
+                         f"{args.train_samples} sampled/img; EmbeddingProposalsRes5ROIHeads.forward(targets) (labelling, whole-grid Res5, "
+                         "ROIAlign + Res5 + mean, box predictor, losses) + GroundingHead (box branch) + backward (Res5 data + weight "
+                         "gradients, ROIAlign backward) + SGD step" + (f"; gradients all-reduced by DDP over {world} ranks" if world > 1 else "")
+                         + "; `miopen` = the same module with RES5_BACKEND miopen (torch conv2d autograd)")
 
     if rank == 0:
         R_local = args.images * args.proposals
         if args.res5 == "hip":
-            # Dominant kernel = the 128x128 NT GEMM (template instance CONV=0): the seven 1x1 convolutions of
-            # Res5, the three 121-problem Winograd-domain batched GEMMs, emb_pred and the similarity GEMM.
-            # achieved = the FLOPs those launches execute (2*M*N*K each, = SURVEY 8d's count for the 1x1
-            # convs / FCs; the Winograd GEMMs execute 121/441 of SURVEY's 3x3 count) / their summed
-            # durations, both taken per launch inside the timed region.
+            # the 128x128 f32 NT GEMM (template instance CONV=0): with --res5-dtype fp32 the seven 1x1 convolutions of Res5
+            # and the three 121-problem Winograd-domain batched GEMMs; always emb_pred and the similarity GEMM.
             n0, ms0, fl0 = gemm_plain
             n1, ms1, fl1 = gemm_conv
             achieved = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else float("nan")
@@ -309,12 +461,12 @@ def main():
                               "Winograd-domain batched GEMMs, emb_pred, similarity GEMM)",
                     "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                    "traffic": recorded_traffic(args, "gemm_nt_kernel<float, float, 128, 128, 2, 2, 2, 0, false, 8>"),
+                    "traffic": recorded_traffic(args, "gemm_nt_kernel<float, float, 128, 128, 2, 2, 2, 0, false, 8"),
                     "traffic_unit": f"HBM-side bytes per launch, averaged over this kernel's launches (PMC, profiles/{TRAFFIC_FILE})",
                     "launches_per_step": n0 / args.steps, "avg_launch_ms": ms0 / max(n0, 1),
                     "share_of_step_time": ms0 * 1e-3 / dt2,
                     "executed_flops_per_step": fl0 / args.steps,
-                    "survey_flop_count_rate_tflops": survey_res5_flops / ((ms0 + ms1) * 1e-3) / 1e12,
+                    "survey_flop_count_rate_tflops": survey_res5_flops / ((ms0 + ms1) * 1e-3) / 1e12 if ms0 + ms1 > 0 else None,
                     "note": "survey_flop_count_rate = SURVEY 8d's direct-convolution FLOP count of Res5 over the "
                             "GEMM kernels' time; it exceeds the executed rate because the 3x3 convolutions run in "
                             "the Winograd domain (121 instead of 441 products per tile and channel pair)"}
@@ -330,8 +482,8 @@ def main():
                 ach = 3.0 * fls / (mss * 1e-3) / 1e12 if mss > 0 else float("nan")
                 roof = {"kernel": "gemm_split_kernel (Res5 1x1 convs, Winograd-domain batched GEMMs; fp32 in/out, f16x2 split "
                                   "operands on the f16 matrix pipe)",
-                        "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                        "bound": "mfma", "achieved": ach, "peak": MFMA_16BIT_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_16BIT_PEAK_TFLOPS,
                         "traffic": recorded_traffic(args, "gemm_split_kernel"),
                         "traffic_unit": f"HBM-side bytes per launch, averaged over this kernel's launches (PMC, profiles/{TRAFFIC_FILE})",
                         "launches_per_step": ns / args.steps, "avg_launch_ms": mss / max(ns, 1),
@@ -350,8 +502,8 @@ def main():
                 nc, msc, flc = gemm_conv_bf16
                 ach = flb / (msb * 1e-3) / 1e12 if msb > 0 else float("nan")
                 roof = {"kernel": "gemm_nt_kernel<__bf16,float,128,128,...> (Res5 1x1 convs with bf16 operands)",
-                        "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                        "bound": "mfma", "achieved": ach, "peak": MFMA_16BIT_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_16BIT_PEAK_TFLOPS, "traffic": None,
                         "launches_per_step": nb / args.steps, "avg_launch_ms": msb / max(nb, 1),
                         "share_of_step_time": msb * 1e-3 / dt2,
                         "direct_conv3x3_bf16": {"launches_per_step": nc / args.steps, "avg_launch_ms": msc / max(nc, 1),
@@ -362,7 +514,7 @@ def main():
         else:
             alg_bytes = args.images * 1024 * 50 * 84 * 4 + R_local * 5 * 4 + R_local * 1024 * 14 * 14 * 4
             achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-            roof = {"kernel": "roi_align_nchw_kernel<fwd> (dominant HAND-WRITTEN kernel; Res5 is MIOpen here)",
+            roof = {"kernel": "roi_align_nhwc2nchw_kernel (dominant HAND-WRITTEN kernel; Res5 is MIOpen here)",
                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": dom_ms,
                     "algorithmic_bytes_per_launch": alg_bytes}
@@ -380,23 +532,27 @@ def main():
                        else "f32") + ("" if args.sim_dtype == "fp32" else " (bf16 similarity operands)")),
             "data": "synthetic",
             "config": {"workload": f"{args.images} img/GPU x {args.proposals} proposals, res4 [B,1024,50,84] fp32, "
-                                   f"ROIAlign 14x14 -> Res5({args.res5}) -> mean -> bbox_pred/emb_pred(2048->{args.dim}) -> "
-                                   f"similarity GEMM x {args.classes + 1}-row bank ({args.sim_dtype}); forward only",
-                       "scope": "S2 (full ROI head incl. Res5)", "images_per_gpu": args.images,
+                                   f"EmbeddingProposalsRes5ROIHeads._shared_roi_transform (ROIAlign 14x14 -> Res5({args.res5})) -> mean -> "
+                                   f"EmbeddingFastRCNNOutputLayers.forward (bbox_pred / emb_pred 2048->{args.dim} -> "
+                                   f"similarity GEMM x {args.classes + 1}-row bank, {args.sim_dtype}); forward only",
+                       "scope": "S2 (full ROI head incl. Res5), timed through the plugin surface", "images_per_gpu": args.images,
                        "proposals_per_image": args.proposals, "classes": args.classes, "emb_dim": args.dim,
                        "res5_backend": args.res5, "res5_conv3x3": args.conv3x3 if args.res5 == "hip" else "miopen",
                        "res5_block0": args.block0 if args.res5 == "hip" else "miopen",
                        "res5_dtype": args.res5_dtype,
-                       "parallelism": f"image-sharded x{world}, no collective"},
+                       "parallelism": f"image-sharded x{world}, no data-path collective"},
+            "rccl_ranks": rccl_ranks,
             "scopes": {"S2_full_head_proposals_per_s": props_per_step * args.steps / dt2,
                        "S1_handwritten_kernels_proposals_per_s": None if args.skip_s1 else props_per_step * args.steps / dt1,
-                       "S1_ms_per_step": None if args.skip_s1 else dt1 / args.steps * 1e3},
+                       "S1_ms_per_step": None if args.skip_s1 else dt1 / args.steps * 1e3, **variants},
             "roofline": roof,
         }
         if dt2_f32 is not None:
             out["f32_mfma_reference"] = {"value": props_per_step * args.steps / dt2_f32, "unit": "proposals/s",
                                          "ms_per_step": dt2_f32 / args.steps * 1e3,
-                                         "what": "the same job, same run, with --res5-dtype fp32 (Res5 GEMMs on v_mfma_f32_32x32x2_f32)"}
+                                         "what": "the same job, same run, with RES5_DTYPE fp32 (Res5 GEMMs on v_mfma_f32_32x32x2_f32)"}
+        if train is not None:
+            out["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out))

@@ -394,6 +394,75 @@ int locov_box_head_fwd(const float *x, int64_t R, int C5, int HW, int channels_l
                        float *deltas, float *emb, uint16_t *emb_bf16, float *logits,
                        locov_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * a-3 under autograd: the backward pass of the Res5 stage (the LSM head TRAINS the Res5 convolution weights --
+ * configs/coco_lsm.yaml:8 FREEZE_AT 0, FrozenBN only freezes the statistics -- through
+ * roi_emb_heads.py:323 (whole grid) and :343-347 (sampled proposals); the reference gets these gradients from
+ * cuDNN via torch autograd).  All tensors are channels-last pixel-row matrices as in the forward entry points.
+ *
+ * locov_gemm_nt_f32_ex       : locov_gemm_nt_f32 with an explicit row pitch of W (ldb) and an optional `mask`
+ *                              [M, ldc]: the finished value is kept where mask > 0 and zeroed elsewhere -- the ReLU
+ *                              backward of a saved activation fused into the data-gradient GEMM  dx = g . (s*W)
+ *                              (W given transposed, locov_weight_transpose_scale).
+ * locov_conv3x3_nhwc_f32_ex  : locov_conv3x3_nhwc_f32 with the same mask (3x3 data gradient = convolution with the
+ *                              flipped, transposed filter, locov_conv3x3_weight_flip).
+ * locov_winograd_conv3x3_f32_ex : the same for 7x7 tiles in the Winograd domain.
+ * locov_gemm_tn_f32          : out[b][N,K] = row_scale[n] * sum_m a_b[m,n] * b_b[m,k] -- the weight gradient
+ *                              dW = s * g^T x of a 1x1 convolution (contraction over the pixel rows; split over M,
+ *                              partial tiles reduced in a fixed order: deterministic).  batch problems with strides
+ *                              (elements); workspace: locov_gemm_tn_workspace_bytes(M, N, K, batch).
+ * locov_winograd_wgrad_f32   : dw [N,Cin,3,3] of a 3x3 convolution over R 7x7 tiles, in the Winograd domain:
+ *                              dU_f = ((A (x) A) g)_f^T ((BT (x) BT) x)_f (121 TN GEMMs), dw = row_scale * (G (x) G)^T dU.
+ *                              flags: 0 (position-major rows) or LOCOV_WINO_IN_ROI_MAJOR (both x and g).
+ * locov_im2col3x3_nhwc / locov_conv3x3_wgrad_unpack : the general-grid form of the same gradient
+ *                              (dw_packed [N, 9*Cin] = g^T . im2col(x) through locov_gemm_tn_f32).
+ * locov_relu_mask, locov_spatial_mean_bwd, locov_rows_stride2, locov_roi_align_nhwc_bwd : element-wise pieces --
+ *                              ReLU backward, the mean's broadcast (roi_emb_heads.py:344) fused with it, block 0's
+ *                              stride-2 pixel selection on the whole grid and its adjoint, and the adjoint of
+ *                              locov_roi_align_nhwc_fwd (fp32 atomics into a zeroed channels-last map gradient).
+ * ------------------------------------------------------------------------------------- */
+int locov_gemm_nt_f32_ex(const float *x, int64_t lda, const float *W, int64_t ldb, const float *scale,
+                         const float *shift, const float *residual, const float *mask, float *y, int64_t ldc,
+                         int64_t M, int N, int K, unsigned flags, locov_stream_t stream);
+
+int locov_conv3x3_nhwc_f32_ex(const float *x, int64_t R, int H, int W, int Cin, int pos_major,
+                              const float *w_packed, const float *scale, const float *shift,
+                              const float *residual, const float *mask, float *y, int N, unsigned flags,
+                              locov_stream_t stream);
+
+int locov_winograd_conv3x3_f32_ex(const float *x, int64_t R, int Cin, const float *U, const float *scale,
+                                  const float *shift, const float *mask, float *y, int64_t ldy, int N,
+                                  unsigned flags, void *workspace, int64_t workspace_bytes,
+                                  locov_stream_t stream);
+
+int64_t locov_gemm_tn_workspace_bytes(int64_t M, int N, int K, int batch);
+int locov_gemm_tn_f32(const float *a, int64_t lda, int64_t stride_a, const float *b, int64_t ldb,
+                      int64_t stride_b, float *out, int64_t ldo, int64_t stride_o, int64_t M, int N, int K,
+                      int batch, const float *row_scale, void *workspace, int64_t workspace_bytes,
+                      locov_stream_t stream);
+
+int64_t locov_winograd_wgrad_workspace_bytes(int64_t R, int Cin, int N);
+int locov_winograd_wgrad_f32(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags,
+                             const float *row_scale, float *dw, void *workspace, int64_t workspace_bytes,
+                             locov_stream_t stream);
+
+int locov_weight_transpose_scale(const float *w, int N, int K, const float *row_scale, float *out,
+                                 locov_stream_t stream);
+int locov_conv3x3_weight_flip(const float *w, int N, int Cin, const float *row_scale, float *out,
+                              locov_stream_t stream);
+int locov_im2col3x3_nhwc(const float *x, int64_t R, int H, int W, int C, float *col, locov_stream_t stream);
+int locov_conv3x3_wgrad_unpack(const float *dw_packed, int N, int Cin, const float *row_scale, float *dw,
+                               locov_stream_t stream);
+int locov_relu_mask(const float *g, const float *act, int64_t n, float *out, locov_stream_t stream);
+int locov_spatial_mean_bwd(const float *g, const float *act, int64_t R, int C, int HW, float *out,
+                           locov_stream_t stream);
+int locov_rows_stride2(const float *src, int N, int H, int W, int C, int forward, float *dst,
+                       locov_stream_t stream);
+int locov_roi_align_nhwc_bwd(const float *grad_rows, int64_t grad_ld, int N, int H, int W, int C,
+                             const float *rois, int64_t R, int pooled_h, int pooled_w, float spatial_scale,
+                             int sampling_ratio, int aligned, int bin_stride, int pos_major, float *grad_feat,
+                             locov_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,23 @@ SIGNATURES = {
     "locov_gemm_nt_batched_f32_split": (c_int, [_p, c_int64, c_int64, _p, c_int64, _p, c_int64, c_int64, c_int64, c_int,
                                                 c_int, c_int, c_float, c_float, _p]),
     "locov_sim_gemm_bf16": (c_int, [_p, _p, c_int64, c_int, c_int, _p, c_int64, _p]),
+    "locov_gemm_nt_f32_ex": (c_int, [_p, c_int64, _p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, _p]),
+    "locov_conv3x3_nhwc_f32_ex": (c_int, [_p, c_int64, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, _p, c_int, c_uint, _p]),
+    "locov_winograd_conv3x3_f32_ex": (c_int, [_p, c_int64, c_int, _p, _p, _p, _p, _p, c_int64, c_int, c_uint, _p, c_int64, _p]),
+    "locov_gemm_tn_workspace_bytes": (c_int64, [c_int64, c_int, c_int, c_int]),
+    "locov_gemm_tn_f32": (c_int, [_p, c_int64, c_int64, _p, c_int64, c_int64, _p, c_int64, c_int64, c_int64, c_int, c_int, c_int,
+                                  _p, _p, c_int64, _p]),
+    "locov_winograd_wgrad_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "locov_winograd_wgrad_f32": (c_int, [_p, _p, c_int64, c_int, c_int, c_uint, _p, _p, _p, c_int64, _p]),
+    "locov_weight_transpose_scale": (c_int, [_p, c_int, c_int, _p, _p, _p]),
+    "locov_conv3x3_weight_flip": (c_int, [_p, c_int, c_int, _p, _p, _p]),
+    "locov_im2col3x3_nhwc": (c_int, [_p, c_int64, c_int, c_int, c_int, _p, _p]),
+    "locov_conv3x3_wgrad_unpack": (c_int, [_p, c_int, c_int, _p, _p, _p]),
+    "locov_relu_mask": (c_int, [_p, _p, c_int64, _p, _p]),
+    "locov_spatial_mean_bwd": (c_int, [_p, _p, c_int64, c_int, c_int, _p, _p]),
+    "locov_rows_stride2": (c_int, [_p, c_int, c_int, c_int, c_int, c_int, _p, _p]),
+    "locov_roi_align_nhwc_bwd": (c_int, [_p, c_int64, c_int, c_int, c_int, c_int, _p, c_int64, c_int, c_int, c_float, c_int, c_int,
+                                         c_int, c_int, _p, _p]),
     "locov_box_head_fwd": (c_int, [_p, c_int64, c_int, c_int, c_int, _p, _p, _p, _p, _p, _p, c_int, c_int,
                                    c_int, c_int, _p, _p, _p, _p, _p, _p]),
 }

@@ -9,6 +9,8 @@ struct Epilogue {
     const float *shift;     // [N] or null  (bias)
     const float *residual;  // [M, ldc] or null
     unsigned flags;
+    const float *mask;      // [M, ldc] or null: the finished value is kept where mask > 0 and zeroed elsewhere (the ReLU
+                            // backward of a saved activation, fused into the data-gradient GEMMs; f32 NT kernel only)
 };
 
 // H == 0: plain GEMM.  H > 0: A is the pixel matrix of independent HxW tiles with Cin channels
@@ -42,5 +44,12 @@ void timing_end(int idx, hipStream_t s);
 int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C, int64_t ldc, int64_t M, int N, int K,
                       const Epilogue &epi, float a_scale, float w_scale, hipStream_t s, const char *what,
                       const Batch &bt = Batch{1, 0, 0, 0});
+
+// out[b][N,K] = row_scale[n] * sum_m A_b[m,n] * B_b[m,k]  (gemm_tn.hip: the weight-gradient GEMM; problem b uses
+// A + b*sa, B + b*sb, out + b*so; ws = gemm_tn_workspace_bytes(M, N, K, batch) bytes of device memory)
+int launch_gemm_tn(const float *A, int64_t lda, int64_t sa, const float *B, int64_t ldb, int64_t sb, float *out, int64_t ldo,
+                   int64_t so, int64_t M, int N, int K, int batch, const float *row_scale, float *ws, int64_t ws_bytes,
+                   hipStream_t s, const char *what);
+int64_t gemm_tn_workspace_bytes(int64_t M, int N, int K, int batch);
 
 }  // namespace locov

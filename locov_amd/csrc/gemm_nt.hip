@@ -127,7 +127,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 // past M / N are simply read from a clamped in-bounds row -- they only feed output rows / columns
 // that are never stored -- so no select is needed, and the per-lane global pointers just advance by
 // a wave-uniform delta per K-tile.  MASKED = true keeps the general path (ragged K, ROI-major conv).
-template <typename T, typename TOut, int BM, int BN, int WM, int WN, int OCC, int CONV, bool MASKED, int BK16>
+// EMASK: the epilogue additionally zeroes every value whose `epi.mask` entry is <= 0 (a separate instance, so that the
+// inference kernels' register allocation is untouched).
+template <typename T, typename TOut, int BM, int BN, int WM, int WN, int OCC, int CONV, bool MASKED, int BK16, bool EMASK = false>
 __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__restrict__ A, int64_t lda,
                                                                     const T *__restrict__ B, int64_t ldb,
                                                                     TOut *__restrict__ Cout, int64_t ldc, int64_t M_,
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
             } else {
                 const bool kin = k0 + ch * E < K;
                 ok = ok && kin;
-                off = kin ? aoff : 0;
+                off = kin ? aoff : -(int64_t)(ch * E);       // chunk past K: read the row's first chunk (in bounds), store zero
             }
             ra[i] = *reinterpret_cast<const frag_t *>(a_ptr[i] + off);
             ok_mask |= ok ? (1u << i) : 0u;
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
         for (int i = 0; i < B_CH; i++) {
             const int ch = (tid + i * NT) % BK16;
             const bool kin = k0 + ch * E < K;
-            rb[i] = *reinterpret_cast<const frag_t *>(b_ptr[i] + (kin ? kb : 0));
+            rb[i] = *reinterpret_cast<const frag_t *>(b_ptr[i] + (kin ? kb : -(ch * E)));
             ok_mask |= (b_ok[i] && kin) ? (1u << (16 + i)) : 0u;
         }
     };
@@ -591,7 +593,8 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
     // wave re-lays its sub-tile out through LDS (free after the K-loop) and writes 16 bytes per lane:
     // 4x fewer store (and residual load) instructions, 256-byte contiguous runs per row.
     const bool vec_ok = sizeof(TOut) == 4 && !(epi.flags & 0x800u) && (N % 4 == 0) && (ldc % 4 == 0) &&
-                        ((uintptr_t)Cout % 16 == 0) && (!epi.residual || (uintptr_t)epi.residual % 16 == 0);
+                        ((uintptr_t)Cout % 16 == 0) && (!epi.residual || (uintptr_t)epi.residual % 16 == 0) &&
+                        (!(EMASK && epi.mask) || (uintptr_t)epi.mask % 16 == 0);
     if (vec_ok) {
         constexpr int EPS = TN + 4;                       // padded row (floats): conflict-free b128 reads
         static_assert(WM * WN * TM * EPS * 4 <= 2 * STAGE * 16, "epilogue staging must fit the K-loop LDS");
@@ -619,6 +622,8 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
             const_cast<float *>(epi.residual ? epi.residual + m0 * ldc : reinterpret_cast<float *>(Cout) + m0 * ldc), 0, nrec,
             0x00020000);
         float *ep = reinterpret_cast<float *>(lds) + wave * (TM * EPS);
+        const __amdgpu_buffer_rsrc_t r_msk = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(EMASK && epi.mask ? epi.mask + m0 * ldc : reinterpret_cast<float *>(Cout) + m0 * ldc), 0, nrec, 0x00020000);
         auto tail = [&](auto full_tag) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(full_tag)::value;
             // residual rows are fetched FIRST (16-byte loads, all in flight) so that their latency sits
@@ -657,6 +662,12 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
                     if (relu) {
                         v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
                         v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                    }
+                    if (EMASK && epi.mask) {
+                        const f32x4 mk = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                       r_msk, FULL ? voff : voff + it * vstep, FULL ? it * vstep : 0u, 0));
+                        v[0] = mk[0] > 0.f ? v[0] : 0.f; v[1] = mk[1] > 0.f ? v[1] : 0.f;
+                        v[2] = mk[2] > 0.f ? v[2] : 0.f; v[3] = mk[3] > 0.f ? v[3] : 0.f;
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, FULL ? voff : voff + it * vstep,
                                                            FULL ? it * vstep : 0u, 0);
@@ -697,6 +708,7 @@ __global__ __launch_bounds__(64 * WM *WN, OCC) void gemm_nt_kernel(const T *__re
                 const int64_t m = mb + (r & 3) + 8 * (r >> 2);
                 float v = acc[i][j][r] * sc + sh + res[r];
                 if (relu) v = fmaxf(v, 0.f);
+                if (EMASK && epi.mask && !(epi.mask[(m < M ? m : M - 1) * ldc + nc] > 0.f)) v = 0.f;
                 if (n_ok && m < M) store_out(Cout + m * ldc + n, v);
             }
         }
@@ -732,10 +744,20 @@ static int launch_cfg(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C,
     const bool ragged_k = (posm ? cg.Cin : K) % BK != 0;
     const dim3 grid((unsigned)tiles), block(64 * WM * WN);
 
+    if (epi.mask && !(std::is_same<T, float>::value && std::is_same<TOut, float>::value))
+        return set_error(LOCOV_ERR_UNSUPPORTED, "%s: the epilogue mask needs fp32 operands and output", what);
 #define LOCOV_LAUNCH(CONV, MASKED)                                                                                 \
-    hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, OCC, CONV, MASKED, BK16>), grid, block, dyn_lds_dbg(), s, A, lda, B, \
-                       ldb, \
-                       C, ldc, M, N, K, epi, cg, bt)
+    do {                                                                                                            \
+        if constexpr (std::is_same<T, float>::value && std::is_same<TOut, float>::value) {                          \
+            if (epi.mask) {                                                                                         \
+                hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, OCC, CONV, MASKED, BK16, true>), grid, block, dyn_lds_dbg(), \
+                                   s, A, lda, B, ldb, C, ldc, M, N, K, epi, cg, bt);                               \
+                break;                                                                                              \
+            }                                                                                                       \
+        }                                                                                                           \
+        hipLaunchKernelGGL((gemm_nt_kernel<T, TOut, BM, BN, WM, WN, OCC, CONV, MASKED, BK16>), grid, block, dyn_lds_dbg(), s, A, lda, B, \
+                           ldb, C, ldc, M, N, K, epi, cg, bt);                                                      \
+    } while (0)
     if (posm) {
         if (ragged_k) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: Cin must be a multiple of %d", what, BK);
         LOCOV_LAUNCH(2, false);
@@ -832,6 +854,36 @@ int locov_gemm_nt_f32(const float *x, int64_t lda, const float *W, const float *
     Epilogue epi{scale, shift, residual, flags};
     return launch_gemm_nt<float, float>(x, lda, W, (int64_t)K, y, ldc, M, N, K, epi, as_stream(stream),
                                         "locov_gemm_nt_f32");
+}
+
+int locov_gemm_nt_f32_ex(const float *x, int64_t lda, const float *W, int64_t ldb, const float *scale, const float *shift,
+                         const float *residual, const float *mask, float *y, int64_t ldc, int64_t M, int N, int K,
+                         unsigned flags, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(M >= 0 && N > 0 && K > 0, "locov_gemm_nt_f32_ex: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    if (M == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(x && W && y, "locov_gemm_nt_f32_ex: null pointer");
+    LOCOV_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0, "locov_gemm_nt_f32_ex: K, lda and ldb must be multiples of 4");
+    LOCOV_REQUIRE(lda >= K && ldb >= K && ldc >= N, "locov_gemm_nt_f32_ex: lda < K, ldb < K or ldc < N");
+    LOCOV_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)W % 16 == 0, "locov_gemm_nt_f32_ex: x / W must be 16-byte aligned");
+    Epilogue epi{scale, shift, residual, flags, mask};
+    return launch_gemm_nt<float, float>(x, lda, W, ldb, y, ldc, M, N, K, epi, as_stream(stream), "locov_gemm_nt_f32_ex");
+}
+
+int locov_conv3x3_nhwc_f32_ex(const float *x, int64_t R, int H, int W, int Cin, int pos_major, const float *w_packed,
+                              const float *scale, const float *shift, const float *residual, const float *mask, float *y,
+                              int N, unsigned flags, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(R >= 0 && H > 0 && W > 0 && Cin > 0 && N > 0, "locov_conv3x3_nhwc_f32_ex: bad shape");
+    if (R == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(x && w_packed && y, "locov_conv3x3_nhwc_f32_ex: null pointer");
+    LOCOV_REQUIRE(Cin % 32 == 0, "locov_conv3x3_nhwc_f32_ex: Cin must be a multiple of 32 (got %d)", Cin);
+    LOCOV_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w_packed % 16 == 0, "locov_conv3x3_nhwc_f32_ex: misaligned pointer");
+    LOCOV_REQUIRE(R <= 0x7fffffffLL / (H * W), "locov_conv3x3_nhwc_f32_ex: R too large");
+    Epilogue epi{scale, shift, residual, flags, mask};
+    ConvGeom cg{H, W, Cin, pos_major ? (int)R : 0, 0};
+    return launch_gemm_nt<float, float>(x, (int64_t)Cin, w_packed, (int64_t)9 * Cin, y, (int64_t)N, R * H * W, N, 9 * Cin, epi,
+                                        as_stream(stream), "locov_conv3x3_nhwc_f32_ex", cg);
 }
 
 int locov_gemm_timing_enable(int on)

@@ -74,7 +74,10 @@ constexpr int kNhwcThreads = 256;
 constexpr int kMaxAxisN = 192;     // per-axis LDS table entries (7 x up to 27 samples; larger grids are computed on the fly): keeps the kernel at 6+ workgroups per CU
 
 // grid = (R, OH): one workgroup = one ROI x one output row of bins.
-template <typename TIn, typename TOut>
+// BWD = true is the adjoint with the same sampling geometry: `out` then holds the GRADIENT of the pooled rows (read) and
+// `feat` the gradient of the channels-last map (accumulated with fp32 hardware atomics; the caller zeroes it) -- what
+// autograd needs when the LSM head trains through the even-grid pooler (roi_emb_heads.py:343 under autograd).
+template <typename TIn, typename TOut, bool BWD = false>
 __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
     const TIn *__restrict__ feat, int N, int H, int W, int C, const float *__restrict__ rois, int PH, int PW,
     float scale, int sampling_ratio, int aligned, int bin_stride, int OH, int OW, int pos_major,
@@ -199,6 +202,46 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
         const int c = cq << 2;
         const unsigned ch_off = (unsigned)c * (unsigned)sizeof(TIn);
         float4 acc = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BWD) {
+            if (valid_b) {
+                float4 g = load4(orow + ow * ow_stride + c);
+                g.x *= inv_count; g.y *= inv_count; g.z *= inv_count; g.w *= inv_count;
+                char *gimg = reinterpret_cast<char *>(const_cast<TIn *>(img));
+                auto scatter = [&](unsigned off, float w) {
+                    if (w == 0.f) return;
+                    float *p = reinterpret_cast<float *>(gimg + off);
+                    unsafeAtomicAdd(p, w * g.x);
+                    unsafeAtomicAdd(p + 1, w * g.y);
+                    unsafeAtomicAdd(p + 2, w * g.z);
+                    unsafeAtomicAdd(p + 3, w * g.w);
+                };
+                if (separable) {
+                    const int ny = ypix[1], nxp = xpix[ow][1];
+                    const unsigned y0 = (unsigned)ypix[0] + (unsigned)xpix[ow][0] + ch_off;
+                    const float *xw = xpw + ow * (kSepGrid + 1);
+                    for (int ky = 0; ky < ny; ky++)
+                        for (int kx = 0; kx < nxp; kx++) scatter(y0 + (unsigned)ky * ystride + (unsigned)kx * xstride, ypw[ky] * xw[kx]);
+                } else {
+                    for (int iy = 0; iy < gh; iy++) {
+                        const AxisSampleN ys = use_lds ? ytab[iy] : as_offsets(axis_sample_n(start_h, bin_h, ph, iy, gh, H), ystride);
+                        for (int ix = 0; ix < gw; ix++) {
+                            const AxisSampleN xs = use_lds ? xtab[ow * gw + ix]
+                                                           : as_offsets(axis_sample_n(start_w, bin_w, ow * bin_stride, ix, gw, W), xstride);
+                            scatter((unsigned)ys.lo + (unsigned)xs.lo + ch_off, ys.wh * xs.wh);
+                            scatter((unsigned)ys.lo + (unsigned)xs.hi + ch_off, ys.wh * xs.wl);
+                            scatter((unsigned)ys.hi + (unsigned)xs.lo + ch_off, ys.wl * xs.wh);
+                            scatter((unsigned)ys.hi + (unsigned)xs.hi + ch_off, ys.wl * xs.wl);
+                        }
+                    }
+                }
+            }
+            cq += kNhwcThreads;
+            while (cq >= c4n) {
+                cq -= c4n;
+                ow++;
+            }
+            continue;
+        }
         if (valid_b && separable) {
             const int ny = ypix[1], nxp = xpix[ow][1];
             const unsigned x0 = (unsigned)xpix[ow][0] + ch_off;
@@ -526,6 +569,29 @@ int locov_roi_align_nhwc_ld_fwd(const void *feat, int feat_dtype, int N, int H, 
     return locov_roi_align_nhwc_affine_fwd(feat, feat_dtype, N, H, W, C, (int64_t)C, rois, R, pooled_h, pooled_w,
                                            spatial_scale, sampling_ratio, aligned, bin_stride, pos_major, nullptr, nullptr, 0,
                                            out, out_ld, out_dtype, stream);
+}
+
+int locov_roi_align_nhwc_bwd(const float *grad_rows, int64_t grad_ld, int N, int H, int W, int C, const float *rois, int64_t R,
+                             int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, int aligned, int bin_stride,
+                             int pos_major, float *grad_feat, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(grad_ld >= C && grad_ld % 4 == 0, "locov_roi_align_nhwc_bwd: grad_ld must be >= C and a multiple of 4");
+    LOCOV_REQUIRE((int64_t)H * W * C * 4 < 0xffffffffLL, "locov_roi_align_nhwc_bwd: one image must stay below 4 GiB");
+    LOCOV_REQUIRE(R >= 0 && N > 0 && C > 0 && H > 0 && W > 0 && pooled_h > 0 && pooled_w > 0, "locov_roi_align_nhwc_bwd: bad shape");
+    LOCOV_REQUIRE(spatial_scale > 0.f, "locov_roi_align_nhwc_bwd: spatial_scale must be > 0");
+    LOCOV_REQUIRE(bin_stride == 1 || bin_stride == 2, "locov_roi_align_nhwc_bwd: bin_stride must be 1 or 2");
+    LOCOV_REQUIRE(C % 4 == 0, "locov_roi_align_nhwc_bwd: C must be a multiple of 4");
+    if (R == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(grad_rows && rois && grad_feat, "locov_roi_align_nhwc_bwd: null pointer");
+    LOCOV_REQUIRE(R <= 0x7fffffffLL, "locov_roi_align_nhwc_bwd: R too large");
+    LOCOV_REQUIRE(((uintptr_t)grad_rows | (uintptr_t)grad_feat) % 16 == 0, "locov_roi_align_nhwc_bwd: misaligned pointer");
+    const int OH = (pooled_h + bin_stride - 1) / bin_stride, OW = (pooled_w + bin_stride - 1) / bin_stride;
+    dim3 grid((unsigned)R, (unsigned)OH);
+    hipLaunchKernelGGL((roi_align_nhwc_kernel<float, float, true>), grid, dim3(kNhwcThreads), 0, as_stream(stream),
+                       (const float *)grad_feat, N, H, W, C, rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, bin_stride,
+                       OH, OW, pos_major, const_cast<float *>(grad_rows), grad_ld, (int64_t)C, (const float *)nullptr,
+                       (const float *)nullptr, 0);
+    return check_launch("locov_roi_align_nhwc_bwd");
 }
 
 int locov_roi_align_nhwc_affine_fwd(const void *feat, int feat_dtype, int N, int H, int W, int C, int64_t feat_ld,

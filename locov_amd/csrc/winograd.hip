@@ -55,6 +55,12 @@ __global__ __launch_bounds__(256) void wino_pack_weight_kernel(const float *__re
 
 // x rows [(y*7+x)*ld_pos + r*ld_roi][C]  ->  V [NF*NF][Rc][C]   (position-major input: ld_pos = R, ld_roi = 1;
 // ROI-major input, row = roi*49 + position: ld_pos = 1, ld_roi = 49)
+// GRAD = true applies A (x) A = (AT (x) AT)^T instead of BT (x) BT: the adjoint of the OUTPUT transform, which maps the
+// gradient of a convolution's output into the transform domain (dM) for the weight gradient (locov_winograd_wgrad_f32).
+template <bool GRAD>
+__device__ __forceinline__ constexpr float in_coef(int f, int y) { return GRAD ? AT[y][f] : BT[f][y]; }
+
+template <bool GRAD>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, int64_t ld_pos, int64_t ld_roi, int64_t Rc, int C,
                                                          float *__restrict__ V)
 {
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
             f32x2 a = {0.f, 0.f};
 #pragma unroll
             for (int y = 0; y < 7; y++)
-                if (BT[fy][y] != 0.f) a += BT[fy][y] * d[y][xx];
+                if (in_coef<GRAD>(fy, y) != 0.f) a += in_coef<GRAD>(fy, y) * d[y][xx];
             wv[xx] = a;
         }
 #pragma unroll
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
             f32x2 a = {0.f, 0.f};
 #pragma unroll
             for (int xx = 0; xx < 7; xx++)
-                if (BT[fx][xx] != 0.f) a += BT[fx][xx] * wv[xx];
+                if (in_coef<GRAD>(fx, xx) != 0.f) a += in_coef<GRAD>(fx, xx) * wv[xx];
             __builtin_nontemporal_store(a, reinterpret_cast<f32x2 *>(dst + (int64_t)(fy * NF + fx) * fstride));
         }
     }
@@ -99,8 +105,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restrict__ Mv, int64_t ld_pos, int64_t ld_roi, int64_t Rc, int N,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, int relu,
-                                                          float *__restrict__ y, int64_t ldy)
+                                                          float *__restrict__ y, int64_t ldy, const float *__restrict__ mask)
 {
+    // mask (same rows and pitch as y, or null): the value is kept where mask > 0, zeroed elsewhere -- the ReLU backward of the
+    // saved activation when this convolution is a data gradient (flipped filter)
     const int n2 = N >> 1;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= Rc * n2) return;
@@ -139,6 +147,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
     if (scale) sc = *reinterpret_cast<const f32x2 *>(scale + n);
     if (shift) sh = *reinterpret_cast<const f32x2 *>(shift + n);
     float *dst = y + r * ld_roi * ldy + n;
+    const float *msk = mask ? mask + r * ld_roi * ldy + n : nullptr;
 #pragma unroll
     for (int yy = 0; yy < 7; yy++)
 #pragma unroll
@@ -148,8 +157,41 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
                 v[0] = fmaxf(v[0], 0.f);
                 v[1] = fmaxf(v[1], 0.f);
             }
+            if (msk) {
+                const f32x2 mk = *reinterpret_cast<const f32x2 *>(msk + (int64_t)(yy * 7 + xx) * ld_pos * ldy);
+                v[0] = mk[0] > 0.f ? v[0] : 0.f;
+                v[1] = mk[1] > 0.f ? v[1] : 0.f;
+            }
             *reinterpret_cast<f32x2 *>(dst + (int64_t)(yy * 7 + xx) * ld_pos * ldy) = v;
         }
+}
+
+// dU [NF*NF, N, Cin] -> dw [N, Cin, 3, 3] = row_scale[n] * (G (x) G)^T dU : the adjoint of wino_pack_weight_kernel
+__global__ __launch_bounds__(256) void wino_unpack_wgrad_kernel(const float *__restrict__ dU, int64_t NC, int Cin,
+                                                                const float *__restrict__ row_scale, float *__restrict__ dw)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    double g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+    for (int fy = 0; fy < NF; fy++) {
+        double t[3] = {0, 0, 0};
+#pragma unroll
+        for (int fx = 0; fx < NF; fx++) {
+            const double u = (double)dU[(int64_t)(fy * NF + fx) * NC + i];
+#pragma unroll
+            for (int b = 0; b < 3; b++) t[b] += G[fx][b] * u;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) g[a][b] += G[fy][a] * t[b];
+    }
+    const double sc = row_scale ? (double)row_scale[i / Cin] : 1.0;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) dw[i * 9 + a * 3 + b] = (float)(sc * g[a][b]);
 }
 
 // ROIs per pass: the two transform-domain buffers of a pass (121 * chunk * (Cin + N) floats) are
@@ -193,7 +235,14 @@ int locov_winograd_pack_weight(const float *w, int N, int Cin, float *U, locov_s
 // f16 matrix pipe with V scaled by v_scale (gemm_split.hip); u_scale == 0: fp32 U, fp32 MFMA.
 static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
                             const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
-                            void *workspace, int64_t workspace_bytes, locov_stream_t stream);
+                            void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask = nullptr);
+
+int locov_winograd_conv3x3_f32_ex(const float *x, int64_t R, int Cin, const float *U, const float *scale, const float *shift,
+                                  const float *mask, float *y, int64_t ldy, int N, unsigned flags, void *workspace,
+                                  int64_t workspace_bytes, locov_stream_t stream)
+{
+    return winograd_conv3x3(x, R, Cin, U, 0.f, 0.f, scale, shift, y, ldy, N, flags, workspace, workspace_bytes, stream, mask);
+}
 
 int locov_winograd_conv3x3_f32(const float *x, int64_t R, int Cin, const float *U, const float *scale,
                                const float *shift, float *y, int64_t ldy, int N, unsigned flags, void *workspace,
@@ -213,7 +262,7 @@ int locov_winograd_conv3x3_f32_split(const float *x, int64_t R, int Cin, const v
 
 static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
                             const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
-                            void *workspace, int64_t workspace_bytes, locov_stream_t stream)
+                            void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask)
 {
     LOCOV_REQUIRE(ldy >= N && ldy % 2 == 0, "locov_winograd_conv3x3_f32: ldy must be >= N and even");
     LOCOV_REQUIRE(R >= 0 && Cin > 0 && N > 0, "locov_winograd_conv3x3_f32: bad shape");
@@ -236,7 +285,7 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
         const int64_t rc = R - r0 < chunk ? R - r0 : chunk;
         const int64_t tin = rc * (Cin / 2), tout = rc * (N / 2);
         const bool in_roi_major = (flags & LOCOV_WINO_IN_ROI_MAJOR) != 0;
-        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(tin, 256)), dim3(256), 0, s,
+        hipLaunchKernelGGL(wino_input_kernel<false>, dim3((unsigned)ceil_div(tin, 256)), dim3(256), 0, s,
                            x + r0 * (in_roi_major ? 49 : 1) * Cin, in_roi_major ? (int64_t)1 : R, in_roi_major ? (int64_t)49 : (int64_t)1,
                            rc, Cin, V);
         int rcode = check_launch("locov_winograd_conv3x3_f32 (input transform)");
@@ -254,11 +303,55 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
         const bool roi_major = (flags & LOCOV_WINO_OUT_ROI_MAJOR) != 0;
         hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)ceil_div(tout, 256)), dim3(256), 0, s, Mv, roi_major ? (int64_t)1 : R,
                            roi_major ? (int64_t)49 : (int64_t)1, rc, N, scale, shift, (flags & LOCOV_EPI_RELU) ? 1 : 0,
-                           y + r0 * (roi_major ? 49 : 1) * ldy, ldy);
+                           y + r0 * (roi_major ? 49 : 1) * ldy, ldy, mask ? mask + r0 * (roi_major ? 49 : 1) * ldy : nullptr);
         rcode = check_launch("locov_winograd_conv3x3_f32 (output transform)");
         if (rcode) return rcode;
     }
     return LOCOV_OK;
+}
+
+int64_t locov_winograd_wgrad_workspace_bytes(int64_t R, int Cin, int N)
+{
+    if (R <= 0 || Cin <= 0 || N <= 0) return 0;
+    return (int64_t)NF * NF * (R * ((int64_t)Cin + N) + (int64_t)N * Cin) * (int64_t)sizeof(float) +
+           gemm_tn_workspace_bytes(R, N, Cin, NF * NF);
+}
+
+int locov_winograd_wgrad_f32(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags, const float *row_scale,
+                             float *dw, void *workspace, int64_t workspace_bytes, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(R >= 0 && Cin > 0 && N > 0, "locov_winograd_wgrad_f32: bad shape");
+    LOCOV_REQUIRE(dw, "locov_winograd_wgrad_f32: null output");
+    hipStream_t s = as_stream(stream);
+    if (R == 0) {
+        hipError_t e = hipMemsetAsync(dw, 0, (size_t)N * Cin * 9 * sizeof(float), s);
+        return e == hipSuccess ? LOCOV_OK : set_error(LOCOV_ERR_LAUNCH, "locov_winograd_wgrad_f32: memset failed");
+    }
+    LOCOV_REQUIRE(x && g && workspace, "locov_winograd_wgrad_f32: null pointer");
+    LOCOV_REQUIRE(Cin % 4 == 0 && N % 4 == 0, "locov_winograd_wgrad_f32: Cin and N must be multiples of 4 (got %d, %d)", Cin, N);
+    LOCOV_REQUIRE(((uintptr_t)x | (uintptr_t)g | (uintptr_t)dw | (uintptr_t)workspace) % 16 == 0, "locov_winograd_wgrad_f32: misaligned pointer");
+    LOCOV_REQUIRE(!(flags & ~(unsigned)LOCOV_WINO_IN_ROI_MAJOR), "locov_winograd_wgrad_f32: unsupported flags 0x%x", flags);
+    LOCOV_REQUIRE(workspace_bytes >= locov_winograd_wgrad_workspace_bytes(R, Cin, N), "locov_winograd_wgrad_f32: workspace too small (%lld bytes)",
+                  (long long)workspace_bytes);
+    float *V = static_cast<float *>(workspace);
+    float *dM = V + (int64_t)NF * NF * R * Cin;
+    float *dU = dM + (int64_t)NF * NF * R * N;
+    float *tn_ws = dU + (int64_t)NF * NF * N * Cin;
+    const bool rm = (flags & LOCOV_WINO_IN_ROI_MAJOR) != 0;
+    const int64_t ld_pos = rm ? 1 : R, ld_roi = rm ? 49 : 1;
+    hipLaunchKernelGGL(wino_input_kernel<false>, dim3((unsigned)ceil_div(R * (Cin / 2), 256)), dim3(256), 0, s, x, ld_pos, ld_roi, R, Cin, V);
+    int rc = check_launch("locov_winograd_wgrad_f32 (input transform)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino_input_kernel<true>, dim3((unsigned)ceil_div(R * (N / 2), 256)), dim3(256), 0, s, g, ld_pos, ld_roi, R, N, dM);
+    rc = check_launch("locov_winograd_wgrad_f32 (gradient transform)");
+    if (rc) return rc;
+    // dU_f [N, Cin] = dM_f^T . V_f   (121 problems, contraction over the ROIs)
+    rc = launch_gemm_tn(dM, (int64_t)N, R * N, V, (int64_t)Cin, R * Cin, dU, (int64_t)Cin, (int64_t)N * Cin, R, N, Cin, NF * NF, nullptr, tn_ws,
+                        workspace_bytes - (int64_t)((char *)tn_ws - (char *)workspace), s, "locov_winograd_wgrad_f32 (batched TN GEMM)");
+    if (rc) return rc;
+    const int64_t NC = (int64_t)N * Cin;
+    hipLaunchKernelGGL(wino_unpack_wgrad_kernel, dim3((unsigned)ceil_div(NC, 256)), dim3(256), 0, s, dU, NC, Cin, row_scale, dw);
+    return check_launch("locov_winograd_wgrad_f32 (filter transform)");
 }
 
 int locov_gemm_nt_batched_f32(const float *x, int64_t lda, int64_t stride_x, const float *W, int64_t stride_w, float *y,

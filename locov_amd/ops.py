@@ -521,9 +521,247 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torc
     return order[keep.bool()]
 
 
+# --------------------------------------------------------------------------------------
+# Backward-pass building blocks of the Res5 stage (csrc/gemm_tn.hip, res5_bwd.hip, the mask epilogue of gemm_nt.hip and
+# the gradient transforms of winograd.hip); composed by locov_amd/res5_train.py.
+_WS = {}
+
+
+def _workspace(tag: str, ref: torch.Tensor, nbytes: int) -> torch.Tensor:
+    """Cached device scratch (grows to the largest request), one per (tag, device, stream)."""
+    key = (tag, ref.device, torch.cuda.current_stream(ref.device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _WS.pop(key, None)
+        ws = _WS[key] = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=ref.device)
+    return ws
+
+
+def linear_ex(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, scale=None, residual=None,
+              mask=None, relu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """linear() with the weight rows optionally strided (a column block of a wider matrix) and an optional `mask` [M,N]:
+    the finished value is kept where mask > 0 and zeroed elsewhere (ReLU backward fused into a data-gradient GEMM)."""
+    x = _rows(x, "x")
+    weight = _rows(weight, "weight")
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K or K % 4:
+        raise ValueError(f"linear_ex: x {tuple(x.shape)} weight {tuple(weight.shape)} (K must be a multiple of 4)")
+    bias = _dev(bias, "bias") if bias is not None else None
+    scale = _dev(scale, "scale") if scale is not None else None
+    residual = _dev(residual, "residual") if residual is not None else None
+    mask = _dev(mask, "mask") if mask is not None else None
+    for t, name in ((residual, "residual"), (mask, "mask")):
+        if t is not None and tuple(t.shape) != (M, N):
+            raise ValueError(f"linear_ex: {name} must be [M,N]")
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device) if out is None else out
+    if tuple(y.shape) != (M, N) or not y.is_contiguous():
+        raise ValueError("linear_ex: out must be a contiguous [M,N] tensor")
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_gemm_nt_f32_ex(_ptr(x), x.stride(0) if M else K, _ptr(weight), weight.stride(0), _ptr(scale),
+                                               _ptr(bias), _ptr(residual), _ptr(mask), _ptr(y), N, M, N, K,
+                                               _lib.EPI_RELU if relu else 0, _stream(x)), "locov_gemm_nt_f32_ex")
+    return y
+
+
+def conv3x3_nhwc_ex(x: torch.Tensor, w_packed: torch.Tensor, H: int, W: int, *, scale=None, shift=None, residual=None,
+                    mask=None, relu: bool = False, pos_major: bool = False) -> torch.Tensor:
+    """conv3x3_nhwc() with the optional epilogue mask of linear_ex."""
+    x = _dev(x, "x")
+    w_packed = _dev(w_packed, "w_packed")
+    M, Cin = x.shape
+    N = w_packed.shape[0]
+    if w_packed.shape[1] != 9 * Cin or M % (H * W) != 0:
+        raise ValueError("conv3x3_nhwc_ex: inconsistent shapes")
+    scale = _dev(scale, "scale") if scale is not None else None
+    shift = _dev(shift, "shift") if shift is not None else None
+    residual = _dev(residual, "residual") if residual is not None else None
+    mask = _dev(mask, "mask") if mask is not None else None
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_conv3x3_nhwc_f32_ex(_ptr(x), M // (H * W), H, W, Cin, int(pos_major), _ptr(w_packed), _ptr(scale),
+                                                    _ptr(shift), _ptr(residual), _ptr(mask), _ptr(y), N,
+                                                    _lib.EPI_RELU if relu else 0, _stream(x)), "locov_conv3x3_nhwc_f32_ex")
+    return y
+
+
+def winograd_conv3x3_ex(x: torch.Tensor, U: torch.Tensor, *, scale=None, shift=None, mask=None, relu: bool = False,
+                        roi_major: bool = True) -> torch.Tensor:
+    """winograd_conv3x3() on the f32 MFMA with the optional output mask (rows of x, mask and the result in one order:
+    ROI-major by default)."""
+    x = _dev(x, "x")
+    U = _dev(U, "U")
+    M, Cin = x.shape
+    if U.dim() != 3 or U.shape[0] != 121 or U.shape[2] != Cin or M % 49 != 0:
+        raise ValueError("winograd_conv3x3_ex: inconsistent shapes")
+    N, R = U.shape[1], M // 49
+    scale = _dev(scale, "scale") if scale is not None else None
+    shift = _dev(shift, "shift") if shift is not None else None
+    mask = _dev(mask, "mask") if mask is not None else None
+    if mask is not None and tuple(mask.shape) != (M, N):
+        raise ValueError("winograd_conv3x3_ex: mask must be [49*R, N]")
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    ws = _workspace("wino", x, int(lib.locov_winograd_workspace_bytes(R, Cin, N)))
+    flags = (_lib.EPI_RELU if relu else 0) | ((_lib.WINO_OUT_ROI_MAJOR | _lib.WINO_IN_ROI_MAJOR) if roi_major else 0)
+    with torch.cuda.device(x.device):
+        check(lib.locov_winograd_conv3x3_f32_ex(_ptr(x), R, Cin, _ptr(U), _ptr(scale), _ptr(shift), _ptr(mask), _ptr(y), N, N,
+                                                flags, _ptr(ws), ws.numel(), _stream(x)), "locov_winograd_conv3x3_f32_ex")
+    return y
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[N,K] = row_scale[n] * sum_m a[m,n] * b[m,k]  (a [M,N], b [M,K], rows may be strided): the weight gradient
+    of a 1x1 convolution, dW = s * g^T x.  Deterministic (fixed-order reduction of the M chunks)."""
+    a, b = _rows(a, "a"), _rows(b, "b")
+    M, N = a.shape
+    K = b.shape[1]
+    if b.shape[0] != M or N % 4 or K % 4:
+        raise ValueError(f"gemm_tn: a {tuple(a.shape)} b {tuple(b.shape)} (N, K must be multiples of 4)")
+    row_scale = _dev(row_scale, "row_scale") if row_scale is not None else None
+    out = torch.empty((N, K), dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    ws = _workspace("tn", a, int(lib.locov_gemm_tn_workspace_bytes(M, N, K, 1)))
+    with torch.cuda.device(a.device):
+        check(lib.locov_gemm_tn_f32(_ptr(a), a.stride(0) if M else N, 0, _ptr(b), b.stride(0) if M else K, 0, _ptr(out), K, 0,
+                                    M, N, K, 1, _ptr(row_scale), _ptr(ws), ws.numel(), _stream(a)), "locov_gemm_tn_f32")
+    return out
+
+
+def winograd_wgrad(x: torch.Tensor, g: torch.Tensor, row_scale: Optional[torch.Tensor] = None,
+                   roi_major: bool = True) -> torch.Tensor:
+    """dw [N,Cin,3,3] = row_scale[n] * d/dw of conv3x3(x) . g over R 7x7 tiles, in the Winograd domain.
+    x [49*R, Cin], g [49*R, N], both in the same row order."""
+    x, g = _dev(x, "x"), _dev(g, "g")
+    M, Cin = x.shape
+    N = g.shape[1]
+    if g.shape[0] != M or M % 49 or Cin % 4 or N % 4:
+        raise ValueError("winograd_wgrad: inconsistent shapes")
+    R = M // 49
+    row_scale = _dev(row_scale, "row_scale") if row_scale is not None else None
+    dw = torch.empty((N, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    ws = _workspace("wino_wgrad", x, int(lib.locov_winograd_wgrad_workspace_bytes(R, Cin, N)))
+    with torch.cuda.device(x.device):
+        check(lib.locov_winograd_wgrad_f32(_ptr(x), _ptr(g), R, Cin, N, _lib.WINO_IN_ROI_MAJOR if roi_major else 0,
+                                           _ptr(row_scale), _ptr(dw), _ptr(ws), ws.numel(), _stream(x)),
+              "locov_winograd_wgrad_f32")
+    return dw
+
+
+def weight_transpose_scale(w: torch.Tensor, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """w [N,K] -> [K,N] with out[k,n] = row_scale[n] * w[n,k]."""
+    w = _dev(w, "w")
+    N, K = w.shape
+    row_scale = _dev(row_scale, "row_scale") if row_scale is not None else None
+    out = torch.empty((K, N), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        check(_lib.load().locov_weight_transpose_scale(_ptr(w), N, K, _ptr(row_scale), _ptr(out), _stream(w)),
+              "locov_weight_transpose_scale")
+    return out
+
+
+def conv3x3_weight_flip(w: torch.Tensor, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """w [N,Cin,3,3] -> [Cin,N,3,3] with out[c,n,a,b] = row_scale[n] * w[n,c,2-a,2-b]: the filter of the data gradient."""
+    w = _dev(w, "w")
+    N, Cin = w.shape[:2]
+    row_scale = _dev(row_scale, "row_scale") if row_scale is not None else None
+    out = torch.empty((Cin, N, 3, 3), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        check(_lib.load().locov_conv3x3_weight_flip(_ptr(w), N, Cin, _ptr(row_scale), _ptr(out), _stream(w)),
+              "locov_conv3x3_weight_flip")
+    return out
+
+
+def im2col3x3(x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """x [R*H*W, C] ROI-major pixel rows -> [R*H*W, 9*C] 3x3 / pad 1 patches (column = tap*C + c)."""
+    x = _dev(x, "x")
+    M, C = x.shape
+    if M % (H * W) or C % 4:
+        raise ValueError("im2col3x3: inconsistent shapes")
+    col = torch.empty((M, 9 * C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_im2col3x3_nhwc(_ptr(x), M // (H * W), H, W, C, _ptr(col), _stream(x)), "locov_im2col3x3_nhwc")
+    return col
+
+
+def conv3x3_wgrad_unpack(dw_packed: torch.Tensor, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[N, 9*Cin] (column = tap*Cin + c) -> [N,Cin,3,3], rows scaled."""
+    dw_packed = _dev(dw_packed, "dw_packed")
+    N, K9 = dw_packed.shape
+    Cin = K9 // 9
+    row_scale = _dev(row_scale, "row_scale") if row_scale is not None else None
+    dw = torch.empty((N, Cin, 3, 3), dtype=torch.float32, device=dw_packed.device)
+    with torch.cuda.device(dw.device):
+        check(_lib.load().locov_conv3x3_wgrad_unpack(_ptr(dw_packed), N, Cin, _ptr(row_scale), _ptr(dw), _stream(dw)),
+              "locov_conv3x3_wgrad_unpack")
+    return dw
+
+
+def relu_mask(g: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
+    """g where act > 0, else 0."""
+    g, act = _dev(g, "g"), _dev(act, "act")
+    if g.shape != act.shape or g.numel() % 4:
+        raise ValueError("relu_mask: shapes must match, numel % 4 == 0")
+    out = torch.empty_like(g)
+    with torch.cuda.device(g.device):
+        check(_lib.load().locov_relu_mask(_ptr(g), _ptr(act), g.numel(), _ptr(out), _stream(g)), "locov_relu_mask")
+    return out
+
+
+def spatial_mean_bwd(g: torch.Tensor, act: Optional[torch.Tensor], hw: int) -> torch.Tensor:
+    """g [R,C] -> [R*hw, C] ROI-major rows: g[r]/hw broadcast over the positions, zeroed where act <= 0."""
+    g = _dev(g, "g")
+    R, C = g.shape
+    act = _dev(act, "act") if act is not None else None
+    if act is not None and tuple(act.shape) != (R * hw, C):
+        raise ValueError("spatial_mean_bwd: act must be [R*hw, C]")
+    out = torch.empty((R * hw, C), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        check(_lib.load().locov_spatial_mean_bwd(_ptr(g), _ptr(act), R, C, hw, _ptr(out), _stream(g)), "locov_spatial_mean_bwd")
+    return out
+
+
+def rows_stride2(src: torch.Tensor, N: int, H: int, W: int, forward: bool) -> torch.Tensor:
+    """forward: channels-last map [N,H,W,C] -> rows of its even pixels [N*OH*OW, C]; else the adjoint (rows -> zero-filled map)."""
+    src = _dev(src, "src")
+    C = src.shape[-1]
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    out = torch.empty((N * OH * OW, C) if forward else (N, H, W, C), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        check(_lib.load().locov_rows_stride2(_ptr(src), N, H, W, C, int(forward), _ptr(out), _stream(src)), "locov_rows_stride2")
+    return out
+
+
+def roi_align_nhwc_bwd(grad_rows: torch.Tensor, feat_shape, rois: torch.Tensor, output_size: int, spatial_scale: float,
+                       sampling_ratio: int = 0, aligned: bool = True, bin_stride: int = 1, pos_major: bool = False) -> torch.Tensor:
+    """Adjoint of roi_align_nhwc: grad_rows [o*o*R, C] -> gradient of the channels-last map [N,H,W,C]."""
+    grad_rows = _rows(grad_rows, "grad_rows")
+    rois = _dev(rois, "rois")
+    N, H, W, C = feat_shape
+    gf = torch.zeros((N, H, W, C), dtype=torch.float32, device=grad_rows.device)
+    with torch.cuda.device(gf.device):
+        check(_lib.load().locov_roi_align_nhwc_bwd(_ptr(grad_rows), grad_rows.stride(0) if grad_rows.shape[0] else C, N, H, W, C,
+                                                   _ptr(rois), rois.shape[0], output_size, output_size, float(spatial_scale),
+                                                   int(sampling_ratio), int(aligned), int(bin_stride), int(pos_major), _ptr(gf),
+                                                   _stream(gf)), "locov_roi_align_nhwc_bwd")
+    return gf
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    """[N,H,W,C] -> [N,C,H,W] (the transpose kernel of nchw_to_nhwc with the roles of HW and C swapped)."""
+    x = _dev(x, "x")
+    N, H, W, C = x.shape
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_nchw_to_nhwc(_ptr(x), N, H * W, C, 1, _ptr(out), F32, _stream(x)), "locov_nchw_to_nhwc")
+    return out
+
+
 class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b on the f32 MFMA NT-GEMM kernel; backward re-uses the same kernel on transposed
-    operands (grad_x = g W, grad_W = g^T x, grad_b = sum g)."""
+    """y = x W^T + b on the f32 MFMA NT-GEMM kernel; backward: grad_x = g W as an NT GEMM against the transposed
+    weight (one small weight-sized transpose), grad_W = g^T x on the TN kernel (no activation-sized transposes),
+    grad_b = sum g."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -536,10 +774,14 @@ class _LinearFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
         gx = gw = gb = None
+        N, K = weight.shape
         if ctx.needs_input_grad[0]:
-            gx = linear(g, weight.t().contiguous())               # [M,N] . ([K,N])^T
+            gx = linear(g, weight_transpose_scale(weight.detach()))           # [M,N] . ([K,N])^T
         if ctx.needs_input_grad[1]:
-            gw = linear(g.t().contiguous(), x.t().contiguous())   # [N,M] . ([K,M])^T
+            if N % 4 == 0 and K % 4 == 0:
+                gw = gemm_tn(g, x)                                            # g^T x, contraction over the rows
+            else:                                                             # odd sizes (e.g. an 81-way cls_score): transposed copies
+                gw = linear(g.t().contiguous(), x.t().contiguous())
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(dim=0)
         return gx, gw, gb

@@ -1,0 +1,231 @@
+"""The Res5 stage under autograd on the hand-written gfx950 kernels (forward + data gradients + weight gradients).
+
+The LSM configuration trains the Res5 convolution weights (configs/coco_lsm.yaml:8 `FREEZE_AT: 0`; FrozenBN only
+freezes the statistics) through two call sites of ovr/modeling/roi_heads/roi_emb_heads.py:
+    :323      visual_grid_features = self.res5(features)            -- the whole res4 grid
+    :343-344  box_features = self._shared_roi_transform(...).mean() -- the sampled proposals (4 x 200 per GPU)
+The reference differentiates both through cuDNN (torch autograd).  Here every tensor is a channels-last pixel-row
+matrix [R*H*W, C] (ROI-major rows) and one torch.autograd.Function covers the whole stage:
+
+  forward   per bottleneck: 1x1 (GEMM, FrozenBN + ReLU in the epilogue) -> 3x3 (Winograd domain for 7x7 tiles, implicit
+            GEMM otherwise) -> 1x1 (+ projection shortcut / identity residual, ReLU); the post-ReLU activations are kept.
+  backward  with g the gradient of a block's output already masked by (output > 0):
+              dW3 = s3 * g^T y2                      TN GEMM over the pixel rows (gemm_tn.hip)
+              g2  = (g . s3 W3) * [y2 > 0]           NT GEMM, mask fused into the epilogue (gemm_nt.hip)
+              dW2 = s2 * wgrad3x3(y1, g2)            Winograd domain (121 TN GEMMs) or im2col + TN GEMM
+              g1  = conv3x3(g2, flip(s2 W2)) * [y1 > 0]
+              dW1 = s1 * g1^T x ;  dWs = ss * g^T x
+              gx  = (g1 . s1 W1 + g [. ss Ws]) * [x > 0]      = the masked gradient of the previous block's output
+            FrozenBN scales are folded into the transposed weights (data gradients) and applied to the rows of the
+            weight gradients; the statistics receive no gradient (buffers), exactly as in the reference.
+
+Gradients are exact fp32 (f32 MFMA); the forward runs in the arithmetic of the inference path (`split` = f16x2 split
+operands, or f32 MFMA).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import ops
+
+__all__ = ["res5_rows", "res5_grid", "roi_align_even_rows", "to_nhwc", "Res5RowsFn"]
+
+
+import os
+
+_NO_WINO_BWD = bool(int(os.environ.get("LOCOV_RES5_BWD_DIRECT", "0")))      # developer A/B: 3x3 gradients in the direct form
+
+
+def _wino_ok(H: int, W: int, cin: int, cout: int) -> bool:
+    return H == 7 and W == 7 and cin % 32 == 0 and cout % 4 == 0
+
+
+class Res5RowsFn(torch.autograd.Function):
+    """out = Res5(x0) on ROI-major pixel rows.  x0 [R*H*W, Cin] is the stage input already sub-sampled by block 0's
+    stride (the even positions: STRIDE_IN_1X1).  Returns the rows [R*H*W, Cout], or with `pooled` their per-ROI mean [R, Cout].
+    weights: the convolution weights in module order (block 0: conv1, conv2, conv3, shortcut; then conv1..conv3 of the
+    following blocks) -- passed as inputs so that autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, x0, stage, R, H, W, pooled, split, *weights):
+        x = ops._dev(x0.detach(), "x0")
+        saved: List[torch.Tensor] = []
+        meta = []
+        wi = 0
+        for blk in stage:
+            has_sc = blk.shortcut is not None
+            w1, s1, b1 = stage._packed(blk.conv1)
+            w3, s3, b3 = stage._packed(blk.conv3)
+            c2 = blk.conv2
+            y1 = stage._linear(split, x, w1, b1, scale=s1, relu=True)
+            wino = _wino_ok(H, W, c2.in_channels, c2.out_channels)
+            if wino:
+                u2, s2, b2 = stage._packed(c2, winograd=True)
+                y2 = ops.winograd_conv3x3(y1, stage._split(u2) if split else u2, scale=s2, shift=b2, relu=True,
+                                          roi_major=True, in_roi_major=True)
+            else:
+                w2, s2, b2 = stage._packed(c2)
+                y2 = ops.conv3x3_nhwc(y1, w2, H, W, scale=s2, shift=b2, relu=True, pos_major=False)
+            if has_sc:
+                ws, ss, bs = stage._packed(blk.shortcut)
+                sc = stage._linear(split, x, ws, bs, scale=ss)
+            else:
+                sc = x
+            out = stage._linear(split, y2, w3, b3, scale=s3, residual=sc, relu=True)
+            saved += [x, y1, y2, out]
+            meta.append((has_sc, wino, wi))
+            wi += 4 if has_sc else 3
+            x = out
+        ctx.stage, ctx.meta, ctx.geom, ctx.pooled = stage, meta, (R, H, W), pooled
+        ctx.nw = len(weights)
+        ctx.save_for_backward(*saved)
+        if pooled:
+            return ops.spatial_mean(x.view(R, H, W, x.shape[1]), channels_last=1)
+        return x
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        stage, (R, H, W) = ctx.stage, ctx.geom
+        saved = ctx.saved_tensors
+        need_x = ctx.needs_input_grad[0]
+        need_w = ctx.needs_input_grad[7:]
+        gw: List[Optional[torch.Tensor]] = [None] * ctx.nw
+        grad_out = ops._dev(grad_out, "grad_out")
+        out_last = saved[-1]
+        # gradient of the last block's output, masked by its ReLU
+        g = ops.spatial_mean_bwd(grad_out, out_last, H * W) if ctx.pooled else ops.relu_mask(grad_out, out_last)
+        for bi in range(len(stage) - 1, -1, -1):
+            blk = stage[bi]
+            has_sc, wino, wi = ctx.meta[bi]
+            x, y1, y2, _ = saved[4 * bi: 4 * bi + 4]
+            w1, s1, _ = stage._packed(blk.conv1)
+            w3, s3, _ = stage._packed(blk.conv3)
+            c2 = blk.conv2
+            # conv3: dW3 = s3 * g^T y2 ; g2 = (g . s3 W3) [y2 > 0]
+            if need_w[wi + 2]:
+                gw[wi + 2] = ops.gemm_tn(g, y2, s3).view_as(blk.conv3.weight)
+            g2 = ops.linear_ex(g, ops.weight_transpose_scale(w3, s3), mask=y2)
+            # conv2 (3x3): dW2 = s2 * wgrad(y1, g2) ; g1 = conv3x3(g2, flip(s2 W2)) [y1 > 0]
+            _, s2, _ = stage._packed(c2)
+            w2 = c2.weight.detach()
+            if need_w[wi + 1]:
+                if wino and c2.out_channels % 4 == 0 and not _NO_WINO_BWD:
+                    gw[wi + 1] = ops.winograd_wgrad(y1, g2, s2, roi_major=True)
+                else:
+                    gw[wi + 1] = ops.conv3x3_wgrad_unpack(ops.gemm_tn(g2, ops.im2col3x3(y1, H, W)), s2)
+            wflip = ops.conv3x3_weight_flip(w2, s2)                       # [Cin, Cout, 3, 3]
+            if _wino_ok(H, W, c2.out_channels, c2.in_channels) and not _NO_WINO_BWD:
+                g1 = ops.winograd_conv3x3_ex(g2, ops.winograd_pack_weight(wflip), mask=y1, roi_major=True)
+            else:
+                g1 = ops.conv3x3_nhwc_ex(g2, ops.pack_conv3x3_weight(wflip), H, W, mask=y1, pos_major=False)
+            del g2
+            # conv1 (+ shortcut): dW1 = s1 * g1^T x ; gx = (g1 . s1 W1 + shortcut path) [x > 0]
+            if need_w[wi]:
+                gw[wi] = ops.gemm_tn(g1, x, s1).view_as(blk.conv1.weight)
+            if has_sc:
+                ws, ss, _ = stage._packed(blk.shortcut)
+                if need_w[wi + 3]:
+                    gw[wi + 3] = ops.gemm_tn(g, x, ss).view_as(blk.shortcut.weight)
+            first = bi == 0
+            if first and not need_x:
+                g = None
+                break
+            # the input of block 0 is the pooler output (no ReLU in front of it); every other block's input is the
+            # post-ReLU output of its predecessor, whose mask turns gx into that block's masked output gradient
+            mask = None if first else x
+            gx = ops.linear_ex(g1, ops.weight_transpose_scale(w1, s1), residual=None if has_sc else g,
+                               mask=None if has_sc else mask)
+            if has_sc:
+                gx = ops.linear_ex(g, ops.weight_transpose_scale(ws, ss), residual=gx, mask=mask)
+            del g1
+            g = gx
+        return (g, None, None, None, None, None, None, *gw)
+
+
+def _stage_weights(stage) -> Tuple[torch.Tensor, ...]:
+    ws = []
+    for blk in stage:
+        ws += [blk.conv1.weight, blk.conv2.weight, blk.conv3.weight]
+        if blk.shortcut is not None:
+            ws.append(blk.shortcut.weight)
+    return tuple(ws)
+
+
+def res5_rows(stage, x0: torch.Tensor, R: int, H: int, W: int, pooled: bool = False, split: bool = True) -> torch.Tensor:
+    """Differentiable Res5 on ROI-major pixel rows (see Res5RowsFn)."""
+    assert stage.supports_rows_path(), "the rows path needs FrozenBN, STRIDE_IN_1X1 and ungrouped convolutions"
+    return Res5RowsFn.apply(x0, stage, R, H, W, pooled, split, *_stage_weights(stage))
+
+
+class _ToNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.nchw_to_nhwc(x.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.nhwc_to_nchw(g)
+
+
+class _ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.nhwc_to_nchw(x.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.nchw_to_nhwc(g)
+
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """[N,C,H,W] -> [N,H,W,C], differentiable."""
+    return _ToNHWC.apply(x)
+
+
+class _RoiAlignEvenRows(torch.autograd.Function):
+    """Even-grid ROIAlign of a channels-last map -> ROI-major rows [oh*ow*R, C] (oh = P/2), differentiable in the map."""
+
+    @staticmethod
+    def forward(ctx, nhwc, rois, P, scale, sampling_ratio, aligned):
+        out = ops.roi_align_nhwc(nhwc.detach(), rois, P, scale, sampling_ratio, aligned, bin_stride=2, pos_major=False)
+        ctx.save_for_backward(rois)
+        ctx.args = (tuple(nhwc.shape), P, scale, sampling_ratio, aligned)
+        return out.view(-1, nhwc.shape[3])
+
+    @staticmethod
+    def backward(ctx, g):
+        (rois,) = ctx.saved_tensors
+        shape, P, scale, sampling_ratio, aligned = ctx.args
+        return ops.roi_align_nhwc_bwd(g, shape, rois, P, scale, sampling_ratio, aligned, bin_stride=2, pos_major=False), \
+            None, None, None, None, None
+
+
+def roi_align_even_rows(nhwc, rois, P, scale, sampling_ratio, aligned) -> torch.Tensor:
+    return _RoiAlignEvenRows.apply(nhwc, rois, int(P), float(scale), int(sampling_ratio), bool(aligned))
+
+
+class _Stride2Rows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, nhwc):
+        N, H, W, _ = nhwc.shape
+        ctx.dims = (N, H, W)
+        return ops.rows_stride2(nhwc.detach(), N, H, W, True)
+
+    @staticmethod
+    def backward(ctx, g):
+        N, H, W = ctx.dims
+        return ops.rows_stride2(g, N, H, W, False)
+
+
+def res5_grid(stage, nhwc: torch.Tensor, split: bool = True) -> torch.Tensor:
+    """roi_emb_heads.py:323 -- the stage applied to the whole channels-last res4 map [N,H,W,Cin] -> logical NCHW
+    [N, Cout, ceil(H/2), ceil(W/2)], differentiable in the map and the convolution weights.  Block 0's stride-2 1x1
+    convolutions read the even pixels; the 3x3 convolutions run as implicit GEMMs over the (H/2 x W/2) grid."""
+    N, H, W, _ = nhwc.shape
+    assert stage[0].stride == 2 and stage[0].stride_in_1x1
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    rows = _Stride2Rows.apply(nhwc)
+    y = res5_rows(stage, rows, N, OH, OW, pooled=False, split=split)
+    return _ToNCHW.apply(y.view(N, OH, OW, y.shape[1]))

@@ -251,18 +251,37 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
     def _build_res5_block(cls, cfg):
         return build_res5_block(cfg)
 
-    def _fused_path_ok(self, features: List[torch.Tensor]) -> bool:
-        """The channels-last hand-written path: inference (no autograd graph needed), one feature
-        level, FrozenBN Res5 whose block 0 strides in its 1x1 convs, even pooler resolution."""
+    def _rows_path_ok(self, features: List[torch.Tensor]) -> bool:
+        """The channels-last hand-written path: one feature level, FrozenBN Res5 whose block 0 strides in its
+        1x1 convs, even pooler resolution."""
         if self.res5_backend != "hip" or len(features) != 1:
-            return False
-        if torch.is_grad_enabled() and (features[0].requires_grad or any(p.requires_grad for p in self.res5.parameters())):
             return False
         ph, pw = self.pooler.output_size
         return (hasattr(self.res5, "forward_rows") and self.res5.supports_rows_path() and self.res5[0].stride == 2
-                and ph == pw and ph % 2 == 0 and features[0].shape[1] % 32 == 0)
+                and ph == pw and ph % 2 == 0 and features[0].shape[1] % 32 == 0 and features[0].is_cuda)
 
-    def _shared_roi_transform(self, features: List[torch.Tensor], boxes: List[Boxes], pooled: bool = False):
+    def _needs_graph(self, features: List[torch.Tensor]) -> bool:
+        return torch.is_grad_enabled() and (features[0].requires_grad or any(p.requires_grad for p in self.res5.parameters()))
+
+    def _fused_path_ok(self, features: List[torch.Tensor]) -> bool:
+        """The inference form of the rows path (no autograd graph needed)."""
+        return self._rows_path_ok(features) and not self._needs_graph(features)
+
+    def _train_path_ok(self, features: List[torch.Tensor]) -> bool:
+        """The differentiable form (locov_amd/res5_train.py): forward, data and weight gradients on the HIP kernels."""
+        return self._rows_path_ok(features) and self.res5_dtype in ("fp32", "f16x2")
+
+    def _res5_grid(self, feature: torch.Tensor, nhwc: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """roi_emb_heads.py:323: self.res5(features) on the whole res4 grid -> [N, C5, H/2, W/2]."""
+        if not self._train_path_ok([feature]):
+            return self.res5(feature)
+        from .. import res5_train
+        if nhwc is None:
+            nhwc = res5_train.to_nhwc(feature)
+        return res5_train.res5_grid(self.res5, nhwc, split=self.res5_dtype == "f16x2")
+
+    def _shared_roi_transform(self, features: List[torch.Tensor], boxes: List[Boxes], pooled: bool = False,
+                              nhwc: Optional[torch.Tensor] = None):
         """roi_emb_heads.py:243-245: res5(pooler(features, boxes)) -> [R, C5, P/2, P/2]; with `pooled` the spatial
         mean of that tensor, [R, C5] (:262,:344,:356), which on the hand-written path in split arithmetic comes fused
         out of Res5's last 1x1 convolution.
@@ -270,6 +289,19 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         MI355X path: ROIAlign is evaluated on a channels-last copy of the map and only at the even
         bins the stride-2 1x1 convs of block 0 read; Res5 then runs as MFMA GEMMs over pixel rows.
         The result is returned as a logical NCHW tensor in channels-last memory."""
+        if self._needs_graph(features) and self._train_path_ok(features):
+            # training: the same pipeline as differentiable HIP ops (even-grid ROIAlign -> Res5 rows with data and
+            # weight gradients -> mean); `nhwc` lets the caller share the channels-last copy with the whole-grid call
+            from .. import res5_train
+            assert len(boxes) == features[0].shape[0]
+            rois = convert_boxes_to_pooler_format(boxes)
+            P = self.pooler.output_size[0]
+            if nhwc is None:
+                nhwc = res5_train.to_nhwc(features[0])
+            x0 = res5_train.roi_align_even_rows(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned)
+            R, o = rois.shape[0], P // 2
+            y = res5_train.res5_rows(self.res5, x0, R, o, o, pooled=pooled, split=self.res5_dtype == "f16x2")
+            return y if pooled else y.view(R, o, o, y.shape[1]).permute(0, 3, 1, 2)
         if not self._fused_path_ok(features):
             x = self.pooler(features, boxes)                 # :244
             x = self.res5(x)                                 # :245
@@ -362,10 +394,15 @@ class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
             return self.inference_detection(features, proposals)
         proposals = self.label_and_sample_proposals(proposals, targets)
         del targets
-        visual_grid_features = self.res5(features[self.in_features[0]])          # :323
+        feats = [features[f] for f in self.in_features]
+        nhwc = None
+        if self._train_path_ok(feats) and self._needs_graph(feats):
+            from .. import res5_train
+            nhwc = res5_train.to_nhwc(feats[0])          # one channels-last copy (and one gradient transpose) for both calls
+        visual_grid_features = self._res5_grid(feats[0], nhwc)                   # :323
         proposal_boxes = [x.proposal_boxes for x in proposals]
         boxes_per_image = [len(x) for x in proposals]
-        box_features = self._shared_roi_transform([features[f] for f in self.in_features], proposal_boxes, pooled=True)   # :343-344
+        box_features = self._shared_roi_transform(feats, proposal_boxes, pooled=True, nhwc=nhwc)   # :343-344
         del features
         losses = {}
         predictions = self.box_predictor(box_features)                           # :345

@@ -1,0 +1,442 @@
+"""GPU parity of the Res5 stage under autograd (roi_emb_heads.py:323,343-347 with trainable Res5 convolutions,
+configs/coco_lsm.yaml:8): the hand-written forward / data-gradient / weight-gradient kernels against a float64
+torch-autograd evaluation of the oracle's bottleneck chain (oracle.bottleneck, oracle/lsm_oracle.py) on the same inputs.
+Gate: every gradient within 1e-4 of the float64 one relative to that gradient's largest entry."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device")
+    import locov_amd
+    from locov_amd import _lib
+    _lib.load()
+    return locov_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rel_err(got: torch.Tensor, want: torch.Tensor) -> float:
+    want = want.double().cpu()
+    return float((got.detach().double().cpu() - want).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (777, 64, 96), (4097, 256, 36), (31, 4, 2048), (39200, 512, 256)])
+def test_gemm_tn_vs_float64(pkg, M, N, K):
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, N, generator=g).cuda()
+    b = torch.randn(M, K, generator=g).cuda()
+    s = (torch.rand(N, generator=g) + 0.5).cuda()
+    want = (a.double().t() @ b.double()) * s.double()[:, None]
+    got = ops.gemm_tn(a, b, s)
+    assert rel_err(got, want) < 2e-6
+    assert torch.equal(got, ops.gemm_tn(a, b, s)), "the chunk reduction must be deterministic"
+    # strided operands (column blocks of wider matrices), no scale
+    wide_a = torch.randn(M, N + 8, generator=g).cuda()
+    wide_b = torch.randn(M, K + 12, generator=g).cuda()
+    got = ops.gemm_tn(wide_a[:, 4:4 + N], wide_b[:, 8:8 + K])
+    want = wide_a[:, 4:4 + N].double().t() @ wide_b[:, 8:8 + K].double()
+    assert rel_err(got, want) < 2e-6
+
+
+def test_gemm_tn_empty(pkg):
+    ops = pkg.ops
+    out = ops.gemm_tn(torch.zeros(0, 8, device="cuda"), torch.zeros(0, 12, device="cuda"))
+    assert out.shape == (8, 12) and float(out.abs().max()) == 0.0
+
+
+def test_linear_ex_mask_and_strided_weight(pkg):
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(5)
+    for (M, N, K) in ((300, 96, 64), (1000, 260, 128), (129, 36, 40)):
+        x = torch.randn(M, K, generator=g).cuda()
+        wide = torch.randn(N, K + 16, generator=g).cuda()
+        w = wide[:, 8:8 + K]
+        res = torch.randn(M, N, generator=g).cuda()
+        act = torch.randn(M, N, generator=g).cuda()
+        sc = (torch.rand(N, generator=g) + 0.5).cuda()
+        want = (x.double() @ w.double().t()) * sc.double() + res.double()
+        want = torch.where(act.double() > 0, want, torch.zeros_like(want))
+        got = ops.linear_ex(x, w, scale=sc, residual=res, mask=act)
+        assert rel_err(got, want) < 2e-6
+        assert float(got[act <= 0].abs().max()) == 0.0
+        # without a mask the extended entry equals the plain one bit for bit
+        assert torch.equal(ops.linear_ex(x, w.contiguous(), scale=sc, residual=res), ops.linear(x, w.contiguous(), scale=sc, residual=res))
+
+
+def test_small_backward_kernels(pkg):
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(6)
+    w = torch.randn(70, 52, generator=g).cuda()
+    s = torch.randn(70, generator=g).cuda()
+    assert torch.equal(ops.weight_transpose_scale(w, s), (w * s[:, None]).t().contiguous())
+    assert torch.equal(ops.weight_transpose_scale(w), w.t().contiguous())
+    w3 = torch.randn(24, 40, 3, 3, generator=g).cuda()
+    s3 = torch.randn(24, generator=g).cuda()
+    want = (w3 * s3[:, None, None, None]).flip(2, 3).permute(1, 0, 2, 3).contiguous()
+    assert torch.equal(ops.conv3x3_weight_flip(w3, s3), want)
+    # im2col == unfold (tap-major columns)
+    x = torch.randn(3, 8, 5, 6, generator=g).cuda()
+    rows = x.permute(0, 2, 3, 1).reshape(-1, 8).contiguous()
+    col = ops.im2col3x3(rows, 5, 6)
+    want = F.unfold(x, 3, padding=1).view(3, 8, 9, 30).permute(0, 3, 2, 1).reshape(90, 72)
+    assert torch.equal(col, want.contiguous())
+    p = torch.randn(24, 9 * 40, generator=g).cuda()
+    want = (p.view(24, 9, 40).permute(0, 2, 1).reshape(24, 40, 3, 3) * s3[:, None, None, None]).contiguous()
+    assert torch.equal(ops.conv3x3_wgrad_unpack(p, s3), want)
+    a, gr = torch.randn(50, 12, generator=g).cuda(), torch.randn(50, 12, generator=g).cuda()
+    assert torch.equal(ops.relu_mask(gr, a), torch.where(a > 0, gr, torch.zeros_like(gr)))
+    gp = torch.randn(7, 12, generator=g).cuda()
+    act = torch.randn(7 * 9, 12, generator=g).cuda()
+    want = torch.where(act > 0, (gp * (1.0 / 9.0)).repeat_interleave(9, 0), torch.zeros_like(act))
+    torch.testing.assert_close(ops.spatial_mean_bwd(gp, act, 9), want, rtol=1e-6, atol=0)
+    m = torch.randn(2, 5, 7, 8, generator=g).cuda()          # [N,H,W,C], odd sizes
+    assert torch.equal(ops.rows_stride2(m, 2, 5, 7, True).view(2, 3, 4, 8), m[:, ::2, ::2])
+    r = torch.randn(2 * 3 * 4, 8, generator=g).cuda()
+    back = ops.rows_stride2(r, 2, 5, 7, False)
+    want = torch.zeros_like(m)
+    want[:, ::2, ::2] = r.view(2, 3, 4, 8)
+    assert torch.equal(back, want)
+    assert torch.equal(ops.nhwc_to_nchw(m), m.permute(0, 3, 1, 2).contiguous())
+
+
+def test_roi_align_even_backward_is_the_adjoint(pkg, oracle):
+    """<ROIAlign_even(F), G> == <F, ROIAlign_even^T(G)>, and the backward equals the oracle's torchvision-style
+    roi_align_backward fed the gradient at the even bins only."""
+    ops = pkg.ops
+    rng = np.random.default_rng(8)
+    N, C, H, W, R = 2, 32, 50, 84, 60
+    feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    boxes = [oracle.synth_boxes(rng, R // 2), oracle.synth_boxes(rng, R // 2)]
+    boxes[0][0] = [-40.0, -30.0, 20.0, 25.0]           # partly outside the map
+    boxes[1][1] = [5.0, 5.0, 5.0, 5.0]                 # empty box
+    rois = oracle.boxes_to_pooler_format(boxes)
+    nhwc = ops.nchw_to_nhwc(dev(feat))
+    for pos_major in (False, True):
+        y = ops.roi_align_nhwc(nhwc, dev(rois), 14, 1 / 16, 0, True, bin_stride=2, pos_major=pos_major)
+        G = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).cuda()
+        gf = ops.roi_align_nhwc_bwd(G.view(-1, C), (N, H, W, C), dev(rois), 14, 1 / 16, 0, True, bin_stride=2, pos_major=pos_major)
+        lhs = float((y.double() * G.double()).sum())
+        rhs = float((nhwc.double() * gf.double()).sum())
+        assert abs(lhs - rhs) <= 1e-5 * float(y.double().norm() * G.double().norm())
+        if not pos_major:
+            g14 = np.zeros((R, C, 14, 14), np.float32)
+            g14[:, :, ::2, ::2] = G.view(R, 7, 7, C).permute(0, 3, 1, 2).cpu().numpy()
+            want = oracle.roi_align_backward(g14, (N, C, H, W), rois, 1 / 16, 0, True)
+            got = gf.permute(0, 3, 1, 2).cpu().numpy()
+            assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1.0)
+
+
+@pytest.mark.parametrize("R,Cin,N", [(5, 32, 48), (70, 64, 64), (300, 128, 96)])
+def test_winograd_gradients_vs_float64(pkg, R, Cin, N):
+    """3x3 convolution of 7x7 tiles: weight gradient (Winograd-domain TN GEMMs) and masked data gradient (Winograd
+    convolution with the flipped filter) against float64 autograd of F.conv2d."""
+    ops = pkg.ops
+    gen = torch.Generator().manual_seed(R)
+    x = torch.randn(R, Cin, 7, 7, generator=gen)
+    w = torch.randn(N, Cin, 3, 3, generator=gen) * 0.1
+    s = torch.rand(N, generator=gen) + 0.5
+    gy = torch.randn(R, N, 7, 7, generator=gen)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    (F.conv2d(xd, wd, padding=1) * s.double().view(1, -1, 1, 1) * gy.double()).sum().backward()
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(R * 49, -1).contiguous().cuda()
+    dw = ops.winograd_wgrad(rows(x), rows(gy), s.cuda(), roi_major=True)
+    assert rel_err(dw, wd.grad) < 2e-5
+    # position-major rows give the same gradient
+    prow = lambda t: t.permute(2, 3, 0, 1).reshape(49 * R, -1).contiguous().cuda()
+    dwp = ops.winograd_wgrad(prow(x), prow(gy), s.cuda(), roi_major=False)
+    assert rel_err(dwp, wd.grad) < 2e-5
+    if N % 32 == 0:           # the data gradient is a convolution FROM the N output channels
+        act = torch.randn(R, Cin, 7, 7, generator=gen)
+        U = ops.winograd_pack_weight(ops.conv3x3_weight_flip(w.cuda(), s.cuda()))
+        gx = ops.winograd_conv3x3_ex(rows(gy), U, mask=rows(act), roi_major=True)
+        want = torch.where(act.double() > 0, xd.grad, torch.zeros_like(xd.grad))
+        assert rel_err(gx.view(R, 7, 7, Cin).permute(0, 3, 1, 2), want) < 2e-5
+
+
+@pytest.mark.parametrize("R,H,W,Cin,N", [(3, 13, 21, 32, 40), (2, 25, 42, 64, 64)])
+def test_grid_conv3x3_gradients_vs_float64(pkg, R, H, W, Cin, N):
+    """The general-grid form: weight gradient = TN GEMM against im2col patches, data gradient = implicit-GEMM convolution
+    with the flipped filter and the mask epilogue."""
+    ops = pkg.ops
+    gen = torch.Generator().manual_seed(H)
+    x = torch.randn(R, Cin, H, W, generator=gen)
+    w = torch.randn(N, Cin, 3, 3, generator=gen) * 0.1
+    s = torch.rand(N, generator=gen) + 0.5
+    gy = torch.randn(R, N, H, W, generator=gen)
+    act = torch.randn(R, Cin, H, W, generator=gen)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    (F.conv2d(xd, wd, padding=1) * s.double().view(1, -1, 1, 1) * gy.double()).sum().backward()
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(R * H * W, -1).contiguous().cuda()
+    dw = ops.conv3x3_wgrad_unpack(ops.gemm_tn(rows(gy), ops.im2col3x3(rows(x), H, W)), s.cuda())
+    assert rel_err(dw, wd.grad) < 2e-6
+    if N % 32 == 0:
+        wfp = ops.pack_conv3x3_weight(ops.conv3x3_weight_flip(w.cuda(), s.cuda()))
+        gx = ops.conv3x3_nhwc_ex(rows(gy), wfp, H, W, mask=rows(act))
+        want = torch.where(act.double() > 0, xd.grad, torch.zeros_like(xd.grad))
+        assert rel_err(gx.view(R, H, W, Cin).permute(0, 3, 1, 2), want) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ the stage
+def _stage(pkg, oracle, in_ch, mid, out_ch, seed):
+    from locov_amd.config import get_cfg
+    from locov_amd.res5 import build_res5_block
+    cfg = get_cfg()
+    cfg.MODEL.RESNETS.RES2_OUT_CHANNELS = out_ch // 8
+    cfg.MODEL.RESNETS.WIDTH_PER_GROUP = mid // 8
+    res5, oc = build_res5_block(cfg)
+    assert oc == out_ch
+    params = oracle.make_res5_params(seed, in_ch=in_ch, mid=mid, out_ch=out_ch)
+    res5.load_state_dict(params)
+    return res5.cuda().train(), params
+
+
+def _float64_stage(oracle, params, x, masks=None):
+    """The oracle's bottleneck chain (oracle.bottleneck = [D2-upstream] BottleneckBlock.forward) with autograd on, in
+    float64.  masks = None: oracle.bottleneck itself.  masks = [(y1 > 0, y2 > 0, out > 0)] per block, NCHW bool: the same
+    chain with every ReLU replaced by the given 0/1 pattern.
+
+    Why: a ReLU's derivative is a step function.  A pre-activation that is zero to within fp32 rounding can land on either
+    side in an fp32 forward and in the float64 one; such a unit passes its whole gradient in one evaluation and none in the
+    other, so ONE flipped unit moves entries of a weight gradient by ~1e-3 of the largest entry (measured: 1 of 263 000 units
+    of the stage output flips at R = 21, and d/dW of the last convolution then differs by 2e-3) -- any two correct fp32
+    implementations differ from float64, and from each other, by that much.  The gradient gate is therefore evaluated on the
+    function the device actually computed: float64 arithmetic, the device's active set.  The forward (and hence the active
+    set, up to such ties) is gated separately against the plain oracle."""
+    p = {k: v.double().requires_grad_(".norm." not in k) for k, v in params.items()}
+    y = x
+    for i, stride in enumerate((2, 1, 1)):
+        pre = f"{i}."
+        if masks is None:
+            y = oracle.bottleneck(y, p, pre, stride, True)
+            continue
+        m1, m2, m3 = (m.double() for m in masks[i])
+        o = oracle.frozen_bn(F.conv2d(y, p[pre + "conv1.weight"], stride=stride), p, pre + "conv1.norm.") * m1
+        o = oracle.frozen_bn(F.conv2d(o, p[pre + "conv2.weight"], padding=1), p, pre + "conv2.norm.") * m2
+        o = oracle.frozen_bn(F.conv2d(o, p[pre + "conv3.weight"]), p, pre + "conv3.norm.")
+        sc = y
+        if (pre + "shortcut.weight") in p:
+            sc = oracle.frozen_bn(F.conv2d(y, p[pre + "shortcut.weight"], stride=stride), p, pre + "shortcut.norm.")
+        y = (o + sc) * m3
+    return y, p
+
+
+def _device_masks(fn_out, R, H, W):
+    """The active sets of the device forward: (y1 > 0, y2 > 0, out > 0) per block as NCHW bool tensors on the CPU, read from
+    the activations Res5RowsFn saved for its backward."""
+    node, stack = None, [fn_out.grad_fn]
+    while stack:                                        # the Res5RowsFn node may sit behind view / layout nodes
+        n = stack.pop()
+        if n is None:
+            continue
+        if "Res5RowsFn" in type(n).__name__:
+            node = n
+            break
+        stack += [f for f, _ in n.next_functions]
+    saved = node.saved_tensors
+    nchw = lambda t: (t.detach().view(R, H, W, -1).permute(0, 3, 1, 2) > 0).cpu()
+    return [tuple(nchw(saved[4 * b + j]) for j in (1, 2, 3)) for b in range(len(saved) // 4)]
+
+
+def test_float64_reference_with_its_own_masks_is_the_oracle(oracle):
+    """The masked restatement used by the gradient gates equals oracle.bottleneck when given the oracle's own active sets."""
+    params = oracle.make_res5_params(3, in_ch=32, mid=16, out_ch=64)
+    x = torch.randn(3, 32, 14, 14, generator=torch.Generator().manual_seed(2)).double()
+    y, _ = _float64_stage(oracle, params, x)
+    masks, t = [], x
+    p = {k: v.double() for k, v in params.items()}
+    for i, stride in enumerate((2, 1, 1)):
+        pre = f"{i}."
+        o1 = F.relu(oracle.frozen_bn(F.conv2d(t, p[pre + "conv1.weight"], stride=stride), p, pre + "conv1.norm."))
+        o2 = F.relu(oracle.frozen_bn(F.conv2d(o1, p[pre + "conv2.weight"], padding=1), p, pre + "conv2.norm."))
+        t = oracle.bottleneck(t, p, pre, stride, True)
+        masks.append((o1 > 0, o2 > 0, t > 0))
+    ym, _ = _float64_stage(oracle, params, x, masks)
+    assert torch.equal(y.detach(), ym.detach())
+
+
+def _weight_keys(params):
+    return [k for k in params if k.endswith(".weight") and ".norm." not in k]
+
+
+@pytest.mark.parametrize("dims,R,split", [((128, 64, 256), 21, False), ((128, 64, 256), 21, True),
+                                          ((1024, 512, 2048), 12, False), ((1024, 512, 2048), 12, True)])
+def test_res5_rows_gradients_vs_float64(pkg, oracle, dims, R, split):
+    """ROI tiles (7x7 after block 0's stride): d loss / d {stage input, every convolution weight} with the spatial mean
+    behind the stage (roi_emb_heads.py:343-344), small and configs/coco_lsm.yaml channel sizes, both forward arithmetics."""
+    from locov_amd import res5_train
+    in_ch, mid, out_ch = dims
+    res5, params = _stage(pkg, oracle, in_ch, mid, out_ch, seed=R)
+    gen = torch.Generator().manual_seed(17)
+    x14 = torch.randn(R, in_ch, 14, 14, generator=gen)
+    gy = torch.randn(R, out_ch, generator=gen)
+    x0 = x14[:, :, ::2, ::2].permute(0, 2, 3, 1).reshape(R * 49, in_ch).contiguous().cuda().requires_grad_(True)
+    out = res5_train.res5_rows(res5, x0, R, 7, 7, pooled=True, split=split)
+    with torch.no_grad():
+        y_oracle, _ = _float64_stage(oracle, params, x14.double())
+    assert rel_err(out, y_oracle.mean(dim=[2, 3])) < (2e-5 if split else 1e-5)        # forward: the plain oracle
+    masks = _device_masks(out, R, 7, 7)
+    flips = int((masks[-1][2] != (y_oracle > 0)).sum())
+    assert flips <= 1e-4 * y_oracle.numel(), flips                                       # active sets agree up to fp32 ties
+    xd = x14.double().requires_grad_(True)
+    yd, pd = _float64_stage(oracle, params, xd, masks)
+    (yd.mean(dim=[2, 3]) * gy.double()).sum().backward()
+    (out * gy.cuda()).sum().backward()
+    want_x = xd.grad[:, :, ::2, ::2].permute(0, 2, 3, 1).reshape(R * 49, in_ch)
+    assert float(xd.grad[:, :, 1::2, :].abs().max()) == 0.0       # stride 2: the odd positions carry no gradient
+    errs = {"x0": rel_err(x0.grad, want_x)}
+    sd = dict(res5.named_parameters())
+    for k in _weight_keys(params):
+        errs[k] = rel_err(sd[k].grad, pd[k].grad)
+    assert max(errs.values()) < 1e-4, errs
+    # un-pooled output + plain (non-mean) gradient
+    x0b = x0.detach().clone().requires_grad_(True)
+    res5.zero_grad()
+    rows = res5_train.res5_rows(res5, x0b, R, 7, 7, pooled=False, split=split)
+    G = torch.randn(rows.shape, generator=gen).cuda()
+    masks = _device_masks(rows, R, 7, 7)
+    (rows * G).sum().backward()
+    xd2 = x14.double().requires_grad_(True)
+    yd2, pd2 = _float64_stage(oracle, params, xd2, masks)
+    (yd2 * G.view(R, 7, 7, out_ch).permute(0, 3, 1, 2).double().cpu()).sum().backward()
+    errs = {"x0": rel_err(x0b.grad, xd2.grad[:, :, ::2, ::2].permute(0, 2, 3, 1).reshape(R * 49, in_ch))}
+    for k in _weight_keys(params):
+        errs[k] = rel_err(sd[k].grad, pd2[k].grad)
+    assert max(errs.values()) < 1e-4, errs
+
+
+@pytest.mark.parametrize("dims,N,H,W", [((128, 64, 256), 2, 26, 43), ((1024, 512, 2048), 2, 50, 84)])
+def test_res5_grid_gradients_vs_float64(pkg, oracle, dims, N, H, W):
+    """roi_emb_heads.py:323: the stage on the whole res4 grid (NCHW in, NCHW out), output and gradients w.r.t. the map
+    and every convolution weight."""
+    from locov_amd import res5_train
+    in_ch, mid, out_ch = dims
+    res5, params = _stage(pkg, oracle, in_ch, mid, out_ch, seed=N + H)
+    gen = torch.Generator().manual_seed(23)
+    feat = torch.randn(N, in_ch, H, W, generator=gen)
+    f = feat.cuda().requires_grad_(True)
+    y = res5_train.res5_grid(res5, res5_train.to_nhwc(f), split=False)
+    with torch.no_grad():
+        y_oracle, _ = _float64_stage(oracle, params, feat.double())
+    assert tuple(y.shape) == tuple(y_oracle.shape)
+    assert rel_err(y, y_oracle) < 1e-5                                                   # forward: the plain oracle
+    masks = _device_masks(y, N, y.shape[2], y.shape[3])
+    assert int((masks[-1][2] != (y_oracle > 0)).sum()) <= 1e-4 * y_oracle.numel()
+    fd = feat.double().requires_grad_(True)
+    yd, pd = _float64_stage(oracle, params, fd, masks)
+    G = torch.randn(yd.shape, generator=gen)
+    (yd * G.double()).sum().backward()
+    (y * G.cuda()).sum().backward()
+    errs = {"feat": rel_err(f.grad, fd.grad)}
+    sd = dict(res5.named_parameters())
+    for k in _weight_keys(params):
+        errs[k] = rel_err(sd[k].grad, pd[k].grad)
+    assert max(errs.values()) < 1e-4, errs
+
+
+# ------------------------------------------------------------------------------------------------ the heads
+def _train_heads(pkg, oracle, backend, dtype, small=True):
+    from locov_amd.structures import ShapeSpec
+    cfg = pkg.config.get_cfg()
+    if small:
+        cfg.MODEL.RESNETS.RES2_OUT_CHANNELS = 32        # res5: 128 -> (64) -> 256
+        cfg.MODEL.RESNETS.WIDTH_PER_GROUP = 8
+        cfg.MODEL.ROI_BOX_HEAD.EMB_DIM = 96
+    cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
+    cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED = True
+    cfg.MODEL.ROI_BOX_HEAD.FREEZE_EMB_PRED = False
+    cfg.MODEL.ROI_HEADS.NAME = "EmbeddingProposalsRes5ROIHeads"
+    cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 24 if small else 200
+    cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION = 1.0
+    cfg.MODEL.ROI_HEADS.DETACH_CLASS_PREDICTOR = True
+    cfg.MODEL.ROI_BOX_HEAD.RES5_BACKEND = backend
+    cfg.MODEL.ROI_BOX_HEAD.RES5_DTYPE = dtype
+    c_in = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS * 4
+    torch.manual_seed(3)
+    heads = pkg.build_roi_heads(cfg, {"res4": ShapeSpec(channels=c_in, stride=16)})
+    params = oracle.make_res5_params(9, in_ch=c_in, mid=cfg.MODEL.RESNETS.WIDTH_PER_GROUP * 8, out_ch=heads.output_shape)
+    heads.res5.load_state_dict(params)
+    rng = np.random.default_rng(9)
+    h = oracle.synth_head(rng, heads.output_shape, cfg.MODEL.ROI_BOX_HEAD.EMB_DIM, 80)
+    heads = heads.cuda().train()
+    heads.box_predictor.set_class_embeddings(h["cls_w"])
+    heads.num_classes = heads.box_predictor.num_classes
+    return heads, c_in
+
+
+def _train_batch(pkg, oracle, n_img, r, n_gt, seed):
+    from locov_amd.structures import Boxes, Instances
+    rng = np.random.default_rng(seed)
+    props, targets = [], []
+    for _ in range(n_img):
+        gt = oracle.synth_boxes(rng, n_gt)
+        b = oracle.synth_boxes(rng, r)
+        b[:n_gt] = gt + rng.uniform(-4, 4, gt.shape).astype(np.float32)      # some proposals overlap the ground truth
+        b[:, 2:] = np.maximum(b[:, 2:], b[:, :2] + 1.0)
+        p = Instances((800, 1333))
+        p.proposal_boxes = Boxes(torch.from_numpy(b).cuda())
+        p.objectness_logits = torch.zeros(r, device="cuda")
+        t = Instances((800, 1333))
+        t.gt_boxes = Boxes(torch.from_numpy(gt).cuda())
+        t.gt_classes = torch.from_numpy(rng.integers(0, 80, n_gt)).cuda()
+        props.append(p)
+        targets.append(t)
+    return props, targets
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "f16x2"])
+def test_training_forward_backward_matches_the_stock_library_path(pkg, oracle, dtype):
+    """EmbeddingProposalsRes5ROIHeads.forward with targets (roi_emb_heads.py:311-349), one training step's forward and
+    backward: the hand-written path (RES5_BACKEND hip) against the same module on torch conv2d / MIOpen autograd
+    (RES5_BACKEND miopen) -- same sampled proposals (same RNG seed), losses, region features, grid features and the
+    gradients of the res4 map and of every trainable parameter."""
+    outs = {}
+    for backend in ("miopen", "hip"):
+        heads, c_in = _train_heads(pkg, oracle, backend, dtype)
+        feat = torch.randn(2, c_in, 50, 84, generator=torch.Generator().manual_seed(5)).cuda().requires_grad_(True)
+        props, targets = _train_batch(pkg, oracle, 2, 60, 5, seed=31)
+        torch.manual_seed(77)                                  # the proposal sampler draws from the global RNG
+        grid, box_feats, sampled, losses = heads(None, {"res4": feat}, props, targets)
+        loss = losses["loss_box_reg"] + losses["loss_cls"] + 1e-3 * grid.square().mean() + 1e-2 * torch.cat(box_feats).square().mean()
+        loss.backward()
+        outs[backend] = (grid.detach(), torch.cat(box_feats).detach(), float(losses["loss_box_reg"]), feat.grad.clone(),
+                         {k: p.grad.clone() for k, p in heads.named_parameters() if p.grad is not None})
+    gm, bm, lm, fm, pm = outs["miopen"]
+    gh, bh, lh, fh, ph = outs["hip"]
+    assert tuple(gh.shape) == tuple(gm.shape) == (2, 256, 25, 42)
+    tol = 2e-4            # two fp32 evaluations against each other (neither is the float64 reference)
+    assert rel_err(gh, gm) < tol and rel_err(bh, bm) < tol and abs(lh - lm) <= tol * max(abs(lm), 1e-3)
+    # gradients: two fp32 forwards disagree on a handful of ReLU ties (see _float64_stage), each of which moves single
+    # gradient entries by ~1e-3 of the largest one; the exact gates are the float64 tests above, here the bulk must agree
+    rel_l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    assert rel_l2(fh, fm) < 5e-3 and rel_err(fh, fm) < 5e-2
+    assert set(ph) == set(pm) and any(k.startswith("res5.") for k in ph)
+    worst = max((rel_l2(ph[k], pm[k]), k) for k in ph)
+    assert worst[0] < 5e-3, worst
+
+
+def test_training_step_at_config_sizes_runs_on_the_hip_kernels(pkg, oracle):
+    """configs/coco_lsm.yaml sizes (Res5 1024 -> 512 -> 2048, 200 sampled proposals per image): one forward + backward
+    on the hand-written path; finite gradients for every Res5 convolution and the res4 map."""
+    heads, c_in = _train_heads(pkg, oracle, "hip", "f16x2", small=False)
+    feat = torch.randn(2, c_in, 50, 84, generator=torch.Generator().manual_seed(5)).cuda().requires_grad_(True)
+    props, targets = _train_batch(pkg, oracle, 2, 300, 8, seed=41)
+    grid, box_feats, sampled, losses = heads(None, {"res4": feat}, props, targets)
+    assert tuple(grid.shape) == (2, 2048, 25, 42) and sum(len(s) for s in sampled) == 400
+    (losses["loss_box_reg"] + grid.mean() + torch.cat(box_feats).mean()).backward()
+    assert torch.isfinite(feat.grad).all() and float(feat.grad.abs().max()) > 0
+    n = 0
+    for k, p in heads.res5.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, k
+        n += 1
+    assert n == 10
