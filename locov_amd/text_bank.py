@@ -22,27 +22,55 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-__all__ = ["load_noun_embeddings", "build_class_emb_mtx", "pool_token_embeddings", "TextBankCache"]
+__all__ = ["load_noun_embeddings", "build_class_emb_mtx", "build_lvis_class_emb_mtx", "pool_token_embeddings",
+           "TextBankCache"]
 
 
 def load_noun_embeddings(path: str) -> Dict[str, np.ndarray]:
-    """`{class_name: [D floats]}` JSON -> dict of float32 vectors."""
+    """`{class_name: [D floats]}` JSON (a multi-token class may hold `[T][D]`) -> dict of float32 arrays."""
     with open(path, "r") as f:
         raw = json.load(f)
     return {k: np.asarray(v, dtype=np.float32) for k, v in raw.items()}
 
 
-def build_class_emb_mtx(noun_embeddings: Dict[str, Sequence[float]], thing_classes: Sequence[str]) -> np.ndarray:
-    """coco_instances.py:236-254: [len(thing_classes)+1, D] float32, classes in `thing_classes`
-    order, last row = zeros (background).  A class missing from the file is a KeyError, as in the
-    reference."""
+def build_class_emb_mtx(noun_embeddings: Dict[str, Sequence[float]], thing_classes: Sequence[str],
+                        return_class_embeddings: bool = False):
+    """COCO layout, coco_instances.py:237-254: [len(thing_classes)+1, D] float32, classes in `thing_classes` order,
+    last row = zeros (background).  D is the length of the FIRST entry of the file (:238).  A class whose entry is
+    not a vector (a multi-token `[T, D]` embedding for the grounding predictor, box_emb_grounding_head.py) keeps a ZERO
+    row (:247-250) and, with `return_class_embeddings`, the per-class dict `{idx: array}` the reference then attaches
+    to the metadata (:252-253) is returned as well (None when every class is a plain vector).  A class missing from
+    the file is a KeyError, as in the reference."""
     first = next(iter(noun_embeddings.values()))
     emb_dim = len(first)
     mtx = np.zeros((len(thing_classes) + 1, emb_dim), dtype=np.float32)
+    class_embeddings, multi = {}, False
     for idx, noun in enumerate(thing_classes):
         vec = np.asarray(noun_embeddings[noun], dtype=np.float32)
-        if vec.ndim != 1 or vec.shape[0] != emb_dim:
-            raise ValueError(f"embedding of {noun!r} has shape {vec.shape}, expected ({emb_dim},)")
+        class_embeddings[idx] = vec
+        if vec.ndim == 1:
+            if vec.shape[0] != emb_dim:
+                raise ValueError(f"embedding of {noun!r} has shape {vec.shape}, expected ({emb_dim},)")
+            mtx[idx, :] = vec
+        else:
+            multi = True
+    if return_class_embeddings:
+        return mtx, (class_embeddings if multi else None)
+    return mtx
+
+
+def build_lvis_class_emb_mtx(noun_embeddings: Optional[Dict[str, Sequence[float]]], thing_classes: Sequence[str]):
+    """LVIS layout, lvis_instances.py:262-278: the bank is optional (no `obj_file` -> no class_emb_mtx: returns None);
+    every class must be a plain vector (the reference assigns the entry straight into its row, :277, so a multi-token
+    entry is a broadcast error there and a ValueError here)."""
+    if noun_embeddings is None:
+        return None
+    emb_dim = len(next(iter(noun_embeddings.values())))
+    mtx = np.zeros((len(thing_classes) + 1, emb_dim), dtype=np.float32)
+    for idx, noun in enumerate(thing_classes):
+        vec = np.asarray(noun_embeddings[noun], dtype=np.float32)
+        if vec.shape != (emb_dim,):
+            raise ValueError(f"could not broadcast the embedding of {noun!r}, shape {vec.shape}, into a row of ({emb_dim},)")
         mtx[idx, :] = vec
     return mtx
 

@@ -19,6 +19,12 @@ which imports Detectron2):
       MultiDistillLossL2 .forward                                     (:211-433)
   G6  ovr/modeling/roi_heads/box_emb_grounding_head.py  GroundingModule.set_class_embeddings /
       .forward (multi-token class scoring)                            (:60-256)
+  G7  text bank: the statements of tools/coco_bert_embeddings.py:26-34 (token pooling),
+      ovr/data/datasets/coco_instances.py:237-254 and lvis_instances.py:269-278 (class_emb_mtx layout).
+      Those statements sit inside a script / inside registration functions that need Detectron2, a BERT
+      checkpoint and the COCO / LVIS annotation files, so they are executed IN PLACE: the line ranges are read
+      from the reference files at generation time and exec'd on seeded stand-in inputs (the fixture holds only
+      inputs and outputs).          python tests/golden/make_golden.py g7   regenerates G7 alone.
 
 Detectron2 / fvcore are not installed, so import-time names are satisfied with
 inert stand-ins (below).  The ONLY stand-in whose behaviour reaches a golden
@@ -132,8 +138,69 @@ def cuda_to_cpu_shim():
     torch.Tensor.cuda = lambda self, *a, **k: self
 
 
+def _ref_lines(rel, first, last):
+    """Source lines first..last (1-based, inclusive) of a reference file, dedented, as a code object."""
+    import textwrap
+    with open(os.path.join(REF, rel)) as f:
+        lines = f.read().splitlines()[first - 1:last]
+    return compile(textwrap.dedent("\n".join(lines)), f"{rel}:{first}-{last}", "exec")
+
+
+def make_g7():
+    import json
+    rng = np.random.default_rng(SEED)
+    g7 = {}
+    # --- token pooling: tools/coco_bert_embeddings.py:26-34 on a stand-in for the BERT encoder's output
+    K, T, D = 9, 6, 32
+    special = np.zeros((K, T), np.int64)
+    special[:, 0] = 1
+    for k in range(K):
+        special[k, 1 + 1 + (k % 4):] = 1               # 1..4 real tokens, then [SEP] / padding
+    emb = rng.standard_normal((K, T, D)).astype(np.float32)
+    ns = {"torch": torch, "class_list": [f"class {k}" for k in range(K)],
+          "encoded_class_list": {"special_tokens_mask": torch.from_numpy(special), "input_embeddings": torch.from_numpy(emb)}}
+    exec(_ref_lines("tools/coco_bert_embeddings.py", 26, 34), ns)
+    g7["pool_input_embeddings"], g7["pool_special_tokens_mask"] = emb, special
+    g7["pool_embeddings"] = ns["embeddings"].numpy()
+    g7["pool_json"] = np.asarray(json.dumps(ns["class_name_to_bertemb"]))       # what the script writes to disk
+    # --- class_emb_mtx layout, COCO: ovr/data/datasets/coco_instances.py:237-254 (one class with a multi-token [T, D] entry)
+    names = [f"noun{k}" for k in range(7)]
+    table = {n: rng.standard_normal(D).astype(np.float32).tolist() for n in names}
+    table["noun3"] = rng.standard_normal((3, D)).astype(np.float32).tolist()   # multi-token entry -> its row stays zero
+    things = ["noun5", "noun0", "noun3", "noun6"]
+
+    class Meta:
+        def __init__(self):
+            self.thing_classes, self.fields = things, {}
+
+        def set(self, **kw):
+            self.fields.update(kw)
+
+    meta = Meta()
+    ns = {"np": np, "noun_embeddings": json.loads(json.dumps(table)), "dataset_metadata": meta}
+    exec(_ref_lines("ovr/data/datasets/coco_instances.py", 237, 254), ns)
+    g7["bank_json"] = np.asarray(json.dumps(table))
+    g7["bank_thing_classes"] = np.asarray(things)
+    g7["coco_class_emb_mtx"] = meta.fields["class_emb_mtx"]
+    g7["coco_multi_token_idx"] = np.asarray(sorted(k for k, v in meta.fields["class_embeddings"].items() if v.ndim == 2))
+    g7["coco_multi_token_emb"] = meta.fields["class_embeddings"][2]
+    # --- LVIS: ovr/data/datasets/lvis_instances.py:269-278 (1-D entries only)
+    things_l = ["noun6", "noun1", "noun2"]
+    meta = Meta()
+    meta.thing_classes = things_l
+    ns = {"np": np, "noun_embeddings": json.loads(json.dumps(table)), "metadata": meta}
+    exec(_ref_lines("ovr/data/datasets/lvis_instances.py", 269, 278), ns)
+    g7["lvis_thing_classes"] = np.asarray(things_l)
+    g7["lvis_class_emb_mtx"] = meta.fields["class_emb_mtx"]
+    np.savez_compressed(os.path.join(OUT, "g7_text_bank.npz"), **g7)
+    print("wrote g7_text_bank.npz")
+
+
 def main():
     assert os.path.isdir(REF), f"reference not found at {REF}"
+    if sys.argv[1:] == ["g7"]:
+        make_g7()
+        return
     install_standins()
     cuda_to_cpu_shim()
     misc = load("ovr.misc", "ovr/misc.py")
@@ -301,6 +368,7 @@ def main():
                 scores2, _ = gm(x)                                       # second call (num_tok was mutated in place)
                 assert torch.equal(scores, scores2)
     np.savez_compressed(os.path.join(OUT, "g6_grounding_module.npz"), **g6)
+    make_g7()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")

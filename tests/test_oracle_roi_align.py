@@ -173,3 +173,52 @@ def test_roi_pooler_multilevel_scatter(oracle):
     for i in range(17):
         want = oracle.roi_align(feats[lv[i]], rois[i:i + 1], (7, 7), scales[lv[i]], 0, True)
         np.testing.assert_array_equal(out[i:i + 1], want)
+
+
+def test_roi_align_matches_torch_grid_sample_on_interior_boxes(oracle):
+    """Third-party pin of the bilinear sampling: torch.nn.functional.grid_sample(mode="bilinear", align_corners=True)
+    interpolates at index coordinates with the pixel centres on the integers -- the same samples torchvision's
+    roi_align(aligned=True) takes -- so for boxes whose every sample lies inside [0, H-1] x [0, W-1] (no border rules
+    involved) the oracle's output must equal the mean of grid_sample's values over each bin's adaptive sampling grid.
+    grid_sample is PyTorch's own kernel, not this repository's arithmetic."""
+    rng = np.random.default_rng(2024)
+    N, C, H, W, P, s = 2, 5, 50, 84, 14, 1.0 / 16
+    feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    rois = []
+    while len(rois) < 120:
+        b = rng.integers(0, N)
+        w = 2.0 ** rng.uniform(4.0, np.log2(700.0))
+        h = 2.0 ** rng.uniform(4.0, np.log2(600.0))
+        x0 = rng.uniform(8.0, 16 * (W - 1) + 8 - w) if 16 * (W - 1) - w > 0 else None
+        y0 = rng.uniform(8.0, 16 * (H - 1) + 8 - h) if 16 * (H - 1) - h > 0 else None
+        if x0 is None or y0 is None:
+            continue
+        rois.append([b, x0, y0, x0 + w, y0 + h])
+    rois = np.asarray(rois, np.float32)
+    got = oracle.roi_align(feat, rois, (P, P), s, 0, True)
+    ft = torch.from_numpy(feat).double()
+    worst = 0.0
+    grids_seen = set()
+    for r, roi in enumerate(rois):
+        b = int(roi[0])
+        # the oracle's (= torchvision's) fp32 box arithmetic decides the sampling grid; the sample positions are
+        # then evaluated in float64
+        x0, y0, x1, y1 = [np.float32(v) * np.float32(s) - np.float32(0.5) for v in roi[1:]]
+        rw, rh = np.float32(x1 - x0), np.float32(y1 - y0)
+        bw, bh = np.float32(rw / np.float32(P)), np.float32(rh / np.float32(P))
+        gw, gh = int(np.ceil(bw)), int(np.ceil(bh))
+        grids_seen.add((gh, gw))
+        # sample coordinate, rounded step by step in fp32 as the kernel forms it: (start + p*bin) + ((i + .5)*bin)/grid
+        f32 = np.float32
+        coord = lambda start, bin_, g: ((start + np.arange(P, dtype=f32)[:, None] * bin_).astype(f32)
+                                        + (((np.arange(g, dtype=f32)[None, :] + f32(0.5)) * bin_).astype(f32) / f32(g)).astype(f32)).astype(f32)
+        xs, ys = coord(x0, bw, gw).astype(np.float64), coord(y0, bh, gh).astype(np.float64)                 # [P, g]
+        assert xs.min() >= 0 and xs.max() <= W - 1 and ys.min() >= 0 and ys.max() <= H - 1, "box generator: not interior"
+        gx = torch.from_numpy(2.0 * xs.reshape(-1) / (W - 1) - 1.0)
+        gy = torch.from_numpy(2.0 * ys.reshape(-1) / (H - 1) - 1.0)
+        grid = torch.stack(torch.meshgrid(gy, gx, indexing="ij")[::-1], dim=-1)[None]                        # [1, P*gh, P*gw, (x, y)]
+        samp = torch.nn.functional.grid_sample(ft[b:b + 1], grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+        want = samp.view(C, P, gh, P, gw).mean(dim=(2, 4)).numpy()
+        worst = max(worst, float(np.abs(got[r] - want).max()))
+    assert len(grids_seen) >= 4, grids_seen                    # adaptive grids 1..4 per axis are all exercised
+    assert worst <= 2e-6, worst

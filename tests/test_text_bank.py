@@ -29,17 +29,37 @@ def test_json_to_class_emb_mtx(tmp_path):
         text_bank.build_class_emb_mtx(loaded, ["zebra"])
 
 
-def test_token_pooling_matches_reference_formula():
-    g = torch.Generator().manual_seed(1)
-    x = torch.randn(5, 7, 16, generator=g)
-    special = torch.zeros(5, 7, dtype=torch.int64)
-    special[:, 0] = 1
-    special[:, 4:] = 1
-    special[2, 3] = 1
-    mask = (1 - special).to(torch.float32)
-    want = (x * mask[:, :, None]).sum(1) / mask.sum(1)[:, None]          # coco_bert_embeddings.py:26-30
-    got = text_bank.pool_token_embeddings(x.numpy(), special.numpy())
-    np.testing.assert_allclose(got, want.numpy(), rtol=1e-6, atol=1e-7)
+def test_g7_token_pooling_matches_the_reference_script(golden_dir):
+    """pool_token_embeddings against the embeddings tools/coco_bert_embeddings.py:26-34 produced (its own statements,
+    run by tests/golden/make_golden.py on a stand-in for the BERT encoder output), incl. the JSON it writes."""
+    import os
+    g = np.load(os.path.join(golden_dir, "g7_text_bank.npz"))
+    got = text_bank.pool_token_embeddings(g["pool_input_embeddings"], g["pool_special_tokens_mask"])
+    np.testing.assert_allclose(got, g["pool_embeddings"], rtol=1e-6, atol=1e-7)
+    table = json.loads(str(g["pool_json"]))
+    assert list(table) == [f"class {k}" for k in range(got.shape[0])]
+    np.testing.assert_allclose(np.asarray([table[k] for k in table], np.float32), got, rtol=1e-6, atol=1e-7)
+
+
+def test_g7_class_emb_mtx_layouts_match_the_reference(golden_dir, tmp_path):
+    """COCO (coco_instances.py:237-254: a multi-token class keeps a zero row and goes to the class_embeddings dict) and
+    LVIS (lvis_instances.py:269-278) bank layouts against what the reference's statements built from the same JSON."""
+    import os
+    g = np.load(os.path.join(golden_dir, "g7_text_bank.npz"))
+    p = tmp_path / "nouns.json"
+    p.write_text(str(g["bank_json"]))
+    table = text_bank.load_noun_embeddings(str(p))
+    mtx, per_class = text_bank.build_class_emb_mtx(table, [str(c) for c in g["bank_thing_classes"]], return_class_embeddings=True)
+    np.testing.assert_array_equal(mtx, g["coco_class_emb_mtx"])
+    assert sorted(k for k, v in per_class.items() if v.ndim == 2) == g["coco_multi_token_idx"].tolist()
+    np.testing.assert_array_equal(per_class[2], g["coco_multi_token_emb"])
+    assert np.all(mtx[2] == 0) and np.all(mtx[-1] == 0)
+    np.testing.assert_array_equal(text_bank.build_class_emb_mtx(table, [str(c) for c in g["bank_thing_classes"]]), mtx)
+    lv = text_bank.build_lvis_class_emb_mtx(table, [str(c) for c in g["lvis_thing_classes"]])
+    np.testing.assert_array_equal(lv, g["lvis_class_emb_mtx"])
+    assert text_bank.build_lvis_class_emb_mtx(None, ["a"]) is None                 # no obj_file: no bank (lvis_instances.py:262-263)
+    with pytest.raises(ValueError):
+        text_bank.build_lvis_class_emb_mtx(table, ["noun3"])                        # multi-token entry: broadcast error in the reference
 
 
 def test_bank_swap_like_evaluation(tmp_path):
