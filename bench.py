@@ -199,29 +199,12 @@ class Workload:
 class TrainWorkload:
     """One LSM training step of the path (see the module docstring)."""
 
-    def __init__(self, args, device, backend, world):
+    def __init__(self, args, device, backend, world, data_seed=1992):
         import torch
         import locov_amd
         from locov_amd.grounding_head import GroundingHead
-        from locov_amd.structures import Boxes, Instances
         self.args, self.device = args, device
-        gen = torch.Generator().manual_seed(1992)
-        B, R = args.train_images, args.proposals
-        self.features = torch.randn(B, 1024, 50, 84, generator=gen).to(device)
-        self.proposals, self.targets = [], []
-        for _ in range(B):
-            gt = synth_boxes(gen, 7)
-            b = synth_boxes(gen, R)
-            b[:7] = (gt + torch.rand(7, 4, generator=gen) * 8 - 4).clamp(min=0)
-            b[:, 2:] = torch.maximum(b[:, 2:], b[:, :2] + 1.0)
-            p = Instances((800, 1333))
-            p.proposal_boxes = Boxes(b.to(device))
-            p.objectness_logits = torch.zeros(R, device=device)
-            t = Instances((800, 1333))
-            t.gt_boxes = Boxes(gt.to(device))
-            t.gt_classes = torch.randint(0, args.classes, (7,), generator=gen).to(device)
-            self.proposals.append(p)
-            self.targets.append(t)
+        self.set_data(data_seed)
         self.heads, cfg = build_heads(args, device, res5=backend, train=True)
         cfg.MODEL.MMSS_HEAD.DISTILLATION_LOSS = False
         cfg.MODEL.MMSS_HEAD.GROUNDING.LOSS = "cross_entropy"
@@ -231,10 +214,6 @@ class TrainWorkload:
         # weight tying of distill_prop_mmss_gcnn.py:117-125: emb_pred IS the grounding head's v2l_projection
         self.heads.box_predictor.emb_pred.weight = self.grounding.v2l_projection.weight
         self.heads.box_predictor.emb_pred.bias = self.grounding.v2l_projection.bias
-        self.caption = {"input_embeddings": torch.randn(B, 70, args.dim, generator=gen).to(device),
-                        "attention_mask": torch.ones(B, 70, device=device),
-                        "special_tokens_mask": torch.zeros(B, 70, device=device)}
-        self.caption["special_tokens_mask"][:, 0] = 1
         n_regions = 100                                                                  # MMSS_HEAD.SPATIAL_DROPOUT
         heads, grounding, dev_ = self.heads, self.grounding, device
 
@@ -262,11 +241,43 @@ class TrainWorkload:
         params = [p for p in self.module.parameters() if p.requires_grad]
         self.opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=1e-4)   # coco_lsm.yaml:104-105
 
-    def step(self):
+    def set_data(self, seed):
+        """Synthetic batch of one rank: res4 maps, proposals (a few of them near the ground truth), targets, captions."""
+        import torch
+        from locov_amd.structures import Boxes, Instances
+        args, device = self.args, self.device
+        gen = torch.Generator().manual_seed(seed)
+        B, R = args.train_images, args.proposals
+        self.features = torch.randn(B, 1024, 50, 84, generator=gen).to(device)
+        self.proposals, self.targets = [], []
+        for _ in range(B):
+            gt = synth_boxes(gen, 7)
+            b = synth_boxes(gen, R)
+            b[:7] = (gt + torch.rand(7, 4, generator=gen) * 8 - 4).clamp(min=0)
+            b[:, 2:] = torch.maximum(b[:, 2:], b[:, :2] + 1.0)
+            p = Instances((800, 1333))
+            p.proposal_boxes = Boxes(b.to(device))
+            p.objectness_logits = torch.zeros(R, device=device)
+            t = Instances((800, 1333))
+            t.gt_boxes = Boxes(gt.to(device))
+            t.gt_classes = torch.randint(0, args.classes, (7,), generator=gen).to(device)
+            self.proposals.append(p)
+            self.targets.append(t)
+        self.caption = {"input_embeddings": torch.randn(B, 70, args.dim, generator=gen).to(device),
+                        "attention_mask": torch.ones(B, 70, device=device),
+                        "special_tokens_mask": torch.zeros(B, 70, device=device)}
+        self.caption["special_tokens_mask"][:, 0] = 1
+
+    def forward_backward(self, scale: float = 1.0):
+        """Forward + backward of one step (gradients ACCUMULATE into .grad; under DDP they are averaged over the ranks)."""
         feat = self.features.detach().requires_grad_(True)          # the backbone trains (FREEZE_AT 0): res4 needs its gradient
         loss, n_sampled = self.run(feat, self.proposals, self.targets, self.caption)
+        (loss * scale).backward()
+        return loss.detach(), n_sampled
+
+    def step(self):
         self.opt.zero_grad(set_to_none=True)
-        loss.backward()
+        _, n_sampled = self.forward_backward()
         self.opt.step()
         return n_sampled
 
@@ -433,7 +444,7 @@ def main():
     if args.mode == "train":
         train = {}
         for backend in ("hip", "miopen"):
-            tw = TrainWorkload(args, device, backend, world)
+            tw = TrainWorkload(args, device, backend, world, data_seed=1992 + rank)
             n_sampled = tw.step()
             steps = max(args.steps // 2, 3)
             dtt = timed(tw.step, steps, 2)

@@ -1,0 +1,79 @@
+"""The N > 1 product path on the GPU box (train_ovnet.py:100-107 launches one process per GPU,
+ovr/engine/trainer.py:61-66 wraps the model in DistributedDataParallel): two ranks run one LSM training step of the ROI
+heads + GroundingHead under DDP on their own image shards, and the gradients DDP leaves on every rank must equal the
+average of the two shards' gradients computed by ONE process.  Also: `bench.py --gpus 2` started WITHOUT a launcher starts
+its two ranks itself and reports n_gpus = 2."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    return env
+
+
+def test_ddp_training_step_matches_single_process(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "tests", "ddp_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ranks = [torch.load(os.path.join(tmp_path, f"rank{i}.pt")) for i in range(2)]
+    ddp_grads = ranks[0]["grads"]
+    assert any(k.startswith("heads.res5.") for k in ddp_grads) and "grounding.v2l_projection.weight" in ddp_grads
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from tests import ddp_worker
+    args = bench.parse(ddp_worker.ARGS)
+    device = torch.device("cuda", 0)
+    tw = bench.TrainWorkload(args, device, "hip", world=1, data_seed=100)
+    losses = []
+    for shard in range(2):                               # the two ranks' shards, one after the other, gradients accumulated
+        tw.set_data(100 + shard)
+        torch.manual_seed(500 + shard)
+        loss, n = tw.forward_backward(scale=0.5)         # DDP averages over the ranks
+        losses.append(float(loss))
+        assert n == ranks[shard]["n_sampled"]
+    for shard in range(2):
+        assert abs(losses[shard] - ranks[shard]["loss"]) <= 1e-5 * max(1.0, abs(losses[shard]))
+    single = {k: p.grad.detach().cpu() for k, p in tw.module.named_parameters() if p.grad is not None}
+    assert set(single) == set(ddp_grads)
+    for k in single:
+        scale = float(single[k].abs().max().clamp_min(1e-30))
+        err = float((single[k] - ddp_grads[k]).abs().max()) / scale
+        assert err <= 1e-5, (k, err)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (it used to run ONE rank and report n_gpus 1)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--steps", "2",
+           "--warmup", "1", "--images", "1", "--proposals", "200", "--classes", "80", "--no-cpu-baseline", "--skip-s1",
+           "--skip-f32-reference", "--skip-variants"]
+    env = _env()
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0
+    assert out["config"]["parallelism"].startswith("image-sharded x2")
