@@ -39,7 +39,8 @@ def test_ddp_training_step_matches_single_process(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     ranks = [torch.load(os.path.join(tmp_path, f"rank{i}.pt")) for i in range(2)]
     ddp_grads = ranks[0]["grads"]
-    assert any(k.startswith("heads.res5.") for k in ddp_grads) and "grounding.v2l_projection.weight" in ddp_grads
+    # (emb_pred IS the grounding head's v2l_projection -- distill_prop_mmss_gcnn.py:117-125 -- and is listed once, under its first name)
+    assert any(k.startswith("heads.res5.") for k in ddp_grads) and "heads.box_predictor.emb_pred.weight" in ddp_grads
 
     sys.path.insert(0, ROOT)
     import bench
