@@ -512,7 +512,7 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torc
     order = torch.argsort(scores, descending=True, stable=True)
     sorted_boxes = boxes[order].contiguous()
     lib = _lib.load()
-    ws = torch.empty((int(lib.locov_nms_workspace_bytes(K)),), dtype=torch.uint8, device=boxes.device)
+    ws = _workspace("nms", boxes, int(lib.locov_nms_workspace_bytes(K)))        # cached: grows to the largest request
     keep = torch.empty((K,), dtype=torch.uint8, device=boxes.device)
     num = torch.empty((1,), dtype=torch.int32, device=boxes.device)
     with torch.cuda.device(boxes.device):

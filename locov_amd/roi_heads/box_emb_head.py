@@ -24,7 +24,7 @@ from torch.nn import functional as F
 
 from .. import ops
 from ..registry import configurable
-from ..structures import Boxes, Instances, ShapeSpec
+from ..structures import Boxes, Instances, ShapeSpec, boxes_class_of
 
 __all__ = ["Box2BoxTransform", "FastRCNNOutputLayers", "EmbeddingFastRCNNOutputLayers", "build_box_predictor",
            "fast_rcnn_inference", "batched_nms"]
@@ -111,19 +111,35 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torc
     return order[torch.as_tensor(keep, dtype=torch.int64, device=boxes.device)]
 
 
+_PER_CLASS_NMS_ABOVE = 40000      # [D2-upstream] detectron2.layers.batched_nms: per-class loop from 40 000 candidates on
+
+
 def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float) -> torch.Tensor:
-    """[D2-upstream] class-wise NMS via per-class coordinate offsets."""
+    """[D2-upstream] class-wise NMS.  Up to 40 000 candidates: ONE NMS over boxes shifted by per-class coordinate offsets
+    (torchvision's batched_nms trick).  Above that -- 1203 classes x 1000 proposals with a low SCORE_THRESH_TEST reach
+    1e5..1e6 candidates, whose K x K/64 suppression bit-matrix would take gigabytes -- the classes are independent, so each
+    runs its own NMS and the kept indices are merged in descending score order, as Detectron2 does."""
     if boxes.numel() == 0:
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
-    max_coordinate = boxes.max()
-    offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
-    return nms(boxes + offsets[:, None], scores, iou_threshold)
+    if boxes.shape[0] < _PER_CLASS_NMS_ABOVE:
+        max_coordinate = boxes.max()
+        offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+        return nms(boxes + offsets[:, None], scores, iou_threshold)
+    keep_mask = torch.zeros_like(scores, dtype=torch.bool)
+    for cid in torch.unique(idxs).tolist():
+        sel = (idxs == cid).nonzero().view(-1)
+        keep_mask[sel[nms(boxes[sel], scores[sel], iou_threshold)]] = True
+    keep = keep_mask.nonzero().view(-1)
+    return keep[scores[keep].argsort(descending=True, stable=True)]
 
 
 def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh: float, nms_thresh: float,
-                                     topk_per_image: int):
+                                     topk_per_image: int, instances_cls=Instances, boxes_cls=Boxes):
     valid_mask = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
     if not valid_mask.all():
+        import warnings
+        warnings.warn(f"fast_rcnn_inference: dropping {int((~valid_mask).sum())} proposals with non-finite boxes / scores "
+                      "(as Detectron2 does) -- the ROI head produced inf / NaN for them", RuntimeWarning, stacklevel=2)
         boxes, scores = boxes[valid_mask], scores[valid_mask]
     scores = scores[:, :-1]
     num_bbox_reg_classes = boxes.shape[1] // 4
@@ -141,17 +157,19 @@ def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh: f
     if topk_per_image >= 0:
         keep = keep[:topk_per_image]
     boxes, scores, filter_inds = boxes[keep], scores[keep], filter_inds[keep]
-    result = Instances(image_shape)
-    result.pred_boxes = Boxes(boxes)
+    result = instances_cls(image_shape)
+    result.pred_boxes = boxes_cls(boxes)
     result.scores = scores
     result.pred_classes = filter_inds[:, 1]
     return result, filter_inds[:, 0]
 
 
 def fast_rcnn_inference(boxes: List[torch.Tensor], scores: List[torch.Tensor], image_shapes, score_thresh: float,
-                        nms_thresh: float, topk_per_image: int):
+                        nms_thresh: float, topk_per_image: int, instances_cls=Instances, boxes_cls=Boxes):
+    """instances_cls / boxes_cls: the classes the results are built with (the caller's own -- Detectron2's under
+    train_ovnet.py -- see structures.boxes_class_of)."""
     result_per_image = [
-        fast_rcnn_inference_single_image(b, s, shape, score_thresh, nms_thresh, topk_per_image)
+        fast_rcnn_inference_single_image(b, s, shape, score_thresh, nms_thresh, topk_per_image, instances_cls, boxes_cls)
         for s, b, shape in zip(scores, boxes, image_shapes)
     ]
     return [x[0] for x in result_per_image], [x[1] for x in result_per_image]
@@ -265,8 +283,9 @@ class FastRCNNOutputLayers(nn.Module):
         boxes = self.predict_boxes(predictions, proposals)
         scores = self.predict_probs(predictions, proposals)
         image_shapes = [x.image_size for x in proposals]
+        instances_cls, boxes_cls = boxes_class_of(proposals)
         return fast_rcnn_inference(boxes, scores, image_shapes, self.test_score_thresh, self.test_nms_thresh,
-                                   self.test_topk_per_image)
+                                   self.test_topk_per_image, instances_cls, boxes_cls)
 
     def predict_boxes(self, predictions, proposals):
         if not len(proposals):
@@ -371,6 +390,10 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
                 x, self.emb_pred.weight.detach(), self.emb_pred.bias.detach(), self.bbox_pred.weight.detach(),
                 self.bbox_pred.bias.detach(), self.cls_score.weight, self._packed_bank(), mode,
                 ops.BF16 if self.sim_gemm_dtype == "bf16" else ops.F32)
+            if not self._cls_bias_is_zero():
+                # set_class_embeddings zeroes the bias (:234); a loaded / edited one is honoured like the reference's
+                # nn.Linear does (the similarity kernel itself carries no bias term)
+                scores = scores + self.cls_score.bias.detach()
             return scores, deltas
         proposal_deltas = hip_linear(x, self.bbox_pred)                   # :196
         if self.detach_cls_predictor:                                     # :197-201
@@ -388,16 +411,40 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
             if self.standardize_emb:
                 x = _rownorm(x, ops.NORM_STANDARDIZE)
         if self.sim_gemm_dtype == "bf16" and not (torch.is_grad_enabled() and x.requires_grad):
-            return ops.sim_gemm_bf16(ops.to_bf16(x), self._packed_bank())
+            scores = ops.sim_gemm_bf16(ops.to_bf16(x), self._packed_bank())
+            return scores if self._cls_bias_is_zero() else scores + self.cls_score.bias.detach()
         return hip_linear(x, self.cls_score)
 
+    def _bank_key(self):
+        w = self.cls_score.weight
+        return (w.data_ptr(), w._version, tuple(w.shape), w.device)
+
     def _packed_bank(self):
+        """bf16 copy of the bank for the bf16 MFMA similarity GEMM, re-packed whenever cls_score.weight is re-assigned,
+        loaded or modified in place (keyed on the tensor's storage and version, like Res5Stage._packed)."""
         if self.sim_gemm_dtype != "bf16":
             return None
-        w = self.cls_score.weight
-        if self._bank_bf16 is None or self._bank_bf16.shape != w.shape or self._bank_bf16.device != w.device:
-            self._bank_bf16 = ops.to_bf16(w.detach())
+        key = self._bank_key()
+        if self._bank_bf16 is None or getattr(self, "_bank_bf16_key", None) != key:
+            self._bank_bf16 = ops.to_bf16(self.cls_score.weight.detach())
+            self._bank_bf16_key = key
         return self._bank_bf16
+
+    def install_packed_bank(self, bank_bf16: torch.Tensor) -> None:
+        """A pre-packed bf16 copy of the CURRENT cls_score.weight (TextBankCache.install: no per-swap conversion)."""
+        assert bank_bf16.dtype == torch.bfloat16 and tuple(bank_bf16.shape) == tuple(self.cls_score.weight.shape)
+        self._bank_bf16 = bank_bf16
+        self._bank_bf16_key = self._bank_key()
+
+    def _cls_bias_is_zero(self) -> bool:
+        b = self.cls_score.bias
+        if b is None:
+            return True
+        key = (b.data_ptr(), b._version)
+        if getattr(self, "_bias_zero_key", None) != key:
+            self._bias_zero = not bool(b.detach().any())        # one host read per (re-)assignment of the bias
+            self._bias_zero_key = key
+        return self._bias_zero
 
     # ------------------------------------------------------------------ bank install (:214-236)
     def set_class_embeddings(self, embs):

@@ -105,17 +105,19 @@ def add_ground_truth_to_proposals(targets: List[Instances], proposals: List[Inst
         return proposals
     out = []
     for gt_i, prop_i in zip(targets, proposals):
-        gt_boxes = gt_i.gt_boxes if isinstance(gt_i, Instances) else gt_i
+        # (the caller's own container classes throughout: Detectron2's Instances / Boxes under train_ovnet.py)
+        inst_cls = type(prop_i)
+        gt_boxes = gt_i.gt_boxes if hasattr(gt_i, "get_fields") else gt_i
         device = prop_i.objectness_logits.device if prop_i.has("objectness_logits") else gt_boxes.device
         gt_logit_value = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
-        gt_proposal = Instances(prop_i.image_size)
+        gt_proposal = inst_cls(prop_i.image_size)
         gt_proposal.proposal_boxes = gt_boxes
         if prop_i.has("objectness_logits"):
             gt_proposal.objectness_logits = gt_logit_value * torch.ones(len(gt_boxes), device=device)
-        keep = Instances(prop_i.image_size)
+        keep = inst_cls(prop_i.image_size)
         for k in gt_proposal.get_fields():
             keep.set(k, prop_i.get(k))
-        out.append(Instances.cat([keep, gt_proposal]))
+        out.append(inst_cls.cat([keep, gt_proposal]))
     return out
 
 

@@ -57,6 +57,18 @@ class Boxes:
     def get_centers(self) -> torch.Tensor:
         return (self.tensor[:, :2] + self.tensor[:, 2:]) / 2
 
+    def scale(self, scale_x: float, scale_y: float) -> None:
+        """[D2-upstream] Boxes.scale (in place): what detector_postprocess applies to pred_boxes
+        (ovr/modeling/meta_arch/ovr_rcnn.py:111, distill_prop_mmss_gcnn.py:556)."""
+        self.tensor[:, 0::2] *= scale_x
+        self.tensor[:, 1::2] *= scale_y
+
+    def inside_box(self, box_size: Tuple[int, int], boundary_threshold: int = 0) -> torch.Tensor:
+        height, width = box_size
+        b = self.tensor
+        return ((b[..., 0] >= -boundary_threshold) & (b[..., 1] >= -boundary_threshold)
+                & (b[..., 2] < width + boundary_threshold) & (b[..., 3] < height + boundary_threshold))
+
     def __getitem__(self, item) -> "Boxes":
         if isinstance(item, int):
             return Boxes(self.tensor[item].view(1, -1))
@@ -203,6 +215,19 @@ class ImageList:
     @property
     def device(self):
         return self.tensor.device
+
+
+def boxes_class_of(proposals: Sequence[Any]):
+    """(Instances class, Boxes class) of the caller's objects: results are built with the SAME classes the caller handed in,
+    so that under Detectron2 the meta-architecture gets detectron2.structures back (detector_postprocess calls
+    pred_boxes.scale / .clip / .nonempty on them) and stand-alone callers get this module's."""
+    for p in proposals:
+        inst_cls = type(p)
+        for name in ("proposal_boxes", "gt_boxes", "pred_boxes"):
+            if p.has(name):
+                return inst_cls, type(p.get(name))
+        return inst_cls, Boxes
+    return Instances, Boxes
 
 
 def boxes_tensor(b: Union[Boxes, torch.Tensor, Any]) -> torch.Tensor:

@@ -116,6 +116,6 @@ class TextBankCache:
         """trainer.py:383-396: set_class_embeddings + propagate num_classes to the ROI heads."""
         box_predictor.set_class_embeddings(self._fp32[name])
         if self.with_bf16 and not (box_predictor.normalize_emb or box_predictor.standardize_emb):
-            box_predictor._bank_bf16 = self._bf16[name]       # pre-packed: no per-swap conversion
+            box_predictor.install_packed_bank(self._bf16[name])   # pre-packed: no per-swap conversion
         if roi_heads is not None and hasattr(roi_heads, "num_classes"):
             roi_heads.num_classes = box_predictor.num_classes

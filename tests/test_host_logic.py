@@ -302,3 +302,21 @@ def test_bench_gpus_n_without_launcher_starts_n_ranks_or_fails_loudly():
     assert r.returncode != 0
     assert "2-rank child exited" in r.stderr
     assert r.stderr.count("bench.py needs a ROCm GPU") >= 1 or "needs a ROCm GPU" in r.stdout + r.stderr
+
+
+def test_batched_nms_per_class_fallback_equals_the_single_launch(monkeypatch):
+    """Above 40 000 candidates batched_nms runs per class (Detectron2's rule; the K x K/64 bit matrix would not fit);
+    both forms must keep the same boxes in the same order."""
+    from locov_amd.roi_heads import box_emb_head as beh
+    g = torch.Generator().manual_seed(11)
+    n = 600
+    xy = torch.rand(n, 2, generator=g) * 200
+    wh = torch.rand(n, 2, generator=g) * 60 + 4
+    boxes = torch.cat([xy, xy + wh], dim=1)
+    scores = torch.rand(n, generator=g)
+    idxs = torch.randint(0, 7, (n,), generator=g)
+    one = beh.batched_nms(boxes, scores, idxs, 0.5)
+    monkeypatch.setattr(beh, "_PER_CLASS_NMS_ABOVE", 100)
+    per_class = beh.batched_nms(boxes, scores, idxs, 0.5)
+    assert torch.equal(one, per_class)
+    assert beh._PER_CLASS_NMS_ABOVE == 100
