@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LOCOV_ABI_VERSION 1
+#define LOCOV_ABI_VERSION 2
 
 #define LOCOV_OK 0
 #define LOCOV_ERR_INVALID_ARG (-1)
@@ -227,7 +227,8 @@ int locov_winograd_conv3x3_f32(const float *x, int64_t R, int Cin, const float *
 int locov_winograd_conv3x3_f32_split(const float *x, int64_t R, int Cin, const void *U_split,
                                      float u_scale, float v_scale, const float *scale,
                                      const float *shift, float *y, int64_t ldy, int N, unsigned flags,
-                                     void *workspace, int64_t workspace_bytes, locov_stream_t stream);
+                                     void *workspace, int64_t workspace_bytes, unsigned *overflow,
+                                     locov_stream_t stream);
 
 int locov_gemm_nt_batched_f32(const float *x, int64_t lda, int64_t stride_x, const float *W,
                               int64_t stride_w, float *y, int64_t ldc, int64_t stride_y,
@@ -276,6 +277,10 @@ int locov_conv3x3_nhwc_bf16(const uint16_t *x, int64_t R, int H, int W, int Cin,
  * split once by locov_split_f16x2_pack into `out`, a buffer of the SAME size as the fp32 matrix
  * (rows * K * 4 bytes; per row and group of 8 columns: 8 hi halves, then 8 lo halves).
  * K % 32 == 0; N, lda, ldc % 4 == 0; 16-byte aligned pointers.  Epilogue as locov_gemm_nt_f32.
+ * RANGE GUARD: `overflow` (device pointer to one 32-bit word, or null) -- a launch in which any x value had
+ * |x_scale * x| >= 65504 (or was NaN) ORs 1 into it; the outputs such a value feeds are inf / NaN.  The word is only
+ * ever set, never cleared: the caller zeroes it, enqueues any number of split launches and reads it once afterwards
+ * (locov_amd's heads then repeat that call on the f32 MFMA).  Costs two v_max3_f32 per staged 16-byte chunk.
  * ------------------------------------------------------------------------------------- */
 int locov_split_f16x2_pack(const float *w, int64_t rows, int K, int64_t ld, float w_scale, void *out,
                            locov_stream_t stream);
@@ -283,7 +288,7 @@ int locov_split_f16x2_pack(const float *w, int64_t rows, int K, int64_t ld, floa
 int locov_gemm_nt_f32_split(const float *x, int64_t lda, const void *W_split, const float *scale,
                             const float *shift, const float *residual, float *y, int64_t ldc,
                             int64_t M, int N, int K, unsigned flags, float x_scale, float w_scale,
-                            locov_stream_t stream);
+                            unsigned *overflow, locov_stream_t stream);
 
 /* The last 1x1 convolution of Res5 fused with the spatial mean behind it (roi_emb_heads.py:245 -> :262,:344,:356):
  *   out[q, n] = mean over p < seg of relu?( scale[n] * (x[q*seg + p, :] . W[n, :]) + shift[n] + residual[p*R + q, n] )
@@ -298,13 +303,14 @@ int64_t locov_gemm_segmean_workspace_bytes(int64_t M, int N);
 int locov_gemm_nt_f32_split_segmean(const float *x, int64_t lda, const void *W_split, const float *scale,
                                     const float *shift, const float *residual, float *out, int64_t M,
                                     int N, int K, int seg, unsigned flags, float x_scale, float w_scale,
-                                    void *workspace, int64_t workspace_bytes, locov_stream_t stream);
+                                    void *workspace, int64_t workspace_bytes, unsigned *overflow,
+                                    locov_stream_t stream);
 
 /* `batch` independent problems (strides in fp32 elements; W_split problem b starts stride_w * 4 bytes * b in) */
 int locov_gemm_nt_batched_f32_split(const float *x, int64_t lda, int64_t stride_x, const void *W_split,
                                     int64_t stride_w, float *y, int64_t ldc, int64_t stride_y,
                                     int64_t M, int N, int K, int batch, float x_scale, float w_scale,
-                                    locov_stream_t stream);
+                                    unsigned *overflow, locov_stream_t stream);
 
 /* Measurement aid (bench.py's roofline block): while enabled, every GEMM-kernel launch made by
  * this library is bracketed by HIP events on its launch stream.  read() waits for them and
@@ -328,6 +334,11 @@ int locov_frozen_bn_fold(const float *weight, const float *bias, const float *ru
  * ------------------------------------------------------------------------------------- */
 int locov_rownorm_fwd(const float *x, int64_t R, int D, int mode, float eps, float *y,
                       locov_stream_t stream);
+
+/* Backward of locov_rownorm_fwd (training with a non-detached class predictor, box_emb_head.py:197-210):
+ * grad_x from the forward INPUT x and grad_y.  L2 with |x| <= eps: the clamp is active, grad_x = grad_y / eps. */
+int locov_rownorm_bwd(const float *x, const float *grad_y, int64_t R, int D, int mode, float eps,
+                      float *grad_x, locov_stream_t stream);
 
 /* fp32 -> bf16 (round-to-nearest-even, NaN preserved) for packing the text bank / embeddings */
 int locov_f32_to_bf16(const float *x, int64_t n, uint16_t *y, locov_stream_t stream);

@@ -21,7 +21,7 @@ WINO_OUT_ROI_MAJOR = 0x100
 WINO_IN_ROI_MAJOR = 0x200
 SEGMEAN_RES_ROI_MAJOR = 0x400
 MAX_LEVELS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _p = c_void_p  # device pointer
 
@@ -56,7 +56,7 @@ SIGNATURES = {
     "locov_winograd_pack_weight": (c_int, [_p, c_int, c_int, _p, _p]),
     "locov_winograd_conv3x3_f32": (c_int, [_p, c_int64, c_int, _p, _p, _p, _p, c_int64, c_int, c_uint, _p, c_int64, _p]),
     "locov_winograd_conv3x3_f32_split": (c_int, [_p, c_int64, c_int, _p, c_float, c_float, _p, _p, _p, c_int64, c_int, c_uint,
-                                                 _p, c_int64, _p]),
+                                                 _p, c_int64, _p, _p]),
     "locov_gemm_nt_batched_f32": (c_int, [_p, c_int64, c_int64, _p, c_int64, _p, c_int64, c_int64, c_int64, c_int,
                                           c_int, c_int, _p]),
     "locov_gemm_timing_enable": (c_int, [c_int]),
@@ -68,17 +68,18 @@ SIGNATURES = {
     "locov_grounding_bwd": (c_int, [_p, c_int, c_int, c_int, _p, _p, c_float, _p, _p, _p, _p]),
     "locov_token_attention_fwd": (c_int, [_p, c_int64, c_int, _p, _p, c_int, c_int, c_float, c_int, c_int, _p, _p, _p, _p]),
     "locov_rownorm_fwd": (c_int, [_p, c_int64, c_int, c_int, c_float, _p, _p]),
+    "locov_rownorm_bwd": (c_int, [_p, _p, c_int64, c_int, c_int, c_float, _p, _p]),
     "locov_f32_to_bf16": (c_int, [_p, c_int64, _p, _p]),
     "locov_gemm_nt_bf16": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, _p]),
     "locov_conv3x3_nhwc_bf16": (c_int, [_p, c_int64, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, c_int, c_uint, _p]),
     "locov_split_f16x2_pack": (c_int, [_p, c_int64, c_int, c_int64, c_float, _p, _p]),
     "locov_gemm_nt_f32_split": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, c_float,
-                                        c_float, _p]),
+                                        c_float, _p, _p]),
     "locov_gemm_segmean_workspace_bytes": (c_int64, [c_int64, c_int]),
     "locov_gemm_nt_f32_split_segmean": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int, c_int, c_int, c_uint, c_float,
-                                                c_float, _p, c_int64, _p]),
+                                                c_float, _p, c_int64, _p, _p]),
     "locov_gemm_nt_batched_f32_split": (c_int, [_p, c_int64, c_int64, _p, c_int64, _p, c_int64, c_int64, c_int64, c_int,
-                                                c_int, c_int, c_float, c_float, _p]),
+                                                c_int, c_int, c_float, c_float, _p, _p]),
     "locov_sim_gemm_bf16": (c_int, [_p, _p, c_int64, c_int, c_int, _p, c_int64, _p]),
     "locov_gemm_nt_f32_ex": (c_int, [_p, c_int64, _p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, _p]),
     "locov_conv3x3_nhwc_f32_ex": (c_int, [_p, c_int64, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, _p, c_int, c_uint, _p]),

@@ -125,6 +125,9 @@ def get_cfg() -> CfgNode:
                 # than the f32 MFMA's, ~2x its speed (activations must stay below 4094 in magnitude); "fp32": the f32 MFMA;
                 # "bf16": bf16 operands (reduced precision, opt-in, not a parity configuration)
                 "RES5_DTYPE": "f16x2",
+                # extension: with "f16x2" every split launch ORs a range-guard word when an activation left fp16's range; the
+                # heads read it once per call and repeat the call on the f32 MFMA (with a warning) if it is set
+                "RES5_OVERFLOW_CHECK": True,
             },
             "RESNETS": {
                 "NUM_GROUPS": 1, "WIDTH_PER_GROUP": 64, "RES2_OUT_CHANNELS": 256,

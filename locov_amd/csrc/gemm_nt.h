@@ -41,9 +41,10 @@ void timing_end(int idx, hipStream_t s);
 
 // y[M,N] = epi(A[M,K] . W[N,K]^T) with fp32 A split on the fly (scaled by a_scale) and W pre-split into f16 (hi, lo)
 // pairs of w_scale * W (gemm_split.hip); same Epilogue / Batch meaning as launch_gemm_nt.
+// overflow: optional device word that the kernel ORs 1 into when an A value left the range a_scale covers (locov_hip.h).
 int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C, int64_t ldc, int64_t M, int N, int K,
                       const Epilogue &epi, float a_scale, float w_scale, hipStream_t s, const char *what,
-                      const Batch &bt = Batch{1, 0, 0, 0});
+                      const Batch &bt = Batch{1, 0, 0, 0}, unsigned *overflow = nullptr);
 
 // out[b][N,K] = row_scale[n] * sum_m A_b[m,n] * B_b[m,k]  (gemm_tn.hip: the weight-gradient GEMM; problem b uses
 // A + b*sa, B + b*sb, out + b*so; ws = gemm_tn_workspace_bytes(M, N, K, batch) bytes of device memory)

@@ -100,7 +100,7 @@ template <bool SEGSUM>
 __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restrict__ A, int64_t lda,
                                                            const float *__restrict__ B, float *__restrict__ Cout,
                                                            int64_t ldc, int64_t M, int N, int K, Epilogue epi, Batch bt,
-                                                           float a_scale, float out_scale, SegSum ss)
+                                                           float a_scale, float out_scale, SegSum ss, unsigned *overflow)
 {
     __shared__ u32x4 lds[2 * STAGEB / 16];
     char *const ldsb = reinterpret_cast<char *>(lds);
@@ -179,8 +179,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
                 b_voff[i], 0, 0, 0);
     };
     f32x4 ra[CH];
+    // Range guard of the split arithmetic: |a_scale * x| must stay below fp16's largest finite value.  Every A value passes
+    // through this thread's registers exactly once on its way into LDS; two v_max3_f32 per chunk keep the running maximum of
+    // |x|, and a launch that saw a value outside the range raises the caller's flag word (locov_hip.h: `overflow`) -- the
+    // outputs fed by that value are inf / NaN, the flag is how the host learns of it without looking at them.
+    float amax = 0.f;
     auto st_a = [&](int i, int stage) {
         u32x2 hi, lo;
+        amax = fmaxf(fmaxf(amax, fabsf(ra[i][0])), fabsf(ra[i][1]));
+        amax = fmaxf(fmaxf(amax, fabsf(ra[i][2])), fabsf(ra[i][3]));
         split4(ra[i], a_scale, hi, lo);
         char *p = ldsb + stage * STAGEB + a_lds[i];
         *reinterpret_cast<u32x2 *>(p) = hi;
@@ -334,6 +341,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
     }
 
     __builtin_amdgcn_s_setprio(3);
+    if (overflow != nullptr && !(amax * a_scale < 65504.f)) atomicOr(overflow, 1u);       // (NaN-safe: a NaN input raises it too)
     // Epilogue (C/D layout of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg): re-lay the wave's sub-tile out
     // through LDS, 16 bytes per lane and row-contiguous from there.
     const bool relu = (epi.flags & LOCOV_EPI_RELU) != 0;
@@ -469,7 +477,8 @@ __global__ __launch_bounds__(256) void segsum_finish_kernel(const float *__restr
 }
 
 int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C, int64_t ldc, int64_t M, int N, int K,
-                      const Epilogue &epi, float a_scale, float w_scale, hipStream_t s, const char *what, const Batch &bt)
+                      const Epilogue &epi, float a_scale, float w_scale, hipStream_t s, const char *what, const Batch &bt,
+                      unsigned *overflow)
 {
     if (!(a_scale > 0.f) || !(w_scale > 0.f)) return set_error(LOCOV_ERR_INVALID_ARG, "%s: operand scales must be positive", what);
     if (K % BK != 0 || K < BK) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: K must be a positive multiple of %d", what, BK);
@@ -486,14 +495,15 @@ int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C,
     const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K * count);     // class 5: split-operand GEMM
     hipLaunchKernelGGL(gemm_split_kernel<false>, dim3((unsigned)tiles), dim3(NT), 0, s, A, lda,
                        reinterpret_cast<const float *>(Wsplit), C, ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale),
-                       SegSum{0, 0, nullptr});
+                       SegSum{0, 0, nullptr}, overflow);
     timing_end(trec, s);
     return check_launch(what);
 }
 
 // The SEGSUM form + its finishing pass: mean over the `seg` rows of every ROI of relu(scale * (x . W^T) + shift + residual)
 int launch_gemm_split_segmean(const float *A, int64_t lda, const void *Wsplit, int64_t M, int N, int K, const Epilogue &epi,
-                              int seg, float a_scale, float w_scale, float *partial, float *out, hipStream_t s, const char *what)
+                              int seg, float a_scale, float w_scale, float *partial, float *out, hipStream_t s, const char *what,
+                              unsigned *overflow)
 {
     if (!(a_scale > 0.f) || !(w_scale > 0.f)) return set_error(LOCOV_ERR_INVALID_ARG, "%s: operand scales must be positive", what);
     if (K % BK != 0 || K < BK) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: K must be a positive multiple of %d", what, BK);
@@ -511,7 +521,7 @@ int launch_gemm_split_segmean(const float *A, int64_t lda, const void *Wsplit, i
     const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K);
     hipLaunchKernelGGL(gemm_split_kernel<true>, dim3((unsigned)tiles), dim3(NT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
                        static_cast<float *>(nullptr), (int64_t)N, M, N, K, epi, Batch{1, 0, 0, 0}, a_scale, 1.f / (a_scale * w_scale),
-                       SegSum{seg, (epi.flags & LOCOV_SEGMEAN_RES_ROI_MAJOR) ? (int64_t)0 : M / seg, partial});
+                       SegSum{seg, (epi.flags & LOCOV_SEGMEAN_RES_ROI_MAJOR) ? (int64_t)0 : M / seg, partial}, overflow);
     timing_end(trec, s);
     int rc = check_launch(what);
     if (rc) return rc;
@@ -542,7 +552,7 @@ int locov_split_f16x2_pack(const float *w, int64_t rows, int K, int64_t ld, floa
 
 int locov_gemm_nt_f32_split(const float *x, int64_t lda, const void *W_split, const float *scale, const float *shift,
                             const float *residual, float *y, int64_t ldc, int64_t M, int N, int K, unsigned flags,
-                            float x_scale, float w_scale, locov_stream_t stream)
+                            float x_scale, float w_scale, unsigned *overflow, locov_stream_t stream)
 {
     LOCOV_REQUIRE(M >= 0 && N > 0 && K > 0, "locov_gemm_nt_f32_split: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
     if (M == 0) return LOCOV_OK;
@@ -550,7 +560,7 @@ int locov_gemm_nt_f32_split(const float *x, int64_t lda, const void *W_split, co
     LOCOV_REQUIRE(lda >= K && ldc >= N, "locov_gemm_nt_f32_split: lda < K or ldc < N");
     Epilogue epi{scale, shift, residual, flags};
     return launch_gemm_split(x, lda, W_split, y, ldc, M, N, K, epi, x_scale, w_scale, as_stream(stream),
-                             "locov_gemm_nt_f32_split");
+                             "locov_gemm_nt_f32_split", Batch{1, 0, 0, 0}, overflow);
 }
 
 int64_t locov_gemm_segmean_workspace_bytes(int64_t M, int N)
@@ -562,7 +572,7 @@ int64_t locov_gemm_segmean_workspace_bytes(int64_t M, int N)
 int locov_gemm_nt_f32_split_segmean(const float *x, int64_t lda, const void *W_split, const float *scale, const float *shift,
                                     const float *residual, float *out, int64_t M, int N, int K, int seg, unsigned flags,
                                     float x_scale, float w_scale, void *workspace, int64_t workspace_bytes,
-                                    locov_stream_t stream)
+                                    unsigned *overflow, locov_stream_t stream)
 {
     LOCOV_REQUIRE(M >= 0 && N > 0 && K > 0, "locov_gemm_nt_f32_split_segmean: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
     if (M == 0) return LOCOV_OK;
@@ -574,12 +584,12 @@ int locov_gemm_nt_f32_split_segmean(const float *x, int64_t lda, const void *W_s
                   "locov_gemm_nt_f32_split_segmean: workspace too small (%lld bytes)", (long long)workspace_bytes);
     Epilogue epi{scale, shift, residual, flags};
     return launch_gemm_split_segmean(x, lda, W_split, M, N, K, epi, seg, x_scale, w_scale, static_cast<float *>(workspace), out,
-                                     as_stream(stream), "locov_gemm_nt_f32_split_segmean");
+                                     as_stream(stream), "locov_gemm_nt_f32_split_segmean", overflow);
 }
 
 int locov_gemm_nt_batched_f32_split(const float *x, int64_t lda, int64_t stride_x, const void *W_split, int64_t stride_w,
                                     float *y, int64_t ldc, int64_t stride_y, int64_t M, int N, int K, int batch,
-                                    float x_scale, float w_scale, locov_stream_t stream)
+                                    float x_scale, float w_scale, unsigned *overflow, locov_stream_t stream)
 {
     LOCOV_REQUIRE(M >= 0 && N > 0 && K > 0 && batch > 0, "locov_gemm_nt_batched_f32_split: bad shape");
     if (M == 0) return LOCOV_OK;
@@ -588,7 +598,7 @@ int locov_gemm_nt_batched_f32_split(const float *x, int64_t lda, int64_t stride_
                   "locov_gemm_nt_batched_f32_split: lda < K, ldc < N or a stride that is not a multiple of 4");
     Epilogue epi{nullptr, nullptr, nullptr, 0u};
     return launch_gemm_split(x, lda, W_split, y, ldc, M, N, K, epi, x_scale, w_scale, as_stream(stream),
-                             "locov_gemm_nt_batched_f32_split", Batch{batch, stride_x, stride_w, stride_y});
+                             "locov_gemm_nt_batched_f32_split", Batch{batch, stride_x, stride_w, stride_y}, overflow);
 }
 
 }  // extern "C"

@@ -121,6 +121,55 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ 
     }
 }
 
+// Backward of rownorm_kernel: one wave per row.
+//   L2          y = x / den, den = max(|x|, eps):   dx = (g - y (y.g)) / den   (den = eps: the clamp is active, dx = g / eps)
+//   standardise y = (x - m) / den, den = std + eps (unbiased std):
+//               dx = (g - mean(g)) / den - (x - m) (g.(x - m)) / (den^2 std (D - 1))     (std = 0: the second term is 0)
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ g, int64_t R, int D,
+                                                          int mode, float eps, float *__restrict__ dx)
+{
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int lane = threadIdx.x & 63;
+    const float *p = x + row * D, *gr = g + row * D;
+    float *q = dx + row * D;
+    if (mode == LOCOV_NORM_L2) {
+        float ss = 0.f, xg = 0.f;
+        for (int k = lane; k < D; k += 64) {
+            ss += p[k] * p[k];
+            xg += p[k] * gr[k];
+        }
+        const float nrm = sqrtf(wave_sum(ss));
+        xg = wave_sum(xg);
+        if (nrm > eps) {
+            const float inv = 1.f / nrm, c = xg * inv * inv * inv;           // (y.g) y / den = x (x.g) / |x|^3
+            for (int k = lane; k < D; k += 64) q[k] = gr[k] * inv - p[k] * c;
+        } else {
+            for (int k = lane; k < D; k += 64) q[k] = gr[k] / eps;
+        }
+    } else if (mode == LOCOV_NORM_STANDARDIZE) {
+        float s = 0.f, sg = 0.f;
+        for (int k = lane; k < D; k += 64) {
+            s += p[k];
+            sg += gr[k];
+        }
+        const float mean = wave_sum(s) / (float)D, gmean = wave_sum(sg) / (float)D;
+        float vs = 0.f, gd = 0.f;
+        for (int k = lane; k < D; k += 64) {
+            const float d = p[k] - mean;
+            vs += d * d;
+            gd += gr[k] * d;
+        }
+        const float sd = sqrtf(wave_sum(vs) / (float)(D - 1));
+        gd = wave_sum(gd);
+        const float den = sd + eps;
+        const float c = sd > 0.f ? gd / (den * den * sd * (float)(D - 1)) : 0.f;
+        for (int k = lane; k < D; k += 64) q[k] = (gr[k] - gmean) / den - (p[k] - mean) * c;
+    } else {
+        for (int k = lane; k < D; k += 64) q[k] = gr[k];
+    }
+}
+
 static int spatial_mean(const float *x, int64_t R, int C, int HW, int channels_last, float *out, hipStream_t s)
 {
     if (HW == 1) {
@@ -186,6 +235,20 @@ int locov_rownorm_fwd(const float *x, int64_t R, int D, int mode, float eps, flo
     if (R == 0) return LOCOV_OK;
     LOCOV_REQUIRE(x && y, "locov_rownorm_fwd: null pointer");
     return rownorm(x, R, D, mode, eps, y, as_stream(stream));
+}
+
+int locov_rownorm_bwd(const float *x, const float *grad_y, int64_t R, int D, int mode, float eps, float *grad_x,
+                      locov_stream_t stream)
+{
+    LOCOV_REQUIRE(R >= 0 && D > 0, "locov_rownorm_bwd: bad shape R=%lld D=%d", (long long)R, D);
+    LOCOV_REQUIRE(mode == LOCOV_NORM_NONE || mode == LOCOV_NORM_L2 || mode == LOCOV_NORM_STANDARDIZE,
+                  "locov_rownorm_bwd: unknown mode %d", mode);
+    LOCOV_REQUIRE(mode != LOCOV_NORM_STANDARDIZE || D > 1, "locov_rownorm_bwd: standardise needs D > 1");
+    if (R == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(x && grad_y && grad_x, "locov_rownorm_bwd: null pointer");
+    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((unsigned)ceil_div(R, 4)), dim3(256), 0, as_stream(stream), x, grad_y, R, D, mode, eps,
+                       grad_x);
+    return check_launch("locov_rownorm_bwd");
 }
 
 int locov_box_head_fwd(const float *x, int64_t R, int C5, int HW, int channels_last, const float *emb_w,

@@ -235,7 +235,8 @@ int locov_winograd_pack_weight(const float *w, int N, int Cin, float *U, locov_s
 // f16 matrix pipe with V scaled by v_scale (gemm_split.hip); u_scale == 0: fp32 U, fp32 MFMA.
 static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
                             const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
-                            void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask = nullptr);
+                            void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask = nullptr,
+                            unsigned *overflow = nullptr);
 
 int locov_winograd_conv3x3_f32_ex(const float *x, int64_t R, int Cin, const float *U, const float *scale, const float *shift,
                                   const float *mask, float *y, int64_t ldy, int N, unsigned flags, void *workspace,
@@ -253,16 +254,17 @@ int locov_winograd_conv3x3_f32(const float *x, int64_t R, int Cin, const float *
 
 int locov_winograd_conv3x3_f32_split(const float *x, int64_t R, int Cin, const void *U_split, float u_scale, float v_scale,
                                      const float *scale, const float *shift, float *y, int64_t ldy, int N,
-                                     unsigned flags, void *workspace, int64_t workspace_bytes, locov_stream_t stream)
+                                     unsigned flags, void *workspace, int64_t workspace_bytes, unsigned *overflow,
+                                     locov_stream_t stream)
 {
     LOCOV_REQUIRE(u_scale > 0.f && v_scale > 0.f, "locov_winograd_conv3x3_f32_split: operand scales must be positive");
     return winograd_conv3x3(x, R, Cin, static_cast<const float *>(U_split), u_scale, v_scale, scale, shift, y, ldy, N, flags,
-                            workspace, workspace_bytes, stream);
+                            workspace, workspace_bytes, stream, nullptr, overflow);
 }
 
 static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
                             const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
-                            void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask)
+                            void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask, unsigned *overflow)
 {
     LOCOV_REQUIRE(ldy >= N && ldy % 2 == 0, "locov_winograd_conv3x3_f32: ldy must be >= N and even");
     LOCOV_REQUIRE(R >= 0 && Cin > 0 && N > 0, "locov_winograd_conv3x3_f32: bad shape");
@@ -294,7 +296,7 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
         if (u_scale > 0.f)
             rcode = launch_gemm_split(V, (int64_t)Cin, U, Mv, (int64_t)N, rc, N, Cin, epi, v_scale, u_scale, s,
                                       "locov_winograd_conv3x3_f32_split (batched GEMM)",
-                                      Batch{NF * NF, rc * Cin, (int64_t)N * Cin, rc * N});
+                                      Batch{NF * NF, rc * Cin, (int64_t)N * Cin, rc * N}, overflow);
         else
             rcode = launch_gemm_nt<float, float>(V, (int64_t)Cin, U, (int64_t)Cin, Mv, (int64_t)N, rc, N, Cin, epi, s,
                                                  "locov_winograd_conv3x3_f32 (batched GEMM)", ConvGeom{0, 0, 0, 0, 0},

@@ -358,7 +358,8 @@ def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool =
         if split is not None:
             check(lib.locov_winograd_conv3x3_f32_split(_ptr(x), R, Cin, _ptr(U), split.scale, float(v_scale), _ptr(scale),
                                                        _ptr(shift), _ptr(y), ldy, N, wflags, _ptr(ws),
-                                                       ws.numel(), _stream(x)), "locov_winograd_conv3x3_f32_split")
+                                                       ws.numel(), _ptr(_overflow_word(x)), _stream(x)),
+                  "locov_winograd_conv3x3_f32_split")
         else:
             check(lib.locov_winograd_conv3x3_f32(_ptr(x), R, Cin, _ptr(U), _ptr(scale), _ptr(shift), _ptr(y), ldy, N,
                                                  wflags, _ptr(ws), ws.numel(), _stream(x)),
@@ -379,6 +380,28 @@ def gemm_nt_batched(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
         check(_lib.load().locov_gemm_nt_batched_f32(_ptr(x), K, M * K, _ptr(w), N * K, _ptr(y), N, M * N, M, N, K, B,
                                                     _stream(x)), "locov_gemm_nt_batched_f32")
     return y
+
+
+_OVERFLOW = {}
+
+
+def _overflow_word(ref: torch.Tensor) -> torch.Tensor:
+    """The device word every split-operand launch of this process ORs its range-guard result into (one per device)."""
+    w = _OVERFLOW.get(ref.device)
+    if w is None:
+        w = _OVERFLOW[ref.device] = torch.zeros(1, dtype=torch.int32, device=ref.device)
+    return w
+
+
+def split_overflow_reset(device) -> None:
+    """Clear the range-guard word of `device` (enqueued on the current stream)."""
+    _overflow_word(torch.empty(0, device=device)).zero_()
+
+
+def split_overflow_raised(device) -> bool:
+    """True when a split-operand launch since the last reset saw |x_scale * x| >= 65504 (ONE host read: it waits for the
+    launches enqueued so far)."""
+    return bool(_overflow_word(torch.empty(0, device=device)).item())
 
 
 class SplitWeight(NamedTuple):
@@ -429,7 +452,8 @@ def linear_split(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tens
     with torch.cuda.device(x.device):
         check(_lib.load().locov_gemm_nt_f32_split(_ptr(x), x.stride(0) if M else K, _ptr(wd), _ptr(scale), _ptr(bias),
                                                   _ptr(residual), _ptr(y), N, M, N, K, _lib.EPI_RELU if relu else 0,
-                                                  float(x_scale), weight.scale, _stream(x)), "locov_gemm_nt_f32_split")
+                                                  float(x_scale), weight.scale, _ptr(_overflow_word(x)), _stream(x)),
+              "locov_gemm_nt_f32_split")
     return y
 
 
@@ -465,7 +489,8 @@ def linear_split_segmean(x: torch.Tensor, weight: SplitWeight, bias: Optional[to
         check(lib.locov_gemm_nt_f32_split_segmean(_ptr(x), x.stride(0) if M else K, _ptr(wd), _ptr(scale), _ptr(bias),
                                                   _ptr(residual), _ptr(out), M, N, K, int(seg),
                                                   (_lib.EPI_RELU if relu else 0) | (_lib.SEGMEAN_RES_ROI_MAJOR if residual_roi_major else 0),
-                                                  float(x_scale), weight.scale, _ptr(ws), ws.numel(), _stream(x)),
+                                                  float(x_scale), weight.scale, _ptr(ws), ws.numel(), _ptr(_overflow_word(x)),
+                                                  _stream(x)),
               "locov_gemm_nt_f32_split_segmean")
     return out
 
@@ -481,7 +506,7 @@ def gemm_nt_batched_split(x: torch.Tensor, w: SplitWeight, x_scale: float = 1.0)
     y = torch.empty((B, M, N), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         check(_lib.load().locov_gemm_nt_batched_f32_split(_ptr(x), K, M * K, _ptr(wd), N * K, _ptr(y), N, M * N, M, N, K,
-                                                          B, float(x_scale), w.scale, _stream(x)),
+                                                          B, float(x_scale), w.scale, _ptr(_overflow_word(x)), _stream(x)),
               "locov_gemm_nt_batched_f32_split")
     return y
 
@@ -842,6 +867,33 @@ def rownorm(x: torch.Tensor, mode: int, eps: float = 1e-12) -> torch.Tensor:
         check(_lib.load().locov_rownorm_fwd(_ptr(x), R, D, int(mode), float(eps), _ptr(y), _stream(x)),
               "locov_rownorm_fwd")
     return y
+
+
+class _RowNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode, eps):
+        x = _dev(x.detach(), "x")
+        ctx.save_for_backward(x)
+        ctx.args = (mode, eps)
+        return rownorm(x, mode, eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        mode, eps = ctx.args
+        g = _dev(g, "grad")
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            check(_lib.load().locov_rownorm_bwd(_ptr(x), _ptr(g), x.shape[0], x.shape[1], int(mode), float(eps), _ptr(dx),
+                                                _stream(x)), "locov_rownorm_bwd")
+        return dx, None, None
+
+
+def rownorm_autograd(x: torch.Tensor, mode: int, eps: float = 1e-12) -> torch.Tensor:
+    """rownorm(), differentiable in x (forward and backward on the HIP kernels)."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _RowNormFn.apply(x, int(mode), float(eps))
+    return rownorm(x.detach(), mode, eps)
 
 
 def to_bf16(x: torch.Tensor) -> torch.Tensor:

@@ -49,8 +49,7 @@ class Res5RowsFn(torch.autograd.Function):
     following blocks) -- passed as inputs so that autograd routes their gradients."""
 
     @staticmethod
-    def forward(ctx, x0, stage, R, H, W, pooled, split, *weights):
-        x = ops._dev(x0.detach(), "x0")
+    def _blocks(stage, x, H, W, split):
         saved: List[torch.Tensor] = []
         meta = []
         wi = 0
@@ -78,19 +77,34 @@ class Res5RowsFn(torch.autograd.Function):
             meta.append((has_sc, wino, wi))
             wi += 4 if has_sc else 3
             x = out
+        return saved, meta, x
+
+    @staticmethod
+    def forward(ctx, x0, stage, R, H, W, pooled, split, guard, *weights):
+        """guard: None, or (on_overflow,) -- check the split arithmetic's range-guard word after the forward and repeat it on
+        the f32 MFMA when an activation left fp16's range (calls on_overflow() first)."""
+        x = ops._dev(x0.detach(), "x0")
+        if split and guard is not None:
+            ops.split_overflow_reset(x.device)
+        saved, meta, out = Res5RowsFn._blocks(stage, x, H, W, split)
+        if split and guard is not None and ops.split_overflow_raised(x.device):
+            if guard[0] is not None:
+                guard[0]()
+            del saved, out
+            saved, meta, out = Res5RowsFn._blocks(stage, x, H, W, False)
         ctx.stage, ctx.meta, ctx.geom, ctx.pooled = stage, meta, (R, H, W), pooled
         ctx.nw = len(weights)
         ctx.save_for_backward(*saved)
         if pooled:
-            return ops.spatial_mean(x.view(R, H, W, x.shape[1]), channels_last=1)
-        return x
+            return ops.spatial_mean(out.view(R, H, W, out.shape[1]), channels_last=1)
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
         stage, (R, H, W) = ctx.stage, ctx.geom
         saved = ctx.saved_tensors
         need_x = ctx.needs_input_grad[0]
-        need_w = ctx.needs_input_grad[7:]
+        need_w = ctx.needs_input_grad[8:]
         gw: List[Optional[torch.Tensor]] = [None] * ctx.nw
         grad_out = ops._dev(grad_out, "grad_out")
         out_last = saved[-1]
@@ -141,7 +155,7 @@ class Res5RowsFn(torch.autograd.Function):
                 gx = ops.linear_ex(g, ops.weight_transpose_scale(ws, ss), residual=gx, mask=mask)
             del g1
             g = gx
-        return (g, None, None, None, None, None, None, *gw)
+        return (g, None, None, None, None, None, None, None, *gw)
 
 
 def _stage_weights(stage) -> Tuple[torch.Tensor, ...]:
@@ -153,10 +167,12 @@ def _stage_weights(stage) -> Tuple[torch.Tensor, ...]:
     return tuple(ws)
 
 
-def res5_rows(stage, x0: torch.Tensor, R: int, H: int, W: int, pooled: bool = False, split: bool = True) -> torch.Tensor:
+def res5_rows(stage, x0: torch.Tensor, R: int, H: int, W: int, pooled: bool = False, split: bool = True,
+              overflow_check: bool = True, on_overflow=None) -> torch.Tensor:
     """Differentiable Res5 on ROI-major pixel rows (see Res5RowsFn)."""
     assert stage.supports_rows_path(), "the rows path needs FrozenBN, STRIDE_IN_1X1 and ungrouped convolutions"
-    return Res5RowsFn.apply(x0, stage, R, H, W, pooled, split, *_stage_weights(stage))
+    guard = (on_overflow,) if overflow_check else None
+    return Res5RowsFn.apply(x0, stage, R, H, W, pooled, split, guard, *_stage_weights(stage))
 
 
 class _ToNHWC(torch.autograd.Function):
@@ -219,7 +235,7 @@ class _Stride2Rows(torch.autograd.Function):
         return ops.rows_stride2(g, N, H, W, False)
 
 
-def res5_grid(stage, nhwc: torch.Tensor, split: bool = True) -> torch.Tensor:
+def res5_grid(stage, nhwc: torch.Tensor, split: bool = True, overflow_check: bool = True, on_overflow=None) -> torch.Tensor:
     """roi_emb_heads.py:323 -- the stage applied to the whole channels-last res4 map [N,H,W,Cin] -> logical NCHW
     [N, Cout, ceil(H/2), ceil(W/2)], differentiable in the map and the convolution weights.  Block 0's stride-2 1x1
     convolutions read the even pixels; the 3x3 convolutions run as implicit GEMMs over the (H/2 x W/2) grid."""
@@ -227,5 +243,5 @@ def res5_grid(stage, nhwc: torch.Tensor, split: bool = True) -> torch.Tensor:
     assert stage[0].stride == 2 and stage[0].stride_in_1x1
     OH, OW = (H + 1) // 2, (W + 1) // 2
     rows = _Stride2Rows.apply(nhwc)
-    y = res5_rows(stage, rows, N, OH, OW, pooled=False, split=split)
+    y = res5_rows(stage, rows, N, OH, OW, pooled=False, split=split, overflow_check=overflow_check, on_overflow=on_overflow)
     return _ToNCHW.apply(y.view(N, OH, OW, y.shape[1]))

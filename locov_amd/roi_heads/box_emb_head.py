@@ -471,12 +471,9 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
 
 
 def _rownorm(x: torch.Tensor, mode: int) -> torch.Tensor:
-    if torch.is_grad_enabled() and x.requires_grad:
-        # differentiable form (training with a non-detached class predictor): torch autograd
-        if mode == ops.NORM_L2:
-            return F.normalize(x, p=2, dim=1)
-        return (x - x.mean(1, keepdim=True)) / (x.std(1, keepdim=True) + 1e-12)
-    return ops.rownorm(x.detach(), mode)
+    """normalize_vec / standardize_vec (logged_module.py:55-72) on the HIP kernels, forward and -- when the class predictor
+    is trained through them -- backward (locov_rownorm_fwd / _bwd)."""
+    return ops.rownorm_autograd(x, mode)
 
 
 def build_box_predictor(cfg, input_shape):

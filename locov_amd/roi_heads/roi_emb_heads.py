@@ -207,12 +207,17 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
     @configurable
     def __init__(self, *, in_features: List[str], pooler: ROIPooler, res5: nn.Module, box_predictor: nn.Module,
                  mask_head: Optional[nn.Module] = None, output_shape: Optional[int] = 0,
-                 res5_backend: str = "hip", res5_conv3x3: str = "winograd", res5_dtype: str = "f16x2", **kwargs):
+                 res5_backend: str = "hip", res5_conv3x3: str = "winograd", res5_dtype: str = "f16x2",
+                 res5_overflow_check: bool = True, **kwargs):
         super().__init__(**kwargs)
         assert res5_backend in ("hip", "miopen") and res5_conv3x3 in ("winograd", "direct") and res5_dtype in ("fp32", "f16x2", "bf16")
         # extension: "f16x2" = fp32 GEMMs formed from split f16 operand pairs on the f16 matrix pipe (fp32-level
         # accuracy, see csrc/gemm_split.hip); "bf16" = reduced-precision GEMM operands (not a parity configuration)
         self.res5_dtype = res5_dtype
+        # the split arithmetic's range guard: read the device flag once per call and, if an activation left fp16's range
+        # (|x| >= 4094 at the activation scale), repeat the call on the f32 MFMA
+        self.res5_overflow_check = res5_overflow_check
+        self._overflow_warned = False
         self.res5_backend = res5_backend      # extension: how the Res5 convolutions run (see res5.py)
         self.res5_conv3x3 = res5_conv3x3      # extension: form of the 3x3 convolutions on the hip backend
         self.in_features = in_features
@@ -247,6 +252,7 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         ret["res5_backend"] = box_head.get("RES5_BACKEND", "hip") if hasattr(box_head, "get") else "hip"
         ret["res5_conv3x3"] = box_head.get("RES5_CONV3X3", "winograd") if hasattr(box_head, "get") else "winograd"
         ret["res5_dtype"] = box_head.get("RES5_DTYPE", "f16x2") if hasattr(box_head, "get") else "f16x2"
+        ret["res5_overflow_check"] = bool(box_head.get("RES5_OVERFLOW_CHECK", True)) if hasattr(box_head, "get") else True
         return ret
 
     @classmethod
@@ -280,7 +286,8 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         from .. import res5_train
         if nhwc is None:
             nhwc = res5_train.to_nhwc(feature)
-        return res5_train.res5_grid(self.res5, nhwc, split=self.res5_dtype == "f16x2")
+        return res5_train.res5_grid(self.res5, nhwc, split=self.res5_dtype == "f16x2", overflow_check=self.res5_overflow_check,
+                                    on_overflow=self._warn_overflow)
 
     def _shared_roi_transform(self, features: List[torch.Tensor], boxes: List[Boxes], pooled: bool = False,
                               nhwc: Optional[torch.Tensor] = None):
@@ -302,12 +309,31 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
                 nhwc = res5_train.to_nhwc(features[0])
             x0 = res5_train.roi_align_even_rows(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned)
             R, o = rois.shape[0], P // 2
-            y = res5_train.res5_rows(self.res5, x0, R, o, o, pooled=pooled, split=self.res5_dtype == "f16x2")
+            y = res5_train.res5_rows(self.res5, x0, R, o, o, pooled=pooled, split=self.res5_dtype == "f16x2",
+                                     overflow_check=self.res5_overflow_check, on_overflow=self._warn_overflow)
             return y if pooled else y.view(R, o, o, y.shape[1]).permute(0, 3, 1, 2)
         if not self._fused_path_ok(features):
             x = self.pooler(features, boxes)                 # :244
             x = self.res5(x)                                 # :245
             return self._pooled_mean(x) if pooled else x
+        if self.res5_dtype == "f16x2" and self.res5_overflow_check:
+            dev = features[0].device
+            ops.split_overflow_reset(dev)
+            out = self._fused_roi_transform(features, boxes, pooled, "f16x2")
+            if not ops.split_overflow_raised(dev):           # one 4-byte read per call
+                return out
+            self._warn_overflow()
+            return self._fused_roi_transform(features, boxes, pooled, "fp32")
+        return self._fused_roi_transform(features, boxes, pooled, self.res5_dtype)
+
+    def _warn_overflow(self):
+        if not self._overflow_warned:
+            import warnings
+            warnings.warn("Res5 activations left the range of the f16x2 split arithmetic (|x| >= 4094): this call was repeated "
+                          "on the f32 MFMA (RES5_DTYPE 'fp32' avoids the retry; reported once per module)", RuntimeWarning, stacklevel=3)
+            self._overflow_warned = True
+
+    def _fused_roi_transform(self, features, boxes, pooled, res5_dtype):
         assert len(boxes) == features[0].shape[0]
         rois = convert_boxes_to_pooler_format(boxes)
         P = self.pooler.output_size[0]
@@ -317,8 +343,8 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         oh = ow = P // 2
         R = rois.shape[0]
         wino = self.res5_conv3x3 == "winograd"
-        split = self.res5_dtype == "f16x2"
-        if self.res5_dtype == "bf16":
+        split = res5_dtype == "f16x2"
+        if res5_dtype == "bf16":
             x0 = torch.empty((oh * ow * R, nhwc.shape[3]), dtype=torch.float32, device=nhwc.device)
             if P == 14 and self.res5[0].shortcut is not None:
                 y = self.res5.forward_from_map(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio,

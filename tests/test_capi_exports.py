@@ -31,7 +31,8 @@ def test_header_and_binding_agree(lib):
 def test_every_symbol_is_exported(lib):
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.locov_abi_version() == 1
+    from locov_amd import _lib
+    assert lib.locov_abi_version() == _lib.ABI_VERSION == 2        # 2: the split entry points carry the range-guard word
 
 
 def test_argument_errors_are_reported_without_a_gpu(lib):

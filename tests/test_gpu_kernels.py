@@ -364,3 +364,48 @@ def test_roi_align_nchw_bit_exact_random_configurations(ops, oracle):
         want = oracle.roi_align(feat, rois, (P, P), scale, ratio, aligned)
         got = ops.roi_align(dev(feat), dev(rois), P, scale, ratio, aligned).cpu().numpy()
         np.testing.assert_array_equal(got, want, err_msg=str((N, C, H, W, P, scale, ratio, aligned)))
+
+
+# ------------------------------------------------------------------ backward of the predictor's pieces
+@pytest.mark.parametrize("mode_name", ["l2", "standardize"])
+def test_rownorm_backward_vs_float64_autograd(ops, mode_name):
+    """locov_rownorm_bwd (normalize_vec / standardize_vec under autograd, box_emb_head.py:197-210 with a trained class
+    predictor) against float64 torch autograd of the reference formulas (logged_module.py:55-72)."""
+    mode = ops.NORM_L2 if mode_name == "l2" else ops.NORM_STANDARDIZE
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(37, 768, generator=g)
+    x[5] = 0.0                                        # |x| = 0 -> the eps clamp / zero variance
+    x[6] = 3.25                                       # constant row: zero variance
+    gy = torch.randn(37, 768, generator=g)
+    xd = x.double().requires_grad_(True)
+    if mode_name == "l2":
+        yd = torch.nn.functional.normalize(xd, p=2, dim=1, eps=1e-12)
+    else:
+        yd = (xd - xd.mean(1, keepdim=True)) / (xd.std(1, keepdim=True) + 1e-12)
+    (yd * gy.double()).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    y = ops.rownorm_autograd(xg, mode)
+    (y * gy.cuda()).sum().backward()
+    rows = [r for r in range(37) if r not in (5, 6)]
+    want, got = xd.grad[rows], xg.grad.cpu().double()[rows]
+    assert float((got - want).abs().max() / want.abs().max()) < 1e-5
+    if mode_name == "l2":
+        # clamped row: y = x / eps, so dx = g / eps (what F.normalize's autograd gives as well)
+        np.testing.assert_allclose(xg.grad[5].cpu().numpy(), (gy[5] / 1e-12).numpy(), rtol=1e-6)
+    else:
+        assert torch.isfinite(xg.grad[5]).all() and torch.isfinite(xg.grad[6]).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 4, 2048), (333, 768, 2048), (65, 81, 96)])
+def test_linear_autograd_vs_float64(ops, M, N, K):
+    """The FC backward (bbox_pred / emb_pred / cls_score under autograd): grad_x as an NT GEMM against the transposed weight,
+    grad_W on the TN kernel (odd sizes: transposed copies), grad_b = column sums."""
+    g = torch.Generator().manual_seed(M)
+    x, w, b, gy = (torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g),
+                   torch.randn(M, N, generator=g))
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    (torch.nn.functional.linear(xd, wd, bd) * gy.double()).sum().backward()
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    (ops.linear_autograd(xg, wg, bg) * gy.cuda()).sum().backward()
+    for got, want in ((xg.grad, xd.grad), (wg.grad, wd.grad), (bg.grad, bd.grad)):
+        assert float((got.cpu().double() - want).abs().max() / want.abs().max()) < 5e-6

@@ -272,9 +272,84 @@ def test_split_gemm_overflow_is_loud(ops):
     x = torch.randn(64, 64, generator=g).cuda()
     x[3, 5] = 1.0e5                                            # 16 * 1e5 > 65504
     w = ops.split_pack((torch.randn(32, 64, generator=g) * 0.1).cuda())
+    ops.split_overflow_reset(x.device)
     y = ops.linear_split(x, w)                                 # default x_scale = 16
     assert not torch.isfinite(y[3]).all() and torch.isfinite(y[:3]).all() and torch.isfinite(y[4:]).all()
+    assert ops.split_overflow_raised(x.device)                 # ... and the launch raised the range-guard word
+    assert ops.split_overflow_raised(x.device)                 # (sticky until reset)
+    ops.split_overflow_reset(x.device)
     assert torch.isfinite(ops.linear_split(x, w, x_scale=0.25)).all()
+    assert not ops.split_overflow_raised(x.device)
+    # just inside the range: 16 * 4093 < 65504 -- finite, no flag; a NaN input raises it
+    x[3, 5] = 4093.0
+    assert torch.isfinite(ops.linear_split(x, w)).all() and not ops.split_overflow_raised(x.device)
+    x[3, 5] = float("nan")
+    ops.linear_split(x, w)
+    assert ops.split_overflow_raised(x.device)
+    ops.split_overflow_reset(x.device)
+    # the batched (Winograd-domain) and mean-fused forms carry the same guard
+    xb = torch.randn(3, 70, 64, generator=g).cuda()
+    wb = ops.split_pack((torch.randn(3, 32, 64, generator=g) * 0.1).cuda())
+    ops.gemm_nt_batched_split(xb, wb, x_scale=1.0)
+    assert not ops.split_overflow_raised(x.device)
+    xb[2, 69, 63] = 7.0e4
+    ops.gemm_nt_batched_split(xb, wb, x_scale=1.0)
+    assert ops.split_overflow_raised(x.device)
+    ops.split_overflow_reset(x.device)
+
+
+def test_heads_repeat_an_out_of_range_call_on_the_f32_mfma():
+    """The default arithmetic is safe as a drop-in: a Res5 activation beyond the split arithmetic's range (|x| >= 4094;
+    here a FrozenBN with heavy-tailed scales up to 10 on a map with entries up to ~5000, as a trained checkpoint may have)
+    does NOT turn into NaN / dropped detections -- the heads read the range-guard word once per call, warn once, and repeat
+    that call on the f32 MFMA; the result equals the RES5_DTYPE 'fp32' heads' bit for bit.  In-range calls are not repeated."""
+    import warnings
+    import locov_amd as pkg
+    from oracle import lsm_oracle as oracle
+    import test_gpu_roi_heads as T
+    oracle.build()
+    cfg = T._small_cfg(pkg)
+    heads, params, h = T._make_heads(pkg, oracle, cfg, 80, 3)
+    cfg32 = T._small_cfg(pkg)
+    cfg32.MODEL.ROI_BOX_HEAD.RES5_DTYPE = "fp32"
+    heads32, _, _ = T._make_heads(pkg, oracle, cfg32, 80, 3)
+    rng = np.random.default_rng(3)
+    with torch.no_grad():
+        for hd in (heads, heads32):                        # heavy-tailed FrozenBN scale on block 0's conv1
+            hd.res5[0].conv1.norm.weight.copy_(torch.from_numpy(np.geomspace(0.5, 10.0, 64).astype(np.float32)))
+    feat = rng.standard_normal((2, 128, 50, 84)).astype(np.float32)
+    props, boxes = T._proposals(pkg, oracle, rng, 2, 150)
+    calls = []
+    orig = heads._fused_roi_transform
+    heads._fused_roi_transform = lambda f, b, p, dt: (calls.append(dt), orig(f, b, p, dt))[1]
+
+    def run(hd, f):
+        with torch.no_grad():
+            return hd.box_predictor(hd._shared_roi_transform([T.dev(f)], [p.proposal_boxes for p in props], pooled=True))[0]
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                     # in range: no warning, one pass
+        ok = run(heads, feat)
+    assert calls == ["f16x2"] and torch.isfinite(ok).all()
+    assert (ok - run(heads32, feat)).abs().max() <= 1e-4
+    big = feat.copy()
+    big[1, :, 20:24, 30:36] *= 1500.0                      # activations of several thousand in one image region
+    calls.clear()
+    with pytest.warns(RuntimeWarning, match="repeated"):
+        got = run(heads, big)
+    assert calls == ["f16x2", "fp32"]
+    want = run(heads32, big)
+    assert torch.isfinite(got).all() and torch.equal(got, want)
+    calls.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                     # reported once per module; the retry itself still happens
+        got2 = run(heads, big)
+    assert calls == ["f16x2", "fp32"] and torch.equal(got2, want)
+    # with the check switched off the old behaviour is visible: non-finite logits for the affected proposals
+    heads.res5_overflow_check = False
+    calls.clear()
+    raw = run(heads, big)
+    assert calls == ["f16x2"] and not torch.isfinite(raw).all()
 
 
 @pytest.mark.parametrize("split", [True, False])
