@@ -278,7 +278,7 @@ int locov_conv3x3_nhwc_bf16(const uint16_t *x, int64_t R, int H, int W, int Cin,
  * (rows * K * 4 bytes; per row and group of 8 columns: 8 hi halves, then 8 lo halves).
  * K % 32 == 0; N, lda, ldc % 4 == 0; 16-byte aligned pointers.  Epilogue as locov_gemm_nt_f32.
  * RANGE GUARD: `overflow` (device pointer to one 32-bit word, or null) -- a launch in which any x value had
- * |x_scale * x| >= 65504 (or was NaN) ORs 1 into it; the outputs such a value feeds are inf / NaN.  The word is only
+ * |x_scale * x| >= 65504 ORs 1 into it; the outputs such a value feeds are inf / NaN.  The word is only
  * ever set, never cleared: the caller zeroes it, enqueues any number of split launches and reads it once afterwards
  * (locov_amd's heads then repeat that call on the f32 MFMA).  Costs two v_max3_f32 per staged 16-byte chunk.
  * ------------------------------------------------------------------------------------- */

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
     }
 
     __builtin_amdgcn_s_setprio(3);
-    if (overflow != nullptr && !(amax * a_scale < 65504.f)) atomicOr(overflow, 1u);       // (NaN-safe: a NaN input raises it too)
+    if (overflow != nullptr && amax * a_scale >= 65504.f) atomicOr(overflow, 1u);
     // Epilogue (C/D layout of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg): re-lay the wave's sub-tile out
     // through LDS, 16 bytes per lane and row-contiguous from there.
     const bool relu = (epi.flags & LOCOV_EPI_RELU) != 0;
