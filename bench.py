@@ -67,6 +67,7 @@ def parse(argv=None):
                         "csrc/gemm_split.hip); fp32 = the f32 MFMA; bf16 = reduced-precision operands (never a headline)")
     p.add_argument("--train-images", type=int, default=4, help="--mode train: images per GPU (IMS_PER_BATCH 32 / 8 GPUs)")
     p.add_argument("--train-samples", type=int, default=200, help="--mode train: ROI_HEADS.BATCH_SIZE_PER_IMAGE (coco_lsm.yaml:32)")
+    p.add_argument("--train-backends", default="hip,miopen", help="--mode train: which Res5 backends to time (profile runs: hip)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--skip-f32-reference", action="store_true",
                    help="do not also time the f32-MFMA form of the Res5 GEMMs (profile runs)")
@@ -443,7 +444,7 @@ def main():
     train = None
     if args.mode == "train":
         train = {}
-        for backend in ("hip", "miopen"):
+        for backend in args.train_backends.split(","):
             tw = TrainWorkload(args, device, backend, world, data_seed=1992 + rank)
             n_sampled = tw.step()
             steps = max(args.steps // 2, 3)
@@ -452,7 +453,8 @@ def main():
                               "sampled_proposals_per_step_per_gpu": n_sampled}
             del tw
             torch.cuda.empty_cache()
-        train["speedup_vs_miopen"] = train["hip"]["sampled_proposals_per_s"] / train["miopen"]["sampled_proposals_per_s"]
+        if "hip" in train and "miopen" in train:
+            train["speedup_vs_miopen"] = train["hip"]["sampled_proposals_per_s"] / train["miopen"]["sampled_proposals_per_s"]
         train["what"] = (f"one LSM training step of the path per iteration: {args.train_images} img/GPU x {args.proposals} proposals -> "
                          f"{args.train_samples} sampled/img; EmbeddingProposalsRes5ROIHeads.forward(targets) (labelling, whole-grid Res5, "
                          "ROIAlign + Res5 + mean, box predictor, losses) + GroundingHead (box branch) + backward (Res5 data + weight "

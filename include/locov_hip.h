@@ -281,9 +281,11 @@ int locov_conv3x3_nhwc_bf16(const uint16_t *x, int64_t R, int H, int W, int Cin,
  * |x_scale * x| >= 65504 ORs 1 into it; the outputs such a value feeds are inf / NaN.  The word is only
  * ever set, never cleared: the caller zeroes it, enqueues any number of split launches and reads it once afterwards
  * (locov_amd's heads then repeat that call on the f32 MFMA).  Costs two v_max3_f32 per staged 16-byte chunk.
+ * locov_split_f16x2_pack raises the same word when |w_scale * w| >= 65504, so that a caller may keep a weight's scale from
+ * one optimizer step to the next (no host read of max |w| per step) and still learn when it stopped covering the data.
  * ------------------------------------------------------------------------------------- */
 int locov_split_f16x2_pack(const float *w, int64_t rows, int K, int64_t ld, float w_scale, void *out,
-                           locov_stream_t stream);
+                           unsigned *overflow, locov_stream_t stream);
 
 int locov_gemm_nt_f32_split(const float *x, int64_t lda, const void *W_split, const float *scale,
                             const float *shift, const float *residual, float *y, int64_t ldc,

@@ -72,7 +72,7 @@ SIGNATURES = {
     "locov_f32_to_bf16": (c_int, [_p, c_int64, _p, _p]),
     "locov_gemm_nt_bf16": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, _p]),
     "locov_conv3x3_nhwc_bf16": (c_int, [_p, c_int64, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, c_int, c_uint, _p]),
-    "locov_split_f16x2_pack": (c_int, [_p, c_int64, c_int, c_int64, c_float, _p, _p]),
+    "locov_split_f16x2_pack": (c_int, [_p, c_int64, c_int, c_int64, c_float, _p, _p, _p]),
     "locov_gemm_nt_f32_split": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, c_float,
                                         c_float, _p, _p]),
     "locov_gemm_segmean_workspace_bytes": (c_int64, [c_int64, c_int]),

@@ -443,13 +443,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
 
 // W [rows, K] fp32 (row pitch ld) -> the split layout of s*W: per row and group of 8 columns, 8 hi halves then 8 lo halves
 __global__ __launch_bounds__(256) void split_pack_kernel(const float *__restrict__ w, int64_t rows, int K, int64_t ld,
-                                                         float s, _Float16 *__restrict__ out)
+                                                         float s, _Float16 *__restrict__ out, unsigned *overflow)
 {
     const int64_t total = rows * K;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / K;
         const int k = (int)(i - r * K), t = k >> 5, e = k & 31;
         const float x = w[r * ld + k] * s;
+        if (overflow != nullptr && fabsf(x) >= 65504.f) atomicOr(overflow, 1u);     // a re-used scale no longer covers the data
         const _Float16 h = (_Float16)x;
         const _Float16 l = (_Float16)(x - (float)h);
         _Float16 *o = out + r * 2 * K + t * 64 + (e >> 3) * 16 + (e & 7);
@@ -537,7 +538,8 @@ using namespace locov;
 
 extern "C" {
 
-int locov_split_f16x2_pack(const float *w, int64_t rows, int K, int64_t ld, float w_scale, void *out, locov_stream_t stream)
+int locov_split_f16x2_pack(const float *w, int64_t rows, int K, int64_t ld, float w_scale, void *out, unsigned *overflow,
+                           locov_stream_t stream)
 {
     LOCOV_REQUIRE(w_scale > 0.f, "locov_split_f16x2_pack: w_scale must be positive");
     LOCOV_REQUIRE(rows >= 0 && K > 0 && K % BK == 0 && ld >= K, "locov_split_f16x2_pack: K must be a multiple of %d, ld >= K", BK);
@@ -546,7 +548,7 @@ int locov_split_f16x2_pack(const float *w, int64_t rows, int K, int64_t ld, floa
     const int64_t total = rows * K;
     const unsigned blocks = (unsigned)(ceil_div(total, 256) < 65536 ? ceil_div(total, 256) : 65536);
     hipLaunchKernelGGL(split_pack_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, rows, K, ld, w_scale,
-                       reinterpret_cast<_Float16 *>(out));
+                       reinterpret_cast<_Float16 *>(out), overflow);
     return check_launch("locov_split_f16x2_pack");
 }
 

@@ -12,6 +12,7 @@
 // 14x14 tile, so 3/4 of the pooler's output bytes are never produced.
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace locov {
@@ -73,7 +74,16 @@ __device__ __forceinline__ float4 tap4(__amdgpu_buffer_rsrc_t r, unsigned off, _
 constexpr int kNhwcThreads = 256;
 constexpr int kMaxAxisN = 192;     // per-axis LDS table entries (7 x up to 27 samples; larger grids are computed on the fly): keeps the kernel at 6+ workgroups per CU
 
-// grid = (R, OH): one workgroup = one ROI x one output row of bins.
+// grid = R * nslices (1-D): one workgroup = one ROI x one CHANNEL SLICE, all OH x OW bins.
+//
+// Why slices: workgroups are dealt round-robin over the 8 XCDs, each with its own 4 MB L2.  With one workgroup per
+// (ROI, bin row) and all channels, every XCD touched every channel of every image: on the map path (2 560 pooled channels,
+// 43 MB per 1333x800 image) each bin's pixels came from beyond L2 -- 11.2 GB of fabric reads per launch pair for 4 GB of
+// output (rocprofv3 FETCH_SIZE, profiles/r01l).  Now blockIdx % nslices selects the slice, i.e. (nslices = 8) the XCD: an
+// XCD only ever reads ITS slice of the channels -- 4 200 pixels x C/8 channels of the image being pooled, 1.3 MB (512
+// channels) to 5.4 MB (2 560) -- and consecutive ROIs (same image) run back to back on it, so the footprints of an image's
+// proposals, which overlap heavily, are served by that XCD's L2.  The per-ROI sampling tables are built once per workgroup
+// for all OH bin rows (they used to be rebuilt per bin row).
 // BWD = true is the adjoint with the same sampling geometry: `out` then holds the GRADIENT of the pooled rows (read) and
 // `feat` the gradient of the channels-last map (accumulated with fp32 hardware atomics; the caller zeroes it) -- what
 // autograd needs when the LSM head trains through the even-grid pooler (roi_emb_heads.py:343 under autograd).
@@ -82,7 +92,7 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
     const TIn *__restrict__ feat, int N, int H, int W, int C, const float *__restrict__ rois, int PH, int PW,
     float scale, int sampling_ratio, int aligned, int bin_stride, int OH, int OW, int pos_major,
     TOut *__restrict__ out, int64_t out_ld, int64_t feat_ld, const float *__restrict__ ch_scale,
-    const float *__restrict__ ch_shift, int relu)
+    const float *__restrict__ ch_shift, int relu, int nslices, int64_t R)
 {
     // feat_ld = elements between consecutive pixels of the map (>= C: the C channels may be a column block
     // of a wider per-pixel vector).  ch_scale / ch_shift / relu: optional per-channel affine + ReLU applied to
@@ -91,9 +101,8 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
     __shared__ AxisSampleN ytab[kMaxAxisN];
     __shared__ AxisSampleN xtab[kMaxAxisN];
 
-    const int64_t r = blockIdx.x;
-    const int oh = blockIdx.y;
-    const int ph = oh * bin_stride;
+    const int slice = (int)(blockIdx.x % (unsigned)nslices);
+    const int64_t r = blockIdx.x / (unsigned)nslices;
     const float *roi = rois + r * 5;
     const int b = (int)roi[0];
 
@@ -114,9 +123,9 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
     const float inv_count = 1.f / (float)(prod > 1 ? prod : 1);
     gh = gh > 0 ? gh : 0;
     gw = gw > 0 ? gw : 0;
-    // table of this bin row's y samples and of every (strided) column's x samples
-    const int nx = OW * gw;
-    const bool use_lds = gh <= kMaxAxisN && nx <= kMaxAxisN;
+    // tables of every (strided) bin row's y samples and of every (strided) column's x samples
+    const int ny = OH * gh, nx = OW * gw;
+    const bool use_lds = ny <= kMaxAxisN && nx <= kMaxAxisN;
     // (the tables hold BYTE offsets into the image -- row offset for y, pixel offset for x -- so that a tap
     // address is two 32-bit adds on top of a wave-uniform buffer descriptor)
     const unsigned xstride = (unsigned)feat_ld * (unsigned)sizeof(TIn), ystride = (unsigned)W * xstride;
@@ -126,8 +135,8 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
         return a;
     };
     if (use_lds) {
-        for (int t = threadIdx.x; t < gh; t += kNhwcThreads)
-            ytab[t] = as_offsets(axis_sample_n(start_h, bin_h, ph, t, gh, H), ystride);
+        for (int t = threadIdx.x; t < ny; t += kNhwcThreads)
+            ytab[t] = as_offsets(axis_sample_n(start_h, bin_h, (t / gh) * bin_stride, t % gh, gh, H), ystride);
         for (int t = threadIdx.x; t < nx; t += kNhwcThreads)
             xtab[t] = as_offsets(axis_sample_n(start_w, bin_w, (t / gw) * bin_stride, t % gw, gw, W), xstride);
     }
@@ -138,21 +147,21 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
     // (grid = ceil(bin size)), so a bin touches at most (gh+1) x (gw+1) distinct pixels instead of 4*gh*gw taps:
     // 9 instead of 16 loads at a 2x2 grid, 25 instead of 64 at 4x4.  Same sum, re-associated (fp32 rounding only).
     constexpr int kSepGrid = 16, kSepCols = 32;
-    __shared__ float ypw[kSepGrid + 1];
+    __shared__ float ypw[kSepCols * (kSepGrid + 1)];
     __shared__ float xpw[kSepCols * (kSepGrid + 1)];
-    __shared__ int ypix[2];                       // {byte offset of the first pixel row, number of rows}
+    __shared__ int ypix[kSepCols][2];             // per bin row: {byte offset of the first pixel row, number of rows}
     __shared__ int xpix[kSepCols][2];
     __shared__ int sep_bad;
-    const bool sep_try = use_lds && gh >= 1 && gw >= 1 && gh <= kSepGrid && gw <= kSepGrid && OW <= kSepCols;
+    const bool sep_try = use_lds && gh >= 1 && gw >= 1 && gh <= kSepGrid && gw <= kSepGrid && OW <= kSepCols && OH <= kSepCols;
     if (threadIdx.x == 0) sep_bad = 0;
     __syncthreads();
-    if (sep_try && (int)threadIdx.x <= OW) {
-        // thread 0: the y axis of this bin row; thread 1 + ow: the x axis of output column ow
-        const bool is_y = threadIdx.x == 0;
-        const int ow_t = (int)threadIdx.x - 1, n = is_y ? gh : gw;
-        const AxisSampleN *tab = is_y ? ytab : xtab + ow_t * gw;
+    if (sep_try && (int)threadIdx.x < OH + OW) {
+        // thread oh: the y axis of bin row oh; thread OH + ow: the x axis of output column ow
+        const bool is_y = (int)threadIdx.x < OH;
+        const int idx_t = is_y ? (int)threadIdx.x : (int)threadIdx.x - OH, n = is_y ? gh : gw;
+        const AxisSampleN *tab = is_y ? ytab + idx_t * gh : xtab + idx_t * gw;
         const unsigned stride = is_y ? ystride : xstride;
-        float *pw = is_y ? ypw : xpw + ow_t * (kSepGrid + 1);
+        float *pw = (is_y ? ypw : xpw) + idx_t * (kSepGrid + 1);
         int base = 0x7fffffff;
         for (int t = 0; t < n; t++)
             if (tab[t].wl != 0.f || tab[t].wh != 0.f) base = min(base, tab[t].lo);
@@ -172,39 +181,49 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
                 num = max(num, khi + 1);
             }
         }
-        if (is_y) {
-            ypix[0] = base == 0x7fffffff ? 0 : base;
-            ypix[1] = num;
-        } else {
-            xpix[ow_t][0] = base == 0x7fffffff ? 0 : base;
-            xpix[ow_t][1] = num;
-        }
+        int (*pix)[2] = is_y ? ypix : xpix;
+        pix[idx_t][0] = base == 0x7fffffff ? 0 : base;
+        pix[idx_t][1] = num;
     }
     __syncthreads();
     const bool separable = sep_try && !sep_bad;
 
-    const int c4n = C >> 2;
+    // this workgroup's channel slice [c_lo, c_hi): multiples of 4 channels
+    const int c4_all = C >> 2, c4s = (c4_all + nslices - 1) / nslices;
+    const int q_lo = slice * c4s, q_hi = min(q_lo + c4s, c4_all);
+    const int c4n = q_hi - q_lo;
+    if (c4n <= 0) return;
     const bool valid_b = b >= 0 && b < N;
     const TIn *img = feat + (int64_t)(valid_b ? b : 0) * H * W * feat_ld;
     const __amdgpu_buffer_rsrc_t img_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<TIn *>(img), 0, (unsigned)H * ystride, 0x00020000);
-    // ROI-major: out[r][oh][ow][c]; position-major: out[oh][ow][r][c] (R = gridDim.x rows per position)
+    // ROI-major: out[r][oh][ow][c]; position-major: out[oh][ow][r][c] (R rows per position)
     // (out_ld = elements between consecutive pixel rows, >= C: the rows may be a column block of a wider matrix)
-    const int64_t ow_stride = pos_major ? (int64_t)gridDim.x * out_ld : out_ld;
-    TOut *orow = pos_major ? out + ((int64_t)oh * OW * gridDim.x + r) * out_ld : out + ((r * OH + oh) * (int64_t)OW) * out_ld;
-    // (output column, channel quad) of this thread: advanced incrementally, no integer division in the loop
-    int ow = 0, cq = threadIdx.x;
-    while (cq >= c4n) {
-        cq -= c4n;
-        ow++;
-    }
-    for (; ow < OW;) {
-        const int c = cq << 2;
+    const int64_t bin_stride_out = pos_major ? R * out_ld : out_ld;
+    TOut *obase = pos_major ? out + r * out_ld : out + (r * OH * (int64_t)OW) * out_ld;
+    // (bin, channel quad) of this thread: advanced incrementally, no integer division in the loop
+    const int nbins = OH * OW;
+    int bin = 0, oh = 0, ow = 0, cq = threadIdx.x;
+    auto normalise = [&]() {
+        while (cq >= c4n) {
+            cq -= c4n;
+            bin++;
+            if (++ow == OW) {
+                ow = 0;
+                oh++;
+            }
+        }
+    };
+    normalise();
+    while (bin < nbins) {
+        const int c = (q_lo + cq) << 2;
         const unsigned ch_off = (unsigned)c * (unsigned)sizeof(TIn);
+        TOut *optr = obase + (int64_t)bin * bin_stride_out + c;
+        const float *yw = ypw + oh * (kSepGrid + 1);
         float4 acc = {0.f, 0.f, 0.f, 0.f};
         if constexpr (BWD) {
             if (valid_b) {
-                float4 g = load4(orow + ow * ow_stride + c);
+                float4 g = load4(optr);
                 g.x *= inv_count; g.y *= inv_count; g.z *= inv_count; g.w *= inv_count;
                 char *gimg = reinterpret_cast<char *>(const_cast<TIn *>(img));
                 auto scatter = [&](unsigned off, float w) {
@@ -216,14 +235,15 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
                     unsafeAtomicAdd(p + 3, w * g.w);
                 };
                 if (separable) {
-                    const int ny = ypix[1], nxp = xpix[ow][1];
-                    const unsigned y0 = (unsigned)ypix[0] + (unsigned)xpix[ow][0] + ch_off;
+                    const int nyp = ypix[oh][1], nxp = xpix[ow][1];
+                    const unsigned y0 = (unsigned)ypix[oh][0] + (unsigned)xpix[ow][0] + ch_off;
                     const float *xw = xpw + ow * (kSepGrid + 1);
-                    for (int ky = 0; ky < ny; ky++)
-                        for (int kx = 0; kx < nxp; kx++) scatter(y0 + (unsigned)ky * ystride + (unsigned)kx * xstride, ypw[ky] * xw[kx]);
+                    for (int ky = 0; ky < nyp; ky++)
+                        for (int kx = 0; kx < nxp; kx++) scatter(y0 + (unsigned)ky * ystride + (unsigned)kx * xstride, yw[ky] * xw[kx]);
                 } else {
                     for (int iy = 0; iy < gh; iy++) {
-                        const AxisSampleN ys = use_lds ? ytab[iy] : as_offsets(axis_sample_n(start_h, bin_h, ph, iy, gh, H), ystride);
+                        const AxisSampleN ys = use_lds ? ytab[oh * gh + iy]
+                                                       : as_offsets(axis_sample_n(start_h, bin_h, oh * bin_stride, iy, gh, H), ystride);
                         for (int ix = 0; ix < gw; ix++) {
                             const AxisSampleN xs = use_lds ? xtab[ow * gw + ix]
                                                            : as_offsets(axis_sample_n(start_w, bin_w, ow * bin_stride, ix, gw, W), xstride);
@@ -236,20 +256,17 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
                 }
             }
             cq += kNhwcThreads;
-            while (cq >= c4n) {
-                cq -= c4n;
-                ow++;
-            }
+            normalise();
             continue;
         }
         if (valid_b && separable) {
-            const int ny = ypix[1], nxp = xpix[ow][1];
+            const int nyp = ypix[oh][1], nxp = xpix[ow][1];
             const unsigned x0 = (unsigned)xpix[ow][0] + ch_off;
             const float *xw = xpw + ow * (kSepGrid + 1);
             // the gather is latency-bound: up to 8 pixels are in flight per lane before any is consumed
             // (pixel counters are wave-uniform -> scalar registers)
-            const unsigned y0 = (unsigned)ypix[0] + x0;
-            const int npix = ny * nxp;
+            const unsigned y0 = (unsigned)ypix[oh][0] + x0;
+            const int npix = nyp * nxp;
             int ky = 0, kx = 0;
             auto group = [&](auto nu_tag) __attribute__((always_inline)) {
                 constexpr int NU = decltype(nu_tag)::value;
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
                 float wgt[NU];
 #pragma unroll
                 for (int u = 0; u < NU; u++) {
-                    wgt[u] = ypw[ky] * xw[kx];
+                    wgt[u] = yw[ky] * xw[kx];
                     v[u] = tap4(img_rsrc, y0 + (unsigned)ky * ystride + (unsigned)kx * xstride, (TIn *)nullptr);
                     if (++kx == nxp) {
                         kx = 0;
@@ -274,13 +291,14 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
             };
             int p = 0;
             for (; p + 8 <= npix; p += 8) group(std::integral_constant<int, 8>{});
-            const int rem = npix - p;                            // 0..7, wave-uniform: binary decomposition
+            const int rem = npix - p;                            // 0..7: binary decomposition
             if (rem & 4) group(std::integral_constant<int, 4>{});
             if (rem & 2) group(std::integral_constant<int, 2>{});
             if (rem & 1) group(std::integral_constant<int, 1>{});
         } else if (valid_b) {
             for (int iy = 0; iy < gh; iy++) {
-                const AxisSampleN ys = use_lds ? ytab[iy] : as_offsets(axis_sample_n(start_h, bin_h, ph, iy, gh, H), ystride);
+                const AxisSampleN ys = use_lds ? ytab[oh * gh + iy]
+                                               : as_offsets(axis_sample_n(start_h, bin_h, oh * bin_stride, iy, gh, H), ystride);
                 const unsigned ylo = (unsigned)ys.lo + ch_off, yhi = (unsigned)ys.hi + ch_off;
                 for (int ix = 0; ix < gw; ix++) {
                     const AxisSampleN xs = use_lds ? xtab[ow * gw + ix]
@@ -311,12 +329,9 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
         if (relu) {
             acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
         }
-        store4(orow + ow * ow_stride + c, acc);
+        store4(optr, acc);
         cq += kNhwcThreads;
-        while (cq >= c4n) {
-            cq -= c4n;
-            ow++;
-        }
+        normalise();
     }
 }
 
@@ -506,6 +521,18 @@ __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
     }
 }
 
+// channel slices per ROI of roi_align_nhwc_kernel: a power of two up to 8 (= one per XCD, see the kernel) that still leaves a
+// slice at least 64 channel quads wide, so that a wave stays inside one bin (wave-uniform pixel loops): 2 048+ channels -> 8,
+// 1 024 -> 4, 512 -> 2, fewer -> 1
+static int nhwc_slices(int C)
+{
+    static const int forced = [] { const char *e = getenv("LOCOV_ROIALIGN_SLICES"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced;
+    int n = 1;
+    while (n < 8 && (C >> 2) / (2 * n) >= 64) n *= 2;
+    return n;
+}
+
 }  // namespace locov
 
 using namespace locov;
@@ -586,11 +613,13 @@ int locov_roi_align_nhwc_bwd(const float *grad_rows, int64_t grad_ld, int N, int
     LOCOV_REQUIRE(R <= 0x7fffffffLL, "locov_roi_align_nhwc_bwd: R too large");
     LOCOV_REQUIRE(((uintptr_t)grad_rows | (uintptr_t)grad_feat) % 16 == 0, "locov_roi_align_nhwc_bwd: misaligned pointer");
     const int OH = (pooled_h + bin_stride - 1) / bin_stride, OW = (pooled_w + bin_stride - 1) / bin_stride;
-    dim3 grid((unsigned)R, (unsigned)OH);
+    const int nslices = nhwc_slices(C);
+    LOCOV_REQUIRE(R * nslices <= 0x7fffffffLL, "locov_roi_align_nhwc_bwd: R too large");
+    dim3 grid((unsigned)(R * nslices));
     hipLaunchKernelGGL((roi_align_nhwc_kernel<float, float, true>), grid, dim3(kNhwcThreads), 0, as_stream(stream),
                        (const float *)grad_feat, N, H, W, C, rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, bin_stride,
                        OH, OW, pos_major, const_cast<float *>(grad_rows), grad_ld, (int64_t)C, (const float *)nullptr,
-                       (const float *)nullptr, 0);
+                       (const float *)nullptr, 0, nslices, R);
     return check_launch("locov_roi_align_nhwc_bwd");
 }
 
@@ -615,12 +644,14 @@ int locov_roi_align_nhwc_affine_fwd(const void *feat, int feat_dtype, int N, int
     LOCOV_REQUIRE(feat && rois && out, "locov_roi_align_nhwc_fwd: null pointer");
     LOCOV_REQUIRE(R <= 0x7fffffffLL, "locov_roi_align_nhwc_fwd: R too large");
     const int OH = (pooled_h + bin_stride - 1) / bin_stride, OW = (pooled_w + bin_stride - 1) / bin_stride;
-    dim3 grid((unsigned)R, (unsigned)OH);
+    const int nslices = nhwc_slices(C);
+    LOCOV_REQUIRE(R * nslices <= 0x7fffffffLL, "locov_roi_align_nhwc_fwd: R too large");
+    dim3 grid((unsigned)(R * nslices));
     hipStream_t s = as_stream(stream);
 #define LOCOV_LAUNCH_NHWC(TI, TO)                                                                                   \
     hipLaunchKernelGGL((roi_align_nhwc_kernel<TI, TO>), grid, dim3(kNhwcThreads), 0, s, (const TI *)feat, N, H, W, C, \
                        rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, bin_stride, OH, OW, pos_major, (TO *)out, out_ld, \
-                       feat_ld, ch_scale, ch_shift, relu)
+                       feat_ld, ch_scale, ch_shift, relu, nslices, R)
     if (feat_dtype == LOCOV_F32 && out_dtype == LOCOV_F32) LOCOV_LAUNCH_NHWC(float, float);
     else if (feat_dtype == LOCOV_F32 && out_dtype == LOCOV_BF16) LOCOV_LAUNCH_NHWC(float, __bf16);
     else if (feat_dtype == LOCOV_BF16 && out_dtype == LOCOV_F32) LOCOV_LAUNCH_NHWC(__bf16, float);

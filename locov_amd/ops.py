@@ -426,9 +426,16 @@ def split_pack(w: torch.Tensor, scale: Optional[float] = None) -> SplitWeight:
     out = torch.empty_like(w)
     rows = w.numel() // K
     with torch.cuda.device(w.device):
-        check(_lib.load().locov_split_f16x2_pack(_ptr(w), rows, K, K, float(scale), _ptr(out), _stream(w)),
-              "locov_split_f16x2_pack")
+        check(_lib.load().locov_split_f16x2_pack(_ptr(w), rows, K, K, float(scale), _ptr(out), _ptr(_overflow_word(w)),
+                                                 _stream(w)), "locov_split_f16x2_pack")
     return SplitWeight(out, float(scale))
+
+
+def split_scale_for(w: torch.Tensor) -> float:
+    """The power of two split_pack would choose for w (max |scale * w| in [2^12, 2^13)); ONE host read of max |w|."""
+    amax = float(w.detach().abs().max()) if w.numel() else 1.0
+    scale = 2.0 ** (12 - math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
+    return min(max(scale, 2.0 ** -100), 2.0 ** 100)
 
 
 def linear_split(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tensor] = None, *,

@@ -111,6 +111,7 @@ class Res5Stage(nn.Sequential):
     def __init__(self, *blocks):
         super().__init__(*blocks)
         self._cache = {}
+        self._scales = {}           # convolution -> (split-operand scale, uses): see _split
 
     def supports_rows_path(self) -> bool:
         b0 = self[0]
@@ -134,6 +135,7 @@ class Res5Stage(nn.Sequential):
         else:
             wp = w.reshape(w.shape[0], w.shape[1])
         scale, shift = ops.frozen_bn_fold(n.weight, n.bias, n.running_mean, n.running_var, n.eps)
+        wp._locov_key = (id(conv), winograd)
         val = (wp, scale, shift)
         self._cache[slot] = (key, val)
         return val
@@ -180,12 +182,26 @@ class Res5Stage(nn.Sequential):
         return out
 
     def _split(self, t: torch.Tensor):
-        """Split-operand packing (ops.split_pack) of a packed fp32 weight, cached per tensor object."""
+        """Split-operand packing (ops.split_pack) of a packed fp32 weight, cached per tensor object.
+        The power-of-two operand scale of a weight is remembered per convolution (`_locov_key`, set by _packed) and
+        re-used while the weights train -- choosing it needs max |w| on the host, i.e. a device sync per packing, ten per
+        training step; weights drift slowly against the 8x headroom the scale leaves, the pack kernel raises the
+        range-guard word if a re-used scale ever stops covering them (the caller then repeats the pass on the f32 MFMA and
+        drops the remembered scales), and every 256 uses the scale is chosen afresh."""
         from . import ops
         hit = self._cache.get(("split", id(t)))
         if hit is not None and hit[0] is t:
             return hit[1]
-        out = ops.split_pack(t.contiguous())
+        key = getattr(t, "_locov_key", None)
+        scale = None
+        if key is not None:
+            rec = self._scales.get(key)
+            if rec is not None and rec[1] < 256:
+                scale, self._scales[key] = rec[0], (rec[0], rec[1] + 1)
+            else:
+                scale = ops.split_scale_for(t)
+                self._scales[key] = (scale, 0)
+        out = ops.split_pack(t.contiguous(), scale)
         stale = [k for k in self._cache if isinstance(k, tuple) and k and k[0] == "split"]
         if len(stale) >= 64:                     # weights that keep changing (training + eval): drop superseded packings
             for k in stale:

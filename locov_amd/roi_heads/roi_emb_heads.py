@@ -327,6 +327,9 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         return self._fused_roi_transform(features, boxes, pooled, self.res5_dtype)
 
     def _warn_overflow(self):
+        if hasattr(self.res5, "_scales"):
+            self.res5._scales.clear()            # remembered operand scales may be what no longer fits
+            self.res5._cache.clear()
         if not self._overflow_warned:
             import warnings
             warnings.warn("Res5 activations left the range of the f16x2 split arithmetic (|x| >= 4094): this call was repeated "
