@@ -1,0 +1,110 @@
+"""Row a-11 against the oracle: SampleAllROIHeads.label_and_sample_proposals
+(ovr/modeling/roi_heads/roi_emb_heads.py:25-118) and box_predictor.losses (:266,:347) vs the numpy restatement of
+Detectron2's definitions in oracle/lsm_oracle.py -- on CPU tensors here and, with the same code, on the device
+(`-m gpu`): which proposals may be drawn and how many, every sampled proposal's class / foreground flag / matched
+ground-truth fields, and both losses."""
+import numpy as np
+import pytest
+import torch
+
+from locov_amd.config import get_cfg
+from locov_amd.structures import Boxes, Instances, ShapeSpec
+
+
+def _heads(detach, batch, pos_frac, device):
+    import locov_amd
+    cfg = get_cfg()
+    cfg.MODEL.RESNETS.RES2_OUT_CHANNELS = 32
+    cfg.MODEL.RESNETS.WIDTH_PER_GROUP = 8
+    cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
+    cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED = True
+    cfg.MODEL.ROI_BOX_HEAD.EMB_DIM = 96
+    cfg.MODEL.ROI_HEADS.NAME = "EmbeddingProposalsRes5ROIHeads"
+    cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = batch
+    cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION = pos_frac
+    cfg.MODEL.ROI_HEADS.DETACH_CLASS_PREDICTOR = detach
+    torch.manual_seed(0)
+    heads = locov_amd.build_roi_heads(cfg, {"res4": ShapeSpec(channels=128, stride=16)}).to(device).train()
+    bank = np.zeros((81, 96), np.float32)
+    bank[:80] = np.random.default_rng(0).standard_normal((80, 96)) * 0.05
+    heads.box_predictor.set_class_embeddings(bank)
+    heads.num_classes = 80
+    return heads
+
+
+def _batch(oracle, rng, device, n_img=3, r=120, n_gt=6):
+    props, targets, raw = [], [], []
+    for i in range(n_img):
+        g = n_gt if i != 1 else 0                                   # one image without ground truth
+        gt = oracle.synth_boxes(rng, g) if g else np.zeros((0, 4), np.float32)
+        b = oracle.synth_boxes(rng, r)
+        if g:
+            jitter = rng.uniform(-12, 12, (3 * g, 4)).astype(np.float32)
+            b[:3 * g] = np.repeat(gt, 3, axis=0) + jitter            # candidates around the ground truth: IoU on both sides of 0.5
+            b[:, 2:] = np.maximum(b[:, 2:], b[:, :2] + 1.0)
+        cls = rng.integers(0, 80, g)
+        p = Instances((800, 1333))
+        p.proposal_boxes = Boxes(torch.from_numpy(b).to(device))
+        p.objectness_logits = torch.from_numpy(rng.standard_normal(r).astype(np.float32)).to(device)
+        t = Instances((800, 1333))
+        t.gt_boxes = Boxes(torch.from_numpy(gt).to(device))
+        t.gt_classes = torch.from_numpy(cls).to(device)
+        props.append(p)
+        targets.append(t)
+        raw.append((b, gt, cls))
+    return props, targets, raw
+
+
+def _check(oracle, device, detach, batch, pos_frac):
+    heads = _heads(detach, batch, pos_frac, device)
+    rng = np.random.default_rng(batch)
+    props, targets, raw = _batch(oracle, rng, device)
+    torch.manual_seed(5)
+    sampled = heads.label_and_sample_proposals(props, targets)
+    assert len(sampled) == len(props)
+    all_boxes, all_gt, all_cls = [], [], []
+    for s, (b, gt, cls) in zip(sampled, raw):
+        cand, idx, labels, best = oracle.label_proposals(b, gt, cls, 80)
+        n_fg, n_bg = oracle.expected_sample_counts(labels, 80, batch, pos_frac)
+        got_boxes = s.proposal_boxes.tensor.cpu().numpy()
+        got_cls = s.gt_classes.cpu().numpy()
+        assert len(s) == n_fg + n_bg and int((got_cls != 80).sum()) == n_fg and int((got_cls == 80).sum()) == n_bg
+        np.testing.assert_array_equal(s.fg_proposal.cpu().numpy(), (got_cls != 80).astype(np.int64))
+        # every sampled row is one of the image's candidates, drawn at most once, with the oracle's label and matched gt
+        key = {tuple(np.round(c, 4)): j for j, c in enumerate(cand)}       # (duplicates among candidates do not occur here)
+        assert len(key) == len(cand)
+        rows = [key[tuple(np.round(x, 4))] for x in got_boxes]
+        assert len(set(rows)) == len(rows)
+        np.testing.assert_array_equal(got_cls, labels[rows])
+        if len(gt):
+            np.testing.assert_array_equal(s.gt_boxes.tensor.cpu().numpy(), gt[idx[rows]])       # ALL target fields are copied (:97-100)
+            assert s.has("gt_classes") and s.has("objectness_logits")
+        # foreground rows have IoU >= 0.5 with their ground truth, background rows < 0.5
+        assert np.all(best[rows][got_cls != 80] >= 0.5) and np.all(best[rows][got_cls == 80] < 0.5)
+        all_boxes.append(got_boxes)
+        all_gt.append(s.gt_boxes.tensor.cpu().numpy() if s.has("gt_boxes") else got_boxes)
+        all_cls.append(got_cls)
+    # losses of the predictor on those proposals (predictions are what they are: random)
+    n = sum(len(s) for s in sampled)
+    g = torch.Generator().manual_seed(9)
+    scores = (torch.randn(n, 81, generator=g) * 2).to(device).requires_grad_(True)
+    deltas = (torch.randn(n, 4, generator=g) * 0.3).to(device).requires_grad_(True)
+    got = heads.box_predictor.losses((scores, deltas), sampled)
+    want = oracle.box_head_losses(scores.detach().cpu().numpy(), deltas.detach().cpu().numpy(), np.concatenate(all_boxes),
+                                  np.concatenate(all_gt), np.concatenate(all_cls), 80, 0.0 if detach else 1.0)
+    assert set(got) == {"loss_cls", "loss_box_reg"}
+    assert abs(float(got["loss_cls"]) - want["loss_cls"]) <= 1e-5 * max(1.0, abs(want["loss_cls"]))
+    assert abs(float(got["loss_box_reg"]) - want["loss_box_reg"]) <= 1e-5 * max(1.0, abs(want["loss_box_reg"]))
+
+
+@pytest.mark.parametrize("detach,batch,pos_frac", [(True, 64, 1.0), (False, 200, 0.25), (False, 16, 0.5)])
+def test_label_sample_and_losses_vs_oracle_cpu(oracle, detach, batch, pos_frac):
+    _check(oracle, "cpu", detach, batch, pos_frac)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("detach,batch,pos_frac", [(True, 64, 1.0), (False, 200, 0.25)])
+def test_label_sample_and_losses_vs_oracle_gpu(oracle, detach, batch, pos_frac):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device")
+    _check(oracle, "cuda", detach, batch, pos_frac)
