@@ -191,7 +191,9 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
     // this workgroup's channel slice [c_lo, c_hi): multiples of 4 channels
     const int c4_all = C >> 2, c4s = (c4_all + nslices - 1) / nslices;
     const int q_lo = slice * c4s, q_hi = min(q_lo + c4s, c4_all);
-    const int c4n = q_hi - q_lo;
+    // (BWD works on single channels, not quads: a wave's atomic instruction then covers 256 contiguous bytes = four full
+    // 64-byte memory-side atomic requests instead of sixteen quarter-used ones)
+    const int c4n = BWD ? 4 * (q_hi - q_lo) : q_hi - q_lo;
     if (c4n <= 0) return;
     const bool valid_b = b >= 0 && b < N;
     const TIn *img = feat + (int64_t)(valid_b ? b : 0) * H * W * feat_ld;
@@ -216,23 +218,18 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
     };
     normalise();
     while (bin < nbins) {
-        const int c = (q_lo + cq) << 2;
+        const int c = BWD ? (q_lo << 2) + cq : (q_lo + cq) << 2;
         const unsigned ch_off = (unsigned)c * (unsigned)sizeof(TIn);
         TOut *optr = obase + (int64_t)bin * bin_stride_out + c;
         const float *yw = ypw + oh * (kSepGrid + 1);
         float4 acc = {0.f, 0.f, 0.f, 0.f};
         if constexpr (BWD) {
             if (valid_b) {
-                float4 g = load4(optr);
-                g.x *= inv_count; g.y *= inv_count; g.z *= inv_count; g.w *= inv_count;
+                const float g = (float)optr[0] * inv_count;
                 char *gimg = reinterpret_cast<char *>(const_cast<TIn *>(img));
                 auto scatter = [&](unsigned off, float w) {
                     if (w == 0.f) return;
-                    float *p = reinterpret_cast<float *>(gimg + off);
-                    unsafeAtomicAdd(p, w * g.x);
-                    unsafeAtomicAdd(p + 1, w * g.y);
-                    unsafeAtomicAdd(p + 2, w * g.z);
-                    unsafeAtomicAdd(p + 3, w * g.w);
+                    unsafeAtomicAdd(reinterpret_cast<float *>(gimg + off), w * g);
                 };
                 if (separable) {
                     const int nyp = ypix[oh][1], nxp = xpix[ow][1];

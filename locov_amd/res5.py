@@ -134,7 +134,14 @@ class Res5Stage(nn.Sequential):
             wp = ops.winograd_pack_weight(w) if winograd else ops.pack_conv3x3_weight(w)
         else:
             wp = w.reshape(w.shape[0], w.shape[1])
-        scale, shift = ops.frozen_bn_fold(n.weight, n.bias, n.running_mean, n.running_var, n.eps)
+        # the FrozenBN fold only depends on the (frozen) statistics: kept across optimizer steps, which only move conv.weight
+        fkey = (n.weight._version, n.bias._version, n.running_mean._version, n.running_var._version, n.weight.data_ptr())
+        fhit = self._cache.get(("fold", id(n)))
+        if fhit is not None and fhit[0] == fkey:
+            scale, shift = fhit[1]
+        else:
+            scale, shift = ops.frozen_bn_fold(n.weight, n.bias, n.running_mean, n.running_var, n.eps)
+            self._cache[("fold", id(n))] = (fkey, (scale, shift))
         wp._locov_key = (id(conv), winograd)
         val = (wp, scale, shift)
         self._cache[slot] = (key, val)
