@@ -14,7 +14,10 @@
  *   - Every pointer is a DEVICE pointer unless the parameter name ends in `_host`.
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
  *     Calls only enqueue work on that stream: no allocation, no synchronisation, no
- *     hidden global state -> safe to capture in a hipGraph.
+ *     hidden global state -> safe to capture in a hipGraph.  The ONE exception is the opt-in
+ *     measurement aid locov_gemm_timing_* at the end of this header: a process-global,
+ *     mutex-guarded list of HIP events, OFF by default, recording nothing while the launch
+ *     stream is being captured; locov_gemm_timing_read() synchronises on those events.
  *   - Outputs are caller-allocated.  Tensors are dense row-major in the stated shape.
  *   - Return value: 0 on success, <0 on error (LOCOV_ERR_*); locov_last_error() returns
  *     a thread-local message for the last failing call on this thread.
@@ -314,12 +317,13 @@ int locov_gemm_nt_batched_f32_split(const float *x, int64_t lda, int64_t stride_
                                     int64_t M, int N, int K, int batch, float x_scale, float w_scale,
                                     unsigned *overflow, locov_stream_t stream);
 
-/* Measurement aid (bench.py's roofline block): while enabled, every GEMM-kernel launch made by
- * this library is bracketed by HIP events on its launch stream.  read() waits for them and
+/* Measurement aid (bench.py's roofline block) -- process-global state, off by default (see Conventions): while
+ * enabled, every GEMM-kernel launch made by this library (from any thread) is bracketed by HIP events on its launch
+ * stream; launches on a stream that is being captured into a hipGraph are not recorded.  read() waits for them and
  * returns, for one kernel class, the number of launches, the sum of their durations (ms) and
  * the FLOPs they executed.  cls: 0 = gemm_nt_kernel<128x128, plain / batched> (1x1 convs, FCs,
  * Winograd-domain GEMMs), 1 = the position-major direct 3x3 conv, 2 = the other tile shapes,
- * 3 / 4 = classes 0 / 1 launched with bf16 operands, 5 = the split-operand GEMM.
+ * 3 / 4 = classes 0 / 1 launched with bf16 operands, 5 = the split-operand GEMM, 6 = the TN (weight-gradient) GEMM.
  * enable(on) clears what was recorded. */
 int locov_gemm_timing_enable(int on);
 int locov_gemm_timing_read(int cls, int64_t *launches, double *ms, double *flops);

@@ -61,6 +61,8 @@ int timing_begin(hipStream_t s, int cls, double flops)
 {
     std::lock_guard<std::mutex> lock(g_timing_mutex);
     if (!g_timing_on) return -1;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return -1;   // never inside a graph capture
     TimingRec r{nullptr, nullptr, cls, flops};
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
     (void)hipEventRecord(r.e0, s);
