@@ -458,6 +458,40 @@ int locov_gemm_tn_f32(const float *a, int64_t lda, int64_t stride_a, const float
                       int batch, const float *row_scale, void *workspace, int64_t workspace_bytes,
                       locov_stream_t stream);
 
+/* The same gradients in the split-operand arithmetic of the forward (3 f16 MFMAs per fp32 product block instead of 16 f32
+ * ones).  A gradient tensor has no a-priori range, so its operand scale is chosen ON THE DEVICE:
+ *   locov_split_scale_from_amax : scale_out[0] = s = 2^(target_log2 - ceil(log2 max|x|)), scale_out[1] = 1/s, scale_out[2] =
+ *                                 bit pattern of max |x| (scratch); three tiny launches, no host read.  scale_out: 16 bytes.
+ *   locov_gemm_nt_f32_split_ex  : locov_gemm_nt_f32_split with the epilogue `mask` of locov_gemm_nt_f32_ex and, when
+ *                                 x_scale_dev is non-null, the operand scale of x read from it (x_scale is then ignored).
+ *   locov_gemm_tn_f32_split     : locov_gemm_tn_f32 with split operands: a (the gradient) scaled by a_scale_dev[0], b (the
+ *                                 activation) by b_scale; both are converted on their way into LDS.  Same workspace,
+ *                                 same fixed-order chunk reduction, same range-guard word.
+ *   locov_winograd_wgrad_f32_split : locov_winograd_wgrad_f32 with its 121 TN GEMMs in that arithmetic (the transformed
+ *                                 gradient's scale is chosen on the device, the transformed activation is scaled by 0.25). */
+int locov_split_scale_from_amax(const float *x, int64_t n, float target_log2, float *scale_out,
+                                locov_stream_t stream);
+int locov_gemm_nt_f32_split_ex(const float *x, int64_t lda, const void *W_split, const float *scale,
+                               const float *shift, const float *residual, const float *mask, float *y,
+                               int64_t ldc, int64_t M, int N, int K, unsigned flags, float x_scale,
+                               const float *x_scale_dev, float w_scale, unsigned *overflow,
+                               locov_stream_t stream);
+int locov_gemm_tn_f32_split(const float *a, int64_t lda, int64_t stride_a, const float *b, int64_t ldb,
+                            int64_t stride_b, float *out, int64_t ldo, int64_t stride_o, int64_t M, int N,
+                            int K, int batch, const float *row_scale, const float *a_scale_dev,
+                            float b_scale, unsigned *overflow, void *workspace, int64_t workspace_bytes,
+                            locov_stream_t stream);
+/* locov_winograd_conv3x3_f32_split with the output `mask` of locov_winograd_conv3x3_f32_ex and, with v_scale_auto != 0, the
+ * scale of the transformed input chosen on the device (the input is a gradient: the data gradient of a 3x3 convolution). */
+int locov_winograd_conv3x3_f32_split_ex(const float *x, int64_t R, int Cin, const void *U_split, float u_scale,
+                                        float v_scale, int v_scale_auto, const float *scale, const float *shift,
+                                        const float *mask, float *y, int64_t ldy, int N, unsigned flags,
+                                        void *workspace, int64_t workspace_bytes, unsigned *overflow,
+                                        locov_stream_t stream);
+int locov_winograd_wgrad_f32_split(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags,
+                                   const float *row_scale, float *dw, unsigned *overflow, void *workspace,
+                                   int64_t workspace_bytes, locov_stream_t stream);
+
 int64_t locov_winograd_wgrad_workspace_bytes(int64_t R, int Cin, int N);
 int locov_winograd_wgrad_f32(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags,
                              const float *row_scale, float *dw, void *workspace, int64_t workspace_bytes,

@@ -44,7 +44,7 @@ void timing_end(int idx, hipStream_t s);
 // overflow: optional device word that the kernel ORs 1 into when an A value left the range a_scale covers (locov_hip.h).
 int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C, int64_t ldc, int64_t M, int N, int K,
                       const Epilogue &epi, float a_scale, float w_scale, hipStream_t s, const char *what,
-                      const Batch &bt = Batch{1, 0, 0, 0}, unsigned *overflow = nullptr);
+                      const Batch &bt = Batch{1, 0, 0, 0}, unsigned *overflow = nullptr, const float *a_scale_dev = nullptr);
 
 // out[b][N,K] = row_scale[n] * sum_m A_b[m,n] * B_b[m,k]  (gemm_tn.hip: the weight-gradient GEMM; problem b uses
 // A + b*sa, B + b*sb, out + b*so; ws = gemm_tn_workspace_bytes(M, N, K, batch) bytes of device memory)
@@ -52,5 +52,9 @@ int launch_gemm_tn(const float *A, int64_t lda, int64_t sa, const float *B, int6
                    int64_t so, int64_t M, int N, int K, int batch, const float *row_scale, float *ws, int64_t ws_bytes,
                    hipStream_t s, const char *what);
 int64_t gemm_tn_workspace_bytes(int64_t M, int N, int K, int batch);
+// the same in split-operand arithmetic (gemm_tn_split.hip): a = gradient, scale {s, 1/s} in device memory; b = activation, scale by value
+int launch_gemm_tn_split(const float *A, int64_t lda, int64_t sa, const float *B, int64_t ldb, int64_t sb, float *out, int64_t ldo,
+                         int64_t so, int64_t M, int N, int K, int batch, const float *row_scale, const float *a_scale_dev, float b_scale,
+                         unsigned *overflow, float *ws, int64_t ws_bytes, hipStream_t s, const char *what);
 
 }  // namespace locov

@@ -96,14 +96,23 @@ struct SegSum {
     float *partial;
 };
 
-template <bool SEGSUM>
+// EMASK: the epilogue zeroes every value whose `epi.mask` entry is <= 0 (ReLU backward of a saved activation: the data
+// gradients of the training step); a_scale_dev: when non-null the operand scale of A is read from device memory
+// (a_scale_dev[0], a power of two chosen on the device from the tensor's max |x| by split_scale_kernel -- gradients have
+// no a-priori range) and `out_scale` holds 1 / w_scale only.
+template <bool SEGSUM, bool EMASK = false>
 __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restrict__ A, int64_t lda,
                                                            const float *__restrict__ B, float *__restrict__ Cout,
                                                            int64_t ldc, int64_t M, int N, int K, Epilogue epi, Batch bt,
-                                                           float a_scale, float out_scale, SegSum ss, unsigned *overflow)
+                                                           float a_scale, float out_scale, SegSum ss, unsigned *overflow,
+                                                           const float *__restrict__ a_scale_dev)
 {
     __shared__ u32x4 lds[2 * STAGEB / 16];
     char *const ldsb = reinterpret_cast<char *>(lds);
+    if (a_scale_dev != nullptr) {
+        a_scale = a_scale_dev[0];
+        out_scale *= a_scale_dev[1];          // = 1 / a_scale (exact: powers of two)
+    }
 
     __builtin_amdgcn_s_setprio(3);
     const int tiles_n = (N + BN - 1) / BN;
@@ -351,6 +360,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
     const int64_t seg_q0 = SEGSUM ? m0 / ss.seg : 0;                 // first ROI of the tile, and the position its first row holds
     const int seg_r0 = SEGSUM ? (int)(m0 - seg_q0 * ss.seg) : 0;
     const float seg_inv = SEGSUM ? 1.0f / (float)ss.seg : 0.f;
+    const __amdgpu_buffer_rsrc_t r_msk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(EMASK && epi.mask ? epi.mask + m0 * ldc : Cout + m0 * ldc), 0, nrec, 0x00020000);
     auto tail = [&](auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
         f32x4 res[NIT];
@@ -394,6 +405,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
                 if (relu) {
                     v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
                     v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                }
+                if (EMASK && !SEGSUM && epi.mask) {
+                    const f32x4 mk = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                   r_msk, FULL ? voff : voff + it * vstep, FULL ? it * vstep : 0u, 2));
+                    v[0] = mk[0] > 0.f ? v[0] : 0.f; v[1] = mk[1] > 0.f ? v[1] : 0.f;
+                    v[2] = mk[2] > 0.f ? v[2] : 0.f; v[3] = mk[3] > 0.f ? v[3] : 0.f;
                 }
                 if (SEGSUM)
                     *reinterpret_cast<f32x4 *>(ep + (it * RPI + rr) * EPS + c4) = v;    // finished value back in place
@@ -477,11 +494,45 @@ __global__ __launch_bounds__(256) void segsum_finish_kernel(const float *__restr
     }
 }
 
+// Operand scale of a tensor whose range is only known on the device (gradients): scale_out = {s, 1/s, amax bits} with
+// s = 2^(target_log2 - ceil(log2(max |x|))), i.e. max |s x| in (2^(target-1), 2^target]; an all-zero (or empty) tensor
+// gets s = 1.  Three tiny launches: init, a grid-wide atomicMax over the bit patterns of |x|, finish.
+__global__ void split_scale_init_kernel(float *out) { reinterpret_cast<unsigned *>(out)[2] = 0u; }
+
+__global__ __launch_bounds__(256) void split_amax_kernel(const float *__restrict__ x, int64_t n4, unsigned *__restrict__ amax_bits)
+{
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
+        m = fmaxf(fmaxf(m, fabsf(v[0])), fabsf(v[1]));
+        m = fmaxf(fmaxf(m, fabsf(v[2])), fabsf(v[3]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));      // non-negative floats order like their bits
+}
+
+__global__ void split_scale_finish_kernel(float *out, float target_log2)
+{
+    const float amax = __uint_as_float(reinterpret_cast<unsigned *>(out)[2]);
+    float s = 1.f;
+    if (amax > 0.f && amax < 3.0e38f) {
+        int e;
+        frexpf(amax, &e);                                 // amax = f * 2^e, f in [0.5, 1)  ->  amax <= 2^e
+        s = ldexpf(1.f, (int)target_log2 - e);
+    }
+    out[0] = s;
+    out[1] = 1.f / s;
+}
+
 int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C, int64_t ldc, int64_t M, int N, int K,
                       const Epilogue &epi, float a_scale, float w_scale, hipStream_t s, const char *what, const Batch &bt,
-                      unsigned *overflow)
+                      unsigned *overflow, const float *a_scale_dev)
 {
+    if (a_scale_dev) a_scale = 1.f;
     if (!(a_scale > 0.f) || !(w_scale > 0.f)) return set_error(LOCOV_ERR_INVALID_ARG, "%s: operand scales must be positive", what);
+    if (epi.mask && ((uintptr_t)epi.mask % 16 != 0 || bt.count > 1))
+        return set_error(LOCOV_ERR_UNSUPPORTED, "%s: the mask must be 16-byte aligned (and batched launches take none)", what);
     if (K % BK != 0 || K < BK) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: K must be a positive multiple of %d", what, BK);
     if (N % 4 != 0 || ldc % 4 != 0 || lda % 4 != 0 || (uintptr_t)A % 16 != 0 || (uintptr_t)Wsplit % 16 != 0 ||
         (uintptr_t)C % 16 != 0 || (epi.residual && (uintptr_t)epi.residual % 16 != 0) ||
@@ -494,9 +545,14 @@ int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C,
     if ((int64_t)BM * (lda > ldc ? lda : ldc) * 4 > 0x7fffffffLL)
         return set_error(LOCOV_ERR_INVALID_ARG, "%s: row pitch too large for 32-bit tile offsets", what);
     const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K * count);     // class 5: split-operand GEMM
-    hipLaunchKernelGGL(gemm_split_kernel<false>, dim3((unsigned)tiles), dim3(NT), 0, s, A, lda,
-                       reinterpret_cast<const float *>(Wsplit), C, ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale),
-                       SegSum{0, 0, nullptr}, overflow);
+    if (epi.mask)
+        hipLaunchKernelGGL((gemm_split_kernel<false, true>), dim3((unsigned)tiles), dim3(NT), 0, s, A, lda,
+                           reinterpret_cast<const float *>(Wsplit), C, ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale),
+                           SegSum{0, 0, nullptr}, overflow, a_scale_dev);
+    else
+        hipLaunchKernelGGL((gemm_split_kernel<false, false>), dim3((unsigned)tiles), dim3(NT), 0, s, A, lda,
+                           reinterpret_cast<const float *>(Wsplit), C, ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale),
+                           SegSum{0, 0, nullptr}, overflow, a_scale_dev);
     timing_end(trec, s);
     return check_launch(what);
 }
@@ -520,9 +576,10 @@ int launch_gemm_split_segmean(const float *A, int64_t lda, const void *Wsplit, i
     if (tiles > 0x7fffffffLL || (double)M * N * 4 > 4294967295.0 || (int64_t)BM * lda * 4 > 0x7fffffffLL)
         return set_error(LOCOV_ERR_INVALID_ARG, "%s: problem too large for 32-bit residual offsets", what);
     const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K);
-    hipLaunchKernelGGL(gemm_split_kernel<true>, dim3((unsigned)tiles), dim3(NT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
+    hipLaunchKernelGGL((gemm_split_kernel<true, false>), dim3((unsigned)tiles), dim3(NT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
                        static_cast<float *>(nullptr), (int64_t)N, M, N, K, epi, Batch{1, 0, 0, 0}, a_scale, 1.f / (a_scale * w_scale),
-                       SegSum{seg, (epi.flags & LOCOV_SEGMEAN_RES_ROI_MAJOR) ? (int64_t)0 : M / seg, partial}, overflow);
+                       SegSum{seg, (epi.flags & LOCOV_SEGMEAN_RES_ROI_MAJOR) ? (int64_t)0 : M / seg, partial}, overflow,
+                       static_cast<const float *>(nullptr));
     timing_end(trec, s);
     int rc = check_launch(what);
     if (rc) return rc;
@@ -563,6 +620,35 @@ int locov_gemm_nt_f32_split(const float *x, int64_t lda, const void *W_split, co
     Epilogue epi{scale, shift, residual, flags};
     return launch_gemm_split(x, lda, W_split, y, ldc, M, N, K, epi, x_scale, w_scale, as_stream(stream),
                              "locov_gemm_nt_f32_split", Batch{1, 0, 0, 0}, overflow);
+}
+
+int locov_split_scale_from_amax(const float *x, int64_t n, float target_log2, float *scale_out, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(n >= 0 && x && scale_out, "locov_split_scale_from_amax: bad arguments");
+    LOCOV_REQUIRE((uintptr_t)x % 16 == 0 && n % 4 == 0, "locov_split_scale_from_amax: x must be 16-byte aligned, n a multiple of 4");
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(split_scale_init_kernel, dim3(1), dim3(1), 0, s, scale_out);
+    if (n > 0) {
+        const int64_t n4 = n / 4;
+        const unsigned blocks = (unsigned)(ceil_div(n4, 256 * 8) < 4096 ? ceil_div(n4, 256 * 8) : 4096);
+        hipLaunchKernelGGL(split_amax_kernel, dim3(blocks), dim3(256), 0, s, x, n4, reinterpret_cast<unsigned *>(scale_out) + 2);
+    }
+    hipLaunchKernelGGL(split_scale_finish_kernel, dim3(1), dim3(1), 0, s, scale_out, target_log2);
+    return check_launch("locov_split_scale_from_amax");
+}
+
+int locov_gemm_nt_f32_split_ex(const float *x, int64_t lda, const void *W_split, const float *scale, const float *shift,
+                               const float *residual, const float *mask, float *y, int64_t ldc, int64_t M, int N, int K,
+                               unsigned flags, float x_scale, const float *x_scale_dev, float w_scale, unsigned *overflow,
+                               locov_stream_t stream)
+{
+    LOCOV_REQUIRE(M >= 0 && N > 0 && K > 0, "locov_gemm_nt_f32_split_ex: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    if (M == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(x && W_split && y, "locov_gemm_nt_f32_split_ex: null pointer");
+    LOCOV_REQUIRE(lda >= K && ldc >= N, "locov_gemm_nt_f32_split_ex: lda < K or ldc < N");
+    Epilogue epi{scale, shift, residual, flags, mask};
+    return launch_gemm_split(x, lda, W_split, y, ldc, M, N, K, epi, x_scale, w_scale, as_stream(stream),
+                             "locov_gemm_nt_f32_split_ex", Batch{1, 0, 0, 0}, overflow, x_scale_dev);
 }
 
 int64_t locov_gemm_segmean_workspace_bytes(int64_t M, int N)

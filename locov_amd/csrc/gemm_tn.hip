@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__rest
 }
 
 // chunking of M: enough (tile, chunk) workgroups to fill the chip, chunks of at least 256 rows, multiples of TBK
-static void tn_split(int64_t M, int N, int K, int batch, int *splits, int64_t *m_chunk)
+// (shared with gemm_tn_split.hip)
+void tn_split_plan(int64_t M, int N, int K, int batch, int *splits, int64_t *m_chunk)
 {
     const int64_t tiles = ceil_div(N, TBM) * ceil_div(K, TBN) * batch;
     int64_t s = ceil_div(1024, tiles);
@@ -177,13 +178,22 @@ static void tn_split(int64_t M, int N, int K, int batch, int *splits, int64_t *m
     *splits = (int)ceil_div(M, mc);
 }
 
+int launch_tn_reduce(const float *ws, int N, int K, int splits, int batch, const float *row_scale, float *out, int64_t ldo, int64_t so,
+                     hipStream_t s, const char *what)
+{
+    const int64_t total = (int64_t)batch * N * (K / 4);
+    const unsigned blocks = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, N, K, splits, batch, row_scale, out, ldo, so);
+    return check_launch(what);
+}
+
 int launch_gemm_tn(const float *A, int64_t lda, int64_t sa, const float *B, int64_t ldb, int64_t sb, float *out, int64_t ldo,
                    int64_t so, int64_t M, int N, int K, int batch, const float *row_scale, float *ws, int64_t ws_bytes,
                    hipStream_t s, const char *what)
 {
     int splits;
     int64_t m_chunk;
-    tn_split(M, N, K, batch, &splits, &m_chunk);
+    tn_split_plan(M, N, K, batch, &splits, &m_chunk);
     const int64_t need = (int64_t)batch * splits * N * K * 4;
     if (ws_bytes < need) return set_error(LOCOV_ERR_INVALID_ARG, "%s: workspace too small (%lld < %lld bytes)", what, (long long)ws_bytes, (long long)need);
     if (N % 4 || K % 4 || lda % 4 || ldb % 4 || ldo % 4 || so % 4 || sa % 4 || sb % 4 || N < 4 || K < 4)
@@ -199,10 +209,7 @@ int launch_gemm_tn(const float *A, int64_t lda, int64_t sa, const float *B, int6
     timing_end(trec, s);
     int rc = check_launch(what);
     if (rc) return rc;
-    const int64_t total = (int64_t)batch * N * (K / 4);
-    const unsigned blocks = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, N, K, splits, batch, row_scale, out, ldo, so);
-    return check_launch(what);
+    return launch_tn_reduce(ws, N, K, splits, batch, row_scale, out, ldo, so, s, what);
 }
 
 int64_t gemm_tn_workspace_bytes(int64_t M, int N, int K, int batch)
@@ -210,7 +217,7 @@ int64_t gemm_tn_workspace_bytes(int64_t M, int N, int K, int batch)
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;
     int splits;
     int64_t m_chunk;
-    tn_split(M, N, K, batch, &splits, &m_chunk);
+    tn_split_plan(M, N, K, batch, &splits, &m_chunk);
     return (int64_t)batch * splits * N * K * 4;
 }
 

@@ -219,7 +219,7 @@ int64_t locov_winograd_workspace_bytes(int64_t R, int Cin, int N)
 {
     if (R <= 0 || Cin <= 0 || N <= 0) return 0;
     const int64_t c = chunk_rois(R, Cin, N);
-    return (int64_t)NF * NF * c * ((int64_t)Cin + N) * (int64_t)sizeof(float);
+    return (int64_t)NF * NF * c * ((int64_t)Cin + N) * (int64_t)sizeof(float) + 16;     // + the device-chosen operand scale (split_ex form)
 }
 
 int locov_winograd_pack_weight(const float *w, int N, int Cin, float *U, locov_stream_t stream)
@@ -236,13 +236,23 @@ int locov_winograd_pack_weight(const float *w, int N, int Cin, float *U, locov_s
 static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
                             const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
                             void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask = nullptr,
-                            unsigned *overflow = nullptr);
+                            unsigned *overflow = nullptr, bool v_scale_auto = false);
 
 int locov_winograd_conv3x3_f32_ex(const float *x, int64_t R, int Cin, const float *U, const float *scale, const float *shift,
                                   const float *mask, float *y, int64_t ldy, int N, unsigned flags, void *workspace,
                                   int64_t workspace_bytes, locov_stream_t stream)
 {
     return winograd_conv3x3(x, R, Cin, U, 0.f, 0.f, scale, shift, y, ldy, N, flags, workspace, workspace_bytes, stream, mask);
+}
+
+int locov_winograd_conv3x3_f32_split_ex(const float *x, int64_t R, int Cin, const void *U_split, float u_scale, float v_scale,
+                                        int v_scale_auto, const float *scale, const float *shift, const float *mask, float *y,
+                                        int64_t ldy, int N, unsigned flags, void *workspace, int64_t workspace_bytes,
+                                        unsigned *overflow, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(u_scale > 0.f && (v_scale_auto || v_scale > 0.f), "locov_winograd_conv3x3_f32_split_ex: operand scales must be positive");
+    return winograd_conv3x3(x, R, Cin, static_cast<const float *>(U_split), u_scale, v_scale_auto ? 1.f : v_scale, scale, shift, y, ldy, N,
+                            flags, workspace, workspace_bytes, stream, mask, overflow, v_scale_auto != 0);
 }
 
 int locov_winograd_conv3x3_f32(const float *x, int64_t R, int Cin, const float *U, const float *scale,
@@ -264,7 +274,8 @@ int locov_winograd_conv3x3_f32_split(const float *x, int64_t R, int Cin, const v
 
 static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
                             const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
-                            void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask, unsigned *overflow)
+                            void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask, unsigned *overflow,
+                            bool v_scale_auto)
 {
     LOCOV_REQUIRE(ldy >= N && ldy % 2 == 0, "locov_winograd_conv3x3_f32: ldy must be >= N and even");
     LOCOV_REQUIRE(R >= 0 && Cin > 0 && N > 0, "locov_winograd_conv3x3_f32: bad shape");
@@ -293,10 +304,18 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
         int rcode = check_launch("locov_winograd_conv3x3_f32 (input transform)");
         if (rcode) return rcode;
         Epilogue epi{nullptr, nullptr, nullptr, 0u};
-        if (u_scale > 0.f)
+        if (u_scale > 0.f) {
+            const float *sc = nullptr;
+            if (v_scale_auto) {       // the input is a gradient: choose the scale of its transform from max |V| on the device
+                float *scw = reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_bytes - 16);
+                rcode = locov_split_scale_from_amax(V, (int64_t)NF * NF * rc * Cin, 13.f, scw, stream);
+                if (rcode) return rcode;
+                sc = scw;
+            }
             rcode = launch_gemm_split(V, (int64_t)Cin, U, Mv, (int64_t)N, rc, N, Cin, epi, v_scale, u_scale, s,
                                       "locov_winograd_conv3x3_f32_split (batched GEMM)",
-                                      Batch{NF * NF, rc * Cin, (int64_t)N * Cin, rc * N}, overflow);
+                                      Batch{NF * NF, rc * Cin, (int64_t)N * Cin, rc * N}, overflow, sc);
+        }
         else
             rcode = launch_gemm_nt<float, float>(V, (int64_t)Cin, U, (int64_t)Cin, Mv, (int64_t)N, rc, N, Cin, epi, s,
                                                  "locov_winograd_conv3x3_f32 (batched GEMM)", ConvGeom{0, 0, 0, 0, 0},
@@ -316,11 +335,26 @@ int64_t locov_winograd_wgrad_workspace_bytes(int64_t R, int Cin, int N)
 {
     if (R <= 0 || Cin <= 0 || N <= 0) return 0;
     return (int64_t)NF * NF * (R * ((int64_t)Cin + N) + (int64_t)N * Cin) * (int64_t)sizeof(float) +
-           gemm_tn_workspace_bytes(R, N, Cin, NF * NF);
+           gemm_tn_workspace_bytes(R, N, Cin, NF * NF) + 16;      // + {scale, 1/scale, amax bits} of the split form
 }
+
+static int winograd_wgrad(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags, const float *row_scale,
+                          float *dw, void *workspace, int64_t workspace_bytes, locov_stream_t stream, bool split, unsigned *overflow);
 
 int locov_winograd_wgrad_f32(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags, const float *row_scale,
                              float *dw, void *workspace, int64_t workspace_bytes, locov_stream_t stream)
+{
+    return winograd_wgrad(x, g, R, Cin, N, flags, row_scale, dw, workspace, workspace_bytes, stream, false, nullptr);
+}
+
+int locov_winograd_wgrad_f32_split(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags, const float *row_scale,
+                                   float *dw, unsigned *overflow, void *workspace, int64_t workspace_bytes, locov_stream_t stream)
+{
+    return winograd_wgrad(x, g, R, Cin, N, flags, row_scale, dw, workspace, workspace_bytes, stream, true, overflow);
+}
+
+static int winograd_wgrad(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags, const float *row_scale,
+                          float *dw, void *workspace, int64_t workspace_bytes, locov_stream_t stream, bool split, unsigned *overflow)
 {
     LOCOV_REQUIRE(R >= 0 && Cin > 0 && N > 0, "locov_winograd_wgrad_f32: bad shape");
     LOCOV_REQUIRE(dw, "locov_winograd_wgrad_f32: null output");
@@ -348,8 +382,17 @@ int locov_winograd_wgrad_f32(const float *x, const float *g, int64_t R, int Cin,
     rc = check_launch("locov_winograd_wgrad_f32 (gradient transform)");
     if (rc) return rc;
     // dU_f [N, Cin] = dM_f^T . V_f   (121 problems, contraction over the ROIs)
-    rc = launch_gemm_tn(dM, (int64_t)N, R * N, V, (int64_t)Cin, R * Cin, dU, (int64_t)Cin, (int64_t)N * Cin, R, N, Cin, NF * NF, nullptr, tn_ws,
-                        workspace_bytes - (int64_t)((char *)tn_ws - (char *)workspace), s, "locov_winograd_wgrad_f32 (batched TN GEMM)");
+    const int64_t tn_bytes = workspace_bytes - (int64_t)((char *)tn_ws - (char *)workspace) - 16;
+    if (split) {
+        // operand scales: dM from its max |.| on the device (last 16 bytes of the workspace), V as in the forward (0.25)
+        float *sc = reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_bytes - 16);
+        rc = locov_split_scale_from_amax(dM, (int64_t)NF * NF * R * N, 13.f, sc, stream);
+        if (rc) return rc;
+        rc = launch_gemm_tn_split(dM, (int64_t)N, R * N, V, (int64_t)Cin, R * Cin, dU, (int64_t)Cin, (int64_t)N * Cin, R, N, Cin, NF * NF,
+                                  nullptr, sc, 0.25f, overflow, tn_ws, tn_bytes, s, "locov_winograd_wgrad_f32_split (batched TN GEMM)");
+    } else
+        rc = launch_gemm_tn(dM, (int64_t)N, R * N, V, (int64_t)Cin, R * Cin, dU, (int64_t)Cin, (int64_t)N * Cin, R, N, Cin, NF * NF, nullptr,
+                            tn_ws, tn_bytes, s, "locov_winograd_wgrad_f32 (batched TN GEMM)");
     if (rc) return rc;
     const int64_t NC = (int64_t)N * Cin;
     hipLaunchKernelGGL(wino_unpack_wgrad_kernel, dim3((unsigned)ceil_div(NC, 256)), dim3(256), 0, s, dU, NC, Cin, row_scale, dw);

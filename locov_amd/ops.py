@@ -661,9 +661,9 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, row_scale: Optional[torch.Tensor] 
 
 
 def winograd_wgrad(x: torch.Tensor, g: torch.Tensor, row_scale: Optional[torch.Tensor] = None,
-                   roi_major: bool = True) -> torch.Tensor:
+                   roi_major: bool = True, split: bool = False) -> torch.Tensor:
     """dw [N,Cin,3,3] = row_scale[n] * d/dw of conv3x3(x) . g over R 7x7 tiles, in the Winograd domain.
-    x [49*R, Cin], g [49*R, N], both in the same row order."""
+    x [49*R, Cin], g [49*R, N], both in the same row order.  split: the 121 TN GEMMs in split-operand arithmetic."""
     x, g = _dev(x, "x"), _dev(g, "g")
     M, Cin = x.shape
     N = g.shape[1]
@@ -675,10 +675,100 @@ def winograd_wgrad(x: torch.Tensor, g: torch.Tensor, row_scale: Optional[torch.T
     lib = _lib.load()
     ws = _workspace("wino_wgrad", x, int(lib.locov_winograd_wgrad_workspace_bytes(R, Cin, N)))
     with torch.cuda.device(x.device):
-        check(lib.locov_winograd_wgrad_f32(_ptr(x), _ptr(g), R, Cin, N, _lib.WINO_IN_ROI_MAJOR if roi_major else 0,
-                                           _ptr(row_scale), _ptr(dw), _ptr(ws), ws.numel(), _stream(x)),
-              "locov_winograd_wgrad_f32")
+        if split and R > 0:
+            check(lib.locov_winograd_wgrad_f32_split(_ptr(x), _ptr(g), R, Cin, N, _lib.WINO_IN_ROI_MAJOR if roi_major else 0,
+                                                     _ptr(row_scale), _ptr(dw), _ptr(_overflow_word(x)), _ptr(ws), ws.numel(),
+                                                     _stream(x)), "locov_winograd_wgrad_f32_split")
+        else:
+            check(lib.locov_winograd_wgrad_f32(_ptr(x), _ptr(g), R, Cin, N, _lib.WINO_IN_ROI_MAJOR if roi_major else 0,
+                                               _ptr(row_scale), _ptr(dw), _ptr(ws), ws.numel(), _stream(x)),
+                  "locov_winograd_wgrad_f32")
     return dw
+
+
+def split_scale_from_amax(x: torch.Tensor, target_log2: float = 13.0) -> torch.Tensor:
+    """Device-side operand scale of a tensor whose range is only known on the device (a gradient): a 4-float device tensor
+    {s, 1/s, bits of max|x|, -} with s the power of two that puts max |s x| in (2^(target-1), 2^target].  No host read."""
+    x = _dev(x, "x")
+    if x.numel() % 4:
+        raise ValueError("split_scale_from_amax: numel must be a multiple of 4")
+    out = torch.empty(4, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_split_scale_from_amax(_ptr(x), x.numel(), float(target_log2), _ptr(out), _stream(x)),
+              "locov_split_scale_from_amax")
+    return out
+
+
+def linear_split_ex(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tensor] = None, *, scale=None, residual=None,
+                    mask=None, relu: bool = False, x_scale: float = 16.0, x_scale_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """linear_split() with the epilogue mask of linear_ex and, optionally, the operand scale of x taken from device
+    memory (split_scale_from_amax): the data-gradient GEMMs of the training step in split arithmetic."""
+    x = _rows(x, "x")
+    wd = _dev(weight.data, "weight")
+    M, K = x.shape
+    N = wd.shape[0]
+    if wd.shape[1] != K or K % 32 or N % 4:
+        raise ValueError(f"linear_split_ex: x {tuple(x.shape)} weight {tuple(wd.shape)} (K % 32 == 0, N % 4 == 0)")
+    bias = _dev(bias, "bias") if bias is not None else None
+    scale = _dev(scale, "scale") if scale is not None else None
+    residual = _dev(residual, "residual") if residual is not None else None
+    mask = _dev(mask, "mask") if mask is not None else None
+    for t_, name in ((residual, "residual"), (mask, "mask")):
+        if t_ is not None and tuple(t_.shape) != (M, N):
+            raise ValueError(f"linear_split_ex: {name} must be [M,N]")
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.load().locov_gemm_nt_f32_split_ex(_ptr(x), x.stride(0) if M else K, _ptr(wd), _ptr(scale), _ptr(bias), _ptr(residual),
+                                                     _ptr(mask), _ptr(y), N, M, N, K, _lib.EPI_RELU if relu else 0, float(x_scale),
+                                                     _ptr(x_scale_dev), weight.scale, _ptr(_overflow_word(x)), _stream(x)),
+              "locov_gemm_nt_f32_split_ex")
+    return y
+
+
+def gemm_tn_split(a: torch.Tensor, b: torch.Tensor, row_scale: Optional[torch.Tensor], a_scale_dev: torch.Tensor,
+                  b_scale: float = 16.0) -> torch.Tensor:
+    """gemm_tn() in split-operand arithmetic: a (gradient) scaled by a_scale_dev[0] (split_scale_from_amax), b (activation)
+    by b_scale."""
+    a, b = _rows(a, "a"), _rows(b, "b")
+    M, N = a.shape
+    K = b.shape[1]
+    if b.shape[0] != M or N % 4 or K % 4 or M == 0:
+        raise ValueError(f"gemm_tn_split: a {tuple(a.shape)} b {tuple(b.shape)} (N, K multiples of 4, M > 0)")
+    row_scale = _dev(row_scale, "row_scale") if row_scale is not None else None
+    out = torch.empty((N, K), dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    ws = _workspace("tn", a, int(lib.locov_gemm_tn_workspace_bytes(M, N, K, 1)))
+    with torch.cuda.device(a.device):
+        check(lib.locov_gemm_tn_f32_split(_ptr(a), a.stride(0), 0, _ptr(b), b.stride(0), 0, _ptr(out), K, 0, M, N, K, 1, _ptr(row_scale),
+                                          _ptr(a_scale_dev), float(b_scale), _ptr(_overflow_word(a)), _ptr(ws), ws.numel(), _stream(a)),
+              "locov_gemm_tn_f32_split")
+    return out
+
+
+def winograd_conv3x3_split_ex(x: torch.Tensor, U: SplitWeight, *, scale=None, shift=None, mask=None, relu: bool = False,
+                              roi_major: bool = True, v_scale: Optional[float] = None) -> torch.Tensor:
+    """winograd_conv3x3() in split arithmetic with the output mask; v_scale None = chosen on the device from max |V| (the input
+    is a gradient)."""
+    x = _dev(x, "x")
+    Ud = _dev(U.data, "U")
+    M, Cin = x.shape
+    if Ud.dim() != 3 or Ud.shape[0] != 121 or Ud.shape[2] != Cin or M % 49 != 0:
+        raise ValueError("winograd_conv3x3_split_ex: inconsistent shapes")
+    N, R = Ud.shape[1], M // 49
+    scale = _dev(scale, "scale") if scale is not None else None
+    shift = _dev(shift, "shift") if shift is not None else None
+    mask = _dev(mask, "mask") if mask is not None else None
+    if mask is not None and tuple(mask.shape) != (M, N):
+        raise ValueError("winograd_conv3x3_split_ex: mask must be [49*R, N]")
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    ws = _workspace("wino", x, int(lib.locov_winograd_workspace_bytes(R, Cin, N)))
+    flags = (_lib.EPI_RELU if relu else 0) | ((_lib.WINO_OUT_ROI_MAJOR | _lib.WINO_IN_ROI_MAJOR) if roi_major else 0)
+    with torch.cuda.device(x.device):
+        check(lib.locov_winograd_conv3x3_f32_split_ex(_ptr(x), R, Cin, _ptr(Ud), U.scale, float(v_scale or 1.0), int(v_scale is None),
+                                                      _ptr(scale), _ptr(shift), _ptr(mask), _ptr(y), N, N, flags, _ptr(ws), ws.numel(),
+                                                      _ptr(_overflow_word(x)), _stream(x)), "locov_winograd_conv3x3_f32_split_ex")
+    return y
 
 
 def weight_transpose_scale(w: torch.Tensor, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:

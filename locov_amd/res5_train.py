@@ -19,8 +19,11 @@ matrix [R*H*W, C] (ROI-major rows) and one torch.autograd.Function covers the wh
             FrozenBN scales are folded into the transposed weights (data gradients) and applied to the rows of the
             weight gradients; the statistics receive no gradient (buffers), exactly as in the reference.
 
-Gradients are exact fp32 (f32 MFMA); the forward runs in the arithmetic of the inference path (`split` = f16x2 split
-operands, or f32 MFMA).
+Arithmetic: with `split` (RES5_DTYPE "f16x2") the forward AND the backward GEMMs form every fp32 product from (hi, lo)
+f16 pairs on the f16 matrix pipe with fp32 accumulation (gemm_split.hip, gemm_tn_split.hip); a gradient tensor has no
+a-priori range, so its power-of-two operand scale is chosen on the device from its max |.| (one small reduction per
+gradient tensor, no host read).  Without it everything runs on the f32 MFMA.  LOCOV_RES5_BWD_F32=1 keeps the backward on
+the f32 MFMA while the forward uses split operands (developer A/B).
 """
 from __future__ import annotations
 
@@ -36,6 +39,7 @@ __all__ = ["res5_rows", "res5_grid", "roi_align_even_rows", "to_nhwc", "Res5Rows
 import os
 
 _NO_WINO_BWD = bool(int(os.environ.get("LOCOV_RES5_BWD_DIRECT", "0")))      # developer A/B: 3x3 gradients in the direct form
+_BWD_F32 = bool(int(os.environ.get("LOCOV_RES5_BWD_F32", "0")))              # developer A/B: backward GEMMs on the f32 MFMA
 
 
 def _wino_ok(H: int, W: int, cin: int, cout: int) -> bool:
@@ -93,6 +97,7 @@ class Res5RowsFn(torch.autograd.Function):
             del saved, out
             saved, meta, out = Res5RowsFn._blocks(stage, x, H, W, False)
         ctx.stage, ctx.meta, ctx.geom, ctx.pooled = stage, meta, (R, H, W), pooled
+        ctx.split = bool(split) and not _BWD_F32
         ctx.nw = len(weights)
         ctx.save_for_backward(*saved)
         if pooled:
@@ -101,6 +106,21 @@ class Res5RowsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        if not ctx.split:
+            return Res5RowsFn._backward(ctx, grad_out, False)
+        # split arithmetic: same range guard as the forward (only a remembered weight scale that stopped fitting can trip
+        # it here -- the activations passed the forward's guard, the gradients' scales are chosen on the device)
+        dev = grad_out.device
+        ops.split_overflow_reset(dev)
+        out = Res5RowsFn._backward(ctx, grad_out, True)
+        if ops.split_overflow_raised(dev):
+            ctx.stage._scales.clear()
+            ctx.stage._cache.clear()
+            out = Res5RowsFn._backward(ctx, grad_out, False)
+        return out
+
+    @staticmethod
+    def _backward(ctx, grad_out, sp):
         stage, (R, H, W) = ctx.stage, ctx.geom
         saved = ctx.saved_tensors
         need_x = ctx.needs_input_grad[0]
@@ -110,6 +130,20 @@ class Res5RowsFn(torch.autograd.Function):
         out_last = saved[-1]
         # gradient of the last block's output, masked by its ReLU
         g = ops.spatial_mean_bwd(grad_out, out_last, H * W) if ctx.pooled else ops.relu_mask(grad_out, out_last)
+        def keyed(t, conv, tag):                       # remembered operand scale of a per-step weight packing (Res5Stage._split)
+            t._locov_key = (id(conv), tag)
+            return t
+
+        def wgrad_1x1(g_, sg_, x_, s_):                # dW = s * g^T x
+            if sp and g_.shape[1] % 4 == 0 and x_.shape[1] % 4 == 0 and g_.shape[0] > 0:
+                return ops.gemm_tn_split(g_, x_, s_, sg_, 16.0)
+            return ops.gemm_tn(g_, x_, s_)
+
+        def dgrad_1x1(g_, sg_, wt, conv, **kw):        # (g . wt^T [+ residual]) [mask]
+            if sp and wt.shape[1] % 32 == 0 and wt.shape[0] % 4 == 0:
+                return ops.linear_split_ex(g_, stage._split(keyed(wt, conv, "t")), x_scale_dev=sg_, **kw)
+            return ops.linear_ex(g_, wt, **kw)
+
         for bi in range(len(stage) - 1, -1, -1):
             blk = stage[bi]
             has_sc, wino, wi = ctx.meta[bi]
@@ -117,31 +151,40 @@ class Res5RowsFn(torch.autograd.Function):
             w1, s1, _ = stage._packed(blk.conv1)
             w3, s3, _ = stage._packed(blk.conv3)
             c2 = blk.conv2
+            sg = ops.split_scale_from_amax(g) if sp else None
             # conv3: dW3 = s3 * g^T y2 ; g2 = (g . s3 W3) [y2 > 0]
             if need_w[wi + 2]:
-                gw[wi + 2] = ops.gemm_tn(g, y2, s3).view_as(blk.conv3.weight)
-            g2 = ops.linear_ex(g, ops.weight_transpose_scale(w3, s3), mask=y2)
+                gw[wi + 2] = wgrad_1x1(g, sg, y2, s3).view_as(blk.conv3.weight)
+            g2 = dgrad_1x1(g, sg, ops.weight_transpose_scale(w3, s3), blk.conv3, mask=y2)
             # conv2 (3x3): dW2 = s2 * wgrad(y1, g2) ; g1 = conv3x3(g2, flip(s2 W2)) [y1 > 0]
             _, s2, _ = stage._packed(c2)
             w2 = c2.weight.detach()
             if need_w[wi + 1]:
                 if wino and c2.out_channels % 4 == 0 and not _NO_WINO_BWD:
-                    gw[wi + 1] = ops.winograd_wgrad(y1, g2, s2, roi_major=True)
+                    gw[wi + 1] = ops.winograd_wgrad(y1, g2, s2, roi_major=True, split=sp)
+                elif sp:
+                    gw[wi + 1] = ops.conv3x3_wgrad_unpack(ops.gemm_tn_split(g2, ops.im2col3x3(y1, H, W), None,
+                                                                            ops.split_scale_from_amax(g2), 16.0), s2)
                 else:
                     gw[wi + 1] = ops.conv3x3_wgrad_unpack(ops.gemm_tn(g2, ops.im2col3x3(y1, H, W)), s2)
             wflip = ops.conv3x3_weight_flip(w2, s2)                       # [Cin, Cout, 3, 3]
             if _wino_ok(H, W, c2.out_channels, c2.in_channels) and not _NO_WINO_BWD:
-                g1 = ops.winograd_conv3x3_ex(g2, ops.winograd_pack_weight(wflip), mask=y1, roi_major=True)
+                uflip = ops.winograd_pack_weight(wflip)
+                if sp:
+                    g1 = ops.winograd_conv3x3_split_ex(g2, stage._split(keyed(uflip, c2, "uflip")), mask=y1, roi_major=True)
+                else:
+                    g1 = ops.winograd_conv3x3_ex(g2, uflip, mask=y1, roi_major=True)
             else:
                 g1 = ops.conv3x3_nhwc_ex(g2, ops.pack_conv3x3_weight(wflip), H, W, mask=y1, pos_major=False)
             del g2
+            sg1 = ops.split_scale_from_amax(g1) if sp else None
             # conv1 (+ shortcut): dW1 = s1 * g1^T x ; gx = (g1 . s1 W1 + shortcut path) [x > 0]
             if need_w[wi]:
-                gw[wi] = ops.gemm_tn(g1, x, s1).view_as(blk.conv1.weight)
+                gw[wi] = wgrad_1x1(g1, sg1, x, s1).view_as(blk.conv1.weight)
             if has_sc:
                 ws, ss, _ = stage._packed(blk.shortcut)
                 if need_w[wi + 3]:
-                    gw[wi + 3] = ops.gemm_tn(g, x, ss).view_as(blk.shortcut.weight)
+                    gw[wi + 3] = wgrad_1x1(g, sg, x, ss).view_as(blk.shortcut.weight)
             first = bi == 0
             if first and not need_x:
                 g = None
@@ -149,10 +192,10 @@ class Res5RowsFn(torch.autograd.Function):
             # the input of block 0 is the pooler output (no ReLU in front of it); every other block's input is the
             # post-ReLU output of its predecessor, whose mask turns gx into that block's masked output gradient
             mask = None if first else x
-            gx = ops.linear_ex(g1, ops.weight_transpose_scale(w1, s1), residual=None if has_sc else g,
-                               mask=None if has_sc else mask)
+            gx = dgrad_1x1(g1, sg1, ops.weight_transpose_scale(w1, s1), blk.conv1, residual=None if has_sc else g,
+                           mask=None if has_sc else mask)
             if has_sc:
-                gx = ops.linear_ex(g, ops.weight_transpose_scale(ws, ss), residual=gx, mask=mask)
+                gx = dgrad_1x1(g, sg, ops.weight_transpose_scale(ws, ss), blk.shortcut, residual=gx, mask=mask)
             del g1
             g = gx
         return (g, None, None, None, None, None, None, None, *gw)

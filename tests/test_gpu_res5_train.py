@@ -440,3 +440,80 @@ def test_training_step_at_config_sizes_runs_on_the_hip_kernels(pkg, oracle):
         assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, k
         n += 1
     assert n == 10
+
+
+# ------------------------------------------------------------------------------------------------ split-arithmetic backward
+def test_split_scale_from_amax(pkg):
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(2)
+    for amax in (3.7e-6, 0.9, 1.0, 517.25):
+        x = torch.randn(1000, 64, generator=g).cuda()
+        x = x / x.abs().max() * amax
+        sc = ops.split_scale_from_amax(x).cpu()
+        s = float(sc[0])
+        assert s == 2.0 ** round(np.log2(s)) and float(sc[1]) == 1.0 / s              # a power of two and its inverse
+        assert 2.0 ** 12 < float(x.abs().max()) * s <= 2.0 ** 13
+    assert float(ops.split_scale_from_amax(torch.zeros(16, 8, device="cuda"))[0]) == 1.0
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (777, 64, 96), (4097, 256, 36), (39200, 512, 256), (31, 4, 2048)])
+def test_gemm_tn_split_vs_float64(pkg, M, N, K):
+    """Weight-gradient GEMM in split arithmetic: gradient-sized entries (1e-5) against activations, float64 reference; error
+    of the order of the f32-MFMA TN kernel's."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(M + K)
+    a = (torch.randn(M, N, generator=g) * 1e-5).cuda()
+    a[::7] *= 30.0                                                        # a spread of magnitudes inside one tensor
+    b = torch.relu(torch.randn(M, K, generator=g)).cuda() * 3.0
+    s = (torch.rand(N, generator=g) + 0.5).cuda()
+    want = (a.double().t() @ b.double()) * s.double()[:, None]
+    sc = ops.split_scale_from_amax(a)
+    ops.split_overflow_reset(a.device)
+    got = ops.gemm_tn_split(a, b, s, sc, 16.0)
+    assert not ops.split_overflow_raised(a.device)
+    err, err32 = rel_err(got, want), rel_err(ops.gemm_tn(a, b, s), want)
+    assert err < 3e-6 and err < 4 * err32 + 1e-6, (err, err32)
+    assert torch.equal(got, ops.gemm_tn_split(a, b, s, sc, 16.0))
+    b[5, 3] = 5000.0                                                      # 16 * 5000 >= 65504: the guard sees it
+    ops.gemm_tn_split(a, b, s, sc, 16.0)
+    assert ops.split_overflow_raised(a.device)
+    ops.split_overflow_reset(a.device)
+
+
+def test_linear_split_ex_mask_and_device_scale(pkg):
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(9)
+    for (M, N, K) in ((300, 96, 64), (1000, 260, 128), (2049, 512, 2048)):
+        x = (torch.randn(M, K, generator=g) * 3e-6).cuda()
+        w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+        res = (torch.randn(M, N, generator=g) * 1e-6).cuda()
+        act = torch.randn(M, N, generator=g).cuda()
+        want = x.double() @ w.double().t() + res.double()
+        want = torch.where(act.double() > 0, want, torch.zeros_like(want))
+        got = ops.linear_split_ex(x, ops.split_pack(w), residual=res, mask=act, x_scale_dev=ops.split_scale_from_amax(x))
+        assert rel_err(got, want) < 3e-6
+        assert float(got[act <= 0].abs().max()) == 0.0
+        # a fixed x_scale of 16 would lose these tiny values to fp16's fixed-point floor: the device scale is what keeps 22 bits
+        coarse = ops.linear_split_ex(x, ops.split_pack(w), residual=res, mask=act, x_scale=16.0)
+        assert rel_err(coarse, want) > 10 * rel_err(got, want)
+
+
+@pytest.mark.parametrize("R,Cin,N", [(70, 64, 64), (300, 128, 96)])
+def test_winograd_gradients_split_vs_float64(pkg, R, Cin, N):
+    ops = pkg.ops
+    gen = torch.Generator().manual_seed(R + 1)
+    x = torch.relu(torch.randn(R, Cin, 7, 7, generator=gen))
+    w = torch.randn(N, Cin, 3, 3, generator=gen) * 0.1
+    s = torch.rand(N, generator=gen) + 0.5
+    gy = torch.randn(R, N, 7, 7, generator=gen) * 2e-5
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    (F.conv2d(xd, wd, padding=1) * s.double().view(1, -1, 1, 1) * gy.double()).sum().backward()
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(R * 49, -1).contiguous().cuda()
+    dw = ops.winograd_wgrad(rows(x), rows(gy), s.cuda(), roi_major=True, split=True)
+    assert rel_err(dw, wd.grad) < 3e-5
+    if N % 32 == 0:
+        act = torch.randn(R, Cin, 7, 7, generator=gen)
+        U = ops.split_pack(ops.winograd_pack_weight(ops.conv3x3_weight_flip(w.cuda(), s.cuda())))
+        gx = ops.winograd_conv3x3_split_ex(rows(gy), U, mask=rows(act), roi_major=True)
+        want = torch.where(act.double() > 0, xd.grad, torch.zeros_like(xd.grad))
+        assert rel_err(gx.view(R, 7, 7, Cin).permute(0, 3, 1, 2), want) < 3e-5
