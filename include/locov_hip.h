@@ -460,7 +460,7 @@ int locov_gemm_tn_f32(const float *a, int64_t lda, int64_t stride_a, const float
 
 /* The same gradients in the split-operand arithmetic of the forward (3 f16 MFMAs per fp32 product block instead of 16 f32
  * ones).  A gradient tensor has no a-priori range, so its operand scale is chosen ON THE DEVICE:
- *   locov_split_scale_from_amax : scale_out[0] = s = 2^(target_log2 - ceil(log2 max|x|)), scale_out[1] = 1/s, scale_out[2] =
+ *   locov_split_scale_from_amax : scale_out[0] = s = the power of two with max |s x| in [2^(target_log2-1), 2^target_log2), scale_out[1] = 1/s, scale_out[2] =
  *                                 bit pattern of max |x| (scratch); three tiny launches, no host read.  scale_out: 16 bytes.
  *   locov_gemm_nt_f32_split_ex  : locov_gemm_nt_f32_split with the epilogue `mask` of locov_gemm_nt_f32_ex and, when
  *                                 x_scale_dev is non-null, the operand scale of x read from it (x_scale is then ignored).

@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void segsum_finish_kernel(const float *__restr
 }
 
 // Operand scale of a tensor whose range is only known on the device (gradients): scale_out = {s, 1/s, amax bits} with
-// s = 2^(target_log2 - ceil(log2(max |x|))), i.e. max |s x| in (2^(target-1), 2^target]; an all-zero (or empty) tensor
+// s = 2^(target_log2 - 1 - floor(log2(max |x|))), i.e. max |s x| in [2^(target-1), 2^target); an all-zero (or empty) tensor
 // gets s = 1.  Three tiny launches: init, a grid-wide atomicMax over the bit patterns of |x|, finish.
 __global__ void split_scale_init_kernel(float *out) { reinterpret_cast<unsigned *>(out)[2] = 0u; }
 

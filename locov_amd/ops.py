@@ -688,7 +688,7 @@ def winograd_wgrad(x: torch.Tensor, g: torch.Tensor, row_scale: Optional[torch.T
 
 def split_scale_from_amax(x: torch.Tensor, target_log2: float = 13.0) -> torch.Tensor:
     """Device-side operand scale of a tensor whose range is only known on the device (a gradient): a 4-float device tensor
-    {s, 1/s, bits of max|x|, -} with s the power of two that puts max |s x| in (2^(target-1), 2^target].  No host read."""
+    {s, 1/s, bits of max|x|, -} with s the power of two that puts max |s x| in [2^(target-1), 2^target).  No host read."""
     x = _dev(x, "x")
     if x.numel() % 4:
         raise ValueError("split_scale_from_amax: numel must be a multiple of 4")
