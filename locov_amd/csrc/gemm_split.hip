@@ -509,7 +509,13 @@ __global__ __launch_bounds__(256) void split_amax_kernel(const float *__restrict
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));      // non-negative floats order like their bits
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {                    // ONE atomic per workgroup (thousands of same-address atomics serialise)
+        m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (m > 0.f) atomicMax(amax_bits, __float_as_uint(m));                             // non-negative floats order like their bits
+    }
 }
 
 __global__ void split_scale_finish_kernel(float *out, float target_log2)
@@ -630,7 +636,7 @@ int locov_split_scale_from_amax(const float *x, int64_t n, float target_log2, fl
     hipLaunchKernelGGL(split_scale_init_kernel, dim3(1), dim3(1), 0, s, scale_out);
     if (n > 0) {
         const int64_t n4 = n / 4;
-        const unsigned blocks = (unsigned)(ceil_div(n4, 256 * 8) < 4096 ? ceil_div(n4, 256 * 8) : 4096);
+        const unsigned blocks = (unsigned)(ceil_div(n4, 256 * 8) < 1024 ? ceil_div(n4, 256 * 8) : 1024);
         hipLaunchKernelGGL(split_amax_kernel, dim3(blocks), dim3(256), 0, s, x, n4, reinterpret_cast<unsigned *>(scale_out) + 2);
     }
     hipLaunchKernelGGL(split_scale_finish_kernel, dim3(1), dim3(1), 0, s, scale_out, target_log2);

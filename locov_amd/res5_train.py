@@ -55,6 +55,7 @@ class Res5RowsFn(torch.autograd.Function):
     @staticmethod
     def _blocks(stage, x, H, W, split):
         saved: List[torch.Tensor] = []
+        cols: List[torch.Tensor] = []                 # im2col patches of y1 per block (general-grid form only)
         meta = []
         wi = 0
         for blk in stage:
@@ -69,8 +70,11 @@ class Res5RowsFn(torch.autograd.Function):
                 y2 = ops.winograd_conv3x3(y1, stage._split(u2) if split else u2, scale=s2, shift=b2, relu=True,
                                           roi_major=True, in_roi_major=True)
             else:
+                # general grid (the whole-grid call): 3x3 as a GEMM over im2col patches -- K = 9 Cin columns in the order of
+                # the packed weight -- so that it runs in the stage's arithmetic; the patches are kept for the weight gradient
                 w2, s2, b2 = stage._packed(c2)
-                y2 = ops.conv3x3_nhwc(y1, w2, H, W, scale=s2, shift=b2, relu=True, pos_major=False)
+                col = ops.im2col3x3(y1, H, W)
+                y2 = stage._linear(split, col, w2, b2, scale=s2, relu=True)
             if has_sc:
                 ws, ss, bs = stage._packed(blk.shortcut)
                 sc = stage._linear(split, x, ws, bs, scale=ss)
@@ -78,10 +82,12 @@ class Res5RowsFn(torch.autograd.Function):
                 sc = x
             out = stage._linear(split, y2, w3, b3, scale=s3, residual=sc, relu=True)
             saved += [x, y1, y2, out]
+            if not wino:
+                cols.append(col)
             meta.append((has_sc, wino, wi))
             wi += 4 if has_sc else 3
             x = out
-        return saved, meta, x
+        return saved + cols, meta, x
 
     @staticmethod
     def forward(ctx, x0, stage, R, H, W, pooled, split, guard, *weights):
@@ -127,7 +133,7 @@ class Res5RowsFn(torch.autograd.Function):
         need_w = ctx.needs_input_grad[8:]
         gw: List[Optional[torch.Tensor]] = [None] * ctx.nw
         grad_out = ops._dev(grad_out, "grad_out")
-        out_last = saved[-1]
+        out_last = saved[4 * len(stage) - 1]
         # gradient of the last block's output, masked by its ReLU
         g = ops.spatial_mean_bwd(grad_out, out_last, H * W) if ctx.pooled else ops.relu_mask(grad_out, out_last)
         def keyed(t, conv, tag):                       # remembered operand scale of a per-step weight packing (Res5Stage._split)
@@ -148,6 +154,7 @@ class Res5RowsFn(torch.autograd.Function):
             blk = stage[bi]
             has_sc, wino, wi = ctx.meta[bi]
             x, y1, y2, _ = saved[4 * bi: 4 * bi + 4]
+            col = None if wino else saved[4 * len(stage) + bi]
             w1, s1, _ = stage._packed(blk.conv1)
             w3, s3, _ = stage._packed(blk.conv3)
             c2 = blk.conv2
@@ -162,11 +169,12 @@ class Res5RowsFn(torch.autograd.Function):
             if need_w[wi + 1]:
                 if wino and c2.out_channels % 4 == 0 and not _NO_WINO_BWD:
                     gw[wi + 1] = ops.winograd_wgrad(y1, g2, s2, roi_major=True, split=sp)
-                elif sp:
-                    gw[wi + 1] = ops.conv3x3_wgrad_unpack(ops.gemm_tn_split(g2, ops.im2col3x3(y1, H, W), None,
-                                                                            ops.split_scale_from_amax(g2), 16.0), s2)
                 else:
-                    gw[wi + 1] = ops.conv3x3_wgrad_unpack(ops.gemm_tn(g2, ops.im2col3x3(y1, H, W)), s2)
+                    colw = col if col is not None else ops.im2col3x3(y1, H, W)
+                    if sp:
+                        gw[wi + 1] = ops.conv3x3_wgrad_unpack(ops.gemm_tn_split(g2, colw, None, ops.split_scale_from_amax(g2), 16.0), s2)
+                    else:
+                        gw[wi + 1] = ops.conv3x3_wgrad_unpack(ops.gemm_tn(g2, colw), s2)
             wflip = ops.conv3x3_weight_flip(w2, s2)                       # [Cin, Cout, 3, 3]
             if _wino_ok(H, W, c2.out_channels, c2.in_channels) and not _NO_WINO_BWD:
                 uflip = ops.winograd_pack_weight(wflip)
@@ -175,7 +183,9 @@ class Res5RowsFn(torch.autograd.Function):
                 else:
                     g1 = ops.winograd_conv3x3_ex(g2, uflip, mask=y1, roi_major=True)
             else:
-                g1 = ops.conv3x3_nhwc_ex(g2, ops.pack_conv3x3_weight(wflip), H, W, mask=y1, pos_major=False)
+                # data gradient on the general grid: the same im2col GEMM with the flipped filter
+                g1 = dgrad_1x1(ops.im2col3x3(g2, H, W), ops.split_scale_from_amax(g2) if sp else None,
+                               ops.pack_conv3x3_weight(wflip), c2, mask=y1)
             del g2
             sg1 = ops.split_scale_from_amax(g1) if sp else None
             # conv1 (+ shortcut): dW1 = s1 * g1^T x ; gx = (g1 . s1 W1 + shortcut path) [x > 0]
