@@ -50,6 +50,9 @@ extern "C" {
 
 /* epilogue flags of the GEMM entry points */
 #define LOCOV_EPI_RELU 1u
+/* locov_gemm_nt_f32_split*: x is ALREADY in the split layout of locov_split_f16x2_pack (written so by its producer),
+ * scaled by x_scale: it is then staged by LDS DMA like W, with no conversion in the kernel */
+#define LOCOV_GEMM_A_SPLIT 0x1000u
 #define LOCOV_SEGMEAN_RES_ROI_MAJOR 0x400u   /* locov_gemm_nt_f32_split_segmean: the residual rows are ROI-major */
 /* locov_winograd_conv3x3_f32{,_split}: write the output rows ROI-major (row = roi * 49 + position) instead of
  * position-major (row = position * R + roi) -- the order locov_gemm_nt_f32_split_segmean consumes */

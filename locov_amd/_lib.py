@@ -20,6 +20,7 @@ EPI_RELU = 1
 WINO_OUT_ROI_MAJOR = 0x100
 WINO_IN_ROI_MAJOR = 0x200
 SEGMEAN_RES_ROI_MAJOR = 0x400
+GEMM_A_SPLIT = 0x1000
 MAX_LEVELS = 8
 ABI_VERSION = 2
 

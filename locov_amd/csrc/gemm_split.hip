@@ -28,6 +28,7 @@
 //     XOR-permuted per row (wswz) for conflict-free fragment reads.
 #include "gemm_nt.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 #ifndef LOCOV_RES_PREFETCH
@@ -100,7 +101,10 @@ struct SegSum {
 // gradients of the training step); a_scale_dev: when non-null the operand scale of A is read from device memory
 // (a_scale_dev[0], a power of two chosen on the device from the tensor's max |x| by split_scale_kernel -- gradients have
 // no a-priori range) and `out_scale` holds 1 / w_scale only.
-template <bool SEGSUM, bool EMASK = false>
+// ASPLIT: A is ALREADY in the split layout of locov_split_f16x2_pack (written that way by its producer) with scale a_scale:
+// it then needs no conversion and takes W's road -- LDS DMA into unpadded, XOR-swizzled 128-byte rows -- instead of
+// buffer loads, 8 v_fma_mix + 2 v_max3 and two 8-byte LDS stores per 16-byte chunk.
+template <bool SEGSUM, bool EMASK = false, bool ASPLIT = false>
 __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restrict__ A, int64_t lda,
                                                            const float *__restrict__ B, float *__restrict__ Cout,
                                                            int64_t ldc, int64_t M, int N, int K, Epilogue epi, Batch bt,
@@ -187,6 +191,22 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
                 r, (__attribute__((address_space(3))) void *)(ldsb + stage * STAGEB + BM * ROWB + (wave * CH + i) * 8 * WROWB), 16,
                 b_voff[i], 0, 0, 0);
     };
+    // ASPLIT: the same DMA for A (rows past M are clamped to the last row: they only feed outputs that are never stored)
+    const char *a_dbase = reinterpret_cast<const char *>(A + m0 * lda);
+    unsigned a_voff[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+        const int row = (wave * CH + i) * 8 + (lane >> 3);
+        const int64_t gm = m0 + row;
+        a_voff[i] = (unsigned)((((gm < M ? gm : M - 1) - m0) * lda * 4) + (((lane & 7) ^ wswz(row)) * 16));
+    }
+    auto dma_a = [&](int stage) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a_dbase), 0, 0xffffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < CH; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                r, (__attribute__((address_space(3))) void *)(ldsb + stage * STAGEB + (wave * CH + i) * 8 * WROWB), 16, a_voff[i], 0, 0, 0);
+    };
     f32x4 ra[CH];
     // Range guard of the split arithmetic: |a_scale * x| must stay below fp16's largest finite value.  Every A value passes
     // through this thread's registers exactly once on its way into LDS; two v_max3_f32 per chunk keep the running maximum of
@@ -221,11 +241,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
 #pragma unroll
     for (int hl = 0; hl < 2; hl++) bfo[hl] = l16 * WROWB + (((2 * kg + hl) ^ wswz(l16)) * 16);
     auto rd_a = [&](int stage, int ga) {
-        const char *As = ldsb + stage * STAGEB + (wm + ga * 32) * ROWB + afo;
+        if constexpr (ASPLIT) {
+            const char *As = ldsb + stage * STAGEB + (wm + ga * 32) * WROWB;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            fa[2 * ga + i][0] = *reinterpret_cast<const f16x8 *>(As + i * 16 * ROWB);
-            fa[2 * ga + i][1] = *reinterpret_cast<const f16x8 *>(As + i * 16 * ROWB + 32);
+            for (int i = 0; i < 2; i++) {
+                fa[2 * ga + i][0] = *reinterpret_cast<const f16x8 *>(As + i * 16 * WROWB + bfo[0]);
+                fa[2 * ga + i][1] = *reinterpret_cast<const f16x8 *>(As + i * 16 * WROWB + bfo[1]);
+            }
+        } else {
+            const char *As = ldsb + stage * STAGEB + (wm + ga * 32) * ROWB + afo;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                fa[2 * ga + i][0] = *reinterpret_cast<const f16x8 *>(As + i * 16 * ROWB);
+                fa[2 * ga + i][1] = *reinterpret_cast<const f16x8 *>(As + i * 16 * ROWB + 32);
+            }
         }
     };
     auto rd_b = [&](int stage, int gb) {
@@ -251,15 +280,22 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
     // prologue: tile 0 -> LDS stage 0 (W by DMA), A tile 1 -> staging registers, fragments of the first quarter
     dma_b(0);
     b_base += BK * 4;                                       // W is fetched ONE tile ahead: b_base addresses tile t+1
+    int k_ptr = 0;
+    if constexpr (ASPLIT) {
+        dma_a(0);
+        a_dbase += BK * 4;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
+    } else {
 #pragma unroll
-    for (int i = 0; i < CH; i++) ra[i] = ld_a(i);
+        for (int i = 0; i < CH; i++) ra[i] = ld_a(i);
 #pragma unroll
-    for (int i = 0; i < CH; i++) st_a(i, 0);
-    int k_ptr = BK < k_last ? BK : k_last;                  // the A tile a_base addresses (two ahead in the loop)
-    a_base += (int64_t)k_ptr * 4;
+        for (int i = 0; i < CH; i++) st_a(i, 0);
+        k_ptr = BK < k_last ? BK : k_last;                  // the A tile a_base addresses (two ahead in the loop)
+        a_base += (int64_t)k_ptr * 4;
 #pragma unroll
-    for (int i = 0; i < CH; i++) ra[i] = ld_a(i);
-    __builtin_amdgcn_s_waitcnt(0x0F70 | CH);                // vmcnt(CH): everything but the A loads just issued has landed
+        for (int i = 0; i < CH; i++) ra[i] = ld_a(i);
+        __builtin_amdgcn_s_waitcnt(0x0F70 | CH);            // vmcnt(CH): everything but the A loads just issued has landed
+    }
     __syncthreads();
     rd_a(0, 0);
     rd_b(0, 0);
@@ -280,11 +316,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
         __builtin_amdgcn_sched_barrier(0);
         dma_b(s ^ 1);
         b_base += BK * 4;
+        if constexpr (ASPLIT) {
+            dma_a(s ^ 1);
+            a_dbase += BK * 4;
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < CH; g++) {
-            st_a(g, s ^ 1);
-            ra[g] = ld_a(g);
+            if constexpr (!ASPLIT) {
+                st_a(g, s ^ 1);
+                ra[g] = ld_a(g);
+            }
             if (g < CH / 2)
                 quarter(0, x, g * 2 * NQM / CH, (g + 1) * 2 * NQM / CH);
             else
@@ -295,7 +337,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
         __builtin_amdgcn_sched_barrier(0);
         // the barrier sits three quarters into the tile (measured 1 % better than the middle: the DMA and the LDS stores
         // get more time, the two fragment groups read behind it are still a full quarter ahead of their use)
-        __builtin_amdgcn_s_waitcnt(0x0F70 | CH);            // vmcnt(CH): the DMA is older than the CH A loads
+        __builtin_amdgcn_s_waitcnt(ASPLIT ? 0x0F70 : (0x0F70 | CH));   // vmcnt(CH): the DMA is older than the CH A loads
         __syncthreads();
         rd_a(s ^ 1, 0);
         rd_b(s ^ 1, y);
@@ -350,7 +392,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
     }
 
     __builtin_amdgcn_s_setprio(3);
-    if (overflow != nullptr && amax * a_scale >= 65504.f) atomicOr(overflow, 1u);
+    if (!ASPLIT && overflow != nullptr && amax * a_scale >= 65504.f) atomicOr(overflow, 1u);
     // Epilogue (C/D layout of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg): re-lay the wave's sub-tile out
     // through LDS, 16 bytes per lane and row-contiguous from there.
     const bool relu = (epi.flags & LOCOV_EPI_RELU) != 0;
@@ -551,7 +593,12 @@ int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C,
     if ((int64_t)BM * (lda > ldc ? lda : ldc) * 4 > 0x7fffffffLL)
         return set_error(LOCOV_ERR_INVALID_ARG, "%s: row pitch too large for 32-bit tile offsets", what);
     const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K * count);     // class 5: split-operand GEMM
-    if (epi.mask)
+    if (epi.flags & LOCOV_GEMM_A_SPLIT) {
+        if (epi.mask || a_scale_dev) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: pre-split A takes no mask / device scale", what);
+        hipLaunchKernelGGL((gemm_split_kernel<false, false, true>), dim3((unsigned)tiles), dim3(NT), 0, s, A, lda,
+                           reinterpret_cast<const float *>(Wsplit), C, ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale),
+                           SegSum{0, 0, nullptr}, overflow, a_scale_dev);
+    } else if (epi.mask)
         hipLaunchKernelGGL((gemm_split_kernel<false, true>), dim3((unsigned)tiles), dim3(NT), 0, s, A, lda,
                            reinterpret_cast<const float *>(Wsplit), C, ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale),
                            SegSum{0, 0, nullptr}, overflow, a_scale_dev);

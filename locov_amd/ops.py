@@ -440,7 +440,7 @@ def split_scale_for(w: torch.Tensor) -> float:
 
 def linear_split(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tensor] = None, *,
                  scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                 relu: bool = False, x_scale: float = 16.0) -> torch.Tensor:
+                 relu: bool = False, x_scale: float = 16.0, x_is_split: bool = False) -> torch.Tensor:
     """y = epi(x . W^T), fp32 in / fp32 out, products on the f16 matrix pipe with split operands (opt-in "f16x2"
     arithmetic).  x [M,K] fp32 (rows may be strided), weight = split_pack(W [N,K]); x_scale = the power of two x is
     multiplied by before the split (|x_scale * x| must stay below 65504: |x| < 4094 at the default)."""
@@ -458,7 +458,8 @@ def linear_split(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tens
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         check(_lib.load().locov_gemm_nt_f32_split(_ptr(x), x.stride(0) if M else K, _ptr(wd), _ptr(scale), _ptr(bias),
-                                                  _ptr(residual), _ptr(y), N, M, N, K, _lib.EPI_RELU if relu else 0,
+                                                  _ptr(residual), _ptr(y), N, M, N, K,
+                                                  (_lib.EPI_RELU if relu else 0) | (_lib.GEMM_A_SPLIT if x_is_split else 0),
                                                   float(x_scale), weight.scale, _ptr(_overflow_word(x)), _stream(x)),
               "locov_gemm_nt_f32_split")
     return y
