@@ -485,12 +485,15 @@ int locov_gemm_tn_f32_split(const float *a, int64_t lda, int64_t stride_a, const
                             float b_scale, unsigned *overflow, void *workspace, int64_t workspace_bytes,
                             locov_stream_t stream);
 /* locov_winograd_conv3x3_f32_split with the output `mask` of locov_winograd_conv3x3_f32_ex and, with v_scale_auto != 0, the
- * scale of the transformed input chosen on the device (the input is a gradient: the data gradient of a 3x3 convolution). */
+ * scale of the transformed input chosen on the device (the input is a gradient: the data gradient of a 3x3 convolution).
+ * y_split_scale > 0: y is written in the split layout of locov_split_f16x2_pack scaled by y_split_scale (N % 32 == 0, ldy == N,
+ * no mask) -- the pre-split A operand (LOCOV_GEMM_A_SPLIT) of the 1x1 convolution that follows; out-of-range values raise
+ * *overflow here.  (With a fixed v_scale the transformed input is handed to the batched GEMM in that layout as well.) */
 int locov_winograd_conv3x3_f32_split_ex(const float *x, int64_t R, int Cin, const void *U_split, float u_scale,
                                         float v_scale, int v_scale_auto, const float *scale, const float *shift,
                                         const float *mask, float *y, int64_t ldy, int N, unsigned flags,
-                                        void *workspace, int64_t workspace_bytes, unsigned *overflow,
-                                        locov_stream_t stream);
+                                        float y_split_scale, void *workspace, int64_t workspace_bytes,
+                                        unsigned *overflow, locov_stream_t stream);
 int locov_winograd_wgrad_f32_split(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags,
                                    const float *row_scale, float *dw, unsigned *overflow, void *workspace,
                                    int64_t workspace_bytes, locov_stream_t stream);

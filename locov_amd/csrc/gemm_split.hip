@@ -629,10 +629,18 @@ int launch_gemm_split_segmean(const float *A, int64_t lda, const void *Wsplit, i
     if (tiles > 0x7fffffffLL || (double)M * N * 4 > 4294967295.0 || (int64_t)BM * lda * 4 > 0x7fffffffLL)
         return set_error(LOCOV_ERR_INVALID_ARG, "%s: problem too large for 32-bit residual offsets", what);
     const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K);
-    hipLaunchKernelGGL((gemm_split_kernel<true, false>), dim3((unsigned)tiles), dim3(NT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
-                       static_cast<float *>(nullptr), (int64_t)N, M, N, K, epi, Batch{1, 0, 0, 0}, a_scale, 1.f / (a_scale * w_scale),
-                       SegSum{seg, (epi.flags & LOCOV_SEGMEAN_RES_ROI_MAJOR) ? (int64_t)0 : M / seg, partial}, overflow,
-                       static_cast<const float *>(nullptr));
+    if (epi.flags & LOCOV_GEMM_A_SPLIT)
+        hipLaunchKernelGGL((gemm_split_kernel<true, false, true>), dim3((unsigned)tiles), dim3(NT), 0, s, A, lda,
+                           reinterpret_cast<const float *>(Wsplit), static_cast<float *>(nullptr), (int64_t)N, M, N, K, epi, Batch{1, 0, 0, 0},
+                           a_scale, 1.f / (a_scale * w_scale),
+                           SegSum{seg, (epi.flags & LOCOV_SEGMEAN_RES_ROI_MAJOR) ? (int64_t)0 : M / seg, partial}, overflow,
+                           static_cast<const float *>(nullptr));
+    else
+        hipLaunchKernelGGL((gemm_split_kernel<true, false, false>), dim3((unsigned)tiles), dim3(NT), 0, s, A, lda,
+                           reinterpret_cast<const float *>(Wsplit), static_cast<float *>(nullptr), (int64_t)N, M, N, K, epi, Batch{1, 0, 0, 0},
+                           a_scale, 1.f / (a_scale * w_scale),
+                           SegSum{seg, (epi.flags & LOCOV_SEGMEAN_RES_ROI_MAJOR) ? (int64_t)0 : M / seg, partial}, overflow,
+                           static_cast<const float *>(nullptr));
     timing_end(trec, s);
     int rc = check_launch(what);
     if (rc) return rc;
@@ -719,7 +727,7 @@ int locov_gemm_nt_f32_split_segmean(const float *x, int64_t lda, const void *W_s
     if (M == 0) return LOCOV_OK;
     LOCOV_REQUIRE(x && W_split && residual && out && workspace, "locov_gemm_nt_f32_split_segmean: null pointer");
     LOCOV_REQUIRE(lda >= K, "locov_gemm_nt_f32_split_segmean: lda < K");
-    LOCOV_REQUIRE(!(flags & ~(unsigned)(LOCOV_EPI_RELU | LOCOV_SEGMEAN_RES_ROI_MAJOR)),
+    LOCOV_REQUIRE(!(flags & ~(unsigned)(LOCOV_EPI_RELU | LOCOV_SEGMEAN_RES_ROI_MAJOR | LOCOV_GEMM_A_SPLIT)),
                   "locov_gemm_nt_f32_split_segmean: unsupported flags 0x%x", flags);
     LOCOV_REQUIRE(workspace_bytes >= locov_gemm_segmean_workspace_bytes(M, N),
                   "locov_gemm_nt_f32_split_segmean: workspace too small (%lld bytes)", (long long)workspace_bytes);

@@ -53,6 +53,28 @@ __global__ __launch_bounds__(256) void wino_pack_weight_kernel(const float *__re
     }
 }
 
+// Store the channel pair (c, c+1) of a row in the SPLIT layout of locov_split_f16x2_pack (per 8 channels: 8 hi halves, then 8
+// lo halves of s*v; the row keeps its fp32 size): the split GEMM then stages this tensor by LDS DMA with no conversion of
+// its own (gemm_split.hip, ASPLIT).  A lane owns two channels = 4 bytes of hi and 4 of lo; neighbouring lanes (c and c+2,
+// same group of 8) trade one word so that the even one stores the hi halves of four channels and the odd one their lo
+// halves -- 8 contiguous bytes per lane, a wave's 512-byte row segment fully written by one instruction, as in fp32.
+// Returns max(|v0|, |v1|) for the caller's range guard.
+__device__ __forceinline__ void store_split_pair(float *row, int c, f32x2 v, float s)
+{
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(v[0]), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(v[1]), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v[0]), "v"(s), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v[1]), "v"(s), "v"(h));
+    const bool odd = (c & 2) != 0;                              // c % 4 == 2: this lane keeps the lo halves
+    const unsigned got = (unsigned)__shfl_xor((int)(odd ? h : l), 1);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 out = odd ? u32x2{got, l} : u32x2{h, got};
+    // byte offset in the row: group of 8 channels = 32 bytes; hi halves of channels 0-3 | 4-7 at +0 | +8, lo at +16 | +24
+    char *p = reinterpret_cast<char *>(row) + (c >> 3) * 32 + ((c >> 2) & 1) * 8 + (odd ? 16 : 0);
+    __builtin_nontemporal_store(out, reinterpret_cast<u32x2 *>(p));
+}
+
 // x rows [(y*7+x)*ld_pos + r*ld_roi][C]  ->  V [NF*NF][Rc][C]   (position-major input: ld_pos = R, ld_roi = 1;
 // ROI-major input, row = roi*49 + position: ld_pos = 1, ld_roi = 49)
 // GRAD = true applies A (x) A = (AT (x) AT)^T instead of BT (x) BT: the adjoint of the OUTPUT transform, which maps the
@@ -60,13 +82,17 @@ __global__ __launch_bounds__(256) void wino_pack_weight_kernel(const float *__re
 template <bool GRAD>
 __device__ __forceinline__ constexpr float in_coef(int f, int y) { return GRAD ? AT[y][f] : BT[f][y]; }
 
-template <bool GRAD>
+// SPLIT: V is written in the split layout scaled by v_scale (the A operand of the split batched GEMM); a value outside fp16's
+// range raises *overflow (the GEMM no longer sees the fp32 values: the range guard moves here).
+template <bool GRAD, bool SPLIT = false>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, int64_t ld_pos, int64_t ld_roi, int64_t Rc, int C,
-                                                         float *__restrict__ V)
+                                                         float *__restrict__ V, float v_scale = 1.f, unsigned *overflow = nullptr)
 {
     const int c2 = C >> 1;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= Rc * c2) return;
+    if (t >= Rc * c2) return;           // (SPLIT: lanes trade words in pairs (t, t^1); C % 4 == 0 makes the count even, so a pair is
+                                        //  live or idle as a whole)
+    float amax = 0.f;
     const int64_t r = t / c2;
     const int c = (int)(t - r * c2) * 2;
     const float *src = x + r * ld_roi * C + c;
@@ -95,17 +121,27 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
 #pragma unroll
             for (int xx = 0; xx < 7; xx++)
                 if (in_coef<GRAD>(fx, xx) != 0.f) a += in_coef<GRAD>(fx, xx) * wv[xx];
-            __builtin_nontemporal_store(a, reinterpret_cast<f32x2 *>(dst + (int64_t)(fy * NF + fx) * fstride));
+            if constexpr (SPLIT) {
+                amax = fmaxf(fmaxf(amax, fabsf(a[0])), fabsf(a[1]));
+                store_split_pair(V + r * C + (int64_t)(fy * NF + fx) * fstride, c, a, v_scale);
+            } else {
+                __builtin_nontemporal_store(a, reinterpret_cast<f32x2 *>(dst + (int64_t)(fy * NF + fx) * fstride));
+            }
         }
     }
+    if (SPLIT && overflow != nullptr && amax * v_scale >= 65504.f) atomicOr(overflow, 1u);
 }
 
 // M [NF*NF][Rc][N]  ->  y rows [(y*7+x)*ld_pos + r*ld_roi] (ldy elements apart) = relu?(acc * scale[n] + shift[n]);
 // position-major output: ld_pos = R, ld_roi = 1; ROI-major output (row = roi*49 + position): ld_pos = 1, ld_roi = 49
+// SPLIT: y is written in the split layout scaled by y_scale (it is then the pre-split A operand of the 1x1 convolution that
+// follows); a finished value outside fp16's range raises *overflow.
+template <bool SPLIT = false>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restrict__ Mv, int64_t ld_pos, int64_t ld_roi, int64_t Rc, int N,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, int relu,
-                                                          float *__restrict__ y, int64_t ldy, const float *__restrict__ mask)
+                                                          float *__restrict__ y, int64_t ldy, const float *__restrict__ mask,
+                                                          float y_scale = 1.f, unsigned *overflow = nullptr)
 {
     // mask (same rows and pitch as y, or null): the value is kept where mask > 0, zeroed elsewhere -- the ReLU backward of the
     // saved activation when this convolution is a data gradient (flipped filter)
@@ -148,6 +184,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
     if (shift) sh = *reinterpret_cast<const f32x2 *>(shift + n);
     float *dst = y + r * ld_roi * ldy + n;
     const float *msk = mask ? mask + r * ld_roi * ldy + n : nullptr;
+    float amax = 0.f;
 #pragma unroll
     for (int yy = 0; yy < 7; yy++)
 #pragma unroll
@@ -162,8 +199,14 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
                 v[0] = mk[0] > 0.f ? v[0] : 0.f;
                 v[1] = mk[1] > 0.f ? v[1] : 0.f;
             }
-            *reinterpret_cast<f32x2 *>(dst + (int64_t)(yy * 7 + xx) * ld_pos * ldy) = v;
+            if constexpr (SPLIT) {
+                amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
+                store_split_pair(y + r * ld_roi * ldy + (int64_t)(yy * 7 + xx) * ld_pos * ldy, n, v, y_scale);
+            } else {
+                *reinterpret_cast<f32x2 *>(dst + (int64_t)(yy * 7 + xx) * ld_pos * ldy) = v;
+            }
         }
+    if (SPLIT && overflow != nullptr && amax * y_scale >= 65504.f) atomicOr(overflow, 1u);
 }
 
 // dU [NF*NF, N, Cin] -> dw [N, Cin, 3, 3] = row_scale[n] * (G (x) G)^T dU : the adjoint of wino_pack_weight_kernel
@@ -236,7 +279,7 @@ int locov_winograd_pack_weight(const float *w, int N, int Cin, float *U, locov_s
 static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
                             const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
                             void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask = nullptr,
-                            unsigned *overflow = nullptr, bool v_scale_auto = false);
+                            unsigned *overflow = nullptr, bool v_scale_auto = false, float y_split_scale = 0.f);
 
 int locov_winograd_conv3x3_f32_ex(const float *x, int64_t R, int Cin, const float *U, const float *scale, const float *shift,
                                   const float *mask, float *y, int64_t ldy, int N, unsigned flags, void *workspace,
@@ -247,12 +290,12 @@ int locov_winograd_conv3x3_f32_ex(const float *x, int64_t R, int Cin, const floa
 
 int locov_winograd_conv3x3_f32_split_ex(const float *x, int64_t R, int Cin, const void *U_split, float u_scale, float v_scale,
                                         int v_scale_auto, const float *scale, const float *shift, const float *mask, float *y,
-                                        int64_t ldy, int N, unsigned flags, void *workspace, int64_t workspace_bytes,
-                                        unsigned *overflow, locov_stream_t stream)
+                                        int64_t ldy, int N, unsigned flags, float y_split_scale, void *workspace,
+                                        int64_t workspace_bytes, unsigned *overflow, locov_stream_t stream)
 {
     LOCOV_REQUIRE(u_scale > 0.f && (v_scale_auto || v_scale > 0.f), "locov_winograd_conv3x3_f32_split_ex: operand scales must be positive");
     return winograd_conv3x3(x, R, Cin, static_cast<const float *>(U_split), u_scale, v_scale_auto ? 1.f : v_scale, scale, shift, y, ldy, N,
-                            flags, workspace, workspace_bytes, stream, mask, overflow, v_scale_auto != 0);
+                            flags, workspace, workspace_bytes, stream, mask, overflow, v_scale_auto != 0, y_split_scale);
 }
 
 int locov_winograd_conv3x3_f32(const float *x, int64_t R, int Cin, const float *U, const float *scale,
@@ -275,7 +318,7 @@ int locov_winograd_conv3x3_f32_split(const float *x, int64_t R, int Cin, const v
 static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
                             const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
                             void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask, unsigned *overflow,
-                            bool v_scale_auto)
+                            bool v_scale_auto, float y_split_scale)
 {
     LOCOV_REQUIRE(ldy >= N && ldy % 2 == 0, "locov_winograd_conv3x3_f32: ldy must be >= N and even");
     LOCOV_REQUIRE(R >= 0 && Cin > 0 && N > 0, "locov_winograd_conv3x3_f32: bad shape");
@@ -288,6 +331,8 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
     LOCOV_REQUIRE(!(flags & ~(unsigned)(LOCOV_EPI_RELU | LOCOV_WINO_OUT_ROI_MAJOR | LOCOV_WINO_IN_ROI_MAJOR)),
                   "locov_winograd_conv3x3_f32: unsupported flags 0x%x",
                   flags);
+    LOCOV_REQUIRE(!(y_split_scale > 0.f) || (N % 32 == 0 && ldy == N && !mask),
+                  "locov_winograd_conv3x3_f32_split: a split-layout output needs N %% 32 == 0, ldy == N and no mask");
     LOCOV_REQUIRE(workspace_bytes >= locov_winograd_workspace_bytes(R, Cin, N),
                   "locov_winograd_conv3x3_f32: workspace too small (%lld bytes)", (long long)workspace_bytes);
     const int64_t chunk = chunk_rois(R, Cin, N);
@@ -298,12 +343,19 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
         const int64_t rc = R - r0 < chunk ? R - r0 : chunk;
         const int64_t tin = rc * (Cin / 2), tout = rc * (N / 2);
         const bool in_roi_major = (flags & LOCOV_WINO_IN_ROI_MAJOR) != 0;
-        hipLaunchKernelGGL(wino_input_kernel<false>, dim3((unsigned)ceil_div(tin, 256)), dim3(256), 0, s,
-                           x + r0 * (in_roi_major ? 49 : 1) * Cin, in_roi_major ? (int64_t)1 : R, in_roi_major ? (int64_t)49 : (int64_t)1,
-                           rc, Cin, V);
+        // split GEMM with a scale known up front: V leaves the transform already in the split layout (staged by DMA in the GEMM)
+        const bool v_split = u_scale > 0.f && !v_scale_auto;
+        if (v_split)
+            hipLaunchKernelGGL((wino_input_kernel<false, true>), dim3((unsigned)ceil_div(tin, 256)), dim3(256), 0, s,
+                               x + r0 * (in_roi_major ? 49 : 1) * Cin, in_roi_major ? (int64_t)1 : R,
+                               in_roi_major ? (int64_t)49 : (int64_t)1, rc, Cin, V, v_scale, overflow);
+        else
+            hipLaunchKernelGGL((wino_input_kernel<false, false>), dim3((unsigned)ceil_div(tin, 256)), dim3(256), 0, s,
+                               x + r0 * (in_roi_major ? 49 : 1) * Cin, in_roi_major ? (int64_t)1 : R,
+                               in_roi_major ? (int64_t)49 : (int64_t)1, rc, Cin, V, 1.f, static_cast<unsigned *>(nullptr));
         int rcode = check_launch("locov_winograd_conv3x3_f32 (input transform)");
         if (rcode) return rcode;
-        Epilogue epi{nullptr, nullptr, nullptr, 0u};
+        Epilogue epi{nullptr, nullptr, nullptr, v_split ? LOCOV_GEMM_A_SPLIT : 0u};
         if (u_scale > 0.f) {
             const float *sc = nullptr;
             if (v_scale_auto) {       // the input is a gradient: choose the scale of its transform from max |V| on the device
@@ -322,9 +374,15 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
                                                  Batch{NF * NF, rc * Cin, (int64_t)N * Cin, rc * N});
         if (rcode) return rcode;
         const bool roi_major = (flags & LOCOV_WINO_OUT_ROI_MAJOR) != 0;
-        hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)ceil_div(tout, 256)), dim3(256), 0, s, Mv, roi_major ? (int64_t)1 : R,
-                           roi_major ? (int64_t)49 : (int64_t)1, rc, N, scale, shift, (flags & LOCOV_EPI_RELU) ? 1 : 0,
-                           y + r0 * (roi_major ? 49 : 1) * ldy, ldy, mask ? mask + r0 * (roi_major ? 49 : 1) * ldy : nullptr);
+        if (y_split_scale > 0.f)
+            hipLaunchKernelGGL((wino_output_kernel<true>), dim3((unsigned)ceil_div(tout, 256)), dim3(256), 0, s, Mv, roi_major ? (int64_t)1 : R,
+                               roi_major ? (int64_t)49 : (int64_t)1, rc, N, scale, shift, (flags & LOCOV_EPI_RELU) ? 1 : 0,
+                               y + r0 * (roi_major ? 49 : 1) * ldy, ldy, static_cast<const float *>(nullptr), y_split_scale, overflow);
+        else
+            hipLaunchKernelGGL((wino_output_kernel<false>), dim3((unsigned)ceil_div(tout, 256)), dim3(256), 0, s, Mv, roi_major ? (int64_t)1 : R,
+                               roi_major ? (int64_t)49 : (int64_t)1, rc, N, scale, shift, (flags & LOCOV_EPI_RELU) ? 1 : 0,
+                               y + r0 * (roi_major ? 49 : 1) * ldy, ldy, mask ? mask + r0 * (roi_major ? 49 : 1) * ldy : nullptr, 1.f,
+                               static_cast<unsigned *>(nullptr));
         rcode = check_launch("locov_winograd_conv3x3_f32 (output transform)");
         if (rcode) return rcode;
     }

@@ -318,7 +318,7 @@ def winograd_pack_weight(w: torch.Tensor) -> torch.Tensor:
 
 def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool = False,
                      out: Optional[torch.Tensor] = None, v_scale: float = 0.25, roi_major: bool = False,
-                     in_roi_major: bool = False) -> torch.Tensor:
+                     in_roi_major: bool = False, out_split_scale: Optional[float] = None) -> torch.Tensor:
     """3x3 / pad 1 / stride 1 convolution of 7x7 position-major tiles in the Winograd domain.
     x [49*R, Cin] (row = pos*R + r), U [121, N, Cin] (winograd_pack_weight) -> [49*R, N].
     out: optional [49*R, N] destination whose rows may be a column block of a wider matrix.
@@ -326,7 +326,10 @@ def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool =
     split operands on the f16 matrix pipe, the transformed input scaled by v_scale (the input transform amplifies
     non-negative data by up to 64x, any data by up to 100x: 0.25 keeps |x| < 4094 in fp16's range, as for the 1x1s).
     roi_major: write the output rows ROI-major (row = r*49 + pos), the order linear_split_segmean reads;
-    in_roi_major: x is given in that order."""
+    in_roi_major: x is given in that order.
+    out_split_scale (split U only): write the output in the split layout of split_pack scaled by that power of two -- the
+    pre-split A operand (`x_is_split`) of the split GEMM that consumes it, which then stages it by LDS DMA with no conversion.
+    The returned tensor is float32-TYPED storage of that layout (same shape and size), not fp32 values."""
     x = _dev(x, "x")
     split = U if isinstance(U, SplitWeight) else None
     U = _dev(split.data if split is not None else U, "U")
@@ -356,11 +359,16 @@ def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool =
               | (_lib.WINO_IN_ROI_MAJOR if in_roi_major else 0))
     with torch.cuda.device(x.device):
         if split is not None:
-            check(lib.locov_winograd_conv3x3_f32_split(_ptr(x), R, Cin, _ptr(U), split.scale, float(v_scale), _ptr(scale),
-                                                       _ptr(shift), _ptr(y), ldy, N, wflags, _ptr(ws),
-                                                       ws.numel(), _ptr(_overflow_word(x)), _stream(x)),
-                  "locov_winograd_conv3x3_f32_split")
+            if out_split_scale is not None and (N % 32 or ldy != N):
+                raise ValueError("winograd_conv3x3: a split-layout output needs N % 32 == 0 and a dense destination")
+            check(lib.locov_winograd_conv3x3_f32_split_ex(_ptr(x), R, Cin, _ptr(U), split.scale, float(v_scale), 0, _ptr(scale),
+                                                          _ptr(shift), None, _ptr(y), ldy, N, wflags,
+                                                          float(out_split_scale or 0.0), _ptr(ws), ws.numel(),
+                                                          _ptr(_overflow_word(x)), _stream(x)),
+                  "locov_winograd_conv3x3_f32_split_ex")
         else:
+            if out_split_scale is not None:
+                raise ValueError("winograd_conv3x3: out_split_scale needs a split U")
             check(lib.locov_winograd_conv3x3_f32(_ptr(x), R, Cin, _ptr(U), _ptr(scale), _ptr(shift), _ptr(y), ldy, N,
                                                  wflags, _ptr(ws), ws.numel(), _stream(x)),
                   "locov_winograd_conv3x3_f32")
@@ -470,7 +478,7 @@ _SEGMEAN_WS = {}
 
 def linear_split_segmean(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tensor], residual: torch.Tensor, seg: int, *,
                          scale: Optional[torch.Tensor] = None, relu: bool = True, x_scale: float = 16.0,
-                         residual_roi_major: bool = False) -> torch.Tensor:
+                         residual_roi_major: bool = False, x_is_split: bool = False) -> torch.Tensor:
     """Res5's last 1x1 convolution fused with the spatial mean behind it:
         out[q, :] = mean_{p < seg} relu(scale * (x[q*seg + p, :] . W^T) + bias + residual[p*R + q, :]),   R = M // seg
     x [M,K] with ROI-major rows, residual [M,N] with POSITION-major rows (the previous block's output; ROI-major rows
@@ -496,7 +504,8 @@ def linear_split_segmean(x: torch.Tensor, weight: SplitWeight, bias: Optional[to
     with torch.cuda.device(x.device):
         check(lib.locov_gemm_nt_f32_split_segmean(_ptr(x), x.stride(0) if M else K, _ptr(wd), _ptr(scale), _ptr(bias),
                                                   _ptr(residual), _ptr(out), M, N, K, int(seg),
-                                                  (_lib.EPI_RELU if relu else 0) | (_lib.SEGMEAN_RES_ROI_MAJOR if residual_roi_major else 0),
+                                                  (_lib.EPI_RELU if relu else 0) | (_lib.SEGMEAN_RES_ROI_MAJOR if residual_roi_major else 0)
+                                                  | (_lib.GEMM_A_SPLIT if x_is_split else 0),
                                                   float(x_scale), weight.scale, _ptr(ws), ws.numel(), _ptr(_overflow_word(x)),
                                                   _stream(x)),
               "locov_gemm_nt_f32_split_segmean")
@@ -767,7 +776,7 @@ def winograd_conv3x3_split_ex(x: torch.Tensor, U: SplitWeight, *, scale=None, sh
     flags = (_lib.EPI_RELU if relu else 0) | ((_lib.WINO_OUT_ROI_MAJOR | _lib.WINO_IN_ROI_MAJOR) if roi_major else 0)
     with torch.cuda.device(x.device):
         check(lib.locov_winograd_conv3x3_f32_split_ex(_ptr(x), R, Cin, _ptr(Ud), U.scale, float(v_scale or 1.0), int(v_scale is None),
-                                                      _ptr(scale), _ptr(shift), _ptr(mask), _ptr(y), N, N, flags, _ptr(ws), ws.numel(),
+                                                      _ptr(scale), _ptr(shift), _ptr(mask), _ptr(y), N, N, flags, 0.0, _ptr(ws), ws.numel(),
                                                       _ptr(_overflow_word(x)), _stream(x)), "locov_winograd_conv3x3_f32_split_ex")
     return y
 

@@ -217,11 +217,22 @@ class Res5Stage(nn.Sequential):
         return out
 
     def _linear(self, split: bool, x, w, bias=None, **kw):
-        """One 1x1 convolution / FC as a GEMM: fp32 MFMA, or (split) split-operand f16 MFMA when the shape allows."""
+        """One 1x1 convolution / FC as a GEMM: fp32 MFMA, or (split) split-operand f16 MFMA when the shape allows.
+        x_is_split=True: x is the split-layout output of the Winograd convolution in front (ACT_SPLIT_SCALE)."""
         from . import ops
         if split and w.shape[1] % 32 == 0 and w.shape[0] % 4 == 0:
             return ops.linear_split(x, self._split(w), bias, **kw)
+        assert not kw.get("x_is_split"), "a split-layout activation needs the split GEMM"
+        kw.pop("x_is_split", None)
+        kw.pop("x_scale", None)
         return ops.linear(x, w, bias, **kw)
+
+    ACT_SPLIT_SCALE = 16.0       # operand scale of activations (|x| < 4094), also used when a producer writes them pre-split
+
+    def _y2_split_ok(self, split: bool, c2, w3) -> bool:
+        """conv2's output can leave the Winograd output transform already in the split layout when its only consumer is the
+        split GEMM of conv3."""
+        return bool(split) and c2.out_channels % 32 == 0 and w3.shape[1] % 32 == 0 and w3.shape[0] % 4 == 0
 
     def _packed_block0_on_map(self):
         """Weights for running block 0's two 1x1 stride-2 convolutions on the feature MAP (see
@@ -287,14 +298,18 @@ class Res5Stage(nn.Sequential):
             y = ops.conv3x3_nhwc_bf16(ops.to_bf16(y), self._bf16(w2), 7, 7, scale=s2, shift=b2, relu=True, pos_major=True)
             x = ops.linear_bf16(ops.to_bf16(y), self._bf16(w3), shift_tail, scale=s3, residual=sc, relu=True)
             return self.forward_rows(x, 7, 7, pos_major=True, start_block=1, bf16=True)
+        y_split = False
         if winograd and c2.in_channels % 32 == 0 and c2.out_channels % 4 == 0:
             u2, s2, b2 = self._packed(c2, winograd=True)
+            y_split = self._y2_split_ok(split, c2, w3)
             y = ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True,
-                                     roi_major=not pm, in_roi_major=not pm)
+                                     roi_major=not pm, in_roi_major=not pm,
+                                     out_split_scale=self.ACT_SPLIT_SCALE if y_split else None)
         else:
             w2, s2, b2 = self._packed(c2)
             y = ops.conv3x3_nhwc(y, w2, 7, 7, scale=s2, shift=b2, relu=True, pos_major=pm)
-        x = self._linear(split, y, w3, shift_tail, scale=s3, residual=sc, relu=True)         # conv3 + FBN + add + ReLU
+        x = self._linear(split, y, w3, shift_tail, scale=s3, residual=sc, relu=True,
+                         **({"x_is_split": True, "x_scale": self.ACT_SPLIT_SCALE} if y_split else {}))     # conv3 + FBN + add + ReLU
         return self.forward_rows(x, 7, 7, pos_major=pm, winograd=winograd, start_block=1, split=split, pooled=pooled)
 
     @torch.no_grad()
@@ -346,12 +361,18 @@ class Res5Stage(nn.Sequential):
             if (use_wino and pooled and last and split and blk.shortcut is None and w3.shape[1] % 32 == 0 and w3.shape[0] % 4 == 0
                     and x.shape[0] * w3.shape[0] * 4 < 2 ** 32):
                 u2, s2, b2 = self._packed(c2, winograd=True)
-                y = ops.winograd_conv3x3(y, self._split(u2), scale=s2, shift=b2, relu=True, roi_major=True, in_roi_major=rm)
-                return ops.linear_split_segmean(y, self._split(w3), b3, x, H * W, scale=s3, relu=True, residual_roi_major=rm)
+                ysp = self._y2_split_ok(True, c2, w3)
+                y = ops.winograd_conv3x3(y, self._split(u2), scale=s2, shift=b2, relu=True, roi_major=True, in_roi_major=rm,
+                                         out_split_scale=self.ACT_SPLIT_SCALE if ysp else None)
+                return ops.linear_split_segmean(y, self._split(w3), b3, x, H * W, scale=s3, relu=True, residual_roi_major=rm,
+                                                x_is_split=ysp, x_scale=self.ACT_SPLIT_SCALE)
+            y_split = False
             if use_wino:
                 u2, s2, b2 = self._packed(c2, winograd=True)
+                y_split = self._y2_split_ok(split, c2, w3)
                 y = ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True,
-                                         roi_major=rm, in_roi_major=rm)                                      # 3x3 + FBN + ReLU
+                                         roi_major=rm, in_roi_major=rm,
+                                         out_split_scale=self.ACT_SPLIT_SCALE if y_split else None)          # 3x3 + FBN + ReLU
             else:
                 w2, s2, b2 = self._packed(c2)
                 y = ops.conv3x3_nhwc(y, w2, H, W, scale=s2, shift=b2, relu=True, pos_major=pos_major)
@@ -360,7 +381,8 @@ class Res5Stage(nn.Sequential):
                 sc = self._linear(split, x, ws, bs, scale=ss)                     # 1x1 shortcut + FBN
             else:
                 sc = x
-            x = self._linear(split, y, w3, b3, scale=s3, residual=sc, relu=True)  # 1x1 + FBN + add + ReLU
+            x = self._linear(split, y, w3, b3, scale=s3, residual=sc, relu=True,
+                             **({"x_is_split": True, "x_scale": self.ACT_SPLIT_SCALE} if y_split else {}))   # 1x1 + FBN + add + ReLU
         if pooled:
             R = x.shape[0] // (H * W)
             return ops.spatial_mean(x.view(H, W, R, x.shape[1]), channels_last=2) if pos_major else \
