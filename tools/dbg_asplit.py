@@ -17,4 +17,7 @@ for name, M, N, K, has_res in (("conv3 K=512 N=2048 +res", 196000, 2048, 512, Tr
         torch.cuda.synchronize(); return (time.perf_counter() - t0) / n, y
     t0, y0 = run(lambda: ops.linear_split(x, wp, residual=r, relu=True))
     t1, y1 = run(lambda: ops.linear_split(xs.data, wp, residual=r, relu=True, x_scale=16.0, x_is_split=True))
+    if os.environ.get("SAVE"):
+        import numpy as np
+        np.save(os.environ["SAVE"] + name.split()[0] + str(K) + ".npy", y1[::97].cpu().numpy())
     print(f"{name}: in-kernel split {t0*1e3:.3f} ms ({2.0*M*N*K/t0/1e12:.0f} TF-eq)   pre-split A {t1*1e3:.3f} ms ({2.0*M*N*K/t1/1e12:.0f} TF-eq)   equal {torch.equal(y0, y1)}  maxdiff {float((y0-y1).abs().max()):.2e}", flush=True)

@@ -1,28 +1,33 @@
-// Wave-specialised, persistent form of the split-operand NT GEMM (gemm_split.hip: same arithmetic, same LDS images, same
-// MFMA sequence per K-tile -- the results are bit-identical), for the large plain / batched launches of the Res5 stage
-// (roi_emb_heads.py:217-245 as GEMMs).
+// Wave-specialised, persistent form of the split-operand NT GEMM for PRE-SPLIT activations (gemm_split.hip, ASPLIT: same
+// arithmetic, same LDS images, same MFMA sequence per K-tile -- the results are bit-identical), for the large plain / batched
+// launches of the Res5 stage whose A operand leaves its producer in the split layout (the Winograd-domain batched GEMMs, the
+// 1x1 convolutions behind the Winograd output transform; roi_emb_heads.py:217-245 as GEMMs).
 //
-// Why.  In gemm_split_kernel every wave does everything: it stages its share of A (buffer loads, the (hi, lo) split in
-// the vector ALU, LDS stores) and of W (LDS DMA), reads its fragments, issues its 48 MFMAs per K-tile and, at the end of
-// the tile, runs the epilogue (residual reads, 64 KB of stores).  Two workgroups per CU run in lockstep -- they start, finish
-// their K-loops and reach their epilogues together -- so the memory-bound epilogue does not overlap the other workgroup's
-// MFMAs: for the K = 512 shapes (16 K-tiles per output tile: the 1x1 convolutions into 2 048 channels, the Winograd-domain
-// batched GEMMs) the launch time is T_mem + T_mfma, not max(T_mem, T_mfma), and inside the K-loop the
-// ~80 staging instructions per K-tile compete with the 48 MFMAs for the wave's single issue stream.
+// Why.  In gemm_split_kernel every wave does everything: staging, fragment reads, 48 MFMAs per K-tile and, at the end of the
+// tile, the epilogue (residual reads, 64 KB of stores).  The two workgroups of a CU run in lockstep, so the memory-bound
+// epilogue does not overlap the other workgroup's MFMAs: for the K = 512 shapes (16 K-tiles per output tile) the launch time is
+// T_mem + T_mfma, not max(T_mem, T_mfma).  A first wave-specialised kernel that still CONVERTED A in
+// the kernel was slower than the plain one: measured with in-kernel cycle stamps, its four staging waves needed ~1 500 cycles
+// per K-tile (4 LDS DMAs 330, 4 buffer loads 170, the split of 4 chunks + 8 LDS stores 560-680, waiting for A 200-400)
+// against 768 cycles of MFMA work -- the plain kernel is bound by the same staging instruction stream, spread over eight waves
+// (tools/experiments/).  With A pre-split the staging of a K-tile is eight LDS DMAs per wave and nothing else, and the roles
+// separate cleanly.
 //
-// Here ONE 512-thread workgroup per CU stays resident and walks over its tiles; its 8 waves have fixed roles (a 512-thread
-// workgroup places waves w and w+4 on the same SIMD, waves 0-3 on four different SIMDs -- tools/probe/simd_probe.hip):
-//   waves 0-3  MFMA      one per SIMD, a 64x64 sub-tile each: fragment reads + MFMAs, nothing else; at the end of a tile
-//                        the accumulators go to an LDS buffer and the next tile starts at once
-//   waves 4-5  staging   the operand stream, continuous across tile boundaries: A two K-tiles ahead in registers, split and
-//                        stored one K-tile ahead; W by LDS DMA one K-tile ahead
-//   waves 6-7  epilogue  drain tile t-1's accumulators from the LDS buffer DURING tile t's K-loop: 8 rows per step, the
-//                        residual rows requested two K-tiles before they are used, stores never waited for
-// One s_barrier per K-tile (all 8 waves) hands the LDS stages over, exactly as in gemm_split_kernel.
+// ONE 768-thread workgroup per CU stays resident and walks over its tiles; its 12 waves have fixed roles (waves w, w+4, w+8
+// share a SIMD, waves 0-3 sit on four different SIMDs -- tools/probe/simd_probe.hip):
+//   waves 0-3   MFMA      one per SIMD, a 64x64 sub-tile each: fragment reads + MFMAs, nothing else; at the end of a tile
+//                         the accumulators go to an LDS buffer and the next tile starts at once
+//   waves 4-7   staging   the operand stream, continuous across tile boundaries: both operands wait two K-tiles ahead in
+//                         registers (one buffer load + one ds_write_b128 per 16-byte chunk, no conversion)
+//   waves 8-11  epilogue  drain tile t-1's accumulators from the LDS buffer DURING tile t's K-loop: 8 rows per step, the
+//                         residual rows requested a whole tile ahead (64 KB per CU in flight), stores never waited for
+// One s_barrier per K-tile (all 12 waves) hands the LDS stages over.
 //
-// LDS: two A stages (20 KB), three W stages (16 KB), the 66 KB accumulator buffer = 154 KB.  Used by launch_gemm_split for K % 64 == 0, K >= 512,
-// N % 128 == 0, no mask, at least 512 tiles; everything else (and the mean-fused last convolution) stays on gemm_split_kernel.
+// LDS: two stages per operand (16 KB each) + the 66 KB accumulator buffer = 130 KB.  Used by launch_gemm_split for
+// LOCOV_GEMM_A_SPLIT launches with K % 64 == 0, K >= 512, N % 128 == 0, no mask, at least two tiles per CU.
 #include "gemm_nt.h"
+
+#include <type_traits>
 
 namespace locov {
 
@@ -34,14 +39,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int ROWB = 160, WROWB = 128;
-constexpr int ASTB = BM * ROWB;                         // one A stage: 20 480 B (two stages: A waits two K-tiles ahead in registers)
-constexpr int WSTB = BN * WROWB;                        // one W stage: 16 384 B (THREE stages: the DMA of K-tile q+2 is in flight while
-                                                        // q is consumed -- with one workgroup per CU nothing else hides its latency)
-constexpr int WBASE = 2 * ASTB;                         // W stages behind the A stages
-constexpr int EPBASE = WBASE + 3 * WSTB;                // 90 112
+constexpr int WROWB = 128;
+constexpr int ASTB = BM * WROWB;                        // one A stage: 16 384 B (pre-split A: unpadded, swizzled rows like W)
+constexpr int WSTB = BN * WROWB;                        // one W stage: 16 384 B
+constexpr int WBASE = 2 * ASTB;                         // two stages each; both operands wait two K-tiles ahead in REGISTERS
+constexpr int EPBASE = WBASE + 2 * WSTB;                // 65 536
 constexpr int EPS = BN + 4;                             // floats per row of the accumulator buffer
-constexpr int EPB = BM * EPS * 4;                       // 67 584   (total 157 696 B of the CU's 160 KB)
+constexpr int EPB = BM * EPS * 4;                       // 67 584   (total 133 120 B)
 constexpr int NTHREADS = 768;                          // 12 waves: 4 MFMA + 4 staging + 4 epilogue (three per SIMD)
 constexpr int NSTEPS = BM / 8;                          // epilogue steps per tile (8 rows each)
 
@@ -150,22 +154,21 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_split_ws_kernel(const float 
         __builtin_amdgcn_s_setprio(3);
         const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
         const int l16 = lane & 15, kg = lane >> 4;
-        const int afo = l16 * ROWB + ((kg >> 1) * 4 + (kg & 1)) * 16;
         int bfo[2];
 #pragma unroll
         for (int hl = 0; hl < 2; hl++) bfo[hl] = l16 * WROWB + (((2 * kg + hl) ^ wswz(l16)) * 16);
         f16x8 fa[4][2], fb[4][2];
         f32x4 acc[4][4];
-        auto rd_a = [&](int stage, int ga) {
-            const char *As = ldsb + stage * ASTB + (wm + ga * 32) * ROWB + afo;
+        auto rd_a = [&](int astage, int ga) {                     // stage = q & 1 (a literal: the K-loop is unrolled by two)
+            const char *As = ldsb + astage * ASTB + (wm + ga * 32) * WROWB;
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                fa[2 * ga + i][0] = *reinterpret_cast<const f16x8 *>(As + i * 16 * ROWB);
-                fa[2 * ga + i][1] = *reinterpret_cast<const f16x8 *>(As + i * 16 * ROWB + 32);
+                fa[2 * ga + i][0] = *reinterpret_cast<const f16x8 *>(As + i * 16 * WROWB + bfo[0]);
+                fa[2 * ga + i][1] = *reinterpret_cast<const f16x8 *>(As + i * 16 * WROWB + bfo[1]);
             }
         };
-        auto rd_b = [&](int wstage_off, int gb) {                 // wstage_off = byte offset of the W stage (q % 3, a run-time value)
-            const char *Bs = ldsb + WBASE + wstage_off + (wn + gb * 32) * WROWB;
+        auto rd_b = [&](int wstage, int gb) {                     // wstage = q & 1 (a literal: the K-loop is unrolled by two)
+            const char *Bs = ldsb + WBASE + wstage * WSTB + (wn + gb * 32) * WROWB;
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 fb[2 * gb + j][0] = *reinterpret_cast<const f16x8 *>(Bs + j * 16 * WROWB + bfo[0]);
@@ -186,11 +189,9 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_split_ws_kernel(const float 
         };
         // one K-tile from LDS stage s (= its parity): (GA0,GBx) (GA0,GBy) (GA1,GBy) | barrier | (GA1,GBx), x = s, y = 1 - s;
         // the fragments of the next K-tile's first quarter are read right behind the barrier (gemm_split.hip)
-        int wcur = 0;                                             // byte offset of the W stage of the current K-tile
         auto ktile = [&](const int s, const bool has_next) __attribute__((always_inline)) {
             const int x = s, y = s ^ 1;
-            const int wnext = wcur == 2 * WSTB ? 0 : wcur + WSTB;
-            rd_b(wcur, y);
+            rd_b(s, y);
             rd_a(s, 1);
             quarter(0, x);
             quarter(0, y);
@@ -199,9 +200,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_split_ws_kernel(const float 
             LOCOV_WS_BARRIER();
             if (has_next) {
                 rd_a(s ^ 1, 0);
-                rd_b(wnext, y);
+                rd_b(s ^ 1, y);
             }
-            wcur = wnext;
             __builtin_amdgcn_sched_barrier(0);
             quarter(1, x);
             __builtin_amdgcn_sched_barrier(0);
@@ -235,25 +235,24 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_split_ws_kernel(const float 
     }
 
     if (wave < 8) {
-        // ------------------------------------------------------------------ staging waves (256 threads: gemm_split_kernel's share per thread)
-        constexpr int CH = 4;
-        const int ts = tid - 256, sw = wave - 4;
-        unsigned a_off[CH];
-        int a_lds[CH];
+        // ------------------------------------------------------------------ staging waves (256 threads)
+        // Neither operand needs a conversion, so a staged 16-byte chunk is one buffer load and one ds_write_b128.  (LDS DMA was
+        // tried first: a dedicated wave ISSUES a 1 KB DMA in 80-150 cycles -- the guide's 25 GB/s per loader wave -- and four
+        // waves x 8 DMAs per K-tile then take ~1 250 cycles against 768 of MFMA work; a load + a store issue in ~60.)  Chunks
+        // wait two K-tiles ahead in registers, as A did in gemm_split_kernel: two LDS stages per operand suffice.
+        constexpr int CH = 4;                                     // chunks per thread, operand and K-tile
+        const int ts = tid - 256;
+        unsigned a_off[CH], b_off[CH];
+        int s_lds[CH];
 #pragma unroll
         for (int i = 0; i < CH; i++) {
             const int idx = ts + i * 256, row = idx >> 3, ch = idx & 7;
-            a_off[i] = (unsigned)(((int64_t)row * lda + ch * 4) * 4);
-            a_lds[i] = row * ROWB + (((ch >> 2) * 4 + ((ch >> 1) & 1)) * 16) + (ch & 1) * 8;
+            a_off[i] = (unsigned)(((int64_t)row * lda * 4) + ch * 16);
+            b_off[i] = (unsigned)(((int64_t)row * K * 4) + ch * 16);
+            s_lds[i] = row * WROWB + ((ch ^ wswz(row)) * 16);       // chunk c of row r sits at slot c ^ wswz(r) (gemm_split.hip)
         }
-        unsigned b_voff[CH];
-#pragma unroll
-        for (int i = 0; i < CH; i++) {
-            const int row = (sw * CH + i) * 8 + (lane >> 3);
-            b_voff[i] = (unsigned)(((int64_t)row * K * 4) + (((lane & 7) ^ wswz(row)) * 16));
-        }
-        // operand cursors: K-tile index -> (tile, kt) -> base pointers.  `ld` runs two K-tiles ahead (A loads), `st` one
-        // (W DMA); rows past M are outside the A descriptor's num_records and read as zero.
+        // operand cursor: K-tile index -> (tile, kt) -> base pointers; rows of A past M are outside the descriptor's
+        // num_records and read as zero (they feed rows that are never stored)
         struct Cursor {
             int k, kt;
             const char *a, *b;
@@ -263,98 +262,64 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_split_ws_kernel(const float 
             int bb, n0;
             int64_t m0;
             tile_coords(tg, my_tile(c.k), bb, m0, n0);
-            const float *Ab = A + (bt.count > 1 ? bb * bt.sa : 0) + m0 * lda;
-            c.a = reinterpret_cast<const char *>(Ab);
+            c.a = reinterpret_cast<const char *>(A + (bt.count > 1 ? bb * bt.sa : 0) + m0 * lda);
             c.b = reinterpret_cast<const char *>(B + (bt.count > 1 ? bb * bt.sb : 0) + (int64_t)n0 * K);
             const int64_t rows = M - m0 < BM ? M - m0 : BM;
             c.a_rec = (unsigned)(((rows - 1) * lda + K) * 4);
             c.kt = 0;
         };
-        auto advance = [&](Cursor &c) {
-            if (++c.kt == KT) {
-                c.k++;
-                if (c.k < T) open_tile(c);
+        Cursor cur{0, 0, nullptr, nullptr, 0u};
+        open_tile(cur);
+        // TWO register sets: while K-tile q+1 waits in one, K-tile q+2 is in flight into the other (with one set the chain
+        // "request, wait out the whole memory latency, store, request" bounded the K-tile period at ~1 450 cycles)
+        u32x4 ra[2][CH], rb[2][CH];
+        auto load = [&](auto set_tag) __attribute__((always_inline)) {       // the K-tile the cursor points at -> register set
+            constexpr int SET = decltype(set_tag)::value;
+            const unsigned koff = (unsigned)cur.kt * (BK * 4);
+            const __amdgpu_buffer_rsrc_t r_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(cur.a), 0, cur.a_rec, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(cur.b), 0, 0xffffffff, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < CH; i++) ra[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(r_a, a_off[i] + koff, 0, 0);
+#pragma unroll
+            for (int i = 0; i < CH; i++) rb[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(r_b, b_off[i] + koff, 0, 0);
+            if (++cur.kt == KT) {
+                cur.k++;
+                if (cur.k < T) open_tile(cur);
             }
         };
-        Cursor ld{0, 0, nullptr, nullptr, 0u}, st{0, 0, nullptr, nullptr, 0u};
-        open_tile(ld);
-        open_tile(st);
-        f32x4 ra[CH];
-        float amax = 0.f;
-        auto ld_a = [&]() {
-            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(ld.a), 0, ld.a_rec, 0x00020000);
+        auto store = [&](auto set_tag, int stage) __attribute__((always_inline)) {
+            constexpr int SET = decltype(set_tag)::value;
 #pragma unroll
-            for (int i = 0; i < CH; i++)
-                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, a_off[i] + (unsigned)ld.kt * (BK * 4), 0, 0));
-            advance(ld);
-        };
-        auto st_a = [&](int stage) {
+            for (int i = 0; i < CH; i++) *reinterpret_cast<u32x4 *>(ldsb + stage * ASTB + s_lds[i]) = ra[SET][i];
 #pragma unroll
-            for (int i = 0; i < CH; i++) {
-                u32x2 hi, lo;
-                amax = fmaxf(fmaxf(amax, fabsf(ra[i][0])), fabsf(ra[i][1]));
-                amax = fmaxf(fmaxf(amax, fabsf(ra[i][2])), fabsf(ra[i][3]));
-                split4(ra[i], a_scale, hi, lo);
-                char *p = ldsb + stage * ASTB + a_lds[i];
-                *reinterpret_cast<u32x2 *>(p) = hi;
-                *reinterpret_cast<u32x2 *>(p + 32) = lo;
-            }
+            for (int i = 0; i < CH; i++) *reinterpret_cast<u32x4 *>(ldsb + WBASE + stage * WSTB + s_lds[i]) = rb[SET][i];
         };
-        auto dma_b = [&](int wstage) {
-            const __amdgpu_buffer_rsrc_t r =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(st.b) + (int64_t)st.kt * (BK * 4), 0, 0xffffffff, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < CH; i++)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    r, (__attribute__((address_space(3))) void *)(ldsb + WBASE + wstage * WSTB + (sw * CH + i) * 8 * WROWB), 16,
-                    b_voff[i], 0, 0, 0);
-            advance(st);
-        };
-        // prologue: K-tile 0 -> A stage 0 / W stage 0, W of K-tile 1 -> W stage 1 (in flight), A of K-tile 1 -> registers
-        dma_b(0);
-        ld_a();
+        std::integral_constant<int, 0> S0;
+        std::integral_constant<int, 1> S1;
+        // prologue: K-tile 0 -> stage 0; K-tile 1 -> set 1, K-tile 2 -> set 0 (in flight)
+        load(S0);
         __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, false));
-        st_a(0);
-        if (Q > 1) {
-            dma_b(1);
-            ld_a();
-        }
+        store(S0, 0);
+        if (Q > 1) load(S1);
+        if (Q > 2) load(S0);
         LOCOV_WS_BARRIER();                                          // barrier P
-        // iteration q (the MFMA waves consume K-tile q): W of K-tile q+2 is requested, A of K-tile q+1 (requested one iteration
-        // ago, as was W of q+1) goes from the registers into A stage (q+1) & 1, A of K-tile q+2 is requested.  The one wait --
-        // "A of q+1 has arrived" = everything but the DMAs just issued -- also covers W of q+1: nothing on this path waits
-        // for an operation younger than one whole iteration.
-        int wreq = 2;                                                // W stage of K-tile q+2
-#ifdef LOCOV_WS_TRACE
-        unsigned long long seg_[4] = {0, 0, 0, 0}, ts_;
-#define WS_SEG(i) do { asm volatile("" ::: "memory"); const unsigned long long n_ = __builtin_readcyclecounter(); seg_[i] += n_ - ts_; ts_ = n_; } while (0)
-#else
-#define WS_SEG(i)
-#endif
-        for (int q = 0; q < Q; q++) {
-#ifdef LOCOV_WS_TRACE
-            ts_ = __builtin_readcyclecounter();
-#endif
-            if (q + 2 < Q) dma_b(wreq);
-            WS_SEG(0);
-            wreq = wreq == 2 ? 0 : wreq + 1;
+        // iteration q (the MFMA waves consume K-tile q from stage q & 1): K-tile q+1 (requested two iterations ago, register set
+        // (q+1) & 1) -> stage (q+1) & 1, free since barrier q-1; K-tile q+3 is requested into the set just emptied.  The wait
+        // leaves K-tile q+2's 2*CH loads in flight.
+        auto iter = [&](auto set_tag, int q) __attribute__((always_inline)) {
+            constexpr int SET = decltype(set_tag)::value;           // = (q + 1) & 1
             if (q + 1 < Q) {
-                if (q + 2 < Q) __builtin_amdgcn_s_waitcnt(waitcnt_imm(CH, false));
+                if (q + 2 < Q) __builtin_amdgcn_s_waitcnt(waitcnt_imm(2 * CH, false));
                 else __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, false));
-                WS_SEG(1);
-                st_a((q + 1) & 1);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                WS_SEG(2);
-                if (q + 2 < Q) ld_a();
-                WS_SEG(3);
+                store(set_tag, SET);
+                if (q + 3 < Q) load(set_tag);
             }
             LOCOV_WS_BARRIER();                                       // barrier q
+        };
+        for (int q = 0; q < Q; q += 2) {                              // Q is even (K % 64 == 0)
+            iter(S1, q);
+            iter(S0, q + 1);
         }
-#ifdef LOCOV_WS_TRACE
-        if (blockIdx.x == 8 && lane == 0 && wave == 4)
-            for (int i = 0; i < 4; i++) g_ws_dbg[8 + i] = seg_[i];
-#endif
-        if (overflow != nullptr && amax * a_scale >= 65504.f) atomicOr(overflow, 1u);
         LOCOV_WS_BARRIER();                                           // barrier D
         ws_report(1);
         return;
@@ -382,54 +347,17 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_split_ws_kernel(const float 
             if (HASRES) rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(epi.residual) + m0 * ldc + n0, 0, nrec, 0x00020000);
             return n0;
         };
-        auto step_off = [&](int step, int j) {                    // byte offset of (row, chunk) in the tile; inactive steps fall outside
+        auto step_off = [&](int step, int j) {                    // byte offset of (row, chunk) in the tile; steps past the tile fall outside
             return step < NSTEPS ? (unsigned)(((int64_t)(step * 8 + rsub[j]) * ldc + ch * 4) * 4) : 0xffffffffu;
         };
-        // Residual pipeline: a slot's residual rows are requested two iterations before the slot is processed, into a ring of
-        // two register sets indexed by the parity of the processing iteration.  Per iteration the order is
-        //     process(slot q)  [reads set q & 1, stores]   then   request(slot q + 2)  [loads into set q & 1],
-        // and EVERY iteration issues exactly 2*SPS stores and 2*SPS loads (with out-of-range offsets when there is nothing to
-        // do), so that "the loads issued two iterations ago have arrived" is the constant s_waitcnt vmcnt(4*SPS): younger
-        // than them are only the previous iteration's stores and loads.  Stores are never waited for sooner than two
-        // iterations after their issue.
-        f32x4 res[2][SPS][EJ];
-        auto request = [&](int set, const __amdgpu_buffer_rsrc_t &rr, int slot) {
-            if (!HASRES) return;
-#pragma unroll
-            for (int s = 0; s < SPS; s++)
-#pragma unroll
-                for (int j = 0; j < EJ; j++)
-                    res[set][s][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, step_off(slot * SPS + s, j), 0, 2));
-        };
-        auto process = [&](int set, const __amdgpu_buffer_rsrc_t &ro, int slot, bool active) {
-            f32x4 v[SPS][EJ];
-            if (active) {
-#pragma unroll
-                for (int s = 0; s < SPS; s++)
-#pragma unroll
-                    for (int j = 0; j < EJ; j++) {
-                        const int step = slot * SPS + s;
-                        v[s][j] = *reinterpret_cast<const f32x4 *>(epbuf + ((step < NSTEPS ? step : 0) * 8 + rsub[j]) * EPS + ch * 4);
-                    }
-            }
-            if (HASRES) __builtin_amdgcn_s_waitcnt(waitcnt_imm(2 * EJ * SPS, true));
-            if (!active && !HASRES) return;
-#pragma unroll
-            for (int s = 0; s < SPS; s++)
-#pragma unroll
-                for (int j = 0; j < EJ; j++) {
-                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                    if (active) {
-                        o = v[s][j] * sc + sh;
-                        if (HASRES) o += res[set][s][j];
-                        if (relu) {
-                            o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f);
-                            o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f);
-                        }
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ro, active ? step_off(slot * SPS + s, j) : 0xffffffffu, 0, 2);
-                }
-        };
+        // Residual pipeline, one whole tile deep.  The epilogue of tile u runs during tile u+1's K-loop, 8 rows (one 16-byte piece
+        // per thread) per step; its residual rows are requested one tile EARLIER, in the same slots of tile u's own K-loop, into
+        // the other of two register sets of NSTEPS pieces -- 64 KB per CU in flight, which is what it takes to stream the
+        // residual at HBM rate (with two K-tiles of lookahead the 16 KB in flight bounded the whole kernel).  Every slot issues
+        // exactly SPS loads and SPS stores (out-of-range offsets where there is nothing to do), so "the piece requested one
+        // tile ago has arrived" is the constant s_waitcnt vmcnt(2*NSTEPS - 2*SPS): the other NSLOT-1 slots' loads and stores are younger.
+        // Stores are never waited for sooner than a tile after their issue.
+        f32x4 res[2][NSTEPS];
         auto open_scale = [&](int n0) {
             sc = f32x4{1.f, 1.f, 1.f, 1.f};
             sh = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -437,42 +365,75 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_split_ws_kernel(const float 
             sc *= out_scale;
             if (epi.shift) sh = *reinterpret_cast<const f32x4 *>(epi.shift + n0 + ch * 4);
         };
-        const int NSLOT = (NSTEPS + SPS - 1) / SPS;               // slots that carry steps (<= KT - 1 by the launch conditions)
-        // Slot schedule in terms of this workgroup's K-tile counter q = t * KT + kt: the accumulators of tile t-1 are in the
-        // buffer behind barrier (t*KT); slot kt of tile t-1's epilogue runs behind barrier (t*KT + kt), kt < NSLOT; the MFMA
-        // waves overwrite the buffer only behind barrier (t*KT + KT - 1).  The last tile is drained behind barrier D.
-        __amdgpu_buffer_rsrc_t ro_cur = r_out;                    // tile being drained
-        __amdgpu_buffer_rsrc_t rr_req = r_res;                    // tile whose residual rows are being requested
+        constexpr int NSLOT_C = (NSTEPS + SPS - 1) / SPS;         // slots that carry steps (<= KT - 1 by the launch conditions)
+        // one slot: process steps [slot*SPS, +SPS) of the tile in the buffer (descriptor ro, register set `set`), then request the
+        // same steps of the tile whose K-loop is running (descriptor rr) into the OTHER set
+        auto slot_work = [&](int slot, int set, const __amdgpu_buffer_rsrc_t &ro, bool drain, const __amdgpu_buffer_rsrc_t &rr, bool req) {
+            f32x4 v[SPS];
+            if (drain) {
+#pragma unroll
+                for (int s = 0; s < SPS; s++) v[s] = *reinterpret_cast<const f32x4 *>(epbuf + ((slot * SPS + s) * 8 + rsub[0]) * EPS + ch * 4);
+            }
+            if (HASRES) __builtin_amdgcn_s_waitcnt(waitcnt_imm(2 * NSTEPS - 2 * SPS, true));   // younger: NSLOT-1 slots of SPS stores + SPS loads
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < SPS; s++) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                if (drain) {
+                    o = v[s] * sc + sh;
+                    if (HASRES) o += res[set][slot * SPS + s];
+                    if (relu) {
+                        o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f);
+                        o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f);
+                    }
+                }
+                if (drain || HASRES)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ro, drain ? step_off(slot * SPS + s, 0) : 0xffffffffu, 0, 2);
+            }
+            if (HASRES) {
+#pragma unroll
+                for (int s = 0; s < SPS; s++)
+                    res[set ^ 1][slot * SPS + s] = __builtin_bit_cast(
+                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, req ? step_off(slot * SPS + s, 0) : 0xffffffffu, 0, 2));
+            }
+        };
+        __amdgpu_buffer_rsrc_t ro_cur = r_out;                    // tile being drained (t - 1)
+        __amdgpu_buffer_rsrc_t rr_cur = r_res;                    // tile whose K-loop is running (t): its residual is requested now
         LOCOV_WS_BARRIER();                                        // barrier P
-        int t = 0, kt = 0;                                         // (tile, K-tile) of iteration q
-        int t2 = 0, kt2 = 2;                                       // ... of iteration q + 2   (KT >= 16)
-        for (int q = 0; q < Q; q++) {
-            LOCOV_WS_BARRIER();                                    // barrier q
-            if (kt == 0 && t > 0) {
-                __amdgpu_buffer_rsrc_t unused = r_res;
-                open_scale(open_out(t - 1, ro_cur, unused));
+        // (slots and register sets are compile-time indices: the tile loop is unrolled by two, the slots of a tile fully)
+        auto tile_body = [&](auto set_tag, int t) __attribute__((always_inline)) {
+            constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+            for (int slot = 0; slot < NSLOT_C; slot++) {
+                LOCOV_WS_BARRIER();                                // barrier q = t*KT + slot
+                if (slot == 0) {
+                    if (t > 0) {
+                        __amdgpu_buffer_rsrc_t unused = r_res;
+                        open_scale(open_out(t - 1, ro_cur, unused));   // tile t-1 is in the buffer now
+                    }
+                    if (HASRES) {
+                        __amdgpu_buffer_rsrc_t unused = r_out;
+                        open_out(t, unused, rr_cur);
+                    }
+                }
+                slot_work(slot, SET, t > 0 ? ro_cur : r_out, t > 0, rr_cur, true);
             }
-            const bool cur = t > 0 && kt < NSLOT;
-            process(q & 1, cur ? ro_cur : r_out, kt, cur);         // (r_out has num_records 0: its stores are dropped)
-            // request the residual rows of the slot processed two iterations from now (tile t2 - 1; for q + 2 >= Q that is the
-            // last tile, drained behind barrier D)
-            const bool req = t2 > 0 && kt2 < NSLOT;
-            if (HASRES && req && kt2 == 0) {
-                __amdgpu_buffer_rsrc_t unused = r_out;
-                open_out(t2 - 1, unused, rr_req);
-            }
-            request(q & 1, req ? rr_req : r_res, req ? kt2 : NSLOT);   // (r_res has num_records 0: the loads return 0)
-            if (++kt == KT) { kt = 0; t++; }
-            if (++kt2 == KT) { kt2 = 0; t2++; }
+            for (int kt = NSLOT_C; kt < KT; kt++) LOCOV_WS_BARRIER();
+        };
+        for (int t = 0; t < T; t += 2) {
+            tile_body(std::integral_constant<int, 0>{}, t);
+            if (t + 1 < T) tile_body(std::integral_constant<int, 1>{}, t + 1);
         }
         LOCOV_WS_BARRIER();                                        // barrier D: the last tile is in the buffer
         {
-            __amdgpu_buffer_rsrc_t rr_last = r_res;
-            open_scale(open_out(T - 1, ro_cur, rr_last));
-            for (int slot = 0; slot < NSLOT; slot++) {             // iteration Q + slot of the same pipeline
-                process((Q + slot) & 1, ro_cur, slot, true);
-                const bool req = slot + 2 < NSLOT;
-                request((Q + slot) & 1, req ? rr_last : r_res, req ? slot + 2 : NSLOT);
+            __amdgpu_buffer_rsrc_t unused = r_res;
+            open_scale(open_out(T - 1, ro_cur, unused));
+            if (T & 1) {
+#pragma unroll
+                for (int slot = 0; slot < NSLOT_C; slot++) slot_work(slot, 1, ro_cur, true, r_res, false);
+            } else {
+#pragma unroll
+                for (int slot = 0; slot < NSLOT_C; slot++) slot_work(slot, 0, ro_cur, true, r_res, false);
             }
         }
         ws_report(2);
