@@ -283,7 +283,7 @@ class TrainWorkload:
         return n_sampled
 
 
-TRAFFIC_FILE = "r02a_pmc_traffic.json"
+TRAFFIC_FILE = "r02b_pmc_traffic.json"
 
 
 def recorded_traffic(args, kernel_key: str):

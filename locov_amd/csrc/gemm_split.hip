@@ -104,6 +104,15 @@ struct SegSum {
 // ASPLIT: A is ALREADY in the split layout of locov_split_f16x2_pack (written that way by its producer) with scale a_scale:
 // it then needs no conversion and takes W's road -- LDS DMA into unpadded, XOR-swizzled 128-byte rows -- instead of
 // buffer loads, 8 v_fma_mix + 2 v_max3 and two 8-byte LDS stores per 16-byte chunk.
+// LOCOV_KTRACE (tools/make_variant.py ktrace gemm_split.hip -DLOCOV_KTRACE=1; never the product): s_memtime stamps inside the
+// K-tile step of a few workgroups of the ASPLIT form, read back by tools/dbg_ktrace.py
+#ifdef LOCOV_KTRACE
+__device__ unsigned long long g_ktrace[4 * 16];
+#define KSTAMP(i) asm volatile("s_memtime %0" : "=s"(kt_[i]))
+#else
+#define KSTAMP(i)
+#endif
+
 template <bool SEGSUM, bool EMASK = false, bool ASPLIT = false>
 __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restrict__ A, int64_t lda,
                                                            const float *__restrict__ B, float *__restrict__ Cout,
@@ -113,6 +122,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
 {
     __shared__ u32x4 lds[2 * STAGEB / 16];
     char *const ldsb = reinterpret_cast<char *>(lds);
+#ifdef LOCOV_KTRACE
+    const unsigned long long kw0_ = __builtin_amdgcn_s_memtime();
+#endif
     if (a_scale_dev != nullptr) {
         a_scale = a_scale_dev[0];
         out_scale *= a_scale_dev[1];          // = 1 / a_scale (exact: powers of two)
@@ -276,6 +288,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
         }
     };
 
+#ifdef LOCOV_KTRACE
+    unsigned long long kt_[7], kd_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kprev_ = 0;
+    const unsigned long long kc0_ = __builtin_amdgcn_s_memtime(), kr0_ = __builtin_amdgcn_s_memrealtime();   // shader clock / 100 MHz
+#endif
     const int k_last = K - BK;                              // k0 of the last K-tile (K % BK == 0)
     // prologue: tile 0 -> LDS stage 0 (W by DMA), A tile 1 -> staging registers, fragments of the first quarter
     dma_b(0);
@@ -311,6 +327,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
         a_base += (int64_t)(kn - k_ptr) * 4;
         k_ptr = kn;
         const int x = s, y = s ^ 1;
+        KSTAMP(0);
         rd_b(s, y);
         rd_a(s, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -321,6 +338,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
             a_dbase += BK * 4;
         }
         __builtin_amdgcn_sched_barrier(0);
+        KSTAMP(1);
 #pragma unroll
         for (int g = 0; g < CH; g++) {
             if constexpr (!ASPLIT) {
@@ -333,17 +351,30 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
                 quarter(0, y, (g - CH / 2) * 2 * NQM / CH, (g - CH / 2 + 1) * 2 * NQM / CH);
             __builtin_amdgcn_sched_barrier(0);
         }
+        KSTAMP(2);
         quarter(1, y, 0, NQM);
         __builtin_amdgcn_sched_barrier(0);
+        KSTAMP(3);
         // the barrier sits three quarters into the tile (measured 1 % better than the middle: the DMA and the LDS stores
         // get more time, the two fragment groups read behind it are still a full quarter ahead of their use)
         __builtin_amdgcn_s_waitcnt(ASPLIT ? 0x0F70 : (0x0F70 | CH));   // vmcnt(CH): the DMA is older than the CH A loads
+        KSTAMP(4);
         __syncthreads();
+        KSTAMP(5);
         rd_a(s ^ 1, 0);
         rd_b(s ^ 1, y);
         __builtin_amdgcn_sched_barrier(0);
         quarter(1, x, 0, NQM);
         __builtin_amdgcn_sched_barrier(0);
+        KSTAMP(6);
+#ifdef LOCOV_KTRACE
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kt_[0]), "+s"(kt_[1]), "+s"(kt_[2]), "+s"(kt_[3]), "+s"(kt_[4]), "+s"(kt_[5]), "+s"(kt_[6])::"memory");
+#pragma unroll
+        for (int i = 0; i < 6; i++) kd_[i] += kt_[i + 1] - kt_[i];
+        if (kprev_ != 0) kd_[6] += kt_[0] - kprev_;
+        kprev_ = kt_[6];
+        kd_[7] += 1;
+#endif
     };
     auto last_tile = [&](const int s) __attribute__((always_inline)) {
         const int x = s, y = s ^ 1;
@@ -391,6 +422,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
         last_tile(0);
     }
 
+#ifdef LOCOV_KTRACE
+    if (ASPLIT && lane == 0 && blockIdx.x >= 3000 && blockIdx.x < 3064)
+#pragma unroll
+        for (int i = 0; i < 8; i++) atomicAdd(&g_ktrace[wave * 16 + i], kd_[i]);
+    const unsigned long long kw2_ = __builtin_amdgcn_s_memtime();
+    if (ASPLIT && lane == 0 && blockIdx.x >= 3000 && blockIdx.x < 3064) {
+        atomicAdd(&g_ktrace[wave * 16 + 8], kw2_ - kc0_);
+        atomicAdd(&g_ktrace[wave * 16 + 9], __builtin_amdgcn_s_memrealtime() - kr0_);
+        atomicAdd(&g_ktrace[wave * 16 + 10], kc0_ - kw0_);          // entry -> first DMA issued (index math)
+    }
+#endif
     __builtin_amdgcn_s_setprio(3);
     if (!ASPLIT && overflow != nullptr && amax * a_scale >= 65504.f) atomicOr(overflow, 1u);
     // Epilogue (C/D layout of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg): re-lay the wave's sub-tile out
@@ -498,6 +540,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
         tail(std::true_type{});
     else
         tail(std::false_type{});
+#ifdef LOCOV_KTRACE
+    {
+        const unsigned long long ke_ = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long kf_ = __builtin_amdgcn_s_memtime();
+        if (ASPLIT && lane == 0 && blockIdx.x >= 3000 && blockIdx.x < 3064) {
+            atomicAdd(&g_ktrace[wave * 16 + 11], ke_ - kw2_);          // epilogue, stores issued
+            atomicAdd(&g_ktrace[wave * 16 + 12], kf_ - ke_);           // stores drained
+            atomicAdd(&g_ktrace[wave * 16 + 13], 1ull);
+        }
+    }
+#endif
 }
 
 // W [rows, K] fp32 (row pitch ld) -> the split layout of s*W: per row and group of 8 columns, 8 hi halves then 8 lo halves
@@ -609,6 +663,21 @@ int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C,
     timing_end(trec, s);
     return check_launch(what);
 }
+
+#ifdef LOCOV_KTRACE
+}  // namespace locov
+extern "C" int locov_dbg_ktrace(unsigned long long *dst, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(locov::g_ktrace), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[64] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(locov::g_ktrace), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+namespace locov {
+#endif
 
 // The SEGSUM form + its finishing pass: mean over the `seg` rows of every ROI of relu(scale * (x . W^T) + shift + residual)
 int launch_gemm_split_segmean(const float *A, int64_t lda, const void *Wsplit, int64_t M, int N, int K, const Epilogue &epi,
