@@ -67,6 +67,10 @@ def parse(argv=None):
                         "csrc/gemm_split.hip); fp32 = the f32 MFMA; bf16 = reduced-precision operands (never a headline)")
     p.add_argument("--train-images", type=int, default=4, help="--mode train: images per GPU (IMS_PER_BATCH 32 / 8 GPUs)")
     p.add_argument("--train-samples", type=int, default=200, help="--mode train: ROI_HEADS.BATCH_SIZE_PER_IMAGE (coco_lsm.yaml:32)")
+    p.add_argument("--train-config", choices=["lsm", "stt"], default="lsm",
+                   help="--mode train: lsm = configs/coco_lsm.yaml step (EmbeddingProposalsRes5ROIHeads + GroundingHead, 4 img x 200 "
+                        "sampled); stt = configs/coco_stt.yaml fine-tune step (EmbeddingRes5ROIHeads, 48 classes, emb_pred frozen, "
+                        "3 img x 512 sampled)")
     p.add_argument("--train-backends", default="hip,miopen", help="--mode train: which Res5 backends to time (profile runs: hip)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--skip-f32-reference", action="store_true",
@@ -117,7 +121,7 @@ def synth_boxes(gen, n: int):
                         (cx + w / 2).clamp(0, 1333), (cy + h / 2).clamp(0, 800)], dim=1).to(torch.float32)
 
 
-def build_heads(args, device, *, dim=None, sim_dtype=None, res5=None, res5_dtype=None, train=False, seed=1992):
+def build_heads(args, device, *, dim=None, sim_dtype=None, res5=None, res5_dtype=None, train=False, seed=1992, stt=False):
     """The plugin exactly as train_ovnet.py gets it: cfg -> build_roi_heads (roi_emb_heads.py:168-214) -> load_embeddings'
     set_class_embeddings (trainer.py:365-396).  Random-init weights (He-init Res5, FrozenBN identity, emb_pred N(0, 0.01))."""
     import torch
@@ -137,11 +141,18 @@ def build_heads(args, device, *, dim=None, sim_dtype=None, res5=None, res5_dtype
     cfg.MODEL.ROI_BOX_HEAD.RES5_BACKEND = res5 or args.res5
     cfg.MODEL.ROI_BOX_HEAD.RES5_CONV3X3 = args.conv3x3
     cfg.MODEL.ROI_BOX_HEAD.RES5_DTYPE = res5_dtype or args.res5_dtype
+    classes = args.classes
+    if stt:                                                                # configs/coco_stt.yaml:17-37
+        cfg.MODEL.ROI_HEADS.NAME = "EmbeddingRes5ROIHeads"
+        cfg.MODEL.ROI_HEADS.NUM_CLASSES = classes = 48
+        cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 512                     # Detectron2's default (not overridden)
+        cfg.MODEL.ROI_HEADS.DETACH_CLASS_PREDICTOR = False
+        cfg.MODEL.ROI_BOX_HEAD.FREEZE_EMB_PRED = True
     torch.manual_seed(seed)                                                # configs/coco_lsm.yaml:126
     heads = locov_amd.build_roi_heads(cfg, {"res4": ShapeSpec(channels=1024, stride=16)}).to(device)
     heads.train(train)
     gen = torch.Generator().manual_seed(seed + 1)
-    bank = torch.randn(args.classes + 1, cfg.MODEL.ROI_BOX_HEAD.EMB_DIM, generator=gen) * 0.05
+    bank = torch.randn(classes + 1, cfg.MODEL.ROI_BOX_HEAD.EMB_DIM, generator=gen) * 0.05
     bank[-1] = 0
     heads.box_predictor.set_class_embeddings(bank)
     heads.num_classes = heads.box_predictor.num_classes
@@ -205,8 +216,33 @@ class TrainWorkload:
         import locov_amd
         from locov_amd.grounding_head import GroundingHead
         self.args, self.device = args, device
+        self.stt = args.train_config == "stt"
+        self.n_images = 3 if self.stt else args.train_images                 # IMS_PER_BATCH 24 / 8 GPUs (coco_stt.yaml:41)
+        self.n_classes = 48 if self.stt else args.classes
         self.set_data(data_seed)
-        self.heads, cfg = build_heads(args, device, res5=backend, train=True)
+        self.heads, cfg = build_heads(args, device, res5=backend, train=True, stt=self.stt)
+        if self.stt:
+            heads = self.heads
+
+            class STTStep(torch.nn.Module):
+                """OvrRCNN's training forward from the ROI heads on (ovr_rcnn.py:28-74): losses of EmbeddingRes5ROIHeads."""
+
+                def __init__(self):
+                    super().__init__()
+                    self.heads = heads
+
+                def forward(self, feat, proposals, targets, caption):
+                    _, losses = self.heads(None, {"res4": feat}, proposals, targets)
+                    return sum(losses.values()), self.heads.batch_size_per_image * len(proposals)
+
+            self.module = STTStep()
+            self.run = self.module
+            if world > 1:
+                from torch.nn.parallel import DistributedDataParallel as DDP
+                self.run = DDP(self.module, device_ids=None if args.share_gpu else [device.index], broadcast_buffers=False)
+            params = [p for p in self.module.parameters() if p.requires_grad]
+            self.opt = torch.optim.SGD(params, lr=0.005, momentum=0.9, weight_decay=1e-4)   # coco_stt.yaml:42
+            return
         cfg.MODEL.MMSS_HEAD.DISTILLATION_LOSS = False
         cfg.MODEL.MMSS_HEAD.GROUNDING.LOSS = "cross_entropy"
         cfg.MODEL.MMSS_HEAD.GROUNDING.ALIGN_WORDS_TO_REGIONS = True
@@ -248,7 +284,7 @@ class TrainWorkload:
         from locov_amd.structures import Boxes, Instances
         args, device = self.args, self.device
         gen = torch.Generator().manual_seed(seed)
-        B, R = args.train_images, args.proposals
+        B, R = self.n_images, args.proposals
         self.features = torch.randn(B, 1024, 50, 84, generator=gen).to(device)
         self.proposals, self.targets = [], []
         for _ in range(B):
@@ -261,7 +297,7 @@ class TrainWorkload:
             p.objectness_logits = torch.zeros(R, device=device)
             t = Instances((800, 1333))
             t.gt_boxes = Boxes(gt.to(device))
-            t.gt_classes = torch.randint(0, args.classes, (7,), generator=gen).to(device)
+            t.gt_classes = torch.randint(0, self.n_classes, (7,), generator=gen).to(device)
             self.proposals.append(p)
             self.targets.append(t)
         self.caption = {"input_embeddings": torch.randn(B, 70, args.dim, generator=gen).to(device),
@@ -455,11 +491,19 @@ def main():
             torch.cuda.empty_cache()
         if "hip" in train and "miopen" in train:
             train["speedup_vs_miopen"] = train["hip"]["sampled_proposals_per_s"] / train["miopen"]["sampled_proposals_per_s"]
-        train["what"] = (f"one LSM training step of the path per iteration: {args.train_images} img/GPU x {args.proposals} proposals -> "
-                         f"{args.train_samples} sampled/img; EmbeddingProposalsRes5ROIHeads.forward(targets) (labelling, whole-grid Res5, "
-                         "ROIAlign + Res5 + mean, box predictor, losses) + GroundingHead (box branch) + backward (Res5 data + weight "
-                         "gradients, ROIAlign backward) + SGD step" + (f"; gradients all-reduced by DDP over {world} ranks" if world > 1 else "")
-                         + "; `miopen` = the same module with RES5_BACKEND miopen (torch conv2d autograd)")
+        train["config"] = "configs/coco_stt.yaml" if args.train_config == "stt" else "configs/coco_lsm.yaml"
+        if args.train_config == "stt":
+            train["what"] = (f"one STT fine-tune step of the path per iteration (configs/coco_stt.yaml): 3 img/GPU x {args.proposals} proposals "
+                             "-> 512 sampled/img, 48-class bank, emb_pred frozen; EmbeddingRes5ROIHeads.forward(targets) (labelling, ROIAlign "
+                             "+ Res5 + mean, box predictor, loss_cls + loss_box_reg) + backward (Res5 data + weight gradients, ROIAlign "
+                             "backward) + SGD step" + (f"; gradients all-reduced by DDP over {world} ranks" if world > 1 else "")
+                             + "; `miopen` = the same module with RES5_BACKEND miopen (torch conv2d autograd)")
+        else:
+            train["what"] = (f"one LSM training step of the path per iteration: {args.train_images} img/GPU x {args.proposals} proposals -> "
+                             f"{args.train_samples} sampled/img; EmbeddingProposalsRes5ROIHeads.forward(targets) (labelling, whole-grid Res5, "
+                             "ROIAlign + Res5 + mean, box predictor, losses) + GroundingHead (box branch) + backward (Res5 data + weight "
+                             "gradients, ROIAlign backward) + SGD step" + (f"; gradients all-reduced by DDP over {world} ranks" if world > 1 else "")
+                             + "; `miopen` = the same module with RES5_BACKEND miopen (torch conv2d autograd)")
 
     if rank == 0:
         R_local = args.images * args.proposals
