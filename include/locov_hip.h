@@ -396,6 +396,31 @@ int locov_grounding_bwd(const float *S, int B, int T, int NR, const float *capti
                         const float *grad_r2w, float *grad_S, locov_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Backward of the predictor's dense layers under autograd (locov_pool_fc_bwd, locov_sim_gemm_bwd; the
+ * forward arithmetic they differentiate is box_emb_head.py:196 bbox_pred, :206 emb_pred, :211 cls_score).
+ *
+ * locov_pool_fc_bwd: x [R,C5] (the pooled features; the [R,C5,7,7] form composes with locov_spatial_mean_bwd),
+ *   emb_w [D,C5], bbox_w [4,C5], grad_emb [R,D] and / or grad_deltas [R,4] (either may be null: a detached class
+ *   predictor, roi_heads DETACH_CLASS_PREDICTOR, sends no grad_emb).  Outputs, each optional (null = not wanted):
+ *   grad_x [R,C5] = grad_emb . emb_w + grad_deltas . bbox_w;  grad_emb_w [D,C5] = grad_emb^T x, grad_emb_b [D] = column
+ *   sums; grad_bbox_w [4,C5], grad_bbox_b [4] likewise.  Deterministic (no atomics).  C5 % 4 == 0, D % 4 == 0.
+ * locov_sim_gemm_bwd: grad_logits [R,K1], emb [R,D], bank [K1,D] -> grad_emb [R,D] = grad_logits . bank (any K1) and /
+ *   or grad_bank [K1,D] = grad_logits^T emb (K1 % 4 == 0 only: the reference freezes the bank, box_emb_head.py:234-235,
+ *   so no caller on the path asks for it).  fp32 (the bf16 similarity GEMM is an inference-only option).
+ * workspace: device memory of at least *_workspace_bytes(...) bytes, 256-byte aligned (transposed weight copies and the
+ * TN GEMM's partial tiles); R == 0 writes zero weight gradients and returns.
+ * ------------------------------------------------------------------------------------- */
+int64_t locov_pool_fc_bwd_workspace_bytes(int64_t R, int C5, int D);
+int locov_pool_fc_bwd(const float *x, int64_t R, int C5, const float *emb_w, int D, const float *bbox_w,
+                      const float *grad_emb, const float *grad_deltas, float *grad_x, float *grad_emb_w,
+                      float *grad_emb_b, float *grad_bbox_w, float *grad_bbox_b, void *workspace,
+                      int64_t workspace_bytes, locov_stream_t stream);
+int64_t locov_sim_gemm_bwd_workspace_bytes(int64_t R, int D, int K1);
+int locov_sim_gemm_bwd(const float *grad_logits, const float *emb, const float *bank, int64_t R, int D, int K1,
+                       float *grad_emb, float *grad_bank, void *workspace, int64_t workspace_bytes,
+                       locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * a-4...a-8 in one call: EmbeddingFastRCNNOutputLayers.forward (box_emb_head.py:179-212)
  * preceded by the spatial mean of its caller (roi_emb_heads.py:262,344,356).
  *   x        [R,C5,HW] fp32 (HW may be 1)            pooled  [R,C5]  (out; == x when HW==1 is allowed)

@@ -70,6 +70,10 @@ SIGNATURES = {
     "locov_token_attention_fwd": (c_int, [_p, c_int64, c_int, _p, _p, c_int, c_int, c_float, c_int, c_int, _p, _p, _p, _p]),
     "locov_rownorm_fwd": (c_int, [_p, c_int64, c_int, c_int, c_float, _p, _p]),
     "locov_rownorm_bwd": (c_int, [_p, _p, c_int64, c_int, c_int, c_float, _p, _p]),
+    "locov_pool_fc_bwd_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "locov_pool_fc_bwd": (c_int, [_p, c_int64, c_int, _p, c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int64, _p]),
+    "locov_sim_gemm_bwd_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "locov_sim_gemm_bwd": (c_int, [_p, _p, _p, c_int64, c_int, c_int, _p, _p, _p, c_int64, _p]),
     "locov_f32_to_bf16": (c_int, [_p, c_int64, _p, _p]),
     "locov_gemm_nt_bf16": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, _p]),
     "locov_conv3x3_nhwc_bf16": (c_int, [_p, c_int64, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, c_int, c_uint, _p]),

@@ -1003,6 +1003,88 @@ def rownorm_autograd(x: torch.Tensor, mode: int, eps: float = 1e-12) -> torch.Te
     return rownorm(x.detach(), mode, eps)
 
 
+class _PoolFcFn(torch.autograd.Function):
+    """(emb, deltas) = (x W_emb^T + b_emb, x W_box^T + b_box): the predictor's two FCs on one input (box_emb_head.py:196,206)
+    with their backward in ONE C call (locov_pool_fc_bwd: grad_x accumulated across both layers in the GEMM epilogue, weight
+    gradients as TN GEMMs, bias gradients as column sums)."""
+
+    @staticmethod
+    def forward(ctx, x, emb_w, emb_b, box_w, box_b):
+        x = _rows(x.detach(), "x").contiguous()
+        ctx.save_for_backward(x, emb_w.detach(), box_w.detach())
+        ctx.set_materialize_grads(False)                     # an unused output (detached class predictor) sends None, not zeros
+        ctx.has_bias = (emb_b is not None, box_b is not None)
+        return linear(x, emb_w.detach(), None if emb_b is None else emb_b.detach()), \
+            linear(x, box_w.detach(), None if box_b is None else box_b.detach())
+
+    @staticmethod
+    def backward(ctx, g_emb, g_box):
+        x, emb_w, box_w = ctx.saved_tensors
+        R, C5 = x.shape
+        D = emb_w.shape[0]
+        need = ctx.needs_input_grad
+        if g_emb is None and g_box is None:
+            return None, None, None, None, None
+        g_emb = _dev(g_emb, "grad_emb") if g_emb is not None else None
+        g_box = _dev(g_box, "grad_deltas") if g_box is not None else None
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
+        gx = new(R, C5) if need[0] else None
+        gew = new(D, C5) if need[1] and g_emb is not None else None
+        geb = new(D) if need[2] and ctx.has_bias[0] and g_emb is not None else None
+        gbw = new(4, C5) if need[3] and g_box is not None else None
+        gbb = new(4) if need[4] and ctx.has_bias[1] and g_box is not None else None
+        lib = _lib.load()
+        nbytes = lib.locov_pool_fc_bwd_workspace_bytes(R, C5, D)
+        ws = _workspace("pool_fc_bwd", x, nbytes)
+        with torch.cuda.device(x.device):
+            check(lib.locov_pool_fc_bwd(_ptr(x), R, C5, _ptr(emb_w), D, _ptr(box_w), _ptr(g_emb), _ptr(g_box), _ptr(gx), _ptr(gew),
+                                        _ptr(geb), _ptr(gbw), _ptr(gbb), _ptr(ws), ws.numel(), _stream(x)), "locov_pool_fc_bwd")
+        return gx, gew, geb, gbw, gbb
+
+
+def pool_fc_autograd(x, emb_w, emb_b, box_w, box_b):
+    """Differentiable (emb_pred(x), bbox_pred(x)); x [R,C5], C5 and D multiples of 4, bbox_pred class-agnostic ([4,C5])."""
+    if box_w.shape[0] != 4 or x.shape[1] % 4 or emb_w.shape[0] % 4:
+        return linear_autograd(x, emb_w, emb_b), linear_autograd(x, box_w, box_b)
+    return _PoolFcFn.apply(x, emb_w, emb_b, box_w, box_b)
+
+
+class _SimGemmFn(torch.autograd.Function):
+    """logits = emb . bank^T (+ bias) (box_emb_head.py:211) with locov_sim_gemm_bwd as its backward."""
+
+    @staticmethod
+    def forward(ctx, emb, bank, bias):
+        emb = _rows(emb.detach(), "emb").contiguous()
+        ctx.save_for_backward(emb, bank.detach())
+        ctx.has_bias = bias is not None
+        return linear(emb, bank.detach(), None if bias is None else bias.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        emb, bank = ctx.saved_tensors
+        g = _dev(g, "grad_logits")
+        R, D = emb.shape
+        K1 = bank.shape[0]
+        need = ctx.needs_input_grad
+        ge = torch.empty_like(emb) if need[0] else None
+        gb = torch.empty_like(bank) if need[1] and K1 % 4 == 0 else None
+        lib = _lib.load()
+        ws = _workspace("sim_gemm_bwd", emb, lib.locov_sim_gemm_bwd_workspace_bytes(R, D, K1))
+        with torch.cuda.device(emb.device):
+            check(lib.locov_sim_gemm_bwd(_ptr(g), _ptr(emb), _ptr(bank), R, D, K1, _ptr(ge), _ptr(gb), _ptr(ws), ws.numel(),
+                                         _stream(emb)), "locov_sim_gemm_bwd")
+        if need[1] and gb is None:                           # a trainable bank whose row count is not a multiple of 4
+            gb = linear(g.t().contiguous(), emb.t().contiguous())
+        return ge, gb, (g.sum(dim=0) if ctx.has_bias and need[2] else None)
+
+
+def sim_gemm_autograd(emb: torch.Tensor, bank: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable fp32 similarity GEMM emb [R,D] x bank [K1,D]^T."""
+    if emb.shape[1] % 4 or not (torch.is_grad_enabled() and (emb.requires_grad or bank.requires_grad)):
+        return linear_autograd(emb, bank, bias)
+    return _SimGemmFn.apply(emb, bank, bias)
+
+
 def to_bf16(x: torch.Tensor) -> torch.Tensor:
     x = _dev(x, "x")
     y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)

@@ -395,17 +395,19 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
                 # nn.Linear does (the similarity kernel itself carries no bias term)
                 scores = scores + self.cls_score.bias.detach()
             return scores, deltas
-        proposal_deltas = hip_linear(x, self.bbox_pred)                   # :196
         if self.detach_cls_predictor:                                     # :197-201
+            proposal_deltas = hip_linear(x, self.bbox_pred)               # :196
             with torch.no_grad():
                 scores = self.forward_cls_prediction(x.detach())
-        else:
-            scores = self.forward_cls_prediction(x)
-        return scores, proposal_deltas
+            return scores, proposal_deltas
+        # both FCs read x: one autograd node, one backward call (locov_pool_fc_bwd) that accumulates grad_x across them
+        emb, proposal_deltas = ops.pool_fc_autograd(x, self.emb_pred.weight, self.emb_pred.bias, self.bbox_pred.weight,
+                                                    self.bbox_pred.bias)      # :196, :206
+        return self.forward_cls_prediction(x, emb=emb), proposal_deltas
 
-    def forward_cls_prediction(self, x):                                  # :204-212
+    def forward_cls_prediction(self, x, emb=None):                        # :204-212 (emb: emb_pred(x) when already formed)
         if self.embedding_based:
-            x = hip_linear(x, self.emb_pred)
+            x = hip_linear(x, self.emb_pred) if emb is None else emb
             if self.normalize_emb:
                 x = _rownorm(x, ops.NORM_L2)
             if self.standardize_emb:
@@ -413,6 +415,8 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
         if self.sim_gemm_dtype == "bf16" and not (torch.is_grad_enabled() and x.requires_grad):
             scores = ops.sim_gemm_bf16(ops.to_bf16(x), self._packed_bank())
             return scores if self._cls_bias_is_zero() else scores + self.cls_score.bias.detach()
+        if self.embedding_based:
+            return ops.sim_gemm_autograd(x, self.cls_score.weight, self.cls_score.bias)      # :211
         return hip_linear(x, self.cls_score)
 
     def _bank_key(self):

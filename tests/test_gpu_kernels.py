@@ -409,3 +409,59 @@ def test_linear_autograd_vs_float64(ops, M, N, K):
     (ops.linear_autograd(xg, wg, bg) * gy.cuda()).sum().backward()
     for got, want in ((xg.grad, xd.grad), (wg.grad, wd.grad), (bg.grad, bd.grad)):
         assert float((got.cpu().double() - want).abs().max() / want.abs().max()) < 5e-6
+
+
+@pytest.mark.parametrize("R,C5,D", [(300, 256, 96), (1000, 2048, 768), (0, 128, 32)])
+@pytest.mark.parametrize("detached", [False, True])
+def test_pool_fc_backward_vs_float64(ops, R, C5, D, detached):
+    """locov_pool_fc_bwd: the backward of bbox_pred + emb_pred on one input (box_emb_head.py:196,206) against a
+    float64 torch-autograd evaluation; `detached` = no gradient arrives through the embedding (DETACH_CLASS_PREDICTOR)."""
+    g = torch.Generator().manual_seed(R + D)
+    x, we, be, wb, bb = (torch.randn(R, C5, generator=g), torch.randn(D, C5, generator=g) * 0.05, torch.randn(D, generator=g),
+                         torch.randn(4, C5, generator=g) * 0.05, torch.randn(4, generator=g))
+    ge, gb = torch.randn(R, D, generator=g), torch.randn(R, 4, generator=g)
+    ref = [t.double().requires_grad_(True) for t in (x, we, be, wb, bb)]
+    loss = (torch.nn.functional.linear(ref[0], ref[3], ref[4]) * gb.double()).sum()
+    if not detached:
+        loss = loss + (torch.nn.functional.linear(ref[0], ref[1], ref[2]) * ge.double()).sum()
+    loss.backward()
+    dev = [t.cuda().requires_grad_(True) for t in (x, we, be, wb, bb)]
+    emb, deltas = ops.pool_fc_autograd(*dev)
+    assert tuple(emb.shape) == (R, D) and tuple(deltas.shape) == (R, 4)
+    loss = (deltas * gb.cuda()).sum()
+    if not detached:
+        loss = loss + (emb * ge.cuda()).sum()
+    loss.backward()
+    for got, want, name in zip(dev, ref, ("x", "emb_w", "emb_b", "bbox_w", "bbox_b")):
+        if want.grad is None or (detached and name.startswith("emb")):
+            assert got.grad is None or float(got.grad.abs().max() if got.grad.numel() else 0.0) == 0.0, name
+            continue
+        if R == 0:
+            assert float(got.grad.abs().max()) == 0.0 if got.grad.numel() else True, name
+            continue
+        err = float((got.grad.cpu().double() - want.grad).abs().max() / want.grad.abs().max())
+        assert err < 5e-6, (name, err)
+
+
+@pytest.mark.parametrize("R,D,K1,train_bank", [(500, 96, 81, False), (1000, 768, 1204, False), (300, 64, 48, True), (257, 128, 49, True),
+                                                 (0, 64, 81, False)])
+def test_sim_gemm_backward_vs_float64(ops, R, D, K1, train_bank):
+    """locov_sim_gemm_bwd: grad_emb = g . bank for any class count (81 / 49 / 1204 rows), grad_bank = g^T emb
+    where a test asks for it (the reference freezes the bank, box_emb_head.py:234-235)."""
+    g = torch.Generator().manual_seed(K1)
+    emb, bank, gy = torch.randn(R, D, generator=g), torch.randn(K1, D, generator=g) * 0.05, torch.randn(R, K1, generator=g)
+    ed, bd = emb.double().requires_grad_(True), bank.double().requires_grad_(train_bank)
+    (torch.nn.functional.linear(ed, bd) * gy.double()).sum().backward()
+    eg, bg = emb.cuda().requires_grad_(True), bank.cuda().requires_grad_(train_bank)
+    logits = ops.sim_gemm_autograd(eg, bg)
+    assert tuple(logits.shape) == (R, K1)
+    (logits * gy.cuda()).sum().backward()
+    if R == 0:
+        return
+    want = torch.nn.functional.linear(ed, bd).detach()
+    assert float((logits.detach().cpu().double() - want).abs().max() / want.abs().max()) < 5e-6
+    assert float((eg.grad.cpu().double() - ed.grad).abs().max() / ed.grad.abs().max()) < 5e-6
+    if train_bank:
+        assert float((bg.grad.cpu().double() - bd.grad).abs().max() / bd.grad.abs().max()) < 5e-6
+    else:
+        assert bg.grad is None
