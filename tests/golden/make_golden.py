@@ -15,6 +15,7 @@ which imports Detectron2):
         EmbeddingFastRCNNOutputLayers.{forward, forward_cls_prediction,
         set_class_embeddings}                                         (:179-236)
   G4  ovr/modeling/mmss_heads/grounding_head.py  GroundingHead.forward (:92-388)
+  G8  the same, in the configurations other than the LSM one (hardmax, reconstruction_mse, triplet, one direction)  [make_golden.py g8]
   G5  ovr/modeling/meta_arch/distill_mmss_gcnn.py  MultiDistillLoss, MultiDistillLossJS,
       MultiDistillLossL2 .forward                                     (:211-433)
   G6  ovr/modeling/roi_heads/box_emb_grounding_head.py  GroundingModule.set_class_embeddings /
@@ -36,6 +37,7 @@ executed on the recorded paths.  `Tensor.to("cuda")` / `.cuda()` are mapped to
 CPU because grounding_head.py hard-codes the device.
 """
 import importlib.util
+import json
 import os
 import sys
 import types
@@ -196,10 +198,91 @@ def make_g7():
     print("wrote g7_text_bank.npz")
 
 
+G8_VARIANTS = {        # name -> overrides of the LSM grounding configuration (grounding_head.py:161-343)
+    "hardmax": dict(ALIGNMENT="hardmax"),
+    "recmse": dict(GLOBAL_METRIC="reconstruction_mse", ALIGN_REGIONS_TO_WORDS=False),
+    "hardmax_recmse": dict(ALIGNMENT="hardmax", GLOBAL_METRIC="reconstruction_mse", ALIGN_REGIONS_TO_WORDS=False),
+    "triplet_hardest": dict(LOSS="triplet", NEGATIVE_MINING="hardest", TRIPLET_MARGIN=0.5),
+    "triplet_easiest": dict(LOSS="triplet", NEGATIVE_MINING="easiest", TRIPLET_MARGIN=2.0),
+    "words_only": dict(ALIGN_REGIONS_TO_WORDS=False),
+    "regions_only_hardmax": dict(ALIGNMENT="hardmax", ALIGN_WORDS_TO_REGIONS=False),
+}
+
+
+def make_g8():
+    """G8: GroundingHead.forward (grounding_head.py:92-388) in the configurations OTHER than the LSM one, run from the
+    reference on CPU: losses, batch accuracies, the [B,B] cost matrices and the gradient of the summed losses with respect
+    to v2l_projection.weight.  (reconstruction_mse with ALIGN_REGIONS_TO_WORDS only broadcasts for B*B == NR in the
+    reference, :221-224, so those variants align words only.)"""
+    install_standins()
+    cuda_to_cpu_shim()
+    load("ovr.misc", "ovr/misc.py")
+    load("ovr.modeling.logged_module", "ovr/modeling/logged_module.py")
+    gh = load("ovr.modeling.mmss_heads.grounding_head", "ovr/modeling/mmss_heads/grounding_head.py")
+
+    class _N(dict):
+        __getattr__ = dict.__getitem__
+
+    g = torch.Generator().manual_seed(SEED + 8)
+    V, L, T = 128, 64, 10
+    w = torch.randn(L, V, generator=g) * 0.05
+    b = torch.randn(L, generator=g) * 0.05
+    out = dict(seed=SEED + 8, v2l_w=w.numpy(), v2l_b=b.numpy(), variants=np.array(list(G8_VARIANTS)))
+    inputs = {}
+    for B, NR in ((1, 5), (3, 9)):
+        region = torch.randn(B, NR, V, generator=g)
+        rmask = torch.ones(B, NR, dtype=torch.uint8)
+        if B > 1:
+            rmask[1, NR // 2:] = 0
+        cap = torch.randn(B, T, L, generator=g)
+        att = torch.ones(B, T, dtype=torch.int64)
+        spec = torch.zeros(B, T, dtype=torch.int64)
+        spec[:, 0] = 1
+        for i in range(B):
+            n = T - 2 * i
+            att[i, n:] = 0
+            spec[i, n - 1:] = 1
+        inputs[B] = (region, rmask, cap, att, spec)
+        p = f"b{B}_"
+        out.update({p + "region_features": region.numpy(), p + "region_mask": rmask.numpy(), p + "input_embeddings": cap.numpy(),
+                    p + "attention_mask": att.numpy(), p + "special_tokens_mask": spec.numpy()})
+    for name, over in G8_VARIANTS.items():
+        gcfg = dict(LOCAL_METRIC="dot", GLOBAL_METRIC="aligned_local", ALIGNMENT="softmax", ALIGNMENT_TEMPERATURE=10.0,
+                    LOSS="cross_entropy", NEGATIVE_MINING="random", TRIPLET_MARGIN=1.0, ALIGN_WORDS_TO_REGIONS=True,
+                    ALIGN_REGIONS_TO_WORDS=True, TEXT_INPUT="input_embeddings")
+        gcfg.update(over)
+        both = gcfg["ALIGN_WORDS_TO_REGIONS"] and gcfg["ALIGN_REGIONS_TO_WORDS"]
+        cfg = _N(MODEL=_N(MMSS_HEAD=_N(GROUNDING=_N(gcfg), DISTILLATION_LOSS=both)))
+        out[name + "_cfg"] = np.asarray(json.dumps(gcfg))
+        for B, (region, rmask, cap, att, spec) in inputs.items():
+            head = gh.GroundingHead(cfg, V, L)
+            with torch.no_grad():
+                head.v2l_projection.weight.copy_(w)
+                head.v2l_projection.bias.copy_(b)
+            res = head({"region_features": region, "region_mask": rmask},
+                       {"input_embeddings": cap, "attention_mask": att, "special_tokens_mask": spec})
+            info, losses = res[0], res[1]
+            sum(losses.values()).backward()
+            p = f"{name}_b{B}_"
+            out[p + "loss_names"] = np.array(list(losses.keys()))
+            out[p + "losses"] = np.array([float(v) for v in losses.values()], np.float32)
+            out[p + "info_names"] = np.array(list(info.keys()))
+            out[p + "info"] = np.array([float(v) for v in info.values()], np.float32)
+            out[p + "grad_v2l_w"] = head.v2l_projection.weight.grad.numpy().copy()
+            if both:
+                out[p + "w2r"] = res[2]["w2r"].detach().numpy()
+                out[p + "r2w"] = res[2]["r2w"].detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "g8_grounding_variants.npz"), **out)
+    print("wrote g8_grounding_variants.npz")
+
+
 def main():
     assert os.path.isdir(REF), f"reference not found at {REF}"
     if sys.argv[1:] == ["g7"]:
         make_g7()
+        return
+    if sys.argv[1:] == ["g8"]:
+        make_g8()
         return
     install_standins()
     cuda_to_cpu_shim()

@@ -164,7 +164,82 @@ def test_weight_tying_with_emb_pred(gh_mod):
         lin.weight.mul_(2.0)                               # in-place update through the OTHER module
     l1 = float(sum(head(*_inputs(d))[1].values()))
     assert l0 != l1
+
+
+def _variant_cfg(over, distill):
+    import json
+    c = _cfg(distill)
+    for k, v in (json.loads(over) if isinstance(over, str) else over).items():
+        setattr(c.MODEL.MMSS_HEAD.GROUNDING, k, v)
+    return c
+
+
+def test_other_variants_match_reference_vectors(gh_mod, golden_dir):
+    """grounding_head.py:161-343 beyond the LSM configuration -- hardmax alignment, reconstruction_mse, triplet loss with
+    hardest / easiest negatives, one alignment direction -- against outputs AND v2l_projection gradients recorded from the
+    reference's own GroundingHead (tests/golden/make_golden.py g8)."""
+    g = np.load(os.path.join(golden_dir, "g8_grounding_variants.npz"))
+    for name in (str(n) for n in g["variants"]):
+        over = str(g[name + "_cfg"])
+        for B in (1, 3):
+            p = f"{name}_b{B}_"
+            both = (p + "w2r") in g
+            head = gh_mod.GroundingHead(_variant_cfg(over, both), 128, 64).cuda()
+            with torch.no_grad():
+                head.v2l_projection.weight.copy_(torch.from_numpy(g["v2l_w"]))
+                head.v2l_projection.bias.copy_(torch.from_numpy(g["v2l_b"]))
+            res = head(*_inputs(g, f"b{B}_"))
+            info, losses = res[0], res[1]
+            assert list(losses.keys()) == [str(n) for n in g[p + "loss_names"]], name
+            assert list(info.keys()) == [str(n) for n in g[p + "info_names"]], name
+            np.testing.assert_allclose([float(v.detach()) for v in losses.values()], g[p + "losses"], rtol=2e-5, atol=2e-5, err_msg=p)
+            np.testing.assert_array_equal([float(v) for v in info.values()], g[p + "info"], err_msg=p)
+            if both:
+                np.testing.assert_allclose(res[2]["w2r"].detach().cpu().numpy(), g[p + "w2r"], rtol=2e-5, atol=2e-5, err_msg=p)
+                np.testing.assert_allclose(res[2]["r2w"].detach().cpu().numpy(), g[p + "r2w"], rtol=2e-5, atol=2e-5, err_msg=p)
+            sum(losses.values()).backward()
+            want = g[p + "grad_v2l_w"]
+            got = head.v2l_projection.weight.grad.cpu().numpy()
+            assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-3), (p, np.abs(got - want).max(), np.abs(want).max())
+
+
+def test_random_alignments_and_error_behaviour(gh_mod):
+    """random_categorical / random_top3 (:175-206) draw their alignment: with a near-zero temperature the categorical draw IS
+    the arg-max, so it must reproduce hardmax; top-3 draws stay inside the three best.  Triplet with random negatives (:297-304)
+    lies between the hardest and the easiest choice.  What the reference rejects is rejected the same way."""
+    rng = np.random.default_rng(5)
+    d = _synth(rng, 3, 9, 8, 64, 32)
+    def run(**over):
+        torch.manual_seed(0)
+        head = gh_mod.GroundingHead(_variant_cfg(over, True), 64, 32).cuda()
+        torch.manual_seed(1)
+        with torch.no_grad():
+            return head(*_inputs(d))
+    hard = run(ALIGNMENT="hardmax", ALIGNMENT_TEMPERATURE=1e-6)
+    cat = run(ALIGNMENT="random_categorical", ALIGNMENT_TEMPERATURE=1e-6)
+    # (a caption without a single valid word has nothing to arg-max over: its alignment is a uniform draw in the reference too)
+    has_words = torch.from_numpy((d["attention_mask"] * (1 - d["special_tokens_mask"])).sum(1) > 0).cuda()
+    assert bool(has_words.any()) and not bool(has_words.all())
+    for k in ("w2r", "r2w"):
+        a, b = hard[2][k][has_words], cat[2][k][has_words]
+        assert bool(((a - b).abs() <= 1e-5 * a.abs().clamp_min(1.0)).all()), k
+    top3 = run(ALIGNMENT="random_top3")
+    assert all(torch.isfinite(v) for v in top3[1].values()) and top3[2]["w2r"].shape == (3, 3)
+    # aligned-local cost of a top-3 draw can never beat the arg-max alignment's (it is the smallest achievable distance)
+    best = run(ALIGNMENT="hardmax")
+    # (where there are three valid candidates to draw from: every image here has >= 3 regions, captions need >= 3 words)
+    three_words = torch.from_numpy((d["attention_mask"] * (1 - d["special_tokens_mask"])).sum(1) >= 3).cuda()
+    assert bool(three_words.any())
+    assert bool((top3[2]["w2r"] >= best[2]["w2r"] - 1e-5).all())
+    assert bool((top3[2]["r2w"][three_words] >= best[2]["r2w"][three_words] - 1e-5).all())
+    t_h, t_e, t_r = (run(LOSS="triplet", NEGATIVE_MINING=m)[1] for m in ("hardest", "easiest", "random"))
+    for k in t_r:
+        assert float(t_e[k]) - 1e-6 <= float(t_r[k]) <= float(t_h[k]) + 1e-6, k
     with pytest.raises(NotImplementedError):
-        c = _cfg()
-        c.MODEL.MMSS_HEAD.GROUNDING.LOSS = "triplet"
-        gh_mod.GroundingHead(c, 64, 32)
+        gh_mod.GroundingHead(_variant_cfg(dict(LOCAL_METRIC="cosine"), False), 64, 32).cuda()(*_inputs(d))
+    with pytest.raises(NotImplementedError):
+        gh_mod.GroundingHead(_variant_cfg(dict(ALIGNMENT="optimal_transport"), False), 64, 32).cuda()(*_inputs(d))
+    with pytest.raises(NotImplementedError):
+        gh_mod.GroundingHead(_variant_cfg(dict(GLOBAL_METRIC="emd"), False), 64, 32).cuda()(*_inputs(d))
+    with pytest.raises(Exception, match="Matching loss is not defined"):
+        gh_mod.GroundingHead(_variant_cfg(dict(LOSS="matching"), False), 64, 32).cuda()(*_inputs(d))
