@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_pp_kernel(PPArgs p)
     // everything the tile's epilogue reads is requested during its LAST K-tile step (a null residual / scale / shift reads
     // through an empty descriptor: zeros, no memory access, and the count of outstanding operations stays what that step's
     // barrier wait assumes)
-    constexpr int TILE_LOADS = 2 * NB + MB * NB;
+    constexpr int TILE_LOADS = 2 * NB + MB * NB, TILE_STORES = 2 * MB * (NB / 2);
     auto tile_loads = [&](const Tile &t) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t r_res =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(t.res ? t.res : p.A), 0, t.res ? t.nrec : 0u, 0x00020000);
@@ -261,30 +261,34 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_pp_kernel(PPArgs p)
     // ---- one K-tile step E of the current tile (stage E & 1); quarters as in gemm_split.hip's tile_step ------------------
     Tile cur, nxt;
     bool has_next = false;
+    bool first = true;                                       // no stores of a previous tile are in flight yet
     auto step = [&](auto e_tag) __attribute__((always_inline)) {
         constexpr int E = decltype(e_tag)::value;
         constexpr int s = E & 1, x = s, y = s ^ 1;
         rd_b(s, y);
         rd_a(s, 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (E + 1 < KT) {
-            dma(cur, E + 1, s ^ 1);
-        } else if (has_next) {                               // the stream runs on into the next tile
-            set_a_voff(nxt.m0);
-            dma(nxt, 0, s ^ 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
         quarter(0, x, 0, NQM);
-        __builtin_amdgcn_sched_barrier(0);
         quarter(0, y, 0, NQM);
         __builtin_amdgcn_sched_barrier(0);
-        if (E + 1 == KT) tile_loads(cur);                    // (behind the DMA in issue order: the barrier wait below leaves them in flight)
+        if (E + 1 == KT) tile_loads(cur);                    // younger than the DMA this step waits for
         __builtin_amdgcn_sched_barrier(0);
         quarter(1, y, 0, NQM);
         __builtin_amdgcn_sched_barrier(0);
-        if (E + 1 == KT) __builtin_amdgcn_s_waitcnt((TILE_LOADS & 15) | ((TILE_LOADS >> 4) << 14) | 0x0F70);   // vmcnt(TILE_LOADS)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the DMA has landed
+        // K-tile E+1 (requested behind the barrier of step E-1) must have landed.  What may stay in flight behind it: the
+        // tile's epilogue loads in its last step; in the first step of a tile, the 32 stores of the tile before.
+        if (E + 1 == KT) __builtin_amdgcn_s_waitcnt((TILE_LOADS & 15) | ((TILE_LOADS >> 4) << 14) | 0x0F70);
+        else if (E == 0 && !first) __builtin_amdgcn_s_waitcnt((TILE_STORES & 15) | ((TILE_STORES >> 4) << 14) | 0x0F70);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
+        // K-tile E+2 -> the stage this step has finished reading (its last fragment reads fed MFMAs issued before the barrier)
+        if (E + 2 < KT) {
+            dma(cur, E + 2, s);
+        } else if (has_next) {                               // the stream runs on into the next tile: its K-tiles 0 and 1
+            if (E + 2 == KT) set_a_voff(nxt.m0);
+            dma(nxt, E + 2 - KT, s);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         rd_a(s ^ 1, 0);
         rd_b(s ^ 1, y);
         __builtin_amdgcn_sched_barrier(0);
@@ -296,7 +300,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_pp_kernel(PPArgs p)
     locate(v, cur);
     set_a_voff(cur.m0);
     dma(cur, 0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
+    dma(cur, 1, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * CH));           // vmcnt(8): K-tile 0 has landed
     __syncthreads();
     rd_a(0, 0);
     rd_b(0, 0);
@@ -320,6 +325,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_pp_kernel(PPArgs p)
         step(std::integral_constant<int, 14>{});
         step(std::integral_constant<int, 15>{});
         tile_stores(cur);
+        first = false;
         if (!has_next) break;
         cur = nxt;
         v += P;
