@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
         }
     }
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the LDS-DMA destinations are M0 values)
     const int wm = (wave / WN) * TM, wn = (wave % WN) * TN;
 
     // A staging: chunk i of a thread = row (tid + i*NT) / 8, 16-byte chunk (tid + i*NT) % 8 of the tile row; rows past
