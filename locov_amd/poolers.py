@@ -26,10 +26,14 @@ def convert_boxes_to_pooler_format(box_lists: Sequence[Union[Boxes, torch.Tensor
     if len(tensors) == 0:
         return torch.zeros((0, 5), dtype=torch.float32)
     dev = tensors[0].device
-    sizes = torch.tensor([t.shape[0] for t in tensors], device=dev)
-    idx = torch.repeat_interleave(torch.arange(len(tensors), dtype=torch.float32, device=dev), sizes)
-    boxes = torch.cat(tensors, dim=0).to(torch.float32)
-    return torch.cat([idx[:, None], boxes], dim=1).contiguous()
+    # (batch indices by fill kernels: the row counts are host-side shapes -- no host-to-device copy, no sync, capturable)
+    out = torch.empty((sum(t.shape[0] for t in tensors), 5), dtype=torch.float32, device=dev)
+    r0 = 0
+    for i, t in enumerate(tensors):
+        out[r0:r0 + t.shape[0], 0] = float(i)
+        out[r0:r0 + t.shape[0], 1:] = t
+        r0 += t.shape[0]
+    return out
 
 
 def assign_boxes_to_levels(box_lists, min_level: int, max_level: int, canonical_box_size: int,
