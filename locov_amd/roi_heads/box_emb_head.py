@@ -54,7 +54,7 @@ class Box2BoxTransform:
         dw = ww * torch.log(tgt_w / src_w)
         dh = wh * torch.log(tgt_h / src_h)
         deltas = torch.stack((dx, dy, dw, dh), dim=1)
-        assert (src_w > 0).all().item(), "Input boxes to Box2BoxTransform are not valid!"
+        torch._assert_async((src_w > 0).all())       # "Input boxes to Box2BoxTransform are not valid!" (device-side: no host sync)
         return deltas
 
     def apply_deltas(self, deltas: torch.Tensor, boxes: torch.Tensor) -> torch.Tensor:
@@ -267,16 +267,24 @@ class FastRCNNOutputLayers(nn.Module):
         return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
 
     def box_reg_loss(self, proposal_boxes, gt_boxes, pred_deltas, gt_classes):
+        """[D2-upstream] smooth-L1 over the foreground rows, normalised by ALL rows.  The foreground rows are selected by a
+        mask instead of `nonzero` indices (a data-dependent size = a host sync): background rows get a unit box as source and
+        target (zero deltas, finite everywhere) and weight 0 in the sum -- same value, same gradients."""
         box_dim = proposal_boxes.shape[1]
-        fg_inds = torch.nonzero((gt_classes >= 0) & (gt_classes < self.num_classes), as_tuple=True)[0]
+        fg = (gt_classes >= 0) & (gt_classes < self.num_classes)
         if pred_deltas.shape[1] == box_dim:
-            fg_pred_deltas = pred_deltas[fg_inds]
+            pred = pred_deltas
         else:
-            fg_pred_deltas = pred_deltas.view(-1, self.num_classes, box_dim)[fg_inds, gt_classes[fg_inds]]
+            rows = torch.arange(gt_classes.shape[0], device=gt_classes.device)
+            pred = pred_deltas.view(-1, self.num_classes, box_dim)[rows, gt_classes.clamp(0, self.num_classes - 1)]
         if self.box_reg_loss_type != "smooth_l1":
             raise ValueError(f"Invalid bbox reg loss type '{self.box_reg_loss_type}'")
-        gt_pred_deltas = self.box2box_transform.get_deltas(proposal_boxes[fg_inds], gt_boxes[fg_inds])
-        loss_box_reg = smooth_l1_loss(fg_pred_deltas, gt_pred_deltas, self.smooth_l1_beta, reduction="sum")
+        unit = torch.cat([proposal_boxes.new_zeros(box_dim // 2), proposal_boxes.new_ones(box_dim - box_dim // 2)])   # [0, 0, 1, 1], built on the device
+        src_boxes = torch.where(fg[:, None], proposal_boxes, unit)        # (background rows may be degenerate boxes: they
+        target_boxes = torch.where(fg[:, None], gt_boxes, unit)           # never reach get_deltas' validity check upstream)
+        gt_pred_deltas = self.box2box_transform.get_deltas(src_boxes, target_boxes)
+        per_elem = smooth_l1_loss(pred, gt_pred_deltas, self.smooth_l1_beta, reduction="none")
+        loss_box_reg = (per_elem * fg[:, None].to(per_elem.dtype)).sum()
         return loss_box_reg / max(gt_classes.numel(), 1.0)
 
     def inference(self, predictions, proposals):

@@ -72,7 +72,7 @@ class Matcher:
             default_match_labels = match_quality_matrix.new_full((match_quality_matrix.size(1),), self.labels[0],
                                                                  dtype=torch.int8)
             return default_matches, default_match_labels
-        assert torch.all(match_quality_matrix >= 0)
+        torch._assert_async(torch.all(match_quality_matrix >= 0))      # (device-side assert: no host sync)
         matched_vals, matches = match_quality_matrix.max(dim=0)
         match_labels = matches.new_full(matches.size(), 1, dtype=torch.int8)
         for (l, low, high) in zip(self.labels, self.thresholds[:-1], self.thresholds[1:]):
@@ -96,6 +96,19 @@ def subsample_labels(labels: torch.Tensor, num_samples: int, positive_fraction: 
     perm1 = torch.randperm(positive.numel(), device=positive.device)[:num_pos]
     perm2 = torch.randperm(negative.numel(), device=negative.device)[:num_neg]
     return positive[perm1], negative[perm2]
+
+
+def subsample_order(labels: torch.Tensor, bg_label: int):
+    """The device-only half of subsample_labels: a uniformly random order of all candidates with the foreground ones first,
+    one with the background ones first, and the two population sizes as a device tensor.  Taking the first num_pos / num_neg
+    entries (host integers, known once the sizes have been read -- ONE read for a whole batch) yields the same distribution
+    as the randperm form, without a `nonzero` (= a host sync) per image."""
+    pos = (labels != -1) & (labels != bg_label)
+    neg = labels == bg_label
+    k = torch.rand((2, labels.shape[0]), device=labels.device)
+    pos_order = torch.argsort(k[0] + (~pos).to(k.dtype) * 2.0)
+    neg_order = torch.argsort(k[1] + (~neg).to(k.dtype) * 2.0)
+    return pos_order, neg_order, torch.stack([pos.sum(), neg.sum()])
 
 
 def add_ground_truth_to_proposals(targets: List[Instances], proposals: List[Instances]) -> List[Instances]:
@@ -164,12 +177,26 @@ class SampleAllROIHeads(ROIHeads):
     Kept from the reference (and different from stock Detectron2): EVERY field of the matched target
     is copied onto the sampled proposals, not only the gt_* ones (:97-100), and a 0/1 `fg_proposal`
     field is attached (:102-104).  Changed in HOW: the per-image fg/bg counters stay on the device and
-    are read back once per call instead of two `.item()` host syncs per image (:109-110)."""
+    are read back once per call instead of two `.item()` host syncs per image (:109-110) -- and so are the sizes of the foreground /
+    background populations the sampler needs (`subsample_order`): labelling a batch costs ONE host sync in total."""
 
-    def _label_one_image(self, props: Instances, tgt: Instances):
+    def _match_one_image(self, props: Instances, tgt: Instances):
+        """Everything of one image's labelling that needs no host value: IoU, matching, class labels, sampling orders."""
         iou = pairwise_iou(tgt.gt_boxes, props.proposal_boxes)                 # [num_gt, num_proposals]
         gt_index, match_label = self.proposal_matcher(iou)
-        picked, classes = self._sample_proposals(gt_index, match_label, tgt.gt_classes)
+        if tgt.gt_classes.numel() > 0:                                         # ROIHeads._sample_proposals' labelling
+            labels = tgt.gt_classes[gt_index]
+            labels[match_label == 0] = self.num_classes
+            labels[match_label == -1] = -1
+        else:
+            labels = torch.zeros_like(gt_index) + self.num_classes
+        return (gt_index, labels) + subsample_order(labels, self.num_classes)
+
+    def _finish_one_image(self, props: Instances, tgt: Instances, gt_index, labels, pos_order, neg_order, n_pos_avail, n_neg_avail):
+        num_pos = min(n_pos_avail, int(self.batch_size_per_image * self.positive_fraction))      # subsample_labels' counts
+        num_neg = min(n_neg_avail, self.batch_size_per_image - num_pos)
+        picked = torch.cat([pos_order[:num_pos], neg_order[:num_neg]], dim=0)
+        classes = labels[picked]
         out = props[picked]
         out.gt_classes = classes
         if len(tgt) > 0:
@@ -179,20 +206,22 @@ class SampleAllROIHeads(ROIHeads):
                     out.set(name, value[src])
         is_bg = classes == self.num_classes
         out.set("fg_proposal", (~is_bg).to(classes.dtype))
-        return out, is_bg.sum(), classes.numel()
+        return out, num_neg, num_pos + num_neg
 
     @torch.no_grad()
     def label_and_sample_proposals(self, proposals: List[Instances], targets: List[Instances]) -> List[Instances]:
         if self.proposal_append_gt:
             proposals = add_ground_truth_to_proposals(targets, proposals)
         sampled, bg_counts, totals = [], [], []
-        for props, tgt in zip(proposals, targets):
-            out, n_bg, n = self._label_one_image(props, tgt)
+        matched = [self._match_one_image(props, tgt) for props, tgt in zip(proposals, targets)]     # no host value needed
+        avail = torch.stack([m[-1] for m in matched]).cpu().tolist() if matched else []              # ONE sync for the whole batch
+        for props, tgt, m, (n_pos_avail, n_neg_avail) in zip(proposals, targets, matched, avail):
+            out, n_bg, n = self._finish_one_image(props, tgt, *m[:-1], int(n_pos_avail), int(n_neg_avail))
             sampled.append(out)
             bg_counts.append(n_bg)
             totals.append(n)
         if sampled:
-            bg = torch.stack(bg_counts).to(torch.float64).cpu().numpy()        # one sync for the whole batch
+            bg = np.asarray(bg_counts, dtype=np.float64)
             tot = np.asarray(totals, dtype=np.float64)
             storage = get_event_storage()
             storage.put_scalar("roi_head/num_fg_samples", float(np.mean(tot - bg)))
