@@ -319,7 +319,7 @@ class TrainWorkload:
         return n_sampled
 
 
-TRAFFIC_FILE = "r02b_pmc_traffic.json"
+TRAFFIC_FILE = "r02c_pmc_traffic.json"
 
 
 def recorded_traffic(args, kernel_key: str):
@@ -333,9 +333,10 @@ def recorded_traffic(args, kernel_key: str):
         wl = rec["workload"]
         if any(wl[k] != getattr(args, k) for k in ("images", "proposals", "classes", "dim", "res5", "conv3x3", "block0", "res5_dtype")):
             return None
-        for name, v in rec["kernels"].items():
-            if kernel_key in name:
-                return v["hbm_bytes_per_launch"]
+        hits = [v for name, v in rec["kernels"].items() if kernel_key in name]      # every template instance of the kernel
+        n = sum(v["launches_sampled"] for v in hits)
+        if n:
+            return sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in hits) / n
     except (OSError, KeyError, ValueError):
         pass
     return None
@@ -519,7 +520,7 @@ def main():
                     "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                     "traffic": recorded_traffic(args, "gemm_nt_kernel<float, float, 128, 128, 2, 2, 2, 0, false, 8"),
-                    "traffic_unit": f"HBM-side bytes per launch, averaged over this kernel's launches (PMC, profiles/{TRAFFIC_FILE})",
+                    "traffic_unit": f"HBM-side bytes per launch, averaged over the launches of all instances of this kernel (PMC, profiles/{TRAFFIC_FILE})",
                     "launches_per_step": n0 / args.steps, "avg_launch_ms": ms0 / max(n0, 1),
                     "share_of_step_time": ms0 * 1e-3 / dt2,
                     "executed_flops_per_step": fl0 / args.steps,
@@ -542,7 +543,7 @@ def main():
                         "bound": "mfma", "achieved": ach, "peak": MFMA_16BIT_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / MFMA_16BIT_PEAK_TFLOPS,
                         "traffic": recorded_traffic(args, "gemm_split_kernel"),
-                        "traffic_unit": f"HBM-side bytes per launch, averaged over this kernel's launches (PMC, profiles/{TRAFFIC_FILE})",
+                        "traffic_unit": f"HBM-side bytes per launch, averaged over the launches of all instances of this kernel (PMC, profiles/{TRAFFIC_FILE})",
                         "launches_per_step": ns / args.steps, "avg_launch_ms": mss / max(ns, 1),
                         "share_of_step_time": mss * 1e-3 / dt2,
                         "executed_f16_flops_per_step": 3.0 * fls / args.steps,
