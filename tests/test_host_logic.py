@@ -140,6 +140,49 @@ def test_matcher_and_sampling():
     assert len(pos) == 3 and len(neg) == 4
 
 
+def test_subsample_order_is_the_sync_free_form_of_subsample_labels():
+    """subsample_order: the candidates in random order with the foreground (resp. background) ones first + the population
+    sizes; its first num_pos / num_neg entries are what subsample_labels would draw (same sets, uniform subsets)."""
+    labels = torch.tensor([3, 80, 80, 1, -1, 80, 7, 80, -1, 80])
+    torch.manual_seed(1)
+    pos_order, neg_order, counts = reh.subsample_order(labels, 80)
+    assert counts.tolist() == [3, 5]
+    assert sorted(pos_order[:3].tolist()) == [0, 3, 6] and sorted(neg_order[:5].tolist()) == [1, 2, 5, 7, 9]
+    assert sorted(pos_order.tolist()) == list(range(10)) and sorted(neg_order.tolist()) == list(range(10))
+    # every background candidate is drawn first about equally often
+    hits = torch.zeros(10)
+    for _ in range(400):
+        hits[reh.subsample_order(labels, 80)[1][0]] += 1
+    assert hits[[0, 3, 4, 6, 8]].sum() == 0 and hits[[1, 2, 5, 7, 9]].min() > 40
+
+
+def test_box_reg_loss_by_mask_equals_the_indexed_form(lsm_cfg):
+    """FastRCNNOutputLayers.box_reg_loss selects the foreground rows by a mask (no nonzero, no host sync): same value and
+    gradient as Detectron2's indexed form, also with degenerate background boxes."""
+    from locov_amd.roi_heads import box_emb_head as beh
+    pred = locov_amd.build_box_predictor(lsm_cfg, ShapeSpec(channels=64)) if hasattr(locov_amd, "build_box_predictor") else \
+        beh.build_box_predictor(lsm_cfg, ShapeSpec(channels=64))
+    pred.num_classes = 80
+    g = torch.Generator().manual_seed(3)
+    R = 50
+    xy = torch.rand(R, 2, generator=g) * 500
+    boxes = torch.cat([xy, xy + 20 + torch.rand(R, 2, generator=g) * 100], 1)
+    boxes[7] = torch.tensor([10.0, 10.0, 10.0, 10.0])                 # a degenerate BACKGROUND proposal
+    gt = boxes + torch.randn(R, 4, generator=g) * 5
+    classes = torch.randint(0, 81, (R,), generator=g)
+    classes[7] = 80
+    classes[:5] = torch.tensor([0, 5, 79, 80, 80])
+    deltas = torch.randn(R, 4, generator=g, requires_grad=True)
+    loss = pred.box_reg_loss(boxes, gt, deltas, classes)
+    loss.backward()
+    fg = torch.nonzero((classes >= 0) & (classes < 80), as_tuple=True)[0]
+    d2 = deltas.detach().clone().requires_grad_(True)
+    want = beh.smooth_l1_loss(d2[fg], pred.box2box_transform.get_deltas(boxes[fg], gt[fg]), pred.smooth_l1_beta, reduction="sum") / R
+    want.backward()
+    assert abs(float(loss) - float(want)) <= 1e-6 * max(1.0, abs(float(want)))
+    assert torch.allclose(deltas.grad, d2.grad, atol=1e-7) and float(deltas.grad[7].abs().max()) == 0.0
+
+
 def test_label_and_sample_proposals_contract(lsm_cfg):
     lsm_cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 16
     heads = locov_amd.build_roi_heads(lsm_cfg, {"res4": ShapeSpec(channels=1024, stride=16)})

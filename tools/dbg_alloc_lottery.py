@@ -27,3 +27,15 @@ for i in range(10):
 # cross: y of pair a with r of pair b
 for a, b in ((0, 1), (1, 0), (2, 5), (5, 2)):
     print(f"y{a} + r{b}: {measure(keep[2 * a], keep[2 * b + 1]):.3f} ms")
+
+# one output buffer rewritten by every launch vs two used alternately (what a caller that allocates its result per call sees)
+def measure2(ys, rb, n=6):
+    def f(i):
+        check(lib.locov_gemm_nt_f32_split(_ptr(xs.data), K, _ptr(wp.data), None, None, _ptr(rb), _ptr(ys[i % len(ys)]), N, M, N, K,
+                                          _lib.EPI_RELU | _lib.GEMM_A_SPLIT, 16.0, wp.scale, _ptr(_overflow_word(x)), _stream(x)), "gemm")
+    f(0); f(1); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(n): f(i)
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+for rep in range(3):
+    print(f"one output buffer {measure2([keep[2]], keep[3]):.3f} ms   two alternating {measure2([keep[2], keep[4]], keep[3]):.3f} ms   "
+          f"fresh torch.empty per launch {measure2([torch.empty((M, N), device='cuda') for _ in range(6)], keep[3]):.3f} ms", flush=True)
