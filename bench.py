@@ -81,8 +81,13 @@ def parse(argv=None):
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
     # developer/test knobs: rehearse the multi-process flow on a box with fewer GPUs than ranks
     p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl")
-    p.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (needs --dist-backend gloo)")
-    return p.parse_args(argv)
+    p.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (single-GPU test boxes; implies --dist-backend gloo)")
+    args = p.parse_args(argv)
+    if args.share_gpu and args.dist_backend == "nccl":
+        # RCCL cannot place two ranks on one device (the attempt hangs for minutes before it fails): single-GPU test boxes use gloo
+        print("bench.py: --share-gpu implies --dist-backend gloo", file=sys.stderr)
+        args.dist_backend = "gloo"
+    return args
 
 
 def launch_ranks(args) -> int:
