@@ -128,52 +128,38 @@ class GroundingHead(nn.Module):
         local_distance = local_distance / self.temperature
         local_similarity = torch.where((caption_mask[:, :, None] * region_mask[:, None, :]) > 0, local_similarity,
                                        local_similarity.min().detach() - 100.0)       # :155-159
-        attention_w2r = attention_r2w = None
-        if self.alignment == "softmax":                                               # :161-165
-            if self.align_words:
-                attention_w2r = F.softmax(local_similarity, dim=2)
-            if self.align_regions:
-                attention_r2w = F.softmax(local_similarity, dim=1)
-        elif self.alignment == "hardmax":                                             # :166-174
-            if self.align_words:
-                attention_w2r = F.one_hot(torch.argmax(local_similarity, dim=2), NR).to(torch.float32)
-            if self.align_regions:
-                attention_r2w = F.one_hot(torch.argmax(local_similarity, dim=1), T).to(torch.float32).permute(0, 2, 1)
-        elif self.alignment == "random_categorical":                                  # :175-185
-            if self.align_words:
-                attention_w2r = F.one_hot(_choose_one(F.softmax(local_similarity, dim=2)), NR).to(torch.float32)
-            if self.align_regions:
-                attention_r2w = F.one_hot(_choose_one(F.softmax(local_similarity, dim=1).permute(0, 2, 1)), T
-                                          ).to(torch.float32).permute(0, 2, 1)
-        elif self.alignment == "random_top3":                                         # :186-206
-            if self.align_words:
-                idx = torch.topk(local_similarity, k=3, dim=2).indices
-                attention_w2r = F.one_hot(idx, NR).to(torch.float32).sum(dim=2)
-                attention_w2r = F.one_hot(_choose_one(attention_w2r), NR).to(torch.float32)
-            if self.align_regions:
-                idx = torch.topk(local_similarity, k=3, dim=1).indices
-                attention_r2w = F.one_hot(idx, T).to(torch.float32).sum(dim=1)
-                attention_r2w = F.one_hot(_choose_one(attention_r2w), T).to(torch.float32).permute(0, 2, 1)
-        else:
+        # one alignment rule for both directions: a distribution over the LAST dimension -- regions for every word (w2r), and,
+        # on the transposed similarities, words for every region (r2w; :161-208 spell the two cases out separately)
+        def align(sim):
+            n = sim.shape[-1]
+            if self.alignment == "softmax":
+                return F.softmax(sim, dim=-1)
+            if self.alignment == "hardmax":
+                return F.one_hot(sim.argmax(dim=-1), n).to(torch.float32)
+            if self.alignment == "random_categorical":
+                return F.one_hot(_choose_one(F.softmax(sim, dim=-1)), n).to(torch.float32)
+            if self.alignment == "random_top3":
+                top = F.one_hot(torch.topk(sim, k=3, dim=-1).indices, n).to(torch.float32).sum(dim=-2)
+                return F.one_hot(_choose_one(top), n).to(torch.float32)
             raise NotImplementedError
+
+        attention_w2r = align(local_similarity) if self.align_words else None                                   # [P, T, NR]
+        attention_r2w = align(local_similarity.transpose(1, 2)).transpose(1, 2) if self.align_regions else None   # [P, T, NR]
         ones_w, ones_r = torch.ones_like(num_words), torch.ones_like(num_regions)
         global_dist_w2r = global_dist_r2w = None
-        if self.global_metric == "reconstruction_mse":                                # :215-224 (statement for statement)
+        if self.global_metric == "reconstruction_mse":                                # :215-224 (the reference's own broadcasting)
             if self.align_words:
                 caption_rec = torch.bmm(attention_w2r, image_emb.transpose(1, 2))
-                global_dist_w2r = ((caption_rec - caption_emb) ** 2).mean(dim=2)
-                global_dist_w2r = (global_dist_w2r * caption_mask).sum(dim=1) / torch.max(num_words, other=ones_w)
+                global_dist_w2r = (((caption_rec - caption_emb) ** 2).mean(dim=2) * caption_mask).sum(dim=1) / torch.max(num_words, other=ones_w)
             if self.align_regions:
                 image_rec = torch.bmm(caption_emb.transpose(1, 2), attention_r2w)
                 global_dist_r2w = ((image_rec - image_emb) ** 2).mean(dim=2).mean(dim=1)
                 global_dist_r2w = (global_dist_r2w * region_mask).sum(dim=1) / torch.max(num_regions, other=ones_r)
         elif self.global_metric == "aligned_local":                                   # :226-236
             if self.align_words:
-                attention_w2r = attention_w2r * caption_mask[:, :, None]
-                global_dist_w2r = (attention_w2r * local_distance).sum(dim=2).sum(dim=1) / torch.max(num_words, other=ones_w)
+                global_dist_w2r = (attention_w2r * caption_mask[:, :, None] * local_distance).sum(dim=(1, 2)) / torch.max(num_words, other=ones_w)
             if self.align_regions:
-                attention_r2w = attention_r2w * region_mask[:, None, :]
-                global_dist_r2w = (attention_r2w * local_distance).sum(dim=2).sum(dim=1) / torch.max(num_regions, other=ones_r)
+                global_dist_r2w = (attention_r2w * region_mask[:, None, :] * local_distance).sum(dim=(1, 2)) / torch.max(num_regions, other=ones_r)
         else:
             raise NotImplementedError
         ok = (num_words > 0) + (num_regions > 0)                                      # :240-251
