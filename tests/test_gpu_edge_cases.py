@@ -205,3 +205,32 @@ def test_f32_gemm_random_shapes(pkg):
         got = ops.linear(x, w, sh, scale=sc, residual=res, relu=relu)
         err = (got.double() - ref).abs().max().item()
         assert err <= 4e-6 * max(1.0, float(ref.abs().max())), (M, N, K, pad, use_res, use_aff, relu, err)
+
+
+def test_batched_postprocess_equals_the_per_image_form():
+    """fast_rcnn_inference (roi_emb_heads.py:280,357) takes the whole batch through one set of device ops; it must return exactly
+    what fast_rcnn_inference_single_image returns image by image -- ragged batch, different image sizes, an image without
+    proposals, one without a candidate above the threshold, duplicates (NMS), more survivors than top-k."""
+    from locov_amd.roi_heads import box_emb_head as beh
+    g = torch.Generator().manual_seed(11)
+    sizes, shapes = [120, 0, 300, 40], [(800, 1333), (640, 480), (427, 640), (800, 1200)]
+    K = 17
+    boxes, scores = [], []
+    for n, (h, w) in zip(sizes, shapes):
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([w * 1.1, h * 1.1]) - 20           # some boxes leave the image
+        b = torch.cat([xy, xy + 10 + torch.rand(n, 2, generator=g) * 200], 1)
+        if n >= 100:
+            b[10:40] = b[:30] + torch.rand(30, 4, generator=g) * 3                             # near-duplicates for the NMS
+        s = torch.softmax(torch.randn(n, K + 1, generator=g) * 3, dim=1)
+        boxes.append(b.cuda())
+        scores.append(s.cuda())
+    scores[3] = scores[3] * 1e-3                                                               # nothing above the threshold
+    for thresh, topk in ((0.05, 100), (0.2, 5), (0.0, 20)):
+        got, got_rows = beh.fast_rcnn_inference(boxes, scores, shapes, thresh, 0.5, topk)
+        for i in range(len(sizes)):
+            want, want_rows = beh.fast_rcnn_inference_single_image(boxes[i], scores[i], shapes[i], thresh, 0.5, topk)
+            assert len(got[i]) == len(want), (thresh, topk, i, len(got[i]), len(want))
+            assert torch.equal(got[i].pred_boxes.tensor, want.pred_boxes.tensor)
+            assert torch.equal(got[i].scores, want.scores) and torch.equal(got[i].pred_classes, want.pred_classes)
+            assert torch.equal(got_rows[i], want_rows)
+        assert len(got[1]) == 0 and len(got[3]) == (0 if thresh > 0 else min(topk, len(got[3])))
