@@ -34,6 +34,9 @@
 #ifndef LOCOV_RES_PREFETCH
 #define LOCOV_RES_PREFETCH 4
 #endif
+#ifndef LOCOV_STORE_AUX
+#define LOCOV_STORE_AUX 2     // cache policy bits of the epilogue's stores: 2 = nt (A/B: tools/make_variant.py ... -DLOCOV_STORE_AUX=0)
+#endif
 
 namespace locov {
 
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
                     *reinterpret_cast<f32x4 *>(ep + (it * RPI + rr) * EPS + c4) = v;    // finished value back in place
                 else
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, FULL ? voff : voff + it * vstep,
-                                                           FULL ? it * vstep : 0u, 2);  // aux 2 = nt: streamed once
+                                                           FULL ? it * vstep : 0u, LOCOV_STORE_AUX);  // aux 2 = nt: streamed once
             }
         }
         if (SEGSUM) {
