@@ -54,7 +54,6 @@ constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 16, NB = TN / 16;   // a wav
 constexpr int BK = 32;                      // fp32 columns per K-tile = the k of one v_mfma_f32_16x16x32_f16
 constexpr int ROWB = 160;                   // LDS pitch of an A row: 8 data slots of 16 B + 2 pad (layout below)
 constexpr int WROWB = 128;                  // W tile rows in LDS: unpadded (LDS DMA writes 1 KB runs), XOR-swizzled
-constexpr int STAGEB = BM * ROWB + BN * WROWB;   // bytes per stage
 constexpr int CH = 4;                       // 16-byte chunks per thread, operand and tile
 
 // W rows sit unpadded in LDS with their eight 16-byte chunks XOR-permuted by wswz(row) (a function of (row/2)%8):
@@ -116,14 +115,22 @@ __device__ unsigned long long g_ktrace[4 * 16];
 #define KSTAMP(i)
 #endif
 
-template <bool SEGSUM, bool EMASK = false, bool ASPLIT = false>
-__global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restrict__ A, int64_t lda,
+// WM_: waves along M.  2 = the 128x128 tile, two workgroups per CU; 4 = a 256x128 tile of 8 waves, ONE workgroup per CU: the W
+// tile is shared by twice the rows, so the CU stages 48 KB per K-tile through L2 -> LDS for the MFMA work it staged 64 KB for.
+template <bool SEGSUM, bool EMASK = false, bool ASPLIT = false, int WM_ = 2>
+__global__ __launch_bounds__(128 * WM_, WM_ == 2 ? 2 : 1) void gemm_split_kernel(const float *__restrict__ A, int64_t lda,
                                                            const float *__restrict__ B, float *__restrict__ Cout,
                                                            int64_t ldc, int64_t M, int N, int K, Epilogue epi, Batch bt,
                                                            float a_scale, float out_scale, SegSum ss, unsigned *overflow,
                                                            const float *__restrict__ a_scale_dev)
 {
-    __shared__ u32x4 lds[2 * STAGEB / 16];
+    constexpr int WM = WM_, BM = TM * WM, NT = 64 * WM * WN, NW = WM * WN;
+    constexpr int STAGEB = BM * ROWB + BN * WROWB;        // bytes per stage
+    constexpr int CHB = BN / 8 / NW;                      // LDS-DMA pieces (8 rows each) of the W tile per wave
+    constexpr int EPS = TN + 4;                           // epilogue staging pitch (floats)
+    constexpr int LDSB = 2 * STAGEB > NW * TM * EPS * 4 ? 2 * STAGEB : NW * TM * EPS * 4;
+    static_assert(!SEGSUM || WM_ == 2, "the mean-fused form is written for the 128-row tile");
+    __shared__ u32x4 lds[LDSB / 16];
     char *const ldsb = reinterpret_cast<char *>(lds);
 #ifdef LOCOV_KTRACE
     const unsigned long long kw0_ = __builtin_amdgcn_s_memtime();
@@ -192,18 +199,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
     // (4w + i)*8 .. +7; lane l supplies row l/8 and fetches the GLOBAL chunk (l%8) ^ x(row), x = (row/2) % 8, so that
     // chunk c of row r sits at slot c ^ x(r): the fragment reads below (32 consecutive rows, same c) then touch all
     // 16 sixteen-byte slots of the 256-byte bank window exactly once per 16-lane group.
-    unsigned b_voff[CH];
+    unsigned b_voff[CH];              // (CHB <= CH entries used; a template-dependent array size captured by the lambdas below loses hipcc the host stub)
 #pragma unroll
-    for (int i = 0; i < CH; i++) {
-        const int row = (wave * CH + i) * 8 + (lane >> 3), gn = n0 + row;
+    for (int i = 0; i < CHB; i++) {
+        const int row = (wave * CHB + i) * 8 + (lane >> 3), gn = n0 + row;
         b_voff[i] = (unsigned)(((int64_t)((gn < N ? gn : N - 1) - n0) * K * 4) + (((lane & 7) ^ wswz(row)) * 16));
     }
     auto dma_b = [&](int stage) {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b_base), 0, 0xffffffff, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < CH; i++)
+        for (int i = 0; i < CHB; i++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                r, (__attribute__((address_space(3))) void *)(ldsb + stage * STAGEB + BM * ROWB + (wave * CH + i) * 8 * WROWB), 16,
+                r, (__attribute__((address_space(3))) void *)(ldsb + stage * STAGEB + BM * ROWB + (wave * CHB + i) * 8 * WROWB), 16,
                 b_voff[i], 0, 0, 0);
     };
     // ASPLIT: the same DMA for A (rows past M are clamped to the last row: they only feed outputs that are never stored)
@@ -441,8 +448,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_split_kernel(const float *__restri
     // Epilogue (C/D layout of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg): re-lay the wave's sub-tile out
     // through LDS, 16 bytes per lane and row-contiguous from there.
     const bool relu = (epi.flags & LOCOV_EPI_RELU) != 0;
-    constexpr int EPS = TN + 4;
-    static_assert(WM * WN * TM * EPS * 4 <= 2 * STAGEB, "epilogue staging must fit the K-loop LDS");
+    static_assert(NW * TM * EPS * 4 <= LDSB && LDSB <= 160 * 1024, "epilogue staging must fit the LDS");
     float *ep = reinterpret_cast<float *>(lds) + wave * (TM * EPS);
     const int64_t seg_q0 = SEGSUM ? m0 / ss.seg : 0;                 // first ROI of the tile, and the position its first row holds
     const int seg_r0 = SEGSUM ? (int)(m0 - seg_q0 * ss.seg) : 0;
@@ -645,24 +651,35 @@ int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C,
         return set_error(LOCOV_ERR_UNSUPPORTED, "%s: N, lda, ldc must be multiples of 4 and every pointer 16-byte aligned", what);
     if (bt.count > 1 && epi.residual) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: batched launches take no residual", what);
     const int count = bt.count > 1 ? bt.count : 1;
-    const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN) * count;
+    // tile choice: the 256-row tile (one 8-wave workgroup per CU) where there are enough of them to fill the chip a few times
+    const char *big_e = getenv("LOCOV_SPLIT_BIG");          // (experiment knob; the heuristic below is the product)
+    const int big_env = big_e ? atoi(big_e) : -1;
+    const bool big = big_env >= 0 ? big_env != 0 : false;
+    const int bm = big ? 256 : BM;
+    const int64_t tiles = ceil_div(M, bm) * ceil_div(N, BN) * count;
     if (tiles > 0x7fffffffLL) return set_error(LOCOV_ERR_INVALID_ARG, "%s: problem too large", what);
-    if ((int64_t)BM * (lda > ldc ? lda : ldc) * 4 > 0x7fffffffLL)
+    if ((int64_t)bm * (lda > ldc ? lda : ldc) * 4 > 0x7fffffffLL)
         return set_error(LOCOV_ERR_INVALID_ARG, "%s: row pitch too large for 32-bit tile offsets", what);
     const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K * count);     // class 5: split-operand GEMM
+    const float os = 1.f / (a_scale * w_scale);
+    const float *Bw = reinterpret_cast<const float *>(Wsplit);
+    const SegSum ss0{0, 0, nullptr};
+#define LOCOV_LAUNCH_SPLIT(EM, AS, WMV)                                                                                         \
+    hipLaunchKernelGGL((gemm_split_kernel<false, EM, AS, WMV>), dim3((unsigned)tiles), dim3(64 * WMV * WN), 0, s, A, lda, Bw, C, \
+                       ldc, M, N, K, epi, bt, a_scale, os, ss0, overflow, a_scale_dev)
     if (epi.flags & LOCOV_GEMM_A_SPLIT) {
         if (epi.mask || a_scale_dev) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: pre-split A takes no mask / device scale", what);
-        hipLaunchKernelGGL((gemm_split_kernel<false, false, true>), dim3((unsigned)tiles), dim3(NT), 0, s, A, lda,
-                           reinterpret_cast<const float *>(Wsplit), C, ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale),
-                           SegSum{0, 0, nullptr}, overflow, a_scale_dev);
+        if (big)
+            LOCOV_LAUNCH_SPLIT(false, true, 4);
+        else
+            LOCOV_LAUNCH_SPLIT(false, true, 2);
     } else if (epi.mask)
-        hipLaunchKernelGGL((gemm_split_kernel<false, true>), dim3((unsigned)tiles), dim3(NT), 0, s, A, lda,
-                           reinterpret_cast<const float *>(Wsplit), C, ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale),
-                           SegSum{0, 0, nullptr}, overflow, a_scale_dev);
+        LOCOV_LAUNCH_SPLIT(true, false, 2);
+    else if (big)
+        LOCOV_LAUNCH_SPLIT(false, false, 4);
     else
-        hipLaunchKernelGGL((gemm_split_kernel<false, false>), dim3((unsigned)tiles), dim3(NT), 0, s, A, lda,
-                           reinterpret_cast<const float *>(Wsplit), C, ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale),
-                           SegSum{0, 0, nullptr}, overflow, a_scale_dev);
+        LOCOV_LAUNCH_SPLIT(false, false, 2);
+#undef LOCOV_LAUNCH_SPLIT
     timing_end(trec, s);
     return check_launch(what);
 }

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import threading
 from typing import NamedTuple, Optional, Sequence, Tuple
 
 import torch
@@ -390,25 +391,92 @@ def gemm_nt_batched(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return y
 
 
+class RangeGuard:
+    """One range-guard word of the split arithmetic: a device int32 every split-operand launch made while the guard is
+    ACTIVE (`with ops.range_guard(g):`) ORs 1 into when it saw |scale * x| >= 65504, plus a pinned host mirror.
+
+        g.reset()            zero the word (enqueued on the current stream)
+        g.snapshot()         enqueue the 4-byte copy to pinned memory + an event (no host wait)
+        g.raised()           the mirrored value; waits for the snapshot's event only (takes the snapshot first if none is pending)
+
+    A guard belongs to ONE caller (a module and a stream): nothing else clears or reads it, so a reset enqueued by another
+    module, stream or thread cannot hide a flag raised for this caller."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.word = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.event = None
+
+    def reset(self) -> None:
+        self.word.zero_()
+        self.event = None
+
+    def snapshot(self) -> None:
+        self.host.copy_(self.word, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(self.device))
+
+    def raised(self) -> bool:
+        if self.event is None:
+            self.snapshot()
+        self.event.synchronize()
+        self.event = None
+        return bool(int(self.host[0]))
+
+
+_GUARDS = threading.local()
 _OVERFLOW = {}
 
 
+class range_guard:
+    """Context manager: split-operand launches on `guard.device` made inside the block raise `guard`'s word."""
+
+    def __init__(self, guard: Optional[RangeGuard]):
+        self.guard = guard
+
+    def __enter__(self):
+        st = getattr(_GUARDS, "stack", None)
+        if st is None:
+            st = _GUARDS.stack = []
+        st.append(self.guard)
+        return self.guard
+
+    def __exit__(self, *exc):
+        _GUARDS.stack.pop()
+        return False
+
+
+def active_guard(device) -> Optional[RangeGuard]:
+    """The innermost active guard of this thread for `device` (None outside every range_guard block)."""
+    for g in reversed(getattr(_GUARDS, "stack", None) or ()):
+        if g is not None and g.device == torch.device(device):
+            return g
+    return None
+
+
 def _overflow_word(ref: torch.Tensor) -> torch.Tensor:
-    """The device word every split-operand launch of this process ORs its range-guard result into (one per device)."""
-    w = _OVERFLOW.get(ref.device)
+    """The device word a split-operand launch ORs its range-guard result into: the active guard's (range_guard), else a
+    per-(device, stream) word that nobody reads (launches outside every guard are unguarded by the caller's choice)."""
+    g = active_guard(ref.device)
+    if g is not None:
+        return g.word
+    key = (ref.device, torch.cuda.current_stream(ref.device).cuda_stream)
+    w = _OVERFLOW.get(key)
     if w is None:
-        w = _OVERFLOW[ref.device] = torch.zeros(1, dtype=torch.int32, device=ref.device)
+        w = _OVERFLOW[key] = torch.zeros(1, dtype=torch.int32, device=ref.device)
     return w
 
 
 def split_overflow_reset(device) -> None:
-    """Clear the range-guard word of `device` (enqueued on the current stream)."""
+    """Clear the default (unguarded-launch) word of `device` and the current stream.  Kept for callers that drive single
+    launches by hand (tests, tools); modules own a RangeGuard instead."""
     _overflow_word(torch.empty(0, device=device)).zero_()
 
 
 def split_overflow_raised(device) -> bool:
-    """True when a split-operand launch since the last reset saw |x_scale * x| >= 65504 (ONE host read: it waits for the
-    launches enqueued so far)."""
+    """True when a split-operand launch on the current stream, outside every guard, since the last reset saw
+    |x_scale * x| >= 65504 (ONE host read: it waits for the launches enqueued so far)."""
     return bool(_overflow_word(torch.empty(0, device=device)).item())
 
 

@@ -112,6 +112,39 @@ class Res5Stage(nn.Sequential):
         super().__init__(*blocks)
         self._cache = {}
         self._scales = {}           # convolution -> (split-operand scale, uses): see _split
+        self._guards = {}           # (kind, device, stream) -> ops.RangeGuard
+
+    def range_guard(self, kind: str, device):
+        """This stage's range-guard word of the split arithmetic for `kind` ("fwd": owned by whoever runs a guarded forward;
+        "bwd": raised by Res5RowsFn.backward, never reset there) on `device` and the current stream."""
+        from . import ops
+        key = (kind, torch.device(device), torch.cuda.current_stream(device).cuda_stream)
+        g = self._guards.get(key)
+        if g is None:
+            g = self._guards[key] = ops.RangeGuard(device)
+        return g
+
+    def backward_guard_words(self, device):
+        """Device words of every "bwd" guard of `device` (to be read together with another host read)."""
+        dev = torch.device(device)
+        return [g.word for (kind, d, _), g in self._guards.items() if kind == "bwd" and d == dev]
+
+    def backward_guard_tripped(self) -> None:
+        """A remembered weight scale stopped covering its weight during a backward: forget the scales (they are chosen
+        afresh at the next packing) and clear the words."""
+        self._scales.clear()
+        self._cache.clear()
+        for (kind, _, _), g in self._guards.items():
+            if kind == "bwd":
+                g.reset()
+
+    def backward_guard_raised(self, device) -> bool:
+        """One host read: did a backward since the last check trip the range guard?  (Clears it when it did.)"""
+        words = self.backward_guard_words(device)
+        hit = bool(words) and bool(int(torch.stack([w.reshape(()) for w in words]).max()))
+        if hit:
+            self.backward_guard_tripped()
+        return hit
 
     def supports_rows_path(self) -> bool:
         b0 = self[0]
@@ -194,7 +227,7 @@ class Res5Stage(nn.Sequential):
         re-used while the weights train -- choosing it needs max |w| on the host, i.e. a device sync per packing, ten per
         training step; weights drift slowly against the 8x headroom the scale leaves, the pack kernel raises the
         range-guard word if a re-used scale ever stops covering them (the caller then repeats the pass on the f32 MFMA and
-        drops the remembered scales), and every 256 uses the scale is chosen afresh."""
+        drops the remembered scales), and every 64 uses the scale is chosen afresh."""
         from . import ops
         hit = self._cache.get(("split", id(t)))
         if hit is not None and hit[0] is t:
@@ -203,16 +236,24 @@ class Res5Stage(nn.Sequential):
         scale = None
         if key is not None:
             rec = self._scales.get(key)
-            if rec is not None and rec[1] < 256:
+            if rec is not None and rec[1] < 64:
                 scale, self._scales[key] = rec[0], (rec[0], rec[1] + 1)
             else:
                 scale = ops.split_scale_for(t)
                 self._scales[key] = (scale, 0)
         out = ops.split_pack(t.contiguous(), scale)
-        stale = [k for k in self._cache if isinstance(k, tuple) and k and k[0] == "split"]
-        if len(stale) >= 64:                     # weights that keep changing (training + eval): drop superseded packings
-            for k in stale:
-                del self._cache[k]
+        if key is not None:
+            # ONE live packing per (convolution, tag): a new tensor under the same key (the weights trained, or a per-backward
+            # temporary such as the transposed / flipped filters) supersedes the old one, whose buffers are released here
+            old = self._cache.pop(("split_of", key), None)
+            if old is not None:
+                self._cache.pop(("split", old), None)
+            self._cache[("split_of", key)] = id(t)
+        else:
+            stale = [k for k in self._cache if isinstance(k, tuple) and k and k[0] == "split"]
+            if len(stale) >= 64:                 # un-keyed tensors (tools, tests): bounded
+                for k in stale:
+                    del self._cache[k]
         self._cache[("split", id(t))] = (t, out)
         return out
 

@@ -92,12 +92,17 @@ class Res5RowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, stage, R, H, W, pooled, split, guard, *weights):
         """guard: None, or (on_overflow,) -- check the split arithmetic's range-guard word after the forward and repeat it on
-        the f32 MFMA when an activation left fp16's range (calls on_overflow() first)."""
+        the f32 MFMA when an activation left fp16's range (calls on_overflow() first).  Inside a caller's own
+        `ops.range_guard` block the launches raise THAT guard and nothing is read here: the caller checks once for all the
+        calls it made (EmbeddingProposalsRes5ROIHeads.forward: one read for the whole-grid and the ROI call together)."""
         x = ops._dev(x0.detach(), "x0")
-        if split and guard is not None:
-            ops.split_overflow_reset(x.device)
-        saved, meta, out = Res5RowsFn._blocks(stage, x, H, W, split)
-        if split and guard is not None and ops.split_overflow_raised(x.device):
+        own = None
+        if split and guard is not None and ops.active_guard(x.device) is None:
+            own = stage.range_guard("fwd", x.device)
+            own.reset()
+        with ops.range_guard(own):
+            saved, meta, out = Res5RowsFn._blocks(stage, x, H, W, split)
+        if own is not None and own.raised():
             if guard[0] is not None:
                 guard[0]()
             del saved, out
@@ -114,16 +119,16 @@ class Res5RowsFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         if not ctx.split:
             return Res5RowsFn._backward(ctx, grad_out, False)
-        # split arithmetic: same range guard as the forward (only a remembered weight scale that stopped fitting can trip
-        # it here -- the activations passed the forward's guard, the gradients' scales are chosen on the device)
-        dev = grad_out.device
-        ops.split_overflow_reset(dev)
-        out = Res5RowsFn._backward(ctx, grad_out, True)
-        if ops.split_overflow_raised(dev):
-            ctx.stage._scales.clear()
-            ctx.stage._cache.clear()
-            out = Res5RowsFn._backward(ctx, grad_out, False)
-        return out
+        # Split arithmetic.  What can leave fp16's range here is not data: the activations passed the forward's guard (the
+        # weight-gradient GEMMs and the Winograd transforms see the same tensors at the same scales) and every gradient's
+        # operand scale is chosen on the device from its own max |g|.  Only a REMEMBERED weight scale (Res5Stage._split: chosen
+        # afresh every 64 packings, 8x headroom) that stopped covering a weight could trip the guard -- the pack kernel
+        # raises it.  That is recorded in the stage's "bwd" guard and nothing is read inside autograd (a host read here would
+        # stall DDP's overlapped all-reduce): the ROI heads look at the word together with the ONE host read of the next
+        # step's labelling (SampleAllROIHeads.label_and_sample_proposals) and then drop the remembered scales with a warning;
+        # `stage.backward_guard_raised()` reads it on demand.
+        with ops.range_guard(ctx.stage.range_guard("bwd", grad_out.device)):
+            return Res5RowsFn._backward(ctx, grad_out, True)
 
     @staticmethod
     def _backward(ctx, grad_out, sp):

@@ -39,7 +39,9 @@ class Box2BoxTransform:
         self.weights = tuple(float(w) for w in weights)
         self.scale_clamp = scale_clamp
 
-    def get_deltas(self, src_boxes: torch.Tensor, target_boxes: torch.Tensor) -> torch.Tensor:
+    def get_deltas(self, src_boxes: torch.Tensor, target_boxes: torch.Tensor, check: bool = True) -> torch.Tensor:
+        """check=False: the caller has already established that every source box has positive width and height (the ROI
+        heads' labelling reads that bit with its one host read and raises this same AssertionError there)."""
         src_w = src_boxes[:, 2] - src_boxes[:, 0]
         src_h = src_boxes[:, 3] - src_boxes[:, 1]
         src_cx = src_boxes[:, 0] + 0.5 * src_w
@@ -54,7 +56,8 @@ class Box2BoxTransform:
         dw = ww * torch.log(tgt_w / src_w)
         dh = wh * torch.log(tgt_h / src_h)
         deltas = torch.stack((dx, dy, dw, dh), dim=1)
-        torch._assert_async((src_w > 0).all())       # "Input boxes to Box2BoxTransform are not valid!" (device-side: no host sync)
+        if check:       # (a host read, as in Detectron2; device-side asserts compile to nothing on this ROCm build)
+            assert bool(((src_w > 0) & (src_h > 0)).all()), "Input boxes to Box2BoxTransform are not valid!"
         return deltas
 
     def apply_deltas(self, deltas: torch.Tensor, boxes: torch.Tensor) -> torch.Tensor:
@@ -339,7 +342,9 @@ class FastRCNNOutputLayers(nn.Module):
             x = torch.flatten(x, start_dim=1)
         return hip_linear(x, self.cls_score), hip_linear(x, self.bbox_pred)
 
-    def losses(self, predictions, proposals):
+    def losses(self, predictions, proposals, boxes_validated: bool = False):
+        """boxes_validated: the proposals come from SampleAllROIHeads.label_and_sample_proposals, which has already
+        checked (and raised for) degenerate foreground boxes -- get_deltas' host-side assert is then skipped."""
         scores, proposal_deltas = predictions
         gt_classes = (torch.cat([p.gt_classes for p in proposals], dim=0) if len(proposals)
                       else torch.empty(0, dtype=torch.int64, device=scores.device))
@@ -355,10 +360,11 @@ class FastRCNNOutputLayers(nn.Module):
         else:
             loss_cls = F.cross_entropy(scores, gt_classes, reduction="mean")
         losses = {"loss_cls": loss_cls,
-                  "loss_box_reg": self.box_reg_loss(proposal_boxes, gt_boxes, proposal_deltas, gt_classes)}
+                  "loss_box_reg": self.box_reg_loss(proposal_boxes, gt_boxes, proposal_deltas, gt_classes,
+                                                    boxes_validated=boxes_validated)}
         return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
 
-    def box_reg_loss(self, proposal_boxes, gt_boxes, pred_deltas, gt_classes):
+    def box_reg_loss(self, proposal_boxes, gt_boxes, pred_deltas, gt_classes, boxes_validated: bool = False):
         """[D2-upstream] smooth-L1 over the foreground rows, normalised by ALL rows.  The foreground rows are selected by a
         mask instead of `nonzero` indices (a data-dependent size = a host sync): background rows get a unit box as source and
         target (zero deltas, finite everywhere) and weight 0 in the sum -- same value, same gradients."""
@@ -374,9 +380,12 @@ class FastRCNNOutputLayers(nn.Module):
         unit = torch.cat([proposal_boxes.new_zeros(box_dim // 2), proposal_boxes.new_ones(box_dim - box_dim // 2)])   # [0, 0, 1, 1], built on the device
         src_boxes = torch.where(fg[:, None], proposal_boxes, unit)        # (background rows may be degenerate boxes: they
         target_boxes = torch.where(fg[:, None], gt_boxes, unit)           # never reach get_deltas' validity check upstream)
-        gt_pred_deltas = self.box2box_transform.get_deltas(src_boxes, target_boxes)
+        gt_pred_deltas = self.box2box_transform.get_deltas(src_boxes, target_boxes, check=not boxes_validated)
+        # background / ignored rows are REPLACED, not multiplied by zero: a non-finite prediction in such a row (which the
+        # indexed upstream form never touches) must not reach the value (0 * inf = NaN) or the gradient
+        pred = torch.where(fg[:, None], pred, gt_pred_deltas)
         per_elem = smooth_l1_loss(pred, gt_pred_deltas, self.smooth_l1_beta, reduction="none")
-        loss_box_reg = (per_elem * fg[:, None].to(per_elem.dtype)).sum()
+        loss_box_reg = torch.where(fg[:, None], per_elem, per_elem.new_zeros(())).sum()
         return loss_box_reg / max(gt_classes.numel(), 1.0)
 
     def inference(self, predictions, proposals):

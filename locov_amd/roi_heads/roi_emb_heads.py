@@ -64,6 +64,7 @@ class Matcher:
         assert len(labels) == len(thresholds) - 1
         self.thresholds, self.labels = thresholds, labels
         self.allow_low_quality_matches = allow_low_quality_matches
+        self.check_quality = True          # host-side assert of Detectron2's Matcher (SampleAllROIHeads folds it into its one read)
 
     def __call__(self, match_quality_matrix: torch.Tensor):
         assert match_quality_matrix.dim() == 2
@@ -72,7 +73,11 @@ class Matcher:
             default_match_labels = match_quality_matrix.new_full((match_quality_matrix.size(1),), self.labels[0],
                                                                  dtype=torch.int8)
             return default_matches, default_match_labels
-        torch._assert_async(torch.all(match_quality_matrix >= 0))      # (device-side assert: no host sync)
+        # (Detectron2 asserts `torch.all(match_quality_matrix >= 0)` here, a host sync per image; the labelling below reads the
+        # same bit for the whole batch with its ONE host read and raises the AssertionError there -- `check_quality` is for
+        # other callers)
+        if self.check_quality:
+            assert torch.all(match_quality_matrix >= 0)
         matched_vals, matches = match_quality_matrix.max(dim=0)
         match_labels = matches.new_full(matches.size(), 1, dtype=torch.int8)
         for (l, low, high) in zip(self.labels, self.thresholds[:-1], self.thresholds[1:]):
@@ -181,16 +186,28 @@ class SampleAllROIHeads(ROIHeads):
     background populations the sampler needs (`subsample_order`): labelling a batch costs ONE host sync in total."""
 
     def _match_one_image(self, props: Instances, tgt: Instances):
-        """Everything of one image's labelling that needs no host value: IoU, matching, class labels, sampling orders."""
+        """Everything of one image's labelling that needs no host value: IoU, matching, class labels, sampling orders, and
+        the two validity bits the reference asserts on the host (Matcher: IoU >= 0; Box2BoxTransform.get_deltas: every
+        foreground proposal has positive width and height) as device values for the batch's one read."""
         iou = pairwise_iou(tgt.gt_boxes, props.proposal_boxes)                 # [num_gt, num_proposals]
-        gt_index, match_label = self.proposal_matcher(iou)
+        matcher = self.proposal_matcher
+        was, matcher.check_quality = getattr(matcher, "check_quality", True), False
+        try:
+            gt_index, match_label = matcher(iou)
+        finally:
+            matcher.check_quality = was
         if tgt.gt_classes.numel() > 0:                                         # ROIHeads._sample_proposals' labelling
             labels = tgt.gt_classes[gt_index]
             labels[match_label == 0] = self.num_classes
             labels[match_label == -1] = -1
         else:
             labels = torch.zeros_like(gt_index) + self.num_classes
-        return (gt_index, labels) + subsample_order(labels, self.num_classes)
+        pos_order, neg_order, counts = subsample_order(labels, self.num_classes)
+        box = props.proposal_boxes.tensor
+        fg = (labels >= 0) & (labels != self.num_classes)
+        degenerate = ~(((box[:, 2] - box[:, 0]) > 0) & ((box[:, 3] - box[:, 1]) > 0)) & fg        # (NaN counts as invalid, as upstream)
+        bad = torch.stack([~(iou >= 0).all() if iou.numel() else degenerate.new_zeros(()), degenerate.any()]).to(counts.dtype)
+        return gt_index, labels, pos_order, neg_order, torch.cat([counts, bad])
 
     def _finish_one_image(self, props: Instances, tgt: Instances, gt_index, labels, pos_order, neg_order, n_pos_avail, n_neg_avail):
         num_pos = min(n_pos_avail, int(self.batch_size_per_image * self.positive_fraction))      # subsample_labels' counts
@@ -208,13 +225,35 @@ class SampleAllROIHeads(ROIHeads):
         out.set("fg_proposal", (~is_bg).to(classes.dtype))
         return out, num_neg, num_pos + num_neg
 
+    def _backward_guard_words(self, device):
+        """Device words to read with the labelling sync (none in the base class)."""
+        return []
+
+    def _backward_guard_tripped(self) -> None:
+        pass
+
     @torch.no_grad()
     def label_and_sample_proposals(self, proposals: List[Instances], targets: List[Instances]) -> List[Instances]:
         if self.proposal_append_gt:
             proposals = add_ground_truth_to_proposals(targets, proposals)
         sampled, bg_counts, totals = [], [], []
         matched = [self._match_one_image(props, tgt) for props, tgt in zip(proposals, targets)]     # no host value needed
-        avail = torch.stack([m[-1] for m in matched]).cpu().tolist() if matched else []              # ONE sync for the whole batch
+        # ONE host read for the whole batch: population sizes, the reference's two validity asserts, and -- it costs nothing
+        # here -- the range-guard words the previous step's Res5 backward may have raised (res5_train.Res5RowsFn.backward)
+        avail = []
+        if matched:
+            rows = torch.stack([m[-1] for m in matched])
+            words = self._backward_guard_words(rows.device)
+            if words:
+                flat = torch.cat([rows.reshape(-1), torch.stack([w.reshape(()) for w in words]).to(rows.dtype)]).cpu()
+                rows_h, guard_h = flat[:rows.numel()].view(rows.shape), flat[rows.numel():]
+                if bool(guard_h.any()):
+                    self._backward_guard_tripped()
+            else:
+                rows_h = rows.cpu()
+            assert not bool(rows_h[:, 2].any()), "Matcher: the match quality matrix has negative entries"
+            assert not bool(rows_h[:, 3].any()), "Input boxes to Box2BoxTransform are not valid!"
+            avail = rows_h[:, :2].tolist()
         for props, tgt, m, (n_pos_avail, n_neg_avail) in zip(proposals, targets, matched, avail):
             out, n_bg, n = self._finish_one_image(props, tgt, *m[:-1], int(n_pos_avail), int(n_neg_avail))
             sampled.append(out)
@@ -347,13 +386,42 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
             return self._pooled_mean(x) if pooled else x
         if self.res5_dtype == "f16x2" and self.res5_overflow_check:
             dev = features[0].device
-            ops.split_overflow_reset(dev)
-            out = self._fused_roi_transform(features, boxes, pooled, "f16x2")
-            if not ops.split_overflow_raised(dev):           # one 4-byte read per call
+            if ops.active_guard(dev) is not None:
+                # the caller holds the guard (inference_detection / forward): the launches raise ITS word, it reads the word
+                # once, behind everything it enqueued, and repeats the call on the f32 MFMA itself
+                return self._fused_roi_transform(features, boxes, pooled, "f16x2")
+            guard = self.res5.range_guard("fwd", dev)
+            guard.reset()
+            with ops.range_guard(guard):
+                out = self._fused_roi_transform(features, boxes, pooled, "f16x2")
+            if not guard.raised():                           # one 4-byte read per call
                 return out
             self._warn_overflow()
             return self._fused_roi_transform(features, boxes, pooled, "fp32")
         return self._fused_roi_transform(features, boxes, pooled, self.res5_dtype)
+
+    def _deferred_guard(self, feats: List[torch.Tensor]):
+        """The range guard of a whole forward, read ONCE where the caller synchronises anyway -- or None when this call
+        needs none (not the split arithmetic, check switched off, or not a hand-written path)."""
+        if not (self.res5_dtype == "f16x2" and self.res5_overflow_check and self._rows_path_ok(feats)
+                and hasattr(self.res5, "range_guard")):
+            return None
+        dev = feats[0].device
+        if ops.active_guard(dev) is not None:
+            return None                                      # an outer caller already holds one
+        guard = self.res5.range_guard("fwd", dev)
+        guard.reset()
+        return guard
+
+    def _backward_guard_words(self, device):
+        return self.res5.backward_guard_words(device) if hasattr(self.res5, "backward_guard_words") else []
+
+    def _backward_guard_tripped(self) -> None:
+        import warnings
+        self.res5.backward_guard_tripped()
+        warnings.warn("a remembered split-operand weight scale stopped covering its weight during the previous step's Res5 backward "
+                      "(weights grew 8x within 64 steps): that step's Res5 weight gradients may hold inf / NaN; the scales are "
+                      "chosen afresh from here on", RuntimeWarning, stacklevel=3)
 
     def _warn_overflow(self):
         if hasattr(self.res5, "_scales"):
@@ -425,14 +493,57 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
             assert targets
             proposals = self.label_and_sample_proposals(proposals, targets)
         del targets
+        if not self.training:
+            return self._detect(features, proposals)
         proposal_boxes = [x.proposal_boxes for x in proposals]
-        box_features = self._shared_roi_transform([features[f] for f in self.in_features], proposal_boxes, pooled=True)
+        feats = [features[f] for f in self.in_features]
+        guard = self._deferred_guard(feats)
+        with ops.range_guard(guard):
+            box_features = self._shared_roi_transform(feats, proposal_boxes, pooled=True)
+        if guard is not None and guard.raised():             # the step's one range-guard read
+            self._warn_overflow()
+            box_features = self._with_res5_dtype("fp32", self._shared_roi_transform, feats, proposal_boxes, pooled=True)
         predictions = self.box_predictor(box_features)       # (:261-262: the mean is all the predictor sees)
-        if self.training:
-            del features
-            losses = self.box_predictor.losses(predictions, proposals)
-            return [], losses
+        del features
+        losses = self._predictor_losses(predictions, proposals)
+        return [], losses
+
+    def _predictor_losses(self, predictions, proposals):
+        """box_predictor.losses on proposals that label_and_sample_proposals has validated (its one host read covers
+        get_deltas' "Input boxes ... are not valid!" assert); a predictor without the keyword runs its own check."""
+        import inspect
+        fn = self.box_predictor.losses
+        if "boxes_validated" in inspect.signature(fn).parameters:
+            return fn(predictions, proposals, boxes_validated=True)
+        return fn(predictions, proposals)
+
+    def _with_res5_dtype(self, dtype, fn, *args, **kw):
+        was, self.res5_dtype = self.res5_dtype, dtype
+        try:
+            return fn(*args, **kw)
+        finally:
+            self.res5_dtype = was
+
+    def _detect(self, features, proposals):
+        """The inference half of roi_emb_heads.py:247-282 / :351-360: ROIAlign + Res5 + mean -> box predictor -> post-processing.
+        The split arithmetic's range guard costs NO host synchronisation here: the word is copied to pinned memory behind the
+        predictor (4 bytes, asynchronous) and looked at after the post-processing, whose own host reads have by then waited
+        for it; only a call that actually left the range is repeated (on the f32 MFMA) -- up to the post-processing the step
+        holds no host sync, allocation-free and graph-capturable."""
+        proposal_boxes = [x.proposal_boxes for x in proposals]
+        feats = [features[f] for f in self.in_features]
+        guard = self._deferred_guard(feats) if self._fused_path_ok(feats) else None
+        with ops.range_guard(guard):
+            box_features = self._shared_roi_transform(feats, proposal_boxes, pooled=True)     # :355-356
+            predictions = self.box_predictor(box_features)
+        if guard is not None:
+            guard.snapshot()
         pred_instances, _ = self.box_predictor.inference(predictions, proposals)
+        if guard is not None and guard.raised():
+            self._warn_overflow()
+            box_features = self._fused_roi_transform(feats, proposal_boxes, True, "fp32")
+            predictions = self.box_predictor(box_features)
+            pred_instances, _ = self.box_predictor.inference(predictions, proposals)
         pred_instances = self.forward_with_given_boxes(features, pred_instances)
         return pred_instances, {}
 
@@ -459,25 +570,29 @@ class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
         if self._train_path_ok(feats) and self._needs_graph(feats):
             from .. import res5_train
             nhwc = res5_train.to_nhwc(feats[0])          # one channels-last copy (and one gradient transpose) for both calls
-        visual_grid_features = self._res5_grid(feats[0], nhwc)                   # :323
         proposal_boxes = [x.proposal_boxes for x in proposals]
         boxes_per_image = [len(x) for x in proposals]
-        box_features = self._shared_roi_transform(feats, proposal_boxes, pooled=True, nhwc=nhwc)   # :343-344
+        # ONE range-guard read for both Res5 calls of the step (the whole grid and the sampled proposals); a step that left
+        # the split arithmetic's range repeats both on the f32 MFMA (the graph of the first attempt is simply dropped)
+        guard = self._deferred_guard(feats)
+        with ops.range_guard(guard):
+            visual_grid_features = self._res5_grid(feats[0], nhwc)               # :323
+            box_features = self._shared_roi_transform(feats, proposal_boxes, pooled=True, nhwc=nhwc)   # :343-344
+        if guard is not None and guard.raised():
+            self._warn_overflow()
+            del visual_grid_features, box_features
+            visual_grid_features = self._with_res5_dtype("fp32", self._res5_grid, feats[0], nhwc)
+            box_features = self._with_res5_dtype("fp32", self._shared_roi_transform, feats, proposal_boxes, pooled=True, nhwc=nhwc)
         del features
         losses = {}
         predictions = self.box_predictor(box_features)                           # :345
         box_features = list(box_features.split(boxes_per_image, dim=0))          # :346
-        losses.update(self.box_predictor.losses(predictions, proposals))         # :347
+        losses.update(self._predictor_losses(predictions, proposals))            # :347
         return visual_grid_features, box_features, proposals, losses
 
     def inference_detection(self, features, proposals):
         """roi_emb_heads.py:351-360."""
-        proposal_boxes = [x.proposal_boxes for x in proposals]
-        box_features = self._shared_roi_transform([features[f] for f in self.in_features], proposal_boxes, pooled=True)   # :355-356
-        predictions = self.box_predictor(box_features)
-        pred_instances, _ = self.box_predictor.inference(predictions, proposals)
-        pred_instances = self.forward_with_given_boxes(features, pred_instances)
-        return pred_instances, {}
+        return self._detect(features, proposals)
 
 
 def build_roi_heads(cfg, input_shape: Dict[str, ShapeSpec]):

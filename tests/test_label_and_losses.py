@@ -108,3 +108,85 @@ def test_label_sample_and_losses_vs_oracle_gpu(oracle, detach, batch, pos_frac):
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a ROCm device")
     _check(oracle, "cuda", detach, batch, pos_frac)
+
+
+def test_labelling_raises_the_references_asserts_on_the_host(oracle):
+    """Detectron2's two host-side validity asserts on this path -- Matcher: `torch.all(match_quality_matrix >= 0)`,
+    Box2BoxTransform.get_deltas: `(src_widths > 0).all()` "Input boxes to Box2BoxTransform are not valid!" -- are raised as
+    AssertionError by label_and_sample_proposals' ONE host read (device-side asserts are compiled out of this ROCm build):
+    a NaN proposal box has NaN IoU (fails `>= 0`), and a labelled-foreground box that is not strictly positive in width and
+    height fails the box check."""
+    heads = _heads(True, 64, 1.0, "cpu")
+    rng = np.random.default_rng(3)
+    props, targets, _ = _batch(oracle, rng, "cpu")
+    heads.label_and_sample_proposals(props, targets)                       # valid input: no error
+    # (a NaN proposal box does NOT trip either assert, here or upstream: pairwise_iou is 0 where the intersection is not
+    # positive, so such a box is background and never reaches get_deltas)
+    bad = props[0].proposal_boxes.tensor.clone()
+    bad[5, 0] = float("nan")
+    props[0].proposal_boxes = Boxes(bad)
+    heads.label_and_sample_proposals(props, targets)
+    # Matcher's assert: a match-quality matrix with a negative (or NaN) entry
+    import locov_amd.roi_heads.roi_emb_heads as reh
+    real_iou = reh.pairwise_iou
+    for poison in (-0.25, float("nan")):
+        def fake(a, b, poison=poison):
+            q = real_iou(a, b).clone()
+            if q.numel():
+                q.view(-1)[3] = poison
+            return q
+        reh.pairwise_iou = fake
+        try:
+            with pytest.raises(AssertionError, match="match quality"):
+                heads.label_and_sample_proposals(props, targets)
+        finally:
+            reh.pairwise_iou = real_iou
+    # the box check on its own: labels say foreground, the box has zero width (fed past the matcher)
+    props, targets, _ = _batch(oracle, rng, "cpu")
+    m = heads._match_one_image(props[0], targets[0])
+    assert m[-1].shape == (4,) and int(m[-1][2]) == 0 and int(m[-1][3]) == 0
+    gt = targets[0].gt_boxes.tensor
+    squashed = props[0].proposal_boxes.tensor.clone()
+    squashed[0] = gt[0]
+    squashed[0, 2] = squashed[0, 0]                                        # zero width ...
+    props[0].proposal_boxes = Boxes(squashed)
+    heads.proposal_matcher_orig = heads.proposal_matcher
+    class _AllFg:                                                          # ... and a matcher that still calls row 0 foreground
+        check_quality = True
+        def __call__(self, q):
+            idx, lab = heads.proposal_matcher_orig(q)
+            lab = lab.clone(); lab[0] = 1
+            return idx, lab
+    heads.proposal_matcher = _AllFg()
+    with pytest.raises(AssertionError, match="Input boxes to Box2BoxTransform are not valid"):
+        heads.label_and_sample_proposals(props, targets)
+    # get_deltas keeps the reference's own assert for every other caller
+    from locov_amd.roi_heads.box_emb_head import Box2BoxTransform
+    t = Box2BoxTransform((10.0, 10.0, 5.0, 5.0))
+    with pytest.raises(AssertionError, match="not valid"):
+        t.get_deltas(torch.tensor([[0.0, 0.0, 0.0, 5.0]]), torch.tensor([[0.0, 0.0, 4.0, 5.0]]))
+
+
+def test_box_reg_loss_ignores_non_finite_background_predictions():
+    """The mask-based box regression loss never lets a background / ignored row reach the value or the gradient: an inf or
+    NaN prediction there (which the indexed upstream form does not touch) leaves both exactly as without it."""
+    heads = _heads(False, 16, 0.5, "cpu")
+    bp = heads.box_predictor
+    g = torch.Generator().manual_seed(1)
+    n = 12
+    boxes = torch.rand(n, 4, generator=g) * 100
+    boxes[:, 2:] += boxes[:, :2] + 5
+    gt = boxes + torch.randn(n, 4, generator=g)
+    cls = torch.tensor([3, 80, 80, 7, -1, 80, 1, 80, 80, -1, 5, 80])
+    pred = (torch.randn(n, 4, generator=g) * 0.2)
+    clean = pred.clone().requires_grad_(True)
+    want = bp.box_reg_loss(boxes, gt, clean, cls)
+    want.backward()
+    dirty = pred.clone()
+    dirty[1] = float("inf"); dirty[4] = float("nan"); dirty[8, 2] = -float("inf")
+    dirty.requires_grad_(True)
+    got = bp.box_reg_loss(boxes, gt, dirty, cls)
+    got.backward()
+    assert torch.isfinite(got) and float(got) == float(want)
+    assert torch.isfinite(dirty.grad).all() and torch.equal(dirty.grad, clean.grad)
+    assert not dirty.grad[[1, 2, 4, 5, 7, 8, 9, 11]].any()
