@@ -50,7 +50,9 @@ def parse(argv=None):
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--mode", choices=["infer", "train"], default="infer",
-                   help="train: additionally time one LSM training step of the path (forward + backward + SGD)")
+                   help="train: the detailed training report (one --train-config, hip next to the MIOpen-autograd form of the same "
+                        "module).  The default run already carries a compact `train` object: configs 4 and 5 on the hip backend")
+    p.add_argument("--skip-train", action="store_true", help="no `train` object in the default run (profile runs)")
     p.add_argument("--images", type=int, default=8, help="images per GPU per step (SURVEY.md 8d: N = 8 / GPU)")
     p.add_argument("--proposals", type=int, default=1000)
     p.add_argument("--classes", type=int, default=1203)
@@ -216,12 +218,12 @@ class Workload:
 class TrainWorkload:
     """One LSM training step of the path (see the module docstring)."""
 
-    def __init__(self, args, device, backend, world, data_seed=1992):
+    def __init__(self, args, device, backend, world, data_seed=1992, config=None):
         import torch
         import locov_amd
         from locov_amd.grounding_head import GroundingHead
         self.args, self.device = args, device
-        self.stt = args.train_config == "stt"
+        self.stt = (config or args.train_config) == "stt"
         self.n_images = 3 if self.stt else args.train_images                 # IMS_PER_BATCH 24 / 8 GPUs (coco_stt.yaml:41)
         self.n_classes = 48 if self.stt else args.classes
         self.set_data(data_seed)
@@ -324,7 +326,7 @@ class TrainWorkload:
         return n_sampled
 
 
-TRAFFIC_FILE = "r02c_pmc_traffic.json"
+TRAFFIC_FILE = "r03_pmc_traffic.json"
 
 
 def recorded_traffic(args, kernel_key: str):
@@ -337,6 +339,11 @@ def recorded_traffic(args, kernel_key: str):
             rec = json.load(f)
         wl = rec["workload"]
         if any(wl[k] != getattr(args, k) for k in ("images", "proposals", "classes", "dim", "res5", "conv3x3", "block0", "res5_dtype")):
+            return None
+        # staleness: the PMC pass names the kernel sources it was taken on (locov_amd.build.source_fingerprint at collection
+        # time); a library built from other sources moves different bytes, so the recorded figure is refused
+        from locov_amd import build as _build
+        if rec.get("source_fingerprint") != _build.source_fingerprint():
             return None
         hits = [v for name, v in rec["kernels"].items() if kernel_key in name]      # every template instance of the kernel
         n = sum(v["launches_sampled"] for v in hits)
@@ -367,9 +374,21 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def cpu_model() -> str:
+    """CPU model string of this host (platform.processor() is empty on Linux)."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(args, seconds: float):
-    """The oracle (a port: the reference's Python cannot run here) timed on this
-    host's cores over a bounded sample of the same workload."""
+    """The oracle (a port: the reference's Python cannot run here) timed on this host's cores over a bounded
+    sample of the same workload (forward only, median of >= 5 runs, the 1000-proposal shape and config 1's
+    2 img x 100 proposals x 80 classes; core count and CPU model stated)."""
     import torch
     from oracle import lsm_oracle as oracle
     oracle.build()
@@ -377,25 +396,30 @@ def cpu_baseline(args, seconds: float):
     torch.set_num_threads(ncores)
     os.environ["OMP_NUM_THREADS"] = str(ncores)
     rng = np.random.default_rng(1992)
-    feat = rng.standard_normal((1, 1024, 50, 84)).astype(np.float32)
+    feat = rng.standard_normal((2, 1024, 50, 84)).astype(np.float32)
     params = oracle.make_res5_params(0)
     head = oracle.synth_head(rng, 2048, args.dim, args.classes)
+    head80 = oracle.synth_head(rng, 2048, args.dim, 80)
 
-    def run(n):
-        boxes = oracle.synth_boxes(rng, n)
+    def run(n, images=1, h=head):
+        boxes = [oracle.synth_boxes(rng, n) for _ in range(images)]
         t0 = time.perf_counter()
-        oracle.roi_head_forward(feat, [boxes], params, head)
+        oracle.roi_head_forward(feat[:images], boxes, params, h)
         return time.perf_counter() - t0
 
     run(8)                                   # warm-up (thread pools, page-in)
     t_probe = run(50)
-    n = int(max(50, min(args.proposals, 50 * seconds / max(t_probe, 1e-3) / 2)))
-    times = [run(n) for _ in range(2)]
-    t = float(np.median(times))
-    return {"value": n / t, "unit": "proposals/s", "cores": ncores, "kind": "port",
+    runs = 5
+    # ~2/3 of the budget on the 1000-proposal shape (a bounded sample of one image's proposals), the rest on config 1
+    n = int(max(50, min(args.proposals, 50 * (seconds * 0.66 / runs) / max(t_probe, 1e-3))))
+    t = float(np.median([run(n) for _ in range(runs)]))
+    t1 = float(np.median([run(100, images=2, h=head80) for _ in range(runs)]))
+    model = cpu_model()
+    return {"value": n / t, "unit": "proposals/s", "cores": ncores, "kind": "port", "cpu_model": model,
             "sample": f"{n} proposals of one 1333x800 image, full head (ROIAlign+Res5+mean+FCs+sim K={args.classes}), "
-                      f"median of 2 runs, {t:.2f} s each; torch CPU convs + OpenMP C oracle, "
-                      f"cpu={platform.processor() or platform.machine()}"}
+                      f"median of {runs} runs, {t:.2f} s each; torch CPU convs + OpenMP C oracle, {ncores} cores of {model}",
+            "config1": {"value": 200 / t1, "unit": "proposals/s",
+                        "sample": f"BASELINE config 1: 2 images x 100 proposals, 80-class bank, median of {runs} runs, {t1:.2f} s each"}}
 
 
 def main():
@@ -437,24 +461,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn, steps, warmup, on_start=None, **kw):
+    wall = {}
+
+    def timed(fn, steps, warmup, on_start=None, key=None, **kw):
+        """K steps between barrier + synchronize on both sides; the time is hipEventElapsedTime between two events recorded
+        on the launch stream inside that bracket, max over ranks; the host wall clock of the same bracket is
+        kept beside it (wall[key])."""
         for _ in range(warmup):
             fn()
         barrier()
         if on_start is not None:
             on_start()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        e0.record()
         for _ in range(steps):
             fn(**kw)
+        e1.record()
         barrier()
-        dt = time.perf_counter() - t0
+        dt_wall = time.perf_counter() - t0
+        dt = e0.elapsed_time(e1) * 1e-3
+        if key is not None:
+            wall[key] = max_over_ranks(dt_wall, device if args.dist_backend == "nccl" else None)
         # the slowest rank defines the job's time
         return max_over_ranks(dt, device if args.dist_backend == "nccl" else None)
 
     props_per_step = args.images * args.proposals * world
     # dominant kernel: the library brackets each of its GEMM-kernel launches with HIP events on the
     # launch stream while this is enabled (include/locov_hip.h, locov_gemm_timing_*)
-    dt2 = timed(wl.step_s2, args.steps, args.warmup, on_start=lambda: lib.locov_gemm_timing_enable(1), timed=True)
+    dt2 = timed(wl.step_s2, args.steps, args.warmup, on_start=lambda: lib.locov_gemm_timing_enable(1), key="s2", timed=True)
 
     def gemm_class(cls):
         import ctypes
@@ -483,18 +518,34 @@ def main():
             variants[key + "_proposals_per_s"] = props_per_step * max(args.steps // 2, 3) / dtv
             del h2
 
+    def time_train(config, backend):
+        tw = TrainWorkload(args, device, backend, world, data_seed=1992 + rank, config=config)
+        n_sampled = tw.step()
+        steps = max(args.steps // 2, 3)
+        dtt = timed(tw.step, steps, 2)
+        del tw
+        torch.cuda.empty_cache()
+        return {"sampled_proposals_per_s": n_sampled * world * steps / dtt, "ms_per_step": dtt / steps * 1e3,
+                "sampled_proposals_per_step_per_gpu": n_sampled}
+
     train = None
+    if args.mode == "infer" and not args.skip_train and args.res5 == "hip" and args.res5_dtype in ("f16x2", "fp32"):
+        # BASELINE configs 4 and 5 in the default line (compact: the hand-written path only; `--mode train` adds the
+        # MIOpen-autograd form of the same module): one training step of the path per iteration, forward + backward + SGD,
+        # wrapped in DistributedDataParallel (RCCL all-reduce of the path's gradients) when there is more than one rank
+        train = {"lsm": dict(time_train("lsm", "hip"), config="configs/coco_lsm.yaml",
+                             what=f"{args.train_images} img/GPU x {args.proposals} proposals -> {args.train_samples} sampled/img; "
+                                  "EmbeddingProposalsRes5ROIHeads.forward(targets) (labelling, whole-grid Res5, ROIAlign + Res5 + mean, "
+                                  "predictor, losses) + GroundingHead (box branch) + backward + SGD step"),
+                 "stt": dict(time_train("stt", "hip"), config="configs/coco_stt.yaml",
+                             what=f"3 img/GPU x {args.proposals} proposals -> 512 sampled/img, 48-class bank, emb_pred frozen; "
+                                  "EmbeddingRes5ROIHeads.forward(targets) + backward + SGD step"),
+                 "backend": "hip", "res5_dtype": args.res5_dtype,
+                 "gradient_exchange": (f"DistributedDataParallel over {world} ranks ({args.dist_backend})" if world > 1 else "none (1 rank)")}
     if args.mode == "train":
         train = {}
         for backend in args.train_backends.split(","):
-            tw = TrainWorkload(args, device, backend, world, data_seed=1992 + rank)
-            n_sampled = tw.step()
-            steps = max(args.steps // 2, 3)
-            dtt = timed(tw.step, steps, 2)
-            train[backend] = {"sampled_proposals_per_s": n_sampled * world * steps / dtt, "ms_per_step": dtt / steps * 1e3,
-                              "sampled_proposals_per_step_per_gpu": n_sampled}
-            del tw
-            torch.cuda.empty_cache()
+            train[backend] = time_train(args.train_config, backend)
         if "hip" in train and "miopen" in train:
             train["speedup_vs_miopen"] = train["hip"]["sampled_proposals_per_s"] / train["miopen"]["sampled_proposals_per_s"]
         train["config"] = "configs/coco_stt.yaml" if args.train_config == "stt" else "configs/coco_lsm.yaml"
@@ -587,6 +638,8 @@ def main():
             "unit": "proposals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt2 / args.steps * 1e3,
+            "timing": {"how": "hipEventElapsedTime between two events on the launch stream around the K timed steps, inside the "
+                              "barrier + synchronize bracket, max over ranks", "wall_ms_per_step": wall["s2"] / args.steps * 1e3},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16 operands / f32 accumulate in Res5 (opt-in reduced precision, not the parity configuration)"
                       if args.res5_dtype == "bf16" else

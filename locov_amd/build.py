@@ -49,6 +49,17 @@ def _headers():
     return hs
 
 
+def source_fingerprint() -> str:
+    """sha256[:16] over the kernel sources and headers the library is built from (what a recorded PMC pass is valid for)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(sources() + _headers()):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True

@@ -315,17 +315,19 @@ def test_res5_rows_gradients_vs_float64(pkg, oracle, dims, R, split):
     assert max(errs.values()) < 1e-4, errs
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["f32mfma", "f16x2"])
 @pytest.mark.parametrize("dims,N,H,W", [((128, 64, 256), 2, 26, 43), ((1024, 512, 2048), 2, 50, 84)])
-def test_res5_grid_gradients_vs_float64(pkg, oracle, dims, N, H, W):
+def test_res5_grid_gradients_vs_float64(pkg, oracle, dims, N, H, W, split):
     """roi_emb_heads.py:323: the stage on the whole res4 grid (NCHW in, NCHW out), output and gradients w.r.t. the map
-    and every convolution weight."""
+    and every convolution weight -- on the f32 MFMA and in the DEFAULT split-operand arithmetic (forward, im2col 3x3, TN
+    weight gradients and masked data gradients all on (hi, lo) f16 pairs), same gates."""
     from locov_amd import res5_train
     in_ch, mid, out_ch = dims
     res5, params = _stage(pkg, oracle, in_ch, mid, out_ch, seed=N + H)
     gen = torch.Generator().manual_seed(23)
     feat = torch.randn(N, in_ch, H, W, generator=gen)
     f = feat.cuda().requires_grad_(True)
-    y = res5_train.res5_grid(res5, res5_train.to_nhwc(f), split=False)
+    y = res5_train.res5_grid(res5, res5_train.to_nhwc(f), split=split)
     with torch.no_grad():
         y_oracle, _ = _float64_stage(oracle, params, feat.double())
     assert tuple(y.shape) == tuple(y_oracle.shape)

@@ -222,3 +222,68 @@ def test_roi_align_matches_torch_grid_sample_on_interior_boxes(oracle):
         worst = max(worst, float(np.abs(got[r] - want).max()))
     assert len(grids_seen) >= 4, grids_seen                    # adaptive grids 1..4 per axis are all exercised
     assert worst <= 2e-6, worst
+
+
+def test_roi_align_border_rules_match_torch_grid_sample_border_mode(oracle):
+    """Third-party pin of ROIAlign's BORDER rules.  torchvision's bilinear_interpolate treats a sample (y, x) as
+        outside [-1, H] x [-1, W]            -> contributes 0 (but still counts in the bin's average)
+        otherwise                             -> coordinates clamped to [0, H-1] x [0, W-1], then bilinear
+    (`if (y <= 0) y = 0`, `if (y_low >= H-1) { y_high = y_low = H-1; y = y_low }`).  The second line is exactly what
+    torch.nn.functional.grid_sample(padding_mode="border", align_corners=True) computes, so: evaluate PyTorch's kernel at
+    the oracle's own sample coordinates, zero the samples the first line excludes, average over each bin's adaptive grid,
+    and the oracle must agree -- on boxes that cross every edge and corner of the map, lie partly beyond [-1, H], and
+    sit entirely inside the clamp band (-1, 0) / (H-1, H)."""
+    rng = np.random.default_rng(77)
+    N, C, H, W, P, s = 2, 4, 50, 84, 14, 1.0 / 16
+    feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    iw, ih = 16.0 * W, 16.0 * H                       # the map covers [0, 1344) x [0, 800) image pixels
+    rois = []
+    def add(b, x0, y0, x1, y1):
+        rois.append([b, x0, y0, x1, y1])
+    for k in range(60):                               # boxes straddling each edge / corner, sizes over all adaptive grids
+        b = int(rng.integers(0, N))
+        w = 2.0 ** rng.uniform(4.0, np.log2(600.0))
+        h = 2.0 ** rng.uniform(4.0, np.log2(500.0))
+        side = k % 8
+        cx = {0: 0.0, 1: iw, 4: 0.0, 5: iw, 6: 0.0, 7: iw}.get(side, rng.uniform(0, iw)) + rng.uniform(-0.4, 0.4) * w
+        cy = {2: 0.0, 3: ih, 4: 0.0, 5: ih, 6: ih, 7: 0.0}.get(side, rng.uniform(0, ih)) + rng.uniform(-0.4, 0.4) * h
+        add(b, cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2)
+    # thin boxes entirely inside the clamp bands (samples in (-1, 0) and (H-1, H) map coordinates), and just beyond them
+    for b in range(N):
+        add(b, -6.0, 100.0, -1.0, 300.0)              # x in (-0.875, -0.56): clamped to column 0
+        add(b, 200.0, -7.5, 420.0, -0.5)              # y band above the map
+        add(b, iw - 7.0, 50.0, iw + 6.0, 500.0)       # around the last column: clamp at W-1, some samples in (W-1, W]
+        add(b, 100.0, ih - 5.0, 900.0, ih + 7.0)
+        add(b, -40.0, -40.0, -17.0, -17.0)            # everything below -1: exact zeros
+        add(b, iw + 9.0, 10.0, iw + 60.0, 300.0)      # everything beyond W
+        add(b, -30.0, -30.0, iw + 30.0, ih + 30.0)    # the whole map and more (grid 7 x 4)
+    rois = np.asarray(rois, np.float32)
+    got = oracle.roi_align(feat, rois, (P, P), s, 0, True)
+    ft = torch.from_numpy(feat).double()
+    f32 = np.float32
+    worst, n_clamped, n_zeroed, grids = 0.0, 0, 0, set()
+    for r, roi in enumerate(rois):
+        b = int(roi[0])
+        x0, y0, x1, y1 = [f32(v) * f32(s) - f32(0.5) for v in roi[1:]]
+        rw, rh = f32(x1 - x0), f32(y1 - y0)
+        bw, bh = f32(rw / f32(P)), f32(rh / f32(P))
+        gw, gh = int(np.ceil(bw)), int(np.ceil(bh))
+        grids.add((gh, gw))
+        coord = lambda start, bin_, g: ((start + np.arange(P, dtype=f32)[:, None] * bin_).astype(f32)
+                                        + (((np.arange(g, dtype=f32)[None, :] + f32(0.5)) * bin_).astype(f32) / f32(g)).astype(f32)).astype(f32)
+        xs, ys = coord(x0, bw, gw).reshape(-1), coord(y0, bh, gh).reshape(-1)          # fp32, as the kernel forms them
+        ok_x = ~((xs < f32(-1.0)) | (xs > f32(W)))
+        ok_y = ~((ys < f32(-1.0)) | (ys > f32(H)))
+        n_zeroed += int((~ok_x).sum() + (~ok_y).sum())
+        n_clamped += int((ok_x & ((xs < 0) | (xs > W - 1))).sum() + (ok_y & ((ys < 0) | (ys > H - 1))).sum())
+        gx = torch.from_numpy(2.0 * xs.astype(np.float64) / (W - 1) - 1.0)
+        gy = torch.from_numpy(2.0 * ys.astype(np.float64) / (H - 1) - 1.0)
+        grid = torch.stack(torch.meshgrid(gy, gx, indexing="ij")[::-1], dim=-1)[None]
+        samp = torch.nn.functional.grid_sample(ft[b:b + 1], grid, mode="bilinear", padding_mode="border", align_corners=True)[0]
+        keep = torch.from_numpy(ok_y[:, None] & ok_x[None, :])
+        samp = samp * keep.to(samp.dtype)                                              # the [-1, H] rule: excluded samples add 0
+        want = samp.view(C, P, gh, P, gw).sum(dim=(2, 4)).numpy() / float(max(gh * gw, 1))
+        worst = max(worst, float(np.abs(got[r] - want).max()))
+    assert n_clamped > 300 and n_zeroed > 300, (n_clamped, n_zeroed)                   # both rules are exercised, heavily
+    assert len(grids) >= 6, grids
+    assert worst <= 2e-6, worst

@@ -39,6 +39,9 @@ traffic = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and a separate --p
                    "WRITE_SIZE exact. hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch, averaged over the kernel's "
                    "launches (memory side of L2: includes Infinity-Cache hits).",
            "workload": workload, "kernels": {}}
+sys.path.insert(0, ROOT)
+from locov_amd import build as _build
+traffic["source_fingerprint"] = _build.source_fingerprint()      # bench.py refuses this file for a library built from other sources
 for k in fetch:
     if "locov" not in k:
         continue
