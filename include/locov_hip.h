@@ -128,6 +128,20 @@ int locov_roi_align_from_nhwc_fwd(const float *feat_nhwc, int N, int H, int W, i
                                   float spatial_scale, int sampling_ratio, int aligned, float *out,
                                   locov_stream_t stream);
 
+/* The same with a choice of arithmetic (the pooler of roi_emb_heads.py:182-187,243-245):
+ *   LOCOV_ROIALIGN_EXACT : the call above -- torchvision's per-sample order, un-fused: bit-identical to the CPU oracle.
+ *   LOCOV_ROIALIGN_FAST  : within 1e-5 of it (SURVEY.md 8d's ROIAlign gate).  Separable form: per bin and axis the samples'
+ *     bilinear weights are summed per PIXEL, so a bin costs (gh+1)(gw+1) taps instead of 4 gh gw; and the proposal's
+ *     pixel window x 32 channels is staged in LDS once ("LDS-staged proposal tiles") whenever it fits 192 pixels, so
+ *     that bins sharing pixels share the fetch.  ROIs whose samples lie more than a pixel apart (a forced sampling_ratio
+ *     on a large box) or whose grid exceeds 16 samples per axis take the exact form. */
+#define LOCOV_ROIALIGN_EXACT 0
+#define LOCOV_ROIALIGN_FAST 1
+int locov_roi_align_from_nhwc_fwd_ex(const float *feat_nhwc, int N, int H, int W, int C,
+                                     const float *rois, int64_t R, int pooled_h, int pooled_w,
+                                     float spatial_scale, int sampling_ratio, int aligned, int mode,
+                                     float *out, locov_stream_t stream);
+
 int locov_roi_align_nhwc_fwd(const void *feat, int feat_dtype, int N, int H, int W, int C,
                              const float *rois, int64_t R, int pooled_h, int pooled_w,
                              float spatial_scale, int sampling_ratio, int aligned,
@@ -488,8 +502,11 @@ int locov_gemm_tn_f32(const float *a, int64_t lda, int64_t stride_a, const float
 
 /* The same gradients in the split-operand arithmetic of the forward (3 f16 MFMAs per fp32 product block instead of 16 f32
  * ones).  A gradient tensor has no a-priori range, so its operand scale is chosen ON THE DEVICE:
- *   locov_split_scale_from_amax : scale_out[0] = s = the power of two with max |s x| in [2^(target_log2-1), 2^target_log2), scale_out[1] = 1/s, scale_out[2] =
- *                                 bit pattern of max |x| (scratch); three tiny launches, no host read.  scale_out: 16 bytes.
+ *   locov_split_scale_from_amax : scale_out[0] = s = the power of two with max |s x| in [2^(target_log2-1), 2^target_log2), scale_out[1] = 1/s,
+ *                                 scale_out[2..3] = scratch (max bits, arrival tickets; zero again afterwards); a 16-byte memset and
+ *                                 ONE kernel (the workgroup drawing the last ticket writes the scale), no host read.  scale_out: 16 bytes.
+ *   locov_split_scale_from_amax_zeroed : the same without the memset, for 16 bytes whose words 2..3 are ALREADY zero (fresh from a
+ *                                 zeroed pool, or last used by one of these two calls).
  *   locov_gemm_nt_f32_split_ex  : locov_gemm_nt_f32_split with the epilogue `mask` of locov_gemm_nt_f32_ex and, when
  *                                 x_scale_dev is non-null, the operand scale of x read from it (x_scale is then ignored).
  *   locov_gemm_tn_f32_split     : locov_gemm_tn_f32 with split operands: a (the gradient) scaled by a_scale_dev[0], b (the
@@ -499,6 +516,8 @@ int locov_gemm_tn_f32(const float *a, int64_t lda, int64_t stride_a, const float
  *                                 gradient's scale is chosen on the device, the transformed activation is scaled by 0.25). */
 int locov_split_scale_from_amax(const float *x, int64_t n, float target_log2, float *scale_out,
                                 locov_stream_t stream);
+int locov_split_scale_from_amax_zeroed(const float *x, int64_t n, float target_log2, float *scale_out,
+                                       locov_stream_t stream);
 int locov_gemm_nt_f32_split_ex(const float *x, int64_t lda, const void *W_split, const float *scale,
                                const float *shift, const float *residual, const float *mask, float *y,
                                int64_t ldc, int64_t M, int N, int K, unsigned flags, float x_scale,

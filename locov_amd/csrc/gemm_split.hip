@@ -34,6 +34,9 @@
 #ifndef LOCOV_RES_PREFETCH
 #define LOCOV_RES_PREFETCH 4
 #endif
+#ifndef LOCOV_SPLIT_MINWG
+#define LOCOV_SPLIT_MINWG 2   // launch-bounds occupancy hint of the 128x128 tile: 2 workgroups per CU (3: a 168-register budget, see DESIGN)
+#endif
 #ifndef LOCOV_STORE_AUX
 #define LOCOV_STORE_AUX 2     // cache policy bits of the epilogue's stores: 2 = nt (A/B: tools/make_variant.py ... -DLOCOV_STORE_AUX=0)
 #endif
@@ -118,7 +121,7 @@ __device__ unsigned long long g_ktrace[4 * 16];
 // WM_: waves along M.  2 = the 128x128 tile, two workgroups per CU; 4 = a 256x128 tile of 8 waves, ONE workgroup per CU: the W
 // tile is shared by twice the rows, so the CU stages 48 KB per K-tile through L2 -> LDS for the MFMA work it staged 64 KB for.
 template <bool SEGSUM, bool EMASK = false, bool ASPLIT = false, int WM_ = 2>
-__global__ __launch_bounds__(128 * WM_, WM_ == 2 ? 2 : 1) void gemm_split_kernel(const float *__restrict__ A, int64_t lda,
+__global__ __launch_bounds__(128 * WM_, WM_ == 2 ? LOCOV_SPLIT_MINWG : 1) void gemm_split_kernel(const float *__restrict__ A, int64_t lda,
                                                            const float *__restrict__ B, float *__restrict__ Cout,
                                                            int64_t ldc, int64_t M, int N, int K, Epilogue epi, Batch bt,
                                                            float a_scale, float out_scale, SegSum ss, unsigned *overflow,
@@ -599,12 +602,25 @@ __global__ __launch_bounds__(256) void segsum_finish_kernel(const float *__restr
     }
 }
 
-// Operand scale of a tensor whose range is only known on the device (gradients): scale_out = {s, 1/s, amax bits} with
+// Operand scale of a tensor whose range is only known on the device (gradients): scale_out = {s, 1/s, amax bits, arrivals} with
 // s = 2^(target_log2 - 1 - floor(log2(max |x|))), i.e. max |s x| in [2^(target-1), 2^target); an all-zero (or empty) tensor
-// gets s = 1.  Three tiny launches: init, a grid-wide atomicMax over the bit patterns of |x|, finish.
-__global__ void split_scale_init_kernel(float *out) { reinterpret_cast<unsigned *>(out)[2] = 0u; }
+// gets s = 1.  ONE kernel behind a 16-byte memset: every workgroup folds its max into the word with one atomic and takes an
+// arrival ticket; the workgroup that draws the last ticket turns the max into the scale (the others' atomics are complete by
+// then: each was issued before its workgroup's ticket, and both are device-scope atomics on the same cache line's L2).
+__device__ __forceinline__ void split_scale_finish(float *out, float target_log2)
+{
+    const float amax = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(out) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    float s = 1.f;
+    if (amax > 0.f && amax < 3.0e38f) {
+        int e;
+        frexpf(amax, &e);                                 // amax = f * 2^e, f in [0.5, 1)  ->  amax <= 2^e
+        s = ldexpf(1.f, (int)target_log2 - e);
+    }
+    out[0] = s;
+    out[1] = 1.f / s;
+}
 
-__global__ __launch_bounds__(256) void split_amax_kernel(const float *__restrict__ x, int64_t n4, unsigned *__restrict__ amax_bits)
+__global__ __launch_bounds__(256) void split_amax_kernel(const float *__restrict__ x, int64_t n4, float *__restrict__ out, float target_log2)
 {
     float m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -618,22 +634,16 @@ __global__ __launch_bounds__(256) void split_amax_kernel(const float *__restrict
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {                    // ONE atomic per workgroup (thousands of same-address atomics serialise)
+        unsigned *w = reinterpret_cast<unsigned *>(out);
         m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        if (m > 0.f) atomicMax(amax_bits, __float_as_uint(m));                             // non-negative floats order like their bits
+        if (m > 0.f) atomicMax(w + 2, __float_as_uint(m));                             // non-negative floats order like their bits
+        __threadfence();
+        if (atomicAdd(w + 3, 1u) == gridDim.x - 1) {
+            split_scale_finish(out, target_log2);
+            w[2] = 0u;                         // the scratch words are zero again: the 16 bytes can take the next reduction as they are
+            w[3] = 0u;
+        }
     }
-}
-
-__global__ void split_scale_finish_kernel(float *out, float target_log2)
-{
-    const float amax = __uint_as_float(reinterpret_cast<unsigned *>(out)[2]);
-    float s = 1.f;
-    if (amax > 0.f && amax < 3.0e38f) {
-        int e;
-        frexpf(amax, &e);                                 // amax = f * 2^e, f in [0.5, 1)  ->  amax <= 2^e
-        s = ldexpf(1.f, (int)target_log2 - e);
-    }
-    out[0] = s;
-    out[1] = 1.f / s;
 }
 
 int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C, int64_t ldc, int64_t M, int N, int K,
@@ -772,19 +782,28 @@ int locov_gemm_nt_f32_split(const float *x, int64_t lda, const void *W_split, co
                              "locov_gemm_nt_f32_split", Batch{1, 0, 0, 0}, overflow);
 }
 
-int locov_split_scale_from_amax(const float *x, int64_t n, float target_log2, float *scale_out, locov_stream_t stream)
+static int split_scale_from_amax(const float *x, int64_t n, float target_log2, float *scale_out, bool zeroed, locov_stream_t stream)
 {
     LOCOV_REQUIRE(n >= 0 && x && scale_out, "locov_split_scale_from_amax: bad arguments");
     LOCOV_REQUIRE((uintptr_t)x % 16 == 0 && n % 4 == 0, "locov_split_scale_from_amax: x must be 16-byte aligned, n a multiple of 4");
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(split_scale_init_kernel, dim3(1), dim3(1), 0, s, scale_out);
-    if (n > 0) {
-        const int64_t n4 = n / 4;
-        const unsigned blocks = (unsigned)(ceil_div(n4, 256 * 8) < 1024 ? ceil_div(n4, 256 * 8) : 1024);
-        hipLaunchKernelGGL(split_amax_kernel, dim3(blocks), dim3(256), 0, s, x, n4, reinterpret_cast<unsigned *>(scale_out) + 2);
-    }
-    hipLaunchKernelGGL(split_scale_finish_kernel, dim3(1), dim3(1), 0, s, scale_out, target_log2);
+    if (!zeroed && hipMemsetAsync(scale_out, 0, 16, s) != hipSuccess)
+        return set_error(LOCOV_ERR_LAUNCH, "locov_split_scale_from_amax: memset failed");
+    const int64_t n4 = n / 4;
+    const int64_t want = ceil_div(n4, 256 * 8);
+    const unsigned blocks = (unsigned)(want < 1 ? 1 : want < 1024 ? want : 1024);       // (n == 0: one workgroup writes s = 1)
+    hipLaunchKernelGGL(split_amax_kernel, dim3(blocks), dim3(256), 0, s, x, n4, scale_out, target_log2);
     return check_launch("locov_split_scale_from_amax");
+}
+
+int locov_split_scale_from_amax(const float *x, int64_t n, float target_log2, float *scale_out, locov_stream_t stream)
+{
+    return split_scale_from_amax(x, n, target_log2, scale_out, false, stream);
+}
+
+int locov_split_scale_from_amax_zeroed(const float *x, int64_t n, float target_log2, float *scale_out, locov_stream_t stream)
+{
+    return split_scale_from_amax(x, n, target_log2, scale_out, true, stream);
 }
 
 int locov_gemm_nt_f32_split_ex(const float *x, int64_t lda, const void *W_split, const float *scale, const float *shift,

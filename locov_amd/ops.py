@@ -77,7 +77,7 @@ def level_assign(boxes: torch.Tensor, min_level: int, max_level: int, canonical_
 
 class _ROIAlignFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, rois, ph, pw, scale, sampling_ratio, aligned):
+    def forward(ctx, feat, rois, ph, pw, scale, sampling_ratio, aligned, mode=0):
         N, C, H, W = feat.shape
         R = rois.shape[0]
         out = torch.empty((R, C, ph, pw), dtype=torch.float32, device=feat.device)
@@ -87,10 +87,10 @@ class _ROIAlignFn(torch.autograd.Function):
                 nhwc = torch.empty((N, H, W, C), dtype=torch.float32, device=feat.device)
                 check(_lib.load().locov_nchw_to_nhwc(_ptr(feat), N, C, H, W, _ptr(nhwc), F32, _stream(feat)),
                       "locov_nchw_to_nhwc")
-                check(_lib.load().locov_roi_align_from_nhwc_fwd(_ptr(nhwc), N, H, W, C, _ptr(rois), R, ph, pw,
-                                                                float(scale), int(sampling_ratio), int(aligned),
-                                                                _ptr(out), _stream(feat)),
-                      "locov_roi_align_from_nhwc_fwd")
+                check(_lib.load().locov_roi_align_from_nhwc_fwd_ex(_ptr(nhwc), N, H, W, C, _ptr(rois), R, ph, pw,
+                                                                   float(scale), int(sampling_ratio), int(aligned), int(mode),
+                                                                   _ptr(out), _stream(feat)),
+                      "locov_roi_align_from_nhwc_fwd_ex")
             else:
                 check(_lib.load().locov_roi_align_fwd(_ptr(feat), N, C, H, W, _ptr(rois), R, ph, pw, float(scale),
                                                       int(sampling_ratio), int(aligned), _ptr(out), _stream(feat)),
@@ -109,12 +109,17 @@ class _ROIAlignFn(torch.autograd.Function):
             check(_lib.load().locov_roi_align_bwd(_ptr(grad_out), N, C, H, W, _ptr(rois), rois.shape[0], ph, pw,
                                                   float(scale), int(sampling_ratio), int(aligned), _ptr(gf),
                                                   _stream(gf)), "locov_roi_align_bwd")
-        return gf, None, None, None, None, None, None
+        return gf, None, None, None, None, None, None, None
+
+
+ROIALIGN_MODES = {"exact": 0, "fast": 1}
 
 
 def roi_align(feat: torch.Tensor, rois: torch.Tensor, output_size, spatial_scale: float,
-              sampling_ratio: int = 0, aligned: bool = True) -> torch.Tensor:
-    """feat [N,C,H,W] fp32, rois [R,5] (batch_idx,x0,y0,x1,y1) -> [R,C,ph,pw] (differentiable in feat)."""
+              sampling_ratio: int = 0, aligned: bool = True, mode: str = "exact") -> torch.Tensor:
+    """feat [N,C,H,W] fp32, rois [R,5] (batch_idx,x0,y0,x1,y1) -> [R,C,ph,pw] (differentiable in feat).
+    mode "exact": torchvision's per-sample order, bit-identical to the CPU oracle; "fast": within 1e-5 of it -- separable
+    per-pixel weights and the proposal's pixel window staged in LDS (include/locov_hip.h, LOCOV_ROIALIGN_FAST)."""
     feat = _dev(feat, "feat")
     rois = _dev(rois, "rois")
     if feat.dim() != 4:
@@ -122,7 +127,8 @@ def roi_align(feat: torch.Tensor, rois: torch.Tensor, output_size, spatial_scale
     if rois.dim() != 2 or rois.shape[1] != 5:
         raise ValueError(f"rois must be [R,5], got {tuple(rois.shape)}")
     ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
-    return _ROIAlignFn.apply(feat, rois, int(ph), int(pw), float(spatial_scale), int(sampling_ratio), bool(aligned))
+    return _ROIAlignFn.apply(feat, rois, int(ph), int(pw), float(spatial_scale), int(sampling_ratio), bool(aligned),
+                             ROIALIGN_MODES[mode])
 
 
 def roi_align_levels(feats: Sequence[torch.Tensor], scales: Sequence[float], rois: torch.Tensor,
@@ -770,11 +776,27 @@ def split_scale_from_amax(x: torch.Tensor, target_log2: float = 13.0) -> torch.T
     x = _dev(x, "x")
     if x.numel() % 4:
         raise ValueError("split_scale_from_amax: numel must be a multiple of 4")
-    out = torch.empty(4, dtype=torch.float32, device=x.device)
+    out = _scale_slot(x)
     with torch.cuda.device(x.device):
-        check(_lib.load().locov_split_scale_from_amax(_ptr(x), x.numel(), float(target_log2), _ptr(out), _stream(x)),
-              "locov_split_scale_from_amax")
+        check(_lib.load().locov_split_scale_from_amax_zeroed(_ptr(x), x.numel(), float(target_log2), _ptr(out), _stream(x)),
+              "locov_split_scale_from_amax_zeroed")
     return out
+
+
+_SCALE_SLOTS = {}
+
+
+def _scale_slot(ref: torch.Tensor) -> torch.Tensor:
+    """16 bytes for a device-chosen operand scale, from a per-(device, stream) ring of 2048 zeroed slots: the reduction
+    kernel leaves its scratch words zero again, so a slot needs no memset when the ring comes round to it -- by which time
+    (same stream, 2047 reductions later; a training step takes ~25) every GEMM that read it has long been enqueued."""
+    key = (ref.device, torch.cuda.current_stream(ref.device).cuda_stream)
+    ring = _SCALE_SLOTS.get(key)
+    if ring is None:
+        ring = _SCALE_SLOTS[key] = [torch.zeros(2048, 4, dtype=torch.float32, device=ref.device), 0]
+    i = ring[1]
+    ring[1] = (i + 1) % ring[0].shape[0]
+    return ring[0][i]
 
 
 def linear_split_ex(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tensor] = None, *, scale=None, residual=None,

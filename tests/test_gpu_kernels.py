@@ -465,3 +465,47 @@ def test_sim_gemm_backward_vs_float64(ops, R, D, K1, train_bank):
         assert float((bg.grad.cpu().double() - bd.grad).abs().max() / bd.grad.abs().max()) < 5e-6
     else:
         assert bg.grad is None
+
+
+# ------------------------------------------------------------------ ROIAlign, NCHW contract, FAST form
+def test_roi_align_fast_mode_random_configurations(ops, oracle):
+    """mode="fast" of the pooler contract (separable per-pixel weights, the proposal's pixel window staged in LDS) against the
+    oracle over random configurations: SURVEY.md 8d's ROIAlign gate, max-abs <= 1e-5 (on N(0,1) maps).  Covers staged windows
+    (small boxes), the global separable taps (large boxes), the exact fallback (forced sampling ratio on large boxes,
+    C % 4 != 0, huge grids), boxes outside / across the map border, degenerate and inverted boxes."""
+    rng = np.random.default_rng(616)
+    worst = 0.0
+    for it in range(18):
+        N, C = int(rng.integers(1, 4)), int(rng.choice([4, 8, 32, 36, 64, 100, 33]))
+        H, W = int(rng.integers(4, 52)), int(rng.integers(4, 86))
+        P = int(rng.choice([14, 14, 7, 5]))
+        scale = float(rng.choice([1 / 16, 1 / 16, 1 / 8, 1 / 4]))
+        ratio, aligned = int(rng.choice([0, 0, 0, 1, 2, 4])), bool(rng.integers(4) > 0)
+        feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        rois = _rois(oracle, rng, N, 41, W, H, wild=7)
+        rois[:, 1:] *= (1 / 16) / scale
+        rois[7, 1:] = (64, 64, 64, 64)          # zero-size
+        rois[8, 1:] = (300, 200, 100, 50)       # inverted
+        rois[9, 1:] = (-500, -500, -300, -300)  # entirely outside
+        rois[10, 1:] = (3, 5, 3 + 20 / (16 * scale), 5 + 9 / (16 * scale))   # a small box: window of a few pixels
+        want = oracle.roi_align(feat, rois, (P, P), scale, ratio, aligned)
+        got = ops.roi_align(dev(feat), dev(rois), P, scale, ratio, aligned, mode="fast").cpu().numpy()
+        err = float(np.abs(got - want).max())
+        worst = max(worst, err)
+        assert err <= 1e-5, (it, N, C, H, W, P, scale, ratio, aligned, err)
+        assert np.array_equal(got[9], np.zeros_like(got[9]))
+    assert worst > 0.0                          # (it IS another arithmetic: re-associated sums)
+
+
+def test_roi_align_fast_mode_config_shape_and_exact_mode_unchanged(ops, oracle):
+    rng = np.random.default_rng(1992)
+    feat = rng.standard_normal((2, 1024, 50, 84)).astype(np.float32)
+    rois = oracle.boxes_to_pooler_format([oracle.synth_boxes(rng, 100), oracle.synth_boxes(rng, 100)])
+    want = oracle.roi_align(feat, rois, (14, 14), 1 / 16, 0, True)
+    fast = ops.roi_align(dev(feat), dev(rois), 14, 1 / 16, 0, True, mode="fast").cpu().numpy()
+    assert float(np.abs(fast - want).max()) <= 1e-5
+    np.testing.assert_array_equal(ops.roi_align(dev(feat), dev(rois), 14, 1 / 16, 0, True, mode="exact").cpu().numpy(), want)
+    # gradients flow through either mode (the backward is the exact adjoint of the sampling geometry)
+    f = dev(feat[:, :8]).requires_grad_(True)
+    ops.roi_align(f, dev(rois), 14, 1 / 16, 0, True, mode="fast").sum().backward()
+    assert torch.isfinite(f.grad).all() and float(f.grad.abs().max()) > 0
