@@ -53,6 +53,13 @@ extern "C" {
 /* locov_gemm_nt_f32_split*: x is ALREADY in the split layout of locov_split_f16x2_pack (written so by its producer),
  * scaled by x_scale: it is then staged by LDS DMA like W, with no conversion in the kernel */
 #define LOCOV_GEMM_A_SPLIT 0x1000u
+/* locov_gemm_nt_f32_split{,_segmean}: y is WRITTEN in the split layout of locov_split_f16x2_pack scaled by x_scale (the pre-split
+ * x of the GEMM that consumes it: Res5 block outputs feed the next block's conv1, roi_emb_heads.py:217-245) / the residual
+ * is READ from that layout (the same block output is the next block's identity shortcut).  hi + lo reproduces the fp32 value
+ * to 2^-22 relative (exactly what the consuming GEMM's own split would keep); a finished value outside fp16's range raises the
+ * range-guard word.  N and ldc must be multiples of 8. */
+#define LOCOV_EPI_OUT_SPLIT 0x2000u
+#define LOCOV_EPI_RES_SPLIT 0x4000u
 #define LOCOV_SEGMEAN_RES_ROI_MAJOR 0x400u   /* locov_gemm_nt_f32_split_segmean: the residual rows are ROI-major */
 /* locov_winograd_conv3x3_f32{,_split}: write the output rows ROI-major (row = roi * 49 + position) instead of
  * position-major (row = position * R + roi) -- the order locov_gemm_nt_f32_split_segmean consumes */

@@ -21,6 +21,8 @@ WINO_OUT_ROI_MAJOR = 0x100
 WINO_IN_ROI_MAJOR = 0x200
 SEGMEAN_RES_ROI_MAJOR = 0x400
 GEMM_A_SPLIT = 0x1000
+EPI_OUT_SPLIT = 0x2000
+EPI_RES_SPLIT = 0x4000
 MAX_LEVELS = 8
 ABI_VERSION = 2
 

@@ -89,6 +89,36 @@ __device__ __forceinline__ void split4(const f32x4 &x, float s, u32x2 &hi, u32x2
     }
 }
 
+// Epilogue traffic in the split layout (LOCOV_EPI_OUT_SPLIT / LOCOV_EPI_RES_SPLIT; scale = the launch's activation scale).  In
+// the epilogue lane l owns the four columns c4 = 4 (l % 16) .. c4 + 3 of its row, i.e. the lane pair (l, l ^ 1) owns one group
+// of 8 columns = 32 bytes of the layout: 8 hi halves (the even lane's 16 bytes), then 8 lo halves (the odd lane's).  So both
+// directions are ONE 16-byte access per lane at the byte offset the fp32 value would have, plus one 8-byte exchange inside
+// the pair.
+__device__ __forceinline__ f32x4 unsplit4(const f32x4 &raw, bool odd, float inv_scale)
+{
+    const u32x4 w = __builtin_bit_cast(u32x4, raw);
+    // even lane: hi of columns 0-3 = own words 0,1, lo = the odd lane's words 0,1; odd lane: hi of columns 4-7 = the even
+    // lane's words 2,3, lo = own words 2,3
+    const unsigned s0 = odd ? w[0] : w[2], s1 = odd ? w[1] : w[3];
+    const unsigned r0 = (unsigned)__shfl_xor((int)s0, 1), r1 = (unsigned)__shfl_xor((int)s1, 1);
+    const unsigned h0 = odd ? r0 : w[0], h1 = odd ? r1 : w[1], l0 = odd ? w[2] : r0, l1 = odd ? w[3] : r1;
+    const f16x4 hv = __builtin_bit_cast(f16x4, u32x2{h0, h1}), lv = __builtin_bit_cast(f16x4, u32x2{l0, l1});
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = ((float)hv[j] + (float)lv[j]) * inv_scale;      // hi + lo is exact in fp32 (<= 23 bits apart)
+    return o;
+}
+
+__device__ __forceinline__ u32x4 split4_pair(const f32x4 &v, bool odd, float scale)
+{
+    u32x2 hi, lo;
+    split4(v, scale, hi, lo);
+    // the even lane stores the 8 hi halves of the group (its own 4, then the odd lane's), the odd lane the 8 lo halves
+    const unsigned s0 = odd ? hi[0] : lo[0], s1 = odd ? hi[1] : lo[1];
+    const unsigned r0 = (unsigned)__shfl_xor((int)s0, 1), r1 = (unsigned)__shfl_xor((int)s1, 1);
+    return odd ? u32x4{r0, r1, lo[0], lo[1]} : u32x4{hi[0], hi[1], r0, r1};
+}
+
 }  // namespace
 
 // SEGSUM form (the last 1x1 convolution of Res5 + the spatial mean that follows it, roi_emb_heads.py:262,344,356): the
@@ -451,6 +481,10 @@ __global__ __launch_bounds__(128 * WM_, WM_ == 2 ? LOCOV_SPLIT_MINWG : 1) void g
     // Epilogue (C/D layout of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg): re-lay the wave's sub-tile out
     // through LDS, 16 bytes per lane and row-contiguous from there.
     const bool relu = (epi.flags & LOCOV_EPI_RELU) != 0;
+    const bool out_split = (epi.flags & LOCOV_EPI_OUT_SPLIT) != 0, res_split = (epi.flags & LOCOV_EPI_RES_SPLIT) != 0;
+    const bool odd_lane = (lane & 1) != 0;
+    const float inv_a_scale = 1.f / a_scale;
+    float omax = 0.f;                         // range guard of a split-layout OUTPUT: max |finished value|
     static_assert(NW * TM * EPS * 4 <= LDSB && LDSB <= 160 * 1024, "epilogue staging must fit the LDS");
     float *ep = reinterpret_cast<float *>(lds) + wave * (TM * EPS);
     const int64_t seg_q0 = SEGSUM ? m0 / ss.seg : 0;                 // first ROI of the tile, and the position its first row holds
@@ -497,7 +531,7 @@ __global__ __launch_bounds__(128 * WM_, WM_ == 2 ? LOCOV_SPLIT_MINWG : 1) void g
             for (int it = 0; it < NIT; it++) {
                 f32x4 v = *reinterpret_cast<const f32x4 *>(ep + (it * RPI + rr) * EPS + c4);
                 v = v * sc + sh;
-                if (epi.residual) v += res[it];
+                if (epi.residual) v += res_split ? unsplit4(res[it], odd_lane, inv_a_scale) : res[it];
                 if (relu) {
                     v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
                     v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
@@ -510,11 +544,17 @@ __global__ __launch_bounds__(128 * WM_, WM_ == 2 ? LOCOV_SPLIT_MINWG : 1) void g
                 }
                 if (SEGSUM)
                     *reinterpret_cast<f32x4 *>(ep + (it * RPI + rr) * EPS + c4) = v;    // finished value back in place
-                else
+                else if (out_split) {
+                    omax = fmaxf(fmaxf(omax, fabsf(v[0])), fabsf(v[1]));
+                    omax = fmaxf(fmaxf(omax, fabsf(v[2])), fabsf(v[3]));
+                    __builtin_amdgcn_raw_buffer_store_b128(split4_pair(v, odd_lane, a_scale), r_out, FULL ? voff : voff + it * vstep,
+                                                           FULL ? it * vstep : 0u, LOCOV_STORE_AUX);
+                } else
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, FULL ? voff : voff + it * vstep,
                                                            FULL ? it * vstep : 0u, LOCOV_STORE_AUX);  // aux 2 = nt: streamed once
             }
         }
+        if (!SEGSUM && out_split && overflow != nullptr && omax * a_scale >= 65504.f) atomicOr(overflow, 1u);
         if (SEGSUM) {
             // column sums per ROI: thread t owns column t % 128 and the ROI slots {t / 128, t / 128 + 2} of this tile
             __syncthreads();
@@ -660,6 +700,8 @@ int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C,
         (epi.scale && (uintptr_t)epi.scale % 16 != 0) || (epi.shift && (uintptr_t)epi.shift % 16 != 0))
         return set_error(LOCOV_ERR_UNSUPPORTED, "%s: N, lda, ldc must be multiples of 4 and every pointer 16-byte aligned", what);
     if (bt.count > 1 && epi.residual) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: batched launches take no residual", what);
+    if ((epi.flags & (LOCOV_EPI_OUT_SPLIT | LOCOV_EPI_RES_SPLIT)) && (N % 8 != 0 || ldc % 8 != 0 || epi.mask || a_scale_dev || bt.count > 1))
+        return set_error(LOCOV_ERR_UNSUPPORTED, "%s: a split-layout output / residual needs N and ldc to be multiples of 8, no mask, no device scale, no batch", what);
     const int count = bt.count > 1 ? bt.count : 1;
     // tile choice: the 256-row tile (one 8-wave workgroup per CU) where there are enough of them to fill the chip a few times
     const char *big_e = getenv("LOCOV_SPLIT_BIG");          // (experiment knob; the heuristic below is the product)
@@ -835,7 +877,8 @@ int locov_gemm_nt_f32_split_segmean(const float *x, int64_t lda, const void *W_s
     if (M == 0) return LOCOV_OK;
     LOCOV_REQUIRE(x && W_split && residual && out && workspace, "locov_gemm_nt_f32_split_segmean: null pointer");
     LOCOV_REQUIRE(lda >= K, "locov_gemm_nt_f32_split_segmean: lda < K");
-    LOCOV_REQUIRE(!(flags & ~(unsigned)(LOCOV_EPI_RELU | LOCOV_SEGMEAN_RES_ROI_MAJOR | LOCOV_GEMM_A_SPLIT)),
+    LOCOV_REQUIRE(!(flags & LOCOV_EPI_RES_SPLIT) || N % 8 == 0, "locov_gemm_nt_f32_split_segmean: a split-layout residual needs N %% 8 == 0");
+    LOCOV_REQUIRE(!(flags & ~(unsigned)(LOCOV_EPI_RELU | LOCOV_SEGMEAN_RES_ROI_MAJOR | LOCOV_GEMM_A_SPLIT | LOCOV_EPI_RES_SPLIT)),
                   "locov_gemm_nt_f32_split_segmean: unsupported flags 0x%x", flags);
     LOCOV_REQUIRE(workspace_bytes >= locov_gemm_segmean_workspace_bytes(M, N),
                   "locov_gemm_nt_f32_split_segmean: workspace too small (%lld bytes)", (long long)workspace_bytes);

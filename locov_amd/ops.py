@@ -522,10 +522,13 @@ def split_scale_for(w: torch.Tensor) -> float:
 
 def linear_split(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tensor] = None, *,
                  scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                 relu: bool = False, x_scale: float = 16.0, x_is_split: bool = False) -> torch.Tensor:
+                 relu: bool = False, x_scale: float = 16.0, x_is_split: bool = False, out_split: bool = False,
+                 residual_is_split: bool = False) -> torch.Tensor:
     """y = epi(x . W^T), fp32 in / fp32 out, products on the f16 matrix pipe with split operands (opt-in "f16x2"
     arithmetic).  x [M,K] fp32 (rows may be strided), weight = split_pack(W [N,K]); x_scale = the power of two x is
-    multiplied by before the split (|x_scale * x| must stay below 65504: |x| < 4094 at the default)."""
+    multiplied by before the split (|x_scale * x| must stay below 65504: |x| < 4094 at the default).
+    out_split: y is written in the split layout scaled by x_scale (float32-TYPED storage of that layout: the pre-split x of
+    the next split GEMM, and its residual with residual_is_split); residual_is_split: the residual is such a tensor."""
     x = _rows(x, "x")
     wd = _dev(weight.data, "weight")
     M, K = x.shape
@@ -541,10 +544,19 @@ def linear_split(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tens
     with torch.cuda.device(x.device):
         check(_lib.load().locov_gemm_nt_f32_split(_ptr(x), x.stride(0) if M else K, _ptr(wd), _ptr(scale), _ptr(bias),
                                                   _ptr(residual), _ptr(y), N, M, N, K,
-                                                  (_lib.EPI_RELU if relu else 0) | (_lib.GEMM_A_SPLIT if x_is_split else 0),
+                                                  (_lib.EPI_RELU if relu else 0) | (_lib.GEMM_A_SPLIT if x_is_split else 0)
+                                                  | (_lib.EPI_OUT_SPLIT if out_split else 0)
+                                                  | (_lib.EPI_RES_SPLIT if residual_is_split and residual is not None else 0),
                                                   float(x_scale), weight.scale, _ptr(_overflow_word(x)), _stream(x)),
               "locov_gemm_nt_f32_split")
     return y
+
+
+def split_unpack(t: torch.Tensor, scale: float) -> torch.Tensor:
+    """fp32 values of a tensor held in the split layout (split_pack / out_split): (hi + lo) / scale.  Test / debug aid."""
+    K = t.shape[-1]
+    h = t.contiguous().view(torch.float16).view(*t.shape[:-1], K // 8, 2, 8).float()
+    return ((h[..., 0, :] + h[..., 1, :]) / scale).reshape(t.shape)
 
 
 _SEGMEAN_WS = {}
@@ -552,7 +564,8 @@ _SEGMEAN_WS = {}
 
 def linear_split_segmean(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tensor], residual: torch.Tensor, seg: int, *,
                          scale: Optional[torch.Tensor] = None, relu: bool = True, x_scale: float = 16.0,
-                         residual_roi_major: bool = False, x_is_split: bool = False) -> torch.Tensor:
+                         residual_roi_major: bool = False, x_is_split: bool = False,
+                         residual_is_split: bool = False) -> torch.Tensor:
     """Res5's last 1x1 convolution fused with the spatial mean behind it:
         out[q, :] = mean_{p < seg} relu(scale * (x[q*seg + p, :] . W^T) + bias + residual[p*R + q, :]),   R = M // seg
     x [M,K] with ROI-major rows, residual [M,N] with POSITION-major rows (the previous block's output; ROI-major rows
@@ -579,7 +592,7 @@ def linear_split_segmean(x: torch.Tensor, weight: SplitWeight, bias: Optional[to
         check(lib.locov_gemm_nt_f32_split_segmean(_ptr(x), x.stride(0) if M else K, _ptr(wd), _ptr(scale), _ptr(bias),
                                                   _ptr(residual), _ptr(out), M, N, K, int(seg),
                                                   (_lib.EPI_RELU if relu else 0) | (_lib.SEGMEAN_RES_ROI_MAJOR if residual_roi_major else 0)
-                                                  | (_lib.GEMM_A_SPLIT if x_is_split else 0),
+                                                  | (_lib.GEMM_A_SPLIT if x_is_split else 0) | (_lib.EPI_RES_SPLIT if residual_is_split else 0),
                                                   float(x_scale), weight.scale, _ptr(ws), ws.numel(), _ptr(_overflow_word(x)),
                                                   _stream(x)),
               "locov_gemm_nt_f32_split_segmean")

@@ -20,6 +20,15 @@ import torch.nn.functional as F
 from torch import nn
 
 
+import os
+
+# Block outputs in the split layout (conv3 writes it, the next conv1 stages it by LDS DMA, the next conv3 reads its residual
+# from it): measured on MI355X the next conv1 gains 0.15 ms (2.18 -> 2.03 ms at 8 000 proposals) and each conv3 loses 0.05-0.25 ms to
+# the extra epilogue arithmetic (split + pair exchange, decode of the residual) -- 354 k -> 346 k proposals/s end to end.  Off;
+# LOCOV_RES5_OUT_SPLIT=1 turns it on (tests/test_gpu_split_gemm.py covers the epilogue either way).
+_OUT_SPLIT = bool(int(os.environ.get("LOCOV_RES5_OUT_SPLIT", "0")))
+
+
 class FrozenBatchNorm2d(nn.Module):
     """[D2-upstream] FrozenBatchNorm2d: fixed statistics and affine, y = x*scale + shift."""
 
@@ -263,9 +272,10 @@ class Res5Stage(nn.Sequential):
         from . import ops
         if split and w.shape[1] % 32 == 0 and w.shape[0] % 4 == 0:
             return ops.linear_split(x, self._split(w), bias, **kw)
-        assert not kw.get("x_is_split"), "a split-layout activation needs the split GEMM"
-        kw.pop("x_is_split", None)
-        kw.pop("x_scale", None)
+        assert not (kw.get("x_is_split") or kw.get("out_split") or kw.get("residual_is_split")), \
+            "a split-layout activation needs the split GEMM"
+        for k in ("x_is_split", "x_scale", "out_split", "residual_is_split"):
+            kw.pop(k, None)
         return ops.linear(x, w, bias, **kw)
 
     ACT_SPLIT_SCALE = 16.0       # operand scale of activations (|x| < 4094), also used when a producer writes them pre-split
@@ -274,6 +284,17 @@ class Res5Stage(nn.Sequential):
         """conv2's output can leave the Winograd output transform already in the split layout when its only consumer is the
         split GEMM of conv3."""
         return bool(split) and c2.out_channels % 32 == 0 and w3.shape[1] % 32 == 0 and w3.shape[0] % 4 == 0
+
+    def _out_split_ok(self, split: bool, winograd: bool, bi: int, pooled: bool) -> bool:
+        """Block bi's output can leave its last 1x1 convolution in the split layout (never as fp32) when every reader is a split
+        GEMM of the next block: its conv1 (pre-split A, staged by LDS DMA) and the identity shortcut in its conv3's epilogue
+        (split-layout residual).  Inference only; the stage's final output always stays fp32."""
+        if not (split and winograd) or bi + 1 >= len(self) or not _OUT_SPLIT:
+            return False
+        nxt, cur = self[bi + 1], self[bi]
+        ch = cur.conv3.out_channels
+        return (nxt.shortcut is None and ch % 32 == 0 and nxt.conv1.out_channels % 4 == 0 and nxt.conv3.out_channels % 8 == 0
+                and nxt.conv2.in_channels % 32 == 0 and nxt.conv2.out_channels % 4 == 0)
 
     def _packed_block0_on_map(self):
         """Weights for running block 0's two 1x1 stride-2 convolutions on the feature MAP (see
@@ -349,14 +370,18 @@ class Res5Stage(nn.Sequential):
         else:
             w2, s2, b2 = self._packed(c2)
             y = ops.conv3x3_nhwc(y, w2, 7, 7, scale=s2, shift=b2, relu=True, pos_major=pm)
-        x = self._linear(split, y, w3, shift_tail, scale=s3, residual=sc, relu=True,
-                         **({"x_is_split": True, "x_scale": self.ACT_SPLIT_SCALE} if y_split else {}))     # conv3 + FBN + add + ReLU
-        return self.forward_rows(x, 7, 7, pos_major=pm, winograd=winograd, start_block=1, split=split, pooled=pooled)
+        x_split = self._out_split_ok(split, winograd, 0, pooled)
+        kw3 = {"x_is_split": True, "x_scale": self.ACT_SPLIT_SCALE} if y_split else {}
+        if x_split:
+            kw3.update(out_split=True, x_scale=self.ACT_SPLIT_SCALE)
+        x = self._linear(split, y, w3, shift_tail, scale=s3, residual=sc, relu=True, **kw3)                 # conv3 + FBN + add + ReLU
+        return self.forward_rows(x, 7, 7, pos_major=pm, winograd=winograd, start_block=1, split=split, pooled=pooled,
+                                 x0_is_split=x_split)
 
     @torch.no_grad()
     def forward_rows(self, x0: torch.Tensor, H: int, W: int, pos_major: bool = False,
                      winograd: bool = True, start_block: int = 0, bf16: bool = False, split: bool = False,
-                     pooled: bool = False) -> torch.Tensor:
+                     pooled: bool = False, x0_is_split: bool = False) -> torch.Tensor:
         """Rows are ROI-major (r*H*W + pos) or position-major (pos*R + r); the 1x1 convolutions do not
         care.  The 3x3 one runs, on 7x7 position-major tiles, in the Winograd domain (121 instead of 361
         products per tile and channel pair; `winograd=False` keeps the direct implicit GEMM, which skips
@@ -367,6 +392,8 @@ class Res5Stage(nn.Sequential):
         from . import ops
         assert self.supports_rows_path(), "forward_rows needs FrozenBN, STRIDE_IN_1X1 and ungrouped convs"
         x = x0
+        x_split = bool(x0_is_split)                      # x holds the previous block's output in the split layout (_out_split_ok)
+        assert not x_split or (split and start_block > 0)
         cat = getattr(x0, "_locov_cat", None)            # rows_input(): x0 is the right block of [conv2 out | x0]
         for bi, blk in enumerate(self):
             if bi < start_block:
@@ -388,8 +415,10 @@ class Res5Stage(nn.Sequential):
                     sc = x
                 x = ops.linear_bf16(ops.to_bf16(y), self._bf16(w3), b3, scale=s3, residual=sc, relu=True)
                 continue
-            y = self._linear(split, x, w1, b1, scale=s1, relu=True)               # 1x1 (+stride via x0) + FBN + ReLU
+            xs_kw = {"x_is_split": True, "x_scale": self.ACT_SPLIT_SCALE} if x_split else {}
+            y = self._linear(split, x, w1, b1, scale=s1, relu=True, **xs_kw)      # 1x1 (+stride via x0) + FBN + ReLU
             use_wino = winograd and H == 7 and W == 7 and c2.in_channels % 32 == 0 and c2.out_channels % 4 == 0
+            assert use_wino or not x_split
             rm = not pos_major                     # the Winograd transforms read / write either row order
             if use_wino and bi == 0 and cat is not None and blk.shortcut is not None:
                 u2, s2, b2 = self._packed(c2, winograd=True)
@@ -406,7 +435,7 @@ class Res5Stage(nn.Sequential):
                 y = ops.winograd_conv3x3(y, self._split(u2), scale=s2, shift=b2, relu=True, roi_major=True, in_roi_major=rm,
                                          out_split_scale=self.ACT_SPLIT_SCALE if ysp else None)
                 return ops.linear_split_segmean(y, self._split(w3), b3, x, H * W, scale=s3, relu=True, residual_roi_major=rm,
-                                                x_is_split=ysp, x_scale=self.ACT_SPLIT_SCALE)
+                                                x_is_split=ysp, x_scale=self.ACT_SPLIT_SCALE, residual_is_split=x_split)
             y_split = False
             if use_wino:
                 u2, s2, b2 = self._packed(c2, winograd=True)
@@ -417,13 +446,18 @@ class Res5Stage(nn.Sequential):
             else:
                 w2, s2, b2 = self._packed(c2)
                 y = ops.conv3x3_nhwc(y, w2, H, W, scale=s2, shift=b2, relu=True, pos_major=pos_major)
+            res_split = False
             if blk.shortcut is not None:
                 ws, ss, bs = self._packed(blk.shortcut)
-                sc = self._linear(split, x, ws, bs, scale=ss)                     # 1x1 shortcut + FBN
+                sc = self._linear(split, x, ws, bs, scale=ss, **xs_kw)            # 1x1 shortcut + FBN
             else:
-                sc = x
+                sc, res_split = x, x_split
+            out_split = use_wino and y_split and self._out_split_ok(split, winograd, bi, pooled)
             x = self._linear(split, y, w3, b3, scale=s3, residual=sc, relu=True,
-                             **({"x_is_split": True, "x_scale": self.ACT_SPLIT_SCALE} if y_split else {}))   # 1x1 + FBN + add + ReLU
+                             **({"x_is_split": True, "x_scale": self.ACT_SPLIT_SCALE} if y_split else {}),
+                             **({"out_split": True} if out_split else {}),
+                             **({"residual_is_split": True} if res_split else {}))   # 1x1 + FBN + add + ReLU
+            x_split = out_split
         if pooled:
             R = x.shape[0] // (H * W)
             return ops.spatial_mean(x.view(H, W, R, x.shape[1]), channels_last=2) if pos_major else \

@@ -435,3 +435,52 @@ def test_segmean_random_shapes_both_residual_orders(ops):
     with pytest.raises(LocovError):                           # fewer than 43 rows per ROI: more than four ROIs per tile
         ops.linear_split_segmean(torch.randn(42, 32).cuda(), ops.split_pack(torch.randn(8, 32).cuda()), None,
                                  torch.randn(42, 8).cuda(), 7)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 64, 64), (1000, 512, 2048), (777, 2048, 512), (129, 136, 96)])
+def test_split_layout_output_and_residual(ops, M, N, K):
+    """LOCOV_EPI_OUT_SPLIT / LOCOV_EPI_RES_SPLIT: a GEMM writes its finished values in the split layout (the pre-split A and the
+    residual of the next block) and reads a residual from it.  Unpacked, the output equals the fp32 output to 2^-22 relative
+    (what the consuming GEMM's own split would keep anyway); as a residual it gives the fp32-residual result to the same
+    precision; as a pre-split A it gives BIT-identical results to converting the unpacked values in the kernel; values
+    outside fp16's range raise the guard."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.relu(torch.randn(M, K, generator=g)).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    sc, sh = (torch.rand(N, generator=g) + 0.5).cuda(), torch.randn(N, generator=g).cuda()
+    wp = ops.split_pack(w)
+    y32 = ops.linear_split(x, wp, sh, scale=sc, residual=res, relu=True)
+    ops.split_overflow_reset(x.device)
+    ysp = ops.linear_split(x, wp, sh, scale=sc, residual=res, relu=True, out_split=True)
+    assert not ops.split_overflow_raised(x.device)
+    got = ops.split_unpack(ysp, 16.0)
+    tol = 2.0 ** -21 * y32.abs().clamp_min(2.0 ** -7)                      # 22 bits, absolute floor 2^-25/16 * ... below 2^-7
+    assert bool(((got - y32).abs() <= tol).all()), float(((got - y32).abs() / tol).max())
+    # the split tensor as the residual of another GEMM == its unpacked values as an fp32 residual (bit for bit: hi + lo is exact)
+    if N % 32 == 0:
+        w2 = (torch.randn(N, N, generator=g) * 0.05).cuda()
+        w2p = ops.split_pack(w2)
+        a = torch.relu(torch.randn(M, N, generator=g)).cuda()
+        r1 = ops.linear_split(a, w2p, residual=ysp, relu=True, residual_is_split=True)
+        r2 = ops.linear_split(a, w2p, residual=got, relu=True)
+        assert torch.equal(r1, r2)
+        # ... and as the pre-split A operand ~ converting the unpacked values in the kernel: the same hi / lo halves except where
+        # hi + lo sits exactly on an fp16 rounding tie (the re-split then picks the other neighbour: same value, another pair)
+        z1 = ops.linear_split(ysp, w2p, relu=True, x_is_split=True, x_scale=16.0)
+        z2 = ops.linear_split(got, w2p, relu=True, x_scale=16.0)
+        assert float((z1 - z2).abs().max()) <= 1e-6 * float(z2.abs().max())
+        # mean-fused form with a split residual
+        if M % 49 == 0 or True:
+            Mr = (M // 49) * 49
+            if Mr:
+                s1 = ops.linear_split_segmean(a[:Mr], w2p, None, ysp[:Mr], 49, residual_roi_major=True, residual_is_split=True)
+                s2 = ops.linear_split_segmean(a[:Mr], w2p, None, got[:Mr].contiguous(), 49, residual_roi_major=True)
+                assert torch.equal(s1, s2)
+    # range guard on the OUTPUT
+    big = x.clone()
+    big[3, :] = 4000.0
+    ops.split_overflow_reset(x.device)
+    ops.linear_split(big, ops.split_pack(torch.ones(N, K).cuda()), out_split=True, x_scale=1.0)   # outputs ~4000*K >> 65504
+    assert ops.split_overflow_raised(x.device)
+    ops.split_overflow_reset(x.device)
