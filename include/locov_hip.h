@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LOCOV_ABI_VERSION 2
+#define LOCOV_ABI_VERSION 3
 
 #define LOCOV_OK 0
 #define LOCOV_ERR_INVALID_ARG (-1)
@@ -482,6 +482,12 @@ int locov_box_head_fwd(const float *x, int64_t R, int C5, int HW, int channels_l
  *                              flags: 0 (position-major rows) or LOCOV_WINO_IN_ROI_MAJOR (both x and g).
  * locov_im2col3x3_nhwc / locov_conv3x3_wgrad_unpack : the general-grid form of the same gradient
  *                              (dw_packed [N, 9*Cin] = g^T . im2col(x) through locov_gemm_tn_f32).
+ * amax_out (locov_relu_mask, locov_spatial_mean_bwd, locov_gemm_nt_f32_split_ex, locov_winograd_conv3x3_f32_split_ex): optional
+ *                              16-byte operand-scale slot, ZEROED by the caller; the launch folds max |the tensor it writes| into
+ *                              word 2 (an atomic max on the bit pattern), and a later split GEMM that takes the slot as its
+ *                              x_scale_dev / a_scale_dev derives the tensor's power-of-two scale from that word (words 0-1 stay
+ *                              zero: "not reduced by locov_split_scale_from_amax") -- the gradient is not read a second time
+ *                              just to find its range.
  * locov_relu_mask, locov_spatial_mean_bwd, locov_rows_stride2, locov_roi_align_nhwc_bwd : element-wise pieces --
  *                              ReLU backward, the mean's broadcast (roi_emb_heads.py:344) fused with it, block 0's
  *                              stride-2 pixel selection on the whole grid and its adjoint, and the adjoint of
@@ -529,7 +535,7 @@ int locov_gemm_nt_f32_split_ex(const float *x, int64_t lda, const void *W_split,
                                const float *shift, const float *residual, const float *mask, float *y,
                                int64_t ldc, int64_t M, int N, int K, unsigned flags, float x_scale,
                                const float *x_scale_dev, float w_scale, unsigned *overflow,
-                               locov_stream_t stream);
+                               float *amax_out, locov_stream_t stream);
 int locov_gemm_tn_f32_split(const float *a, int64_t lda, int64_t stride_a, const float *b, int64_t ldb,
                             int64_t stride_b, float *out, int64_t ldo, int64_t stride_o, int64_t M, int N,
                             int K, int batch, const float *row_scale, const float *a_scale_dev,
@@ -544,7 +550,7 @@ int locov_winograd_conv3x3_f32_split_ex(const float *x, int64_t R, int Cin, cons
                                         float v_scale, int v_scale_auto, const float *scale, const float *shift,
                                         const float *mask, float *y, int64_t ldy, int N, unsigned flags,
                                         float y_split_scale, void *workspace, int64_t workspace_bytes,
-                                        unsigned *overflow, locov_stream_t stream);
+                                        unsigned *overflow, float *amax_out, locov_stream_t stream);
 int locov_winograd_wgrad_f32_split(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags,
                                    const float *row_scale, float *dw, unsigned *overflow, void *workspace,
                                    int64_t workspace_bytes, locov_stream_t stream);
@@ -561,9 +567,9 @@ int locov_conv3x3_weight_flip(const float *w, int N, int Cin, const float *row_s
 int locov_im2col3x3_nhwc(const float *x, int64_t R, int H, int W, int C, float *col, locov_stream_t stream);
 int locov_conv3x3_wgrad_unpack(const float *dw_packed, int N, int Cin, const float *row_scale, float *dw,
                                locov_stream_t stream);
-int locov_relu_mask(const float *g, const float *act, int64_t n, float *out, locov_stream_t stream);
+int locov_relu_mask(const float *g, const float *act, int64_t n, float *out, float *amax_out, locov_stream_t stream);
 int locov_spatial_mean_bwd(const float *g, const float *act, int64_t R, int C, int HW, float *out,
-                           locov_stream_t stream);
+                           float *amax_out, locov_stream_t stream);
 int locov_rows_stride2(const float *src, int N, int H, int W, int C, int forward, float *dst,
                        locov_stream_t stream);
 int locov_roi_align_nhwc_bwd(const float *grad_rows, int64_t grad_ld, int N, int H, int W, int C,

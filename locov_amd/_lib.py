@@ -24,7 +24,7 @@ GEMM_A_SPLIT = 0x1000
 EPI_OUT_SPLIT = 0x2000
 EPI_RES_SPLIT = 0x4000
 MAX_LEVELS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _p = c_void_p  # device pointer
 
@@ -99,11 +99,11 @@ SIGNATURES = {
     "locov_split_scale_from_amax": (c_int, [_p, c_int64, c_float, _p, _p]),
     "locov_split_scale_from_amax_zeroed": (c_int, [_p, c_int64, c_float, _p, _p]),
     "locov_gemm_nt_f32_split_ex": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, c_float, _p,
-                                           c_float, _p, _p]),
+                                           c_float, _p, _p, _p]),
     "locov_gemm_tn_f32_split": (c_int, [_p, c_int64, c_int64, _p, c_int64, c_int64, _p, c_int64, c_int64, c_int64, c_int, c_int, c_int,
                                         _p, _p, c_float, _p, _p, c_int64, _p]),
     "locov_winograd_conv3x3_f32_split_ex": (c_int, [_p, c_int64, c_int, _p, c_float, c_float, c_int, _p, _p, _p, _p, c_int64, c_int,
-                                                    c_uint, c_float, _p, c_int64, _p, _p]),
+                                                    c_uint, c_float, _p, c_int64, _p, _p, _p]),
     "locov_winograd_wgrad_f32_split": (c_int, [_p, _p, c_int64, c_int, c_int, c_uint, _p, _p, _p, _p, c_int64, _p]),
     "locov_winograd_wgrad_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
     "locov_winograd_wgrad_f32": (c_int, [_p, _p, c_int64, c_int, c_int, c_uint, _p, _p, _p, c_int64, _p]),
@@ -111,8 +111,8 @@ SIGNATURES = {
     "locov_conv3x3_weight_flip": (c_int, [_p, c_int, c_int, _p, _p, _p]),
     "locov_im2col3x3_nhwc": (c_int, [_p, c_int64, c_int, c_int, c_int, _p, _p]),
     "locov_conv3x3_wgrad_unpack": (c_int, [_p, c_int, c_int, _p, _p, _p]),
-    "locov_relu_mask": (c_int, [_p, _p, c_int64, _p, _p]),
-    "locov_spatial_mean_bwd": (c_int, [_p, _p, c_int64, c_int, c_int, _p, _p]),
+    "locov_relu_mask": (c_int, [_p, _p, c_int64, _p, _p, _p]),
+    "locov_spatial_mean_bwd": (c_int, [_p, _p, c_int64, c_int, c_int, _p, _p, _p]),
     "locov_rows_stride2": (c_int, [_p, c_int, c_int, c_int, c_int, c_int, _p, _p]),
     "locov_roi_align_nhwc_bwd": (c_int, [_p, c_int64, c_int, c_int, c_int, c_int, _p, c_int64, c_int, c_int, c_float, c_int, c_int,
                                          c_int, c_int, _p, _p]),

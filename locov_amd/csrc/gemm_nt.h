@@ -11,7 +11,42 @@ struct Epilogue {
     unsigned flags;
     const float *mask;      // [M, ldc] or null: the finished value is kept where mask > 0 and zeroed elsewhere (the ReLU
                             // backward of a saved activation, fused into the data-gradient GEMMs; f32 NT kernel only)
+    float *amax_out;        // split GEMM only, or null: a 16-byte operand-scale slot {s, 1/s, max bits, -}; the launch folds
+                            // max |finished value| into word 2 (atomicMax on the bit pattern) -- the tensor it writes is the
+                            // operand of a later split GEMM whose scale is then derived from that word (split_scale_of)
 };
+
+// Operand scale from a 16-byte slot: {s, 1/s} as written by locov_split_scale_from_amax, or -- s == 0: a zeroed slot that
+// producers only folded their max |x| into -- the power of two that puts that max in [2^12, 2^13) (1 for an all-zero tensor).
+__device__ __forceinline__ void split_scale_of(const float *slot, float &s, float &inv)
+{
+    s = slot[0];
+    inv = slot[1];
+    if (s == 0.f) {
+        const float amax = __uint_as_float(reinterpret_cast<const unsigned *>(slot)[2]);
+        s = 1.f;
+        if (amax > 0.f && amax < 3.0e38f) {
+            int e;
+            frexpf(amax, &e);
+            s = ldexpf(1.f, 13 - e);
+        }
+        inv = 1.f / s;
+    }
+}
+
+// max |.| of a wave's values -> the slot's word 2.  Thousands of atomics on one address serialise at L2 (20 k waves of a data-gradient
+// GEMM cost more than the separate reduction pass they replace), so a wave first LOOKS at the running max (a plain L2 read) and
+// only a wave that would raise it issues the atomic: after the first few arrivals almost none does.
+__device__ __forceinline__ void amax_fold(float *slot, float m)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) {
+        unsigned *w = reinterpret_cast<unsigned *>(slot) + 2;
+        const unsigned bits = __float_as_uint(m);                      // non-negative floats order like their bit patterns
+        if (bits > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(w, bits);
+    }
+}
 
 // H == 0: plain GEMM.  H > 0: A is the pixel matrix of independent HxW tiles with Cin channels
 // and the GEMM is the implicit form of a 3x3 / pad 1 / stride 1 convolution (K = 9*Cin).

@@ -169,8 +169,9 @@ __global__ __launch_bounds__(128 * WM_, WM_ == 2 ? LOCOV_SPLIT_MINWG : 1) void g
     const unsigned long long kw0_ = __builtin_amdgcn_s_memtime();
 #endif
     if (a_scale_dev != nullptr) {
-        a_scale = a_scale_dev[0];
-        out_scale *= a_scale_dev[1];          // = 1 / a_scale (exact: powers of two)
+        float inv;
+        split_scale_of(a_scale_dev, a_scale, inv);
+        out_scale *= inv;                     // = 1 / a_scale (exact: powers of two)
     }
 
     __builtin_amdgcn_s_setprio(3);
@@ -542,6 +543,10 @@ __global__ __launch_bounds__(128 * WM_, WM_ == 2 ? LOCOV_SPLIT_MINWG : 1) void g
                     v[0] = mk[0] > 0.f ? v[0] : 0.f; v[1] = mk[1] > 0.f ? v[1] : 0.f;
                     v[2] = mk[2] > 0.f ? v[2] : 0.f; v[3] = mk[3] > 0.f ? v[3] : 0.f;
                 }
+                if (EMASK && !SEGSUM && (FULL || wm + it * RPI + rr < (int)rows_here)) {   // (the gradient this launch writes is a later GEMM's operand: its max |.|)
+                    omax = fmaxf(fmaxf(omax, fabsf(v[0])), fabsf(v[1]));
+                    omax = fmaxf(fmaxf(omax, fabsf(v[2])), fabsf(v[3]));
+                }
                 if (SEGSUM)
                     *reinterpret_cast<f32x4 *>(ep + (it * RPI + rr) * EPS + c4) = v;    // finished value back in place
                 else if (out_split) {
@@ -555,6 +560,7 @@ __global__ __launch_bounds__(128 * WM_, WM_ == 2 ? LOCOV_SPLIT_MINWG : 1) void g
             }
         }
         if (!SEGSUM && out_split && overflow != nullptr && omax * a_scale >= 65504.f) atomicOr(overflow, 1u);
+        if (EMASK && !SEGSUM && epi.amax_out != nullptr) amax_fold(epi.amax_out, omax);
         if (SEGSUM) {
             // column sums per ROI: thread t owns column t % 128 and the ROI slots {t / 128, t / 128 + 2} of this tile
             __syncthreads();
@@ -725,7 +731,7 @@ int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C,
             LOCOV_LAUNCH_SPLIT(false, true, 4);
         else
             LOCOV_LAUNCH_SPLIT(false, true, 2);
-    } else if (epi.mask)
+    } else if (epi.mask || epi.amax_out)
         LOCOV_LAUNCH_SPLIT(true, false, 2);
     else if (big)
         LOCOV_LAUNCH_SPLIT(false, false, 4);
@@ -851,13 +857,13 @@ int locov_split_scale_from_amax_zeroed(const float *x, int64_t n, float target_l
 int locov_gemm_nt_f32_split_ex(const float *x, int64_t lda, const void *W_split, const float *scale, const float *shift,
                                const float *residual, const float *mask, float *y, int64_t ldc, int64_t M, int N, int K,
                                unsigned flags, float x_scale, const float *x_scale_dev, float w_scale, unsigned *overflow,
-                               locov_stream_t stream)
+                               float *amax_out, locov_stream_t stream)
 {
     LOCOV_REQUIRE(M >= 0 && N > 0 && K > 0, "locov_gemm_nt_f32_split_ex: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
     if (M == 0) return LOCOV_OK;
     LOCOV_REQUIRE(x && W_split && y, "locov_gemm_nt_f32_split_ex: null pointer");
     LOCOV_REQUIRE(lda >= K && ldc >= N, "locov_gemm_nt_f32_split_ex: lda < K or ldc < N");
-    Epilogue epi{scale, shift, residual, flags, mask};
+    Epilogue epi{scale, shift, residual, flags, mask, amax_out};
     return launch_gemm_split(x, lda, W_split, y, ldc, M, N, K, epi, x_scale, w_scale, as_stream(stream),
                              "locov_gemm_nt_f32_split_ex", Batch{1, 0, 0, 0}, overflow, x_scale_dev);
 }

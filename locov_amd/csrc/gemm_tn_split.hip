@@ -72,8 +72,9 @@ __global__ __launch_bounds__(SNT, 2) void gemm_tn_split_kernel(const float *__re
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const float a_scale = a_scale_dev[0];
-    const float out_scale = a_scale_dev[1] / b_scale;
+    float a_scale, a_inv;
+    split_scale_of(a_scale_dev, a_scale, a_inv);
+    const float out_scale = a_inv / b_scale;
 
     // staging: threads 0-127 own operand A (columns n0..), 128-255 operand B (columns k0..); within a half, t % 32 = the
     // group of 4 columns, t / 32 = the group of 8 m

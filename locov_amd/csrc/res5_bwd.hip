@@ -8,7 +8,7 @@
 //   conv3x3_wgrad_unpack   : [N, 9*Cin] (k = tap*Cin + c) -> [N, Cin, 3, 3], row-scaled
 //   relu_mask / spatial_mean_bwd : ReLU backward of a saved activation, alone or fused with the mean's broadcast
 //   rows_subsample / rows_upsample_add : the stride-2 pixel selection of block 0 on the whole grid and its adjoint
-#include "common.h"
+#include "gemm_nt.h"
 
 namespace locov {
 
@@ -81,25 +81,30 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_unpack_kernel(const float *
 }
 
 // out = act > 0 ? g : 0   (n4 = quads)
+// amax_out (here and in spatial_mean_bwd_kernel): optional operand-scale slot receiving max |out| (gemm_nt.h, amax_fold)
 __global__ __launch_bounds__(256) void relu_mask_kernel(const float *__restrict__ g, const float *__restrict__ act, int64_t n4,
-                                                        float *__restrict__ out)
+                                                        float *__restrict__ out, float *amax_out)
 {
+    float m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const f32x4 a = reinterpret_cast<const f32x4 *>(act)[i];
         f32x4 v = reinterpret_cast<const f32x4 *>(g)[i];
         v[0] = a[0] > 0.f ? v[0] : 0.f; v[1] = a[1] > 0.f ? v[1] : 0.f;
         v[2] = a[2] > 0.f ? v[2] : 0.f; v[3] = a[3] > 0.f ? v[3] : 0.f;
+        m = fmaxf(fmaxf(fmaxf(m, fabsf(v[0])), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
         reinterpret_cast<f32x4 *>(out)[i] = v;
     }
+    if (amax_out != nullptr) amax_fold(amax_out, m);
 }
 
 // out[(r*HW + p), c] = (act[(r*HW + p), c] > 0 ? g[r, c] / HW : 0): the spatial mean's broadcast fused with the ReLU
 // backward of the stage output (ROI-major rows)
 __global__ __launch_bounds__(256) void spatial_mean_bwd_kernel(const float *__restrict__ g, const float *__restrict__ act, int64_t R,
-                                                               int C, int HW, float inv, float *__restrict__ out)
+                                                               int C, int HW, float inv, float *__restrict__ out, float *amax_out)
 {
     const int c4 = C >> 2;
     const int64_t total = R * HW * c4;
+    float m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int cq = (int)(i % c4);
         const int64_t r = i / ((int64_t)HW * c4);
@@ -109,8 +114,10 @@ __global__ __launch_bounds__(256) void spatial_mean_bwd_kernel(const float *__re
             v[0] = a[0] > 0.f ? v[0] : 0.f; v[1] = a[1] > 0.f ? v[1] : 0.f;
             v[2] = a[2] > 0.f ? v[2] : 0.f; v[3] = a[3] > 0.f ? v[3] : 0.f;
         }
+        m = fmaxf(fmaxf(fmaxf(m, fabsf(v[0])), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
         reinterpret_cast<f32x4 *>(out)[i] = v;
     }
+    if (amax_out != nullptr) amax_fold(amax_out, m);
 }
 
 // channels-last map [N, H, W, C] <-> rows of its stride-2 pixels [N, OH, OW, C], OH = (H+1)/2, OW = (W+1)/2
@@ -188,22 +195,23 @@ int locov_conv3x3_wgrad_unpack(const float *dw_packed, int N, int Cin, const flo
     return check_launch("locov_conv3x3_wgrad_unpack");
 }
 
-int locov_relu_mask(const float *g, const float *act, int64_t n, float *out, locov_stream_t stream)
+int locov_relu_mask(const float *g, const float *act, int64_t n, float *out, float *amax_out, locov_stream_t stream)
 {
     LOCOV_REQUIRE(n >= 0 && n % 4 == 0, "locov_relu_mask: n must be a non-negative multiple of 4");
     if (n == 0) return LOCOV_OK;
     LOCOV_REQUIRE(g && act && out && ((uintptr_t)g | (uintptr_t)act | (uintptr_t)out) % 16 == 0, "locov_relu_mask: null or misaligned pointer");
-    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), g, act, n / 4, out);
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), g, act, n / 4, out, amax_out);
     return check_launch("locov_relu_mask");
 }
 
-int locov_spatial_mean_bwd(const float *g, const float *act, int64_t R, int C, int HW, float *out, locov_stream_t stream)
+int locov_spatial_mean_bwd(const float *g, const float *act, int64_t R, int C, int HW, float *out, float *amax_out,
+                           locov_stream_t stream)
 {
     LOCOV_REQUIRE(R >= 0 && C > 0 && HW > 0 && C % 4 == 0, "locov_spatial_mean_bwd: bad shape (C must be a multiple of 4)");
     if (R == 0) return LOCOV_OK;
     LOCOV_REQUIRE(g && out && ((uintptr_t)g | (uintptr_t)act | (uintptr_t)out) % 16 == 0, "locov_spatial_mean_bwd: null or misaligned pointer");
     hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(grid_for(R * HW * (C / 4))), dim3(256), 0, as_stream(stream), g, act, R, C, HW,
-                       1.0f / (float)HW, out);
+                       1.0f / (float)HW, out, amax_out);
     return check_launch("locov_spatial_mean_bwd");
 }
 

@@ -84,15 +84,20 @@ __device__ __forceinline__ constexpr float in_coef(int f, int y) { return GRAD ?
 
 // SPLIT: V is written in the split layout scaled by v_scale (the A operand of the split batched GEMM); a value outside fp16's
 // range raises *overflow (the GEMM no longer sees the fp32 values: the range guard moves here).
+// amax_out (fp32 V only): a 16-byte operand-scale slot whose word 2 receives max |V| (gemm_nt.h, amax_fold) -- the transform of
+// a gradient has no a-priori range, the GEMM that reads V derives its operand scale from that word.
 template <bool GRAD, bool SPLIT = false>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, int64_t ld_pos, int64_t ld_roi, int64_t Rc, int C,
-                                                         float *__restrict__ V, float v_scale = 1.f, unsigned *overflow = nullptr)
+                                                         float *__restrict__ V, float v_scale = 1.f, unsigned *overflow = nullptr,
+                                                         float *amax_out = nullptr)
 {
     const int c2 = C >> 1;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= Rc * c2) return;           // (SPLIT: lanes trade words in pairs (t, t^1); C % 4 == 0 makes the count even, so a pair is
-                                        //  live or idle as a whole)
+    // (no early return: the whole wave meets in amax_fold.  SPLIT: lanes trade words in pairs (t, t^1); C % 4 == 0 makes the count
+    //  even, so a pair is live or idle as a whole)
+    const bool live = t < Rc * c2;
     float amax = 0.f;
+    if (live) {
     const int64_t r = t / c2;
     const int c = (int)(t - r * c2) * 2;
     const float *src = x + r * ld_roi * C + c;
@@ -125,11 +130,14 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
                 amax = fmaxf(fmaxf(amax, fabsf(a[0])), fabsf(a[1]));
                 store_split_pair(V + r * C + (int64_t)(fy * NF + fx) * fstride, c, a, v_scale);
             } else {
+                amax = fmaxf(fmaxf(amax, fabsf(a[0])), fabsf(a[1]));
                 __builtin_nontemporal_store(a, reinterpret_cast<f32x2 *>(dst + (int64_t)(fy * NF + fx) * fstride));
             }
         }
     }
+    }
     if (SPLIT && overflow != nullptr && amax * v_scale >= 65504.f) atomicOr(overflow, 1u);
+    if (!SPLIT && amax_out != nullptr) amax_fold(amax_out, amax);
 }
 
 // M [NF*NF][Rc][N]  ->  y rows [(y*7+x)*ld_pos + r*ld_roi] (ldy elements apart) = relu?(acc * scale[n] + shift[n]);
@@ -141,13 +149,15 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, int relu,
                                                           float *__restrict__ y, int64_t ldy, const float *__restrict__ mask,
-                                                          float y_scale = 1.f, unsigned *overflow = nullptr)
+                                                          float y_scale = 1.f, unsigned *overflow = nullptr, float *amax_out = nullptr)
 {
     // mask (same rows and pitch as y, or null): the value is kept where mask > 0, zeroed elsewhere -- the ReLU backward of the
     // saved activation when this convolution is a data gradient (flipped filter)
     const int n2 = N >> 1;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= Rc * n2) return;
+    const bool live = t < Rc * n2;       // (no early return: the whole wave meets in amax_fold)
+    float amax = 0.f;
+    if (live) {
     const int64_t r = t / n2;
     const int n = (int)(t - r * n2) * 2;
     const float *src = Mv + r * N + n;
@@ -184,7 +194,6 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
     if (shift) sh = *reinterpret_cast<const f32x2 *>(shift + n);
     float *dst = y + r * ld_roi * ldy + n;
     const float *msk = mask ? mask + r * ld_roi * ldy + n : nullptr;
-    float amax = 0.f;
 #pragma unroll
     for (int yy = 0; yy < 7; yy++)
 #pragma unroll
@@ -203,10 +212,13 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
                 amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
                 store_split_pair(y + r * ld_roi * ldy + (int64_t)(yy * 7 + xx) * ld_pos * ldy, n, v, y_scale);
             } else {
+                amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
                 *reinterpret_cast<f32x2 *>(dst + (int64_t)(yy * 7 + xx) * ld_pos * ldy) = v;
             }
         }
+    }
     if (SPLIT && overflow != nullptr && amax * y_scale >= 65504.f) atomicOr(overflow, 1u);
+    if (!SPLIT && amax_out != nullptr) amax_fold(amax_out, amax);
 }
 
 // dU [NF*NF, N, Cin] -> dw [N, Cin, 3, 3] = row_scale[n] * (G (x) G)^T dU : the adjoint of wino_pack_weight_kernel
@@ -279,7 +291,8 @@ int locov_winograd_pack_weight(const float *w, int N, int Cin, float *U, locov_s
 static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
                             const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
                             void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask = nullptr,
-                            unsigned *overflow = nullptr, bool v_scale_auto = false, float y_split_scale = 0.f);
+                            unsigned *overflow = nullptr, bool v_scale_auto = false, float y_split_scale = 0.f,
+                            float *amax_out = nullptr);
 
 int locov_winograd_conv3x3_f32_ex(const float *x, int64_t R, int Cin, const float *U, const float *scale, const float *shift,
                                   const float *mask, float *y, int64_t ldy, int N, unsigned flags, void *workspace,
@@ -291,11 +304,12 @@ int locov_winograd_conv3x3_f32_ex(const float *x, int64_t R, int Cin, const floa
 int locov_winograd_conv3x3_f32_split_ex(const float *x, int64_t R, int Cin, const void *U_split, float u_scale, float v_scale,
                                         int v_scale_auto, const float *scale, const float *shift, const float *mask, float *y,
                                         int64_t ldy, int N, unsigned flags, float y_split_scale, void *workspace,
-                                        int64_t workspace_bytes, unsigned *overflow, locov_stream_t stream)
+                                        int64_t workspace_bytes, unsigned *overflow, float *amax_out, locov_stream_t stream)
 {
     LOCOV_REQUIRE(u_scale > 0.f && (v_scale_auto || v_scale > 0.f), "locov_winograd_conv3x3_f32_split_ex: operand scales must be positive");
+    LOCOV_REQUIRE(!amax_out || !(y_split_scale > 0.f), "locov_winograd_conv3x3_f32_split_ex: amax_out is for an fp32 output");
     return winograd_conv3x3(x, R, Cin, static_cast<const float *>(U_split), u_scale, v_scale_auto ? 1.f : v_scale, scale, shift, y, ldy, N,
-                            flags, workspace, workspace_bytes, stream, mask, overflow, v_scale_auto != 0, y_split_scale);
+                            flags, workspace, workspace_bytes, stream, mask, overflow, v_scale_auto != 0, y_split_scale, amax_out);
 }
 
 int locov_winograd_conv3x3_f32(const float *x, int64_t R, int Cin, const float *U, const float *scale,
@@ -318,7 +332,7 @@ int locov_winograd_conv3x3_f32_split(const float *x, int64_t R, int Cin, const v
 static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
                             const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
                             void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask, unsigned *overflow,
-                            bool v_scale_auto, float y_split_scale)
+                            bool v_scale_auto, float y_split_scale, float *amax_out)
 {
     LOCOV_REQUIRE(ldy >= N && ldy % 2 == 0, "locov_winograd_conv3x3_f32: ldy must be >= N and even");
     LOCOV_REQUIRE(R >= 0 && Cin > 0 && N > 0, "locov_winograd_conv3x3_f32: bad shape");
@@ -349,21 +363,22 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
             hipLaunchKernelGGL((wino_input_kernel<false, true>), dim3((unsigned)ceil_div(tin, 256)), dim3(256), 0, s,
                                x + r0 * (in_roi_major ? 49 : 1) * Cin, in_roi_major ? (int64_t)1 : R,
                                in_roi_major ? (int64_t)49 : (int64_t)1, rc, Cin, V, v_scale, overflow);
-        else
+        else {
+            // (split GEMM on a gradient: the transform folds max |V| into the 16-byte slot at the end of the workspace, zeroed
+            // here, and the GEMM derives V's operand scale from it -- no separate pass over the 121 x rc x Cin values)
+            float *scw = u_scale > 0.f && v_scale_auto ? reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_bytes - 16) : nullptr;
+            if (scw && hipMemsetAsync(scw, 0, 16, s) != hipSuccess) return set_error(LOCOV_ERR_LAUNCH, "locov_winograd_conv3x3_f32_split: memset failed");
             hipLaunchKernelGGL((wino_input_kernel<false, false>), dim3((unsigned)ceil_div(tin, 256)), dim3(256), 0, s,
                                x + r0 * (in_roi_major ? 49 : 1) * Cin, in_roi_major ? (int64_t)1 : R,
-                               in_roi_major ? (int64_t)49 : (int64_t)1, rc, Cin, V, 1.f, static_cast<unsigned *>(nullptr));
+                               in_roi_major ? (int64_t)49 : (int64_t)1, rc, Cin, V, 1.f, static_cast<unsigned *>(nullptr), scw);
+        }
         int rcode = check_launch("locov_winograd_conv3x3_f32 (input transform)");
         if (rcode) return rcode;
         Epilogue epi{nullptr, nullptr, nullptr, v_split ? LOCOV_GEMM_A_SPLIT : 0u};
         if (u_scale > 0.f) {
             const float *sc = nullptr;
-            if (v_scale_auto) {       // the input is a gradient: choose the scale of its transform from max |V| on the device
-                float *scw = reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_bytes - 16);
-                rcode = locov_split_scale_from_amax(V, (int64_t)NF * NF * rc * Cin, 13.f, scw, stream);
-                if (rcode) return rcode;
-                sc = scw;
-            }
+            if (v_scale_auto)         // the input is a gradient: the scale of its transform comes from the slot the transform filled
+                sc = reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_bytes - 16);
             rcode = launch_gemm_split(V, (int64_t)Cin, U, Mv, (int64_t)N, rc, N, Cin, epi, v_scale, u_scale, s,
                                       "locov_winograd_conv3x3_f32_split (batched GEMM)",
                                       Batch{NF * NF, rc * Cin, (int64_t)N * Cin, rc * N}, overflow, sc);
@@ -382,7 +397,7 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
             hipLaunchKernelGGL((wino_output_kernel<false>), dim3((unsigned)ceil_div(tout, 256)), dim3(256), 0, s, Mv, roi_major ? (int64_t)1 : R,
                                roi_major ? (int64_t)49 : (int64_t)1, rc, N, scale, shift, (flags & LOCOV_EPI_RELU) ? 1 : 0,
                                y + r0 * (roi_major ? 49 : 1) * ldy, ldy, mask ? mask + r0 * (roi_major ? 49 : 1) * ldy : nullptr, 1.f,
-                               static_cast<unsigned *>(nullptr));
+                               static_cast<unsigned *>(nullptr), amax_out);
         rcode = check_launch("locov_winograd_conv3x3_f32 (output transform)");
         if (rcode) return rcode;
     }
@@ -436,16 +451,18 @@ static int winograd_wgrad(const float *x, const float *g, int64_t R, int Cin, in
     hipLaunchKernelGGL(wino_input_kernel<false>, dim3((unsigned)ceil_div(R * (Cin / 2), 256)), dim3(256), 0, s, x, ld_pos, ld_roi, R, Cin, V);
     int rc = check_launch("locov_winograd_wgrad_f32 (input transform)");
     if (rc) return rc;
-    hipLaunchKernelGGL(wino_input_kernel<true>, dim3((unsigned)ceil_div(R * (N / 2), 256)), dim3(256), 0, s, g, ld_pos, ld_roi, R, N, dM);
+    float *dm_slot = split ? reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_bytes - 16) : nullptr;
+    if (dm_slot && hipMemsetAsync(dm_slot, 0, 16, s) != hipSuccess) return set_error(LOCOV_ERR_LAUNCH, "locov_winograd_wgrad_f32_split: memset failed");
+    hipLaunchKernelGGL(wino_input_kernel<true>, dim3((unsigned)ceil_div(R * (N / 2), 256)), dim3(256), 0, s, g, ld_pos, ld_roi, R, N, dM, 1.f,
+                       static_cast<unsigned *>(nullptr), dm_slot);
     rc = check_launch("locov_winograd_wgrad_f32 (gradient transform)");
     if (rc) return rc;
     // dU_f [N, Cin] = dM_f^T . V_f   (121 problems, contraction over the ROIs)
     const int64_t tn_bytes = workspace_bytes - (int64_t)((char *)tn_ws - (char *)workspace) - 16;
     if (split) {
         // operand scales: dM from its max |.| on the device (last 16 bytes of the workspace), V as in the forward (0.25)
-        float *sc = reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_bytes - 16);
-        rc = locov_split_scale_from_amax(dM, (int64_t)NF * NF * R * N, 13.f, sc, stream);
-        if (rc) return rc;
+        // operand scales: dM from the max |.| its transform folded into the slot, V as in the forward (0.25)
+        float *sc = dm_slot;
         rc = launch_gemm_tn_split(dM, (int64_t)N, R * N, V, (int64_t)Cin, R * Cin, dU, (int64_t)Cin, (int64_t)N * Cin, R, N, Cin, NF * NF,
                                   nullptr, sc, 0.25f, overflow, tn_ws, tn_bytes, s, "locov_winograd_wgrad_f32_split (batched TN GEMM)");
     } else

@@ -371,7 +371,7 @@ def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool =
             check(lib.locov_winograd_conv3x3_f32_split_ex(_ptr(x), R, Cin, _ptr(U), split.scale, float(v_scale), 0, _ptr(scale),
                                                           _ptr(shift), None, _ptr(y), ldy, N, wflags,
                                                           float(out_split_scale or 0.0), _ptr(ws), ws.numel(),
-                                                          _ptr(_overflow_word(x)), _stream(x)),
+                                                          _ptr(_overflow_word(x)), None, _stream(x)),
                   "locov_winograd_conv3x3_f32_split_ex")
         else:
             if out_split_scale is not None:
@@ -799,23 +799,36 @@ def split_scale_from_amax(x: torch.Tensor, target_log2: float = 13.0) -> torch.T
 _SCALE_SLOTS = {}
 
 
-def _scale_slot(ref: torch.Tensor) -> torch.Tensor:
-    """16 bytes for a device-chosen operand scale, from a per-(device, stream) ring of 2048 zeroed slots: the reduction
-    kernel leaves its scratch words zero again, so a slot needs no memset when the ring comes round to it -- by which time
-    (same stream, 2047 reductions later; a training step takes ~25) every GEMM that read it has long been enqueued."""
+def _scale_slot(ref: torch.Tensor, lazy: bool = False) -> torch.Tensor:
+    """16 bytes for a device-chosen operand scale, from a per-(device, stream) ring of 2048 zeroed slots.  The reduction kernel
+    (split_scale_from_amax) leaves its scratch words zero again; a `lazy` slot (scale_slot: producers fold their max into
+    word 2, consumers derive the scale) stays dirty, so a ring that handed one out is zeroed when it wraps -- one fill per 2048
+    uses, enqueued behind every GEMM that read the old contents (same stream; a training step takes ~40 slots)."""
     key = (ref.device, torch.cuda.current_stream(ref.device).cuda_stream)
     ring = _SCALE_SLOTS.get(key)
     if ring is None:
-        ring = _SCALE_SLOTS[key] = [torch.zeros(2048, 4, dtype=torch.float32, device=ref.device), 0]
+        ring = _SCALE_SLOTS[key] = [torch.zeros(2048, 4, dtype=torch.float32, device=ref.device), 0, False]
     i = ring[1]
+    if i == 0 and ring[2]:
+        ring[0].zero_()
+        ring[2] = False
     ring[1] = (i + 1) % ring[0].shape[0]
+    ring[2] = ring[2] or lazy
     return ring[0][i]
 
 
+def scale_slot(ref: torch.Tensor) -> torch.Tensor:
+    """A zeroed 16-byte operand-scale slot (device) for `amax_out=`: the kernel that writes a gradient folds max |.| into it,
+    the split GEMMs that read the gradient (`x_scale_dev=` / `a_scale_dev=`) derive its power-of-two scale from that."""
+    return _scale_slot(_dev(ref, "ref"), lazy=True)
+
+
 def linear_split_ex(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tensor] = None, *, scale=None, residual=None,
-                    mask=None, relu: bool = False, x_scale: float = 16.0, x_scale_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    mask=None, relu: bool = False, x_scale: float = 16.0, x_scale_dev: Optional[torch.Tensor] = None,
+                    amax_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """linear_split() with the epilogue mask of linear_ex and, optionally, the operand scale of x taken from device
-    memory (split_scale_from_amax): the data-gradient GEMMs of the training step in split arithmetic."""
+    memory (split_scale_from_amax / scale_slot): the data-gradient GEMMs of the training step in split arithmetic.
+    amax_out: scale_slot() that receives max |y|."""
     x = _rows(x, "x")
     wd = _dev(weight.data, "weight")
     M, K = x.shape
@@ -833,7 +846,7 @@ def linear_split_ex(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.T
     with torch.cuda.device(x.device):
         check(_lib.load().locov_gemm_nt_f32_split_ex(_ptr(x), x.stride(0) if M else K, _ptr(wd), _ptr(scale), _ptr(bias), _ptr(residual),
                                                      _ptr(mask), _ptr(y), N, M, N, K, _lib.EPI_RELU if relu else 0, float(x_scale),
-                                                     _ptr(x_scale_dev), weight.scale, _ptr(_overflow_word(x)), _stream(x)),
+                                                     _ptr(x_scale_dev), weight.scale, _ptr(_overflow_word(x)), _ptr(amax_out), _stream(x)),
               "locov_gemm_nt_f32_split_ex")
     return y
 
@@ -859,7 +872,8 @@ def gemm_tn_split(a: torch.Tensor, b: torch.Tensor, row_scale: Optional[torch.Te
 
 
 def winograd_conv3x3_split_ex(x: torch.Tensor, U: SplitWeight, *, scale=None, shift=None, mask=None, relu: bool = False,
-                              roi_major: bool = True, v_scale: Optional[float] = None) -> torch.Tensor:
+                              roi_major: bool = True, v_scale: Optional[float] = None,
+                              amax_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """winograd_conv3x3() in split arithmetic with the output mask; v_scale None = chosen on the device from max |V| (the input
     is a gradient)."""
     x = _dev(x, "x")
@@ -880,7 +894,7 @@ def winograd_conv3x3_split_ex(x: torch.Tensor, U: SplitWeight, *, scale=None, sh
     with torch.cuda.device(x.device):
         check(lib.locov_winograd_conv3x3_f32_split_ex(_ptr(x), R, Cin, _ptr(Ud), U.scale, float(v_scale or 1.0), int(v_scale is None),
                                                       _ptr(scale), _ptr(shift), _ptr(mask), _ptr(y), N, N, flags, 0.0, _ptr(ws), ws.numel(),
-                                                      _ptr(_overflow_word(x)), _stream(x)), "locov_winograd_conv3x3_f32_split_ex")
+                                                      _ptr(_overflow_word(x)), _ptr(amax_out), _stream(x)), "locov_winograd_conv3x3_f32_split_ex")
     return y
 
 
@@ -933,18 +947,18 @@ def conv3x3_wgrad_unpack(dw_packed: torch.Tensor, row_scale: Optional[torch.Tens
     return dw
 
 
-def relu_mask(g: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
-    """g where act > 0, else 0."""
+def relu_mask(g: torch.Tensor, act: torch.Tensor, amax_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """g where act > 0, else 0.  amax_out: scale_slot() that receives max |result|."""
     g, act = _dev(g, "g"), _dev(act, "act")
     if g.shape != act.shape or g.numel() % 4:
         raise ValueError("relu_mask: shapes must match, numel % 4 == 0")
     out = torch.empty_like(g)
     with torch.cuda.device(g.device):
-        check(_lib.load().locov_relu_mask(_ptr(g), _ptr(act), g.numel(), _ptr(out), _stream(g)), "locov_relu_mask")
+        check(_lib.load().locov_relu_mask(_ptr(g), _ptr(act), g.numel(), _ptr(out), _ptr(amax_out), _stream(g)), "locov_relu_mask")
     return out
 
 
-def spatial_mean_bwd(g: torch.Tensor, act: Optional[torch.Tensor], hw: int) -> torch.Tensor:
+def spatial_mean_bwd(g: torch.Tensor, act: Optional[torch.Tensor], hw: int, amax_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """g [R,C] -> [R*hw, C] ROI-major rows: g[r]/hw broadcast over the positions, zeroed where act <= 0."""
     g = _dev(g, "g")
     R, C = g.shape
@@ -953,7 +967,7 @@ def spatial_mean_bwd(g: torch.Tensor, act: Optional[torch.Tensor], hw: int) -> t
         raise ValueError("spatial_mean_bwd: act must be [R*hw, C]")
     out = torch.empty((R * hw, C), dtype=torch.float32, device=g.device)
     with torch.cuda.device(g.device):
-        check(_lib.load().locov_spatial_mean_bwd(_ptr(g), _ptr(act), R, C, hw, _ptr(out), _stream(g)), "locov_spatial_mean_bwd")
+        check(_lib.load().locov_spatial_mean_bwd(_ptr(g), _ptr(act), R, C, hw, _ptr(out), _ptr(amax_out), _stream(g)), "locov_spatial_mean_bwd")
     return out
 
 

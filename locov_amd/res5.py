@@ -189,6 +189,21 @@ class Res5Stage(nn.Sequential):
         self._cache[slot] = (key, val)
         return val
 
+    def _derived(self, conv: Conv2d, tag: str, fn):
+        """A weight-sized tensor derived from conv.weight and its FrozenBN fold (transposed / flipped / re-packed filters of
+        the backward pass), cached until either changes: the two Res5 calls of a training step (whole grid + sampled
+        proposals) run the same backward kernels on the same weights, the second one reuses the first one's operands."""
+        n = conv.norm
+        key = (conv.weight.data_ptr(), conv.weight._version, n.weight._version, n.bias._version, n.running_mean._version,
+               n.running_var._version)
+        slot = ("derived", id(conv), tag)
+        hit = self._cache.get(slot)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        val = fn()
+        self._cache[slot] = (key, val)
+        return val
+
     def _packed_block0_tail(self):
         """Block 0's conv3 and shortcut as ONE GEMM over the K-concatenated operand [conv2 output | stage
         input]:  relu(s3*(W3 y) + b3 + ss*(Ws x) + bs) = relu([y | x] . [s3*W3 | ss*Ws]^T + (b3 + bs)).

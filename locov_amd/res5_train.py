@@ -139,8 +139,16 @@ class Res5RowsFn(torch.autograd.Function):
         gw: List[Optional[torch.Tensor]] = [None] * ctx.nw
         grad_out = ops._dev(grad_out, "grad_out")
         out_last = saved[4 * len(stage) - 1]
+        # Operand scales of the gradients (split arithmetic): every kernel that WRITES a gradient folds max |.| into a zeroed
+        # 16-byte slot (ops.scale_slot) on its way out, and the GEMMs that read the gradient derive its power-of-two scale from
+        # the slot -- no separate pass over the tensor, no host read.
+        slot = (lambda ref: ops.scale_slot(ref)) if sp else (lambda ref: None)
         # gradient of the last block's output, masked by its ReLU
+        # (the two element-wise kernels at the head of the chain keep the separate reduction: their waves all finish together,
+        # so every one of them would issue its atomic -- measured +110 us on the grid's relu_mask against a 10 us reduction)
         g = ops.spatial_mean_bwd(grad_out, out_last, H * W) if ctx.pooled else ops.relu_mask(grad_out, out_last)
+        sg = ops.split_scale_from_amax(g) if sp else None
+
         def keyed(t, conv, tag):                       # remembered operand scale of a per-step weight packing (Res5Stage._split)
             t._locov_key = (id(conv), tag)
             return t
@@ -150,10 +158,11 @@ class Res5RowsFn(torch.autograd.Function):
                 return ops.gemm_tn_split(g_, x_, s_, sg_, 16.0)
             return ops.gemm_tn(g_, x_, s_)
 
-        def dgrad_1x1(g_, sg_, wt, conv, **kw):        # (g . wt^T [+ residual]) [mask]
+        def dgrad_1x1(g_, sg_, wt, conv, amax_out=None, **kw):        # (g . wt^T [+ residual]) [mask]; amax_out: slot of the result
             if sp and wt.shape[1] % 32 == 0 and wt.shape[0] % 4 == 0:
-                return ops.linear_split_ex(g_, stage._split(keyed(wt, conv, "t")), x_scale_dev=sg_, **kw)
-            return ops.linear_ex(g_, wt, **kw)
+                return ops.linear_split_ex(g_, stage._split(keyed(wt, conv, "t")), x_scale_dev=sg_, amax_out=amax_out, **kw), amax_out
+            y_ = ops.linear_ex(g_, wt, **kw)
+            return y_, (ops.split_scale_from_amax(y_) if sp and amax_out is not None else None)
 
         for bi in range(len(stage) - 1, -1, -1):
             blk = stage[bi]
@@ -163,11 +172,11 @@ class Res5RowsFn(torch.autograd.Function):
             w1, s1, _ = stage._packed(blk.conv1)
             w3, s3, _ = stage._packed(blk.conv3)
             c2 = blk.conv2
-            sg = ops.split_scale_from_amax(g) if sp else None
             # conv3: dW3 = s3 * g^T y2 ; g2 = (g . s3 W3) [y2 > 0]
             if need_w[wi + 2]:
                 gw[wi + 2] = wgrad_1x1(g, sg, y2, s3).view_as(blk.conv3.weight)
-            g2 = dgrad_1x1(g, sg, ops.weight_transpose_scale(w3, s3), blk.conv3, mask=y2)
+            g2, sg2 = dgrad_1x1(g, sg, stage._derived(blk.conv3, "wt", lambda: ops.weight_transpose_scale(w3, s3)), blk.conv3,
+                                amax_out=slot(g), mask=y2)
             # conv2 (3x3): dW2 = s2 * wgrad(y1, g2) ; g1 = conv3x3(g2, flip(s2 W2)) [y1 > 0]
             _, s2, _ = stage._packed(c2)
             w2 = c2.weight.detach()
@@ -177,22 +186,23 @@ class Res5RowsFn(torch.autograd.Function):
                 else:
                     colw = col if col is not None else ops.im2col3x3(y1, H, W)
                     if sp:
-                        gw[wi + 1] = ops.conv3x3_wgrad_unpack(ops.gemm_tn_split(g2, colw, None, ops.split_scale_from_amax(g2), 16.0), s2)
+                        gw[wi + 1] = ops.conv3x3_wgrad_unpack(ops.gemm_tn_split(g2, colw, None, sg2, 16.0), s2)
                     else:
                         gw[wi + 1] = ops.conv3x3_wgrad_unpack(ops.gemm_tn(g2, colw), s2)
-            wflip = ops.conv3x3_weight_flip(w2, s2)                       # [Cin, Cout, 3, 3]
+            wflip = stage._derived(c2, "flip", lambda: ops.conv3x3_weight_flip(w2, s2))     # [Cin, Cout, 3, 3]
+            sg1 = slot(g2)
             if _wino_ok(H, W, c2.out_channels, c2.in_channels) and not _NO_WINO_BWD:
-                uflip = ops.winograd_pack_weight(wflip)
+                uflip = stage._derived(c2, "uflip", lambda: ops.winograd_pack_weight(wflip))
                 if sp:
-                    g1 = ops.winograd_conv3x3_split_ex(g2, stage._split(keyed(uflip, c2, "uflip")), mask=y1, roi_major=True)
+                    g1 = ops.winograd_conv3x3_split_ex(g2, stage._split(keyed(uflip, c2, "uflip")), mask=y1, roi_major=True, amax_out=sg1)
                 else:
                     g1 = ops.winograd_conv3x3_ex(g2, uflip, mask=y1, roi_major=True)
             else:
-                # data gradient on the general grid: the same im2col GEMM with the flipped filter
-                g1 = dgrad_1x1(ops.im2col3x3(g2, H, W), ops.split_scale_from_amax(g2) if sp else None,
-                               ops.pack_conv3x3_weight(wflip), c2, mask=y1)
+                # data gradient on the general grid: the same im2col GEMM with the flipped filter (im2col only copies and
+                # zero-pads: the patches have g2's range)
+                g1, sg1 = dgrad_1x1(ops.im2col3x3(g2, H, W), sg2, stage._derived(c2, "flip9", lambda: ops.pack_conv3x3_weight(wflip)), c2,
+                                    amax_out=sg1, mask=y1)
             del g2
-            sg1 = ops.split_scale_from_amax(g1) if sp else None
             # conv1 (+ shortcut): dW1 = s1 * g1^T x ; gx = (g1 . s1 W1 + shortcut path) [x > 0]
             if need_w[wi]:
                 gw[wi] = wgrad_1x1(g1, sg1, x, s1).view_as(blk.conv1.weight)
@@ -207,12 +217,16 @@ class Res5RowsFn(torch.autograd.Function):
             # the input of block 0 is the pooler output (no ReLU in front of it); every other block's input is the
             # post-ReLU output of its predecessor, whose mask turns gx into that block's masked output gradient
             mask = None if first else x
-            gx = dgrad_1x1(g1, sg1, ops.weight_transpose_scale(w1, s1), blk.conv1, residual=None if has_sc else g,
-                           mask=None if has_sc else mask)
+            # (the slot of gx is only needed when a block below reads it: not for the stage input's gradient)
+            gx, sgx = dgrad_1x1(g1, sg1, stage._derived(blk.conv1, "wt", lambda: ops.weight_transpose_scale(w1, s1)), blk.conv1,
+                                amax_out=None if (first or has_sc) else slot(g1),
+                                residual=None if has_sc else g, mask=None if has_sc else mask)
             if has_sc:
-                gx = dgrad_1x1(g, sg, ops.weight_transpose_scale(ws, ss), blk.shortcut, residual=gx, mask=mask)
+                gx, sgx = dgrad_1x1(g, sg, stage._derived(blk.shortcut, "wt", lambda: ops.weight_transpose_scale(ws, ss)), blk.shortcut,
+                                    amax_out=None if first else slot(g),
+                                    residual=gx, mask=mask)
             del g1
-            g = gx
+            g, sg = gx, sgx
         return (g, None, None, None, None, None, None, None, *gw)
 
 

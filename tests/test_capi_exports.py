@@ -32,7 +32,7 @@ def test_every_symbol_is_exported(lib):
     for name in _declared():
         assert hasattr(lib, name), name
     from locov_amd import _lib
-    assert lib.locov_abi_version() == _lib.ABI_VERSION == 2        # 2: the split entry points carry the range-guard word
+    assert lib.locov_abi_version() == _lib.ABI_VERSION == 3        # 2: the split entry points carry the range-guard word; 3: amax_out slots
 
 
 def test_argument_errors_are_reported_without_a_gpu(lib):
