@@ -139,15 +139,19 @@ int locov_roi_align_from_nhwc_fwd(const float *feat_nhwc, int N, int H, int W, i
  *   LOCOV_ROIALIGN_EXACT : the call above -- torchvision's per-sample order, un-fused: bit-identical to the CPU oracle.
  *   LOCOV_ROIALIGN_FAST  : within 1e-5 of it (SURVEY.md 8d's ROIAlign gate).  Separable form: per bin and axis the samples'
  *     bilinear weights are summed per PIXEL, so a bin costs (gh+1)(gw+1) taps instead of 4 gh gw; and the proposal's
- *     pixel window x 32 channels is staged in LDS once ("LDS-staged proposal tiles") whenever it fits 192 pixels, so
- *     that bins sharing pixels share the fetch.  ROIs whose samples lie more than a pixel apart (a forced sampling_ratio
- *     on a large box) or whose grid exceeds 16 samples per axis take the exact form. */
+ *     output bins are cut into regions whose pixel rectangle x 32 channels is staged in LDS once ("LDS-staged proposal
+ *     tiles"; a small box is one region) so that every tap is an LDS read.  A plan kernel computes both per ROI into
+ *     `workspace` (locov_roi_align_plan_bytes(R) bytes, 16-byte aligned; unused by the exact mode).  ROIs whose samples lie
+ *     more than a pixel apart (a forced sampling_ratio on a large box), whose grid exceeds 5 samples per axis, or pooled
+ *     sizes above 16 take the exact arithmetic inside the same launch. */
 #define LOCOV_ROIALIGN_EXACT 0
 #define LOCOV_ROIALIGN_FAST 1
+int64_t locov_roi_align_plan_bytes(int64_t R);
 int locov_roi_align_from_nhwc_fwd_ex(const float *feat_nhwc, int N, int H, int W, int C,
                                      const float *rois, int64_t R, int pooled_h, int pooled_w,
                                      float spatial_scale, int sampling_ratio, int aligned, int mode,
-                                     float *out, locov_stream_t stream);
+                                     void *workspace, int64_t workspace_bytes, float *out,
+                                     locov_stream_t stream);
 
 int locov_roi_align_nhwc_fwd(const void *feat, int feat_dtype, int N, int H, int W, int C,
                              const float *rois, int64_t R, int pooled_h, int pooled_w,

@@ -50,8 +50,9 @@ SIGNATURES = {
                                                 c_float, c_int, c_int, c_int, c_int, _p, _p, c_int, _p, c_int64, c_int, _p]),
     "locov_roi_align_from_nhwc_fwd": (c_int, [_p, c_int, c_int, c_int, c_int, _p, c_int64, c_int, c_int, c_float,
                                               c_int, c_int, _p, _p]),
+    "locov_roi_align_plan_bytes": (c_int64, [c_int64]),
     "locov_roi_align_from_nhwc_fwd_ex": (c_int, [_p, c_int, c_int, c_int, c_int, _p, c_int64, c_int, c_int, c_float,
-                                                 c_int, c_int, c_int, _p, _p]),
+                                                 c_int, c_int, c_int, _p, c_int64, _p, _p]),
     "locov_spatial_mean_fwd": (c_int, [_p, c_int64, c_int, c_int, c_int, _p, _p]),
     "locov_gemm_nt_f32": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, _p]),
     "locov_conv3x3_nhwc_f32": (c_int, [_p, c_int64, c_int, c_int, c_int, c_int, _p, _p, _p, _p, _p, c_int, c_uint,

@@ -29,6 +29,7 @@ CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rd
 FILE_FLAGS = {
     "roi_align.hip": ["-ffp-contract=off"],
     "roi_align_nhwc.hip": ["-ffp-contract=off"],
+    "roi_align_tiles.hip": ["-ffp-contract=off"],
 }
 
 

@@ -37,6 +37,9 @@
 #ifndef LOCOV_SPLIT_MINWG
 #define LOCOV_SPLIT_MINWG 2   // launch-bounds occupancy hint of the 128x128 tile: 2 workgroups per CU (3: a 168-register budget, see DESIGN)
 #endif
+#ifndef LOCOV_SPLIT_ABLATE
+#define LOCOV_SPLIT_ABLATE 0  // ENERGY-ablation builds only (tools/dbg_power.py; results are wrong on purpose): 1 no staging DMA in the
+#endif                        // K-loop, 2 no fragment reads in the K-loop, 4 no MFMAs, 8 no epilogue; operands stay real data
 #ifndef LOCOV_STORE_AUX
 #define LOCOV_STORE_AUX 2     // cache policy bits of the epilogue's stores: 2 = nt (A/B: tools/make_variant.py ... -DLOCOV_STORE_AUX=0)
 #endif
@@ -328,6 +331,10 @@ __global__ __launch_bounds__(128 * WM_, WM_ == 2 ? LOCOV_SPLIT_MINWG : 1) void g
         for (int p = 0; p < NQM; p++) {
             if (p < p0 || p >= p1) continue;
             const int t = p / 3, i = 2 * ga + t / 2, j = 2 * gb + t % 2, w = p % 3;
+            if (LOCOV_SPLIT_ABLATE & 4) {        // keep the fragments alive without the matrix pipe
+                asm volatile("" :: "v"(fa[i][w == 2 ? 1 : 0]), "v"(fb[j][w == 1 ? 1 : 0]));
+                continue;
+            }
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][w == 2 ? 1 : 0], fb[j][w == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
         }
     };
@@ -339,10 +346,12 @@ __global__ __launch_bounds__(128 * WM_, WM_ == 2 ? LOCOV_SPLIT_MINWG : 1) void g
     const int k_last = K - BK;                              // k0 of the last K-tile (K % BK == 0)
     // prologue: tile 0 -> LDS stage 0 (W by DMA), A tile 1 -> staging registers, fragments of the first quarter
     dma_b(0);
+    if (LOCOV_SPLIT_ABLATE & 1) dma_b(1);                   // (ablation without staging: both stages hold real data)
     b_base += BK * 4;                                       // W is fetched ONE tile ahead: b_base addresses tile t+1
     int k_ptr = 0;
     if constexpr (ASPLIT) {
         dma_a(0);
+        if (LOCOV_SPLIT_ABLATE & 1) dma_a(1);
         a_dbase += BK * 4;
         __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
     } else {
@@ -359,6 +368,10 @@ __global__ __launch_bounds__(128 * WM_, WM_ == 2 ? LOCOV_SPLIT_MINWG : 1) void g
     __syncthreads();
     rd_a(0, 0);
     rd_b(0, 0);
+    if (LOCOV_SPLIT_ABLATE & 2) {
+        rd_a(0, 1);
+        rd_b(0, 1);
+    }
     __builtin_amdgcn_s_setprio(0);
 
     // One K-tile that has a successor, computing from LDS stage s (= the tile's parity).  Quarters: (GA0,GBx) (GA0,GBy)
@@ -372,13 +385,15 @@ __global__ __launch_bounds__(128 * WM_, WM_ == 2 ? LOCOV_SPLIT_MINWG : 1) void g
         k_ptr = kn;
         const int x = s, y = s ^ 1;
         KSTAMP(0);
-        rd_b(s, y);
-        rd_a(s, 1);
+        if (!(LOCOV_SPLIT_ABLATE & 2)) {
+            rd_b(s, y);
+            rd_a(s, 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        dma_b(s ^ 1);
+        if (!(LOCOV_SPLIT_ABLATE & 1)) dma_b(s ^ 1);
         b_base += BK * 4;
         if constexpr (ASPLIT) {
-            dma_a(s ^ 1);
+            if (!(LOCOV_SPLIT_ABLATE & 1)) dma_a(s ^ 1);
             a_dbase += BK * 4;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -405,8 +420,10 @@ __global__ __launch_bounds__(128 * WM_, WM_ == 2 ? LOCOV_SPLIT_MINWG : 1) void g
         KSTAMP(4);
         __syncthreads();
         KSTAMP(5);
-        rd_a(s ^ 1, 0);
-        rd_b(s ^ 1, y);
+        if (!(LOCOV_SPLIT_ABLATE & 2)) {
+            rd_a(s ^ 1, 0);
+            rd_b(s ^ 1, y);
+        }
         __builtin_amdgcn_sched_barrier(0);
         quarter(1, x, 0, NQM);
         __builtin_amdgcn_sched_barrier(0);
@@ -594,7 +611,12 @@ __global__ __launch_bounds__(128 * WM_, WM_ == 2 ? LOCOV_SPLIT_MINWG : 1) void g
             }
         }
     };
-    if (rows_here == BM)
+    if (LOCOV_SPLIT_ABLATE & 8) {
+#pragma unroll
+        for (int i = 0; i < MB; i++)
+#pragma unroll
+            for (int j = 0; j < NB; j++) asm volatile("" :: "v"(acc[i][j]));
+    } else if (rows_here == BM)
         tail(std::true_type{});
     else
         tail(std::false_type{});

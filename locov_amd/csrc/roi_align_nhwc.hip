@@ -10,39 +10,12 @@
 // bin_stride = 2 evaluates only even bins (ph, pw even): with STRIDE_IN_1X1=True both stride-2
 // 1x1 convs of Res5 block 0 (roi_emb_heads.py:217-241) read exactly those positions of the
 // 14x14 tile, so 3/4 of the pooler's output bytes are never produced.
-#include "common.h"
+#include "roi_align_common.h"
 
 #include <cstdlib>
 #include <type_traits>
 
 namespace locov {
-
-struct AxisSampleN {
-    int lo, hi;   // pixel index along the axis
-    float wl, wh;
-};
-
-__device__ __forceinline__ AxisSampleN axis_sample_n(float start, float bin, int p, int i, int grid, int size)
-{
-    float v = __fadd_rn(__fadd_rn(start, __fmul_rn((float)p, bin)),
-                        __fdiv_rn(__fmul_rn(__fadd_rn((float)i, .5f), bin), (float)grid));
-    AxisSampleN s;
-    if (v < -1.0f || v > (float)size) {
-        s.lo = 0; s.hi = 0; s.wl = 0.f; s.wh = 0.f;
-        return s;
-    }
-    if (v <= 0.f) v = 0.f;
-    int lo = (int)v, hi;
-    if (lo >= size - 1) {
-        hi = lo = size - 1;
-        v = (float)lo;
-    } else {
-        hi = lo + 1;
-    }
-    const float l = __fsub_rn(v, (float)lo);
-    s.lo = lo; s.hi = hi; s.wl = l; s.wh = __fsub_rn(1.f, l);
-    return s;
-}
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -371,23 +344,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restri
 constexpr int kT2Threads = 256;
 constexpr int kT2Ch = 32;          // channels per workgroup (one 128-byte line per tap; ~25 KiB LDS tile)
 constexpr int kT2Axis = 256;       // per-axis LDS table entries (larger sampling grids: computed on the fly)
-// FAST form (mode 1 of locov_roi_align_from_nhwc_fwd_ex; results within 1e-5 of the exact form, SURVEY.md 8d's gate):
-//  * separable: a bin's value is sum_{pixel rows} sum_{pixel cols} Wy[ky] Wx[kx] F[y0+ky][x0+kx] with Wy / Wx the per-PIXEL sums of
-//    its samples' bilinear weights -- (gh+1)(gw+1) taps instead of 4 gh gw (9 for 16 at a 2x2 grid, 25 for 64 at 4x4);
-//  * LDS-staged proposal window: when the ROI's pixel footprint x this workgroup's 32 channels fits kT2WinPix pixels (two
-//    thirds of the proposals of a 1333x800 image), it is fetched ONCE, one coalesced 128-byte line per pixel, and every
-//    tap is an LDS read: neighbouring bins of a small ROI share their pixels, so the footprint is 3-12x smaller than the
-//    sum of the bins' taps, and it is the texture-address unit (one 16-byte lane load per tap and channel quad), not HBM,
-//    that bounds the gather form.  Larger ROIs take the separable taps from global memory.
-#ifndef LOCOV_T2_STORE16
-#define LOCOV_T2_STORE16 1
-#endif
-constexpr int kT2WinPix = 192;     // 24 KiB: with the 25 KiB transpose tile and the tables 3 workgroups per CU
-constexpr int kT2SepGrid = 16;     // separable tables: up to 16 samples per bin and axis (17 pixels); beyond: the exact form
-constexpr int kT2SepPitch = 20;    // floats per bin in the weight tables (16-byte aligned rows: the first four weights are one LDS read)
-constexpr int kT2SepBins = 32;     // ... and up to 32 bins per axis
 
-template <bool FAST>
 __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
     const float *__restrict__ feat, int N, int H, int W, int C, const float *__restrict__ rois, int PH, int PW,
     float scale, int sampling_ratio, int aligned, float *__restrict__ out)
@@ -396,17 +353,8 @@ __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
     const int bins = PH * PW;
     const int ts = bins | 1;                                  // odd row stride of the transpose tile
     float *tile = smem;                                       // [kT2Ch][ts]
-    float *after_tile = smem + kT2Ch * ts + (4 - (kT2Ch * ts) % 4) % 4;
-    AxisSampleN *ytab = reinterpret_cast<AxisSampleN *>(after_tile);
+    AxisSampleN *ytab = reinterpret_cast<AxisSampleN *>(smem + kT2Ch * ts + (4 - (kT2Ch * ts) % 4) % 4);
     AxisSampleN *xtab = ytab + kT2Axis;
-    // FAST: the window shares the sampling tables' space (they are dead once the per-pixel weights exist); behind it the
-    // per-pixel weight tables [bin][kT2SepGrid + 1] and {first pixel, pixel count} per bin row / column
-    float4 *win = reinterpret_cast<float4 *>(after_tile);
-    float *ypw = after_tile + (FAST ? kT2WinPix * kT2Ch : 0);
-    float *xpw = ypw + kT2SepBins * kT2SepPitch;
-    int *ypix = reinterpret_cast<int *>(xpw + kT2SepBins * kT2SepPitch);           // [kT2SepBins][2]
-    int *xpix = ypix + 2 * kT2SepBins;
-    int *misc = xpix + 2 * kT2SepBins;                                             // {not separable, wy0, wh, wx0, ww}
 
     const int64_t r = blockIdx.x;
     const int c0 = blockIdx.y * kT2Ch;
@@ -439,82 +387,14 @@ __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
         return a;
     };
     if (use_lds) {
-        for (int t = threadIdx.x; t < ny; t += kT2Threads) {
-            const AxisSampleN a = axis_sample_n(start_h, bin_h, t / gh, t % gh, gh, H);
-            ytab[t] = FAST ? a : as_offsets(a, ystride);
-        }
-        for (int t = threadIdx.x; t < nx; t += kT2Threads) {
-            const AxisSampleN a = axis_sample_n(start_w, bin_w, t / gw, t % gw, gw, W);
-            xtab[t] = FAST ? a : as_offsets(a, xstride);
-        }
-    }
-    if (FAST && threadIdx.x == 0) {
-        misc[0] = 0;                               // not separable
-        misc[1] = 0x7fffffff;                      // window: first pixel row, one past the last, first column, one past the last
-        misc[2] = -1;
-        misc[3] = 0x7fffffff;
-        misc[4] = -1;
+        for (int t = threadIdx.x; t < ny; t += kT2Threads)
+            ytab[t] = as_offsets(axis_sample_n(start_h, bin_h, t / gh, t % gh, gh, H), ystride);
+        for (int t = threadIdx.x; t < nx; t += kT2Threads)
+            xtab[t] = as_offsets(axis_sample_n(start_w, bin_w, t / gw, t % gw, gw, W), xstride);
     }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    bool fast = false, staged = false;
-    int wy0 = 0, wx0 = 0, ww = 1, npx = 0;
-    if constexpr (FAST) {
-        // per bin row / column: the pixels its samples touch ({first, count}) and the summed weight of each
-        const bool sep_try = use_lds && gh >= 1 && gw >= 1 && gh <= kT2SepGrid && gw <= kT2SepGrid && PH <= kT2SepBins && PW <= kT2SepBins;
-        if (sep_try && (int)threadIdx.x < PH + PW) {
-            const bool is_y = (int)threadIdx.x < PH;
-            const int i = is_y ? (int)threadIdx.x : (int)threadIdx.x - PH, n = is_y ? gh : gw;
-            const AxisSampleN *tab = is_y ? ytab + i * gh : xtab + i * gw;
-            float *pw = (is_y ? ypw : xpw) + i * kT2SepPitch;
-            int base = 0x7fffffff, num = 0;
-            for (int t = 0; t < n; t++)
-                if (tab[t].wl != 0.f || tab[t].wh != 0.f) base = min(base, tab[t].lo);
-            if (base != 0x7fffffff) {
-                for (int k = 0; k <= n; k++) pw[k] = 0.f;
-                for (int t = 0; t < n; t++) {
-                    const AxisSampleN sm = tab[t];
-                    if (sm.wl == 0.f && sm.wh == 0.f) continue;      // outside [-1, size]: contributes 0 (still counted in the mean)
-                    const int klo = sm.lo - base, khi = sm.hi - base;
-                    if (khi > n) {                                      // samples more than a pixel apart (forced small grid): exact form
-                        misc[0] = 1;
-                        break;
-                    }
-                    pw[klo] += sm.wh;
-                    pw[khi] += sm.wl;
-                    num = max(num, khi + 1);
-                }
-            }
-            int *pix = (is_y ? ypix : xpix) + 2 * i;
-            pix[0] = base == 0x7fffffff ? 0 : base;
-            pix[1] = num;
-            if (num > 0) {                                              // the ROI's pixel window
-                atomicMin(&misc[is_y ? 1 : 3], base);
-                atomicMax(&misc[is_y ? 2 : 4], base + num);
-            }
-        }
-        __syncthreads();
-        fast = sep_try && misc[0] == 0;
-        if (!fast && use_lds) {
-            // exact form below: its tables hold byte offsets (every thread converts the entries it wrote itself)
-            for (int t = threadIdx.x; t < ny; t += kT2Threads) ytab[t] = as_offsets(ytab[t], ystride);
-            for (int t = threadIdx.x; t < nx; t += kT2Threads) xtab[t] = as_offsets(xtab[t], xstride);
-            __syncthreads();
-        }
-        if (fast) {
-            const int y1 = misc[2], x1 = misc[4];
-            wy0 = misc[1];
-            wx0 = misc[3];
-            if (y1 > wy0 && x1 > wx0) {
-                ww = x1 - wx0;
-                npx = (y1 - wy0) * ww;
-            } else {
-                wy0 = wx0 = 0;                     // no sample inside the map: every bin is 0
-            }
-            staged = npx > 0 && npx <= kT2WinPix;
-        }
-    }
     constexpr int QN = kT2Ch / 4;                             // lanes (channel quads) per bin
     constexpr int BPW = 64 / QN;                              // bins per wave instruction
     const int q = lane % QN, sub = lane / QN;
@@ -527,31 +407,6 @@ __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
     auto tap = [&](unsigned off) {
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(img_rsrc, off, 0, 0));
     };
-    if constexpr (FAST) {
-        if (staged) {
-            // the proposal's window -> LDS: pixel p = (row p / ww, column p % ww) of the window, its 128 bytes by 8 lanes; all of a
-            // thread's (at most kT2WinPix / 32) loads are in flight before the first is stored
-            const float inv_ww = 1.0f / (float)ww;
-            const int qq = threadIdx.x & (QN - 1), p0 = threadIdx.x / QN;
-            const unsigned qoff = (unsigned)min(c0 + 4 * qq, C - 4) * (unsigned)sizeof(float);
-            constexpr int PPT = kT2WinPix / (kT2Threads / QN);
-            float4 v[PPT];
-#pragma unroll
-            for (int i = 0; i < PPT; i++) {
-                const int p = p0 + i * (kT2Threads / QN);
-                if (p < npx) {
-                    const int wr = (int)(((float)p + 0.5f) * inv_ww), wc = p - wr * ww;   // exact for these small integers
-                    v[i] = tap((unsigned)(wy0 + wr) * ystride + (unsigned)(wx0 + wc) * xstride + qoff);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < PPT; i++) {
-                const int p = p0 + i * (kT2Threads / QN);
-                if (p < npx) win[p * QN + qq] = v[i];
-            }
-            __syncthreads();
-        }
-    }
     const int ns = gh * gw;                                   // samples per bin
     constexpr int U = 4;                                      // samples in flight per lane (16 x 16-byte loads)
     const float inv_pw = 1.0f / (float)PW;
@@ -564,86 +419,7 @@ __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
         // bin -> (ph, pw): exact for these small integers, and far cheaper than an integer division
         const int ph = bin_ok ? (int)(((float)bin + 0.5f) * inv_pw) : 0, pw = bin_ok ? bin - ph * PW : 0;
         float4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (FAST && fast) {
-            if (bin_ok && c_ok) {
-                const int py0 = ypix[2 * ph], nyp = ypix[2 * ph + 1], px0 = xpix[2 * pw], nxp = xpix[2 * pw + 1];
-                const float *yw = ypw + ph * kT2SepPitch, *xw = xpw + pw * kT2SepPitch;
-                if (staged) {
-                    const float4 *wp = win + ((py0 - wy0) * ww + (px0 - wx0)) * QN + q;
-                    if (nyp <= 4 && nxp <= 4) {
-                        // the common case (a staged ROI has a small sampling grid): the weights of both axes in two LDS reads
-                        const float4 y4 = *reinterpret_cast<const float4 *>(yw), x4 = *reinterpret_cast<const float4 *>(xw);
-                        const float wys[4] = {y4.x, y4.y, y4.z, y4.w}, wxs[4] = {x4.x, x4.y, x4.z, x4.w};
-#pragma unroll
-                        for (int ky = 0; ky < 4; ky++) {
-                            if (ky < nyp) {
-#pragma unroll
-                                for (int kx = 0; kx < 4; kx++) {
-                                    if (kx < nxp) {
-                                        const float w = wys[ky] * wxs[kx];
-                                        const float4 v = wp[(ky * ww + kx) * QN];
-                                        acc.x = fmaf(w, v.x, acc.x);
-                                        acc.y = fmaf(w, v.y, acc.y);
-                                        acc.z = fmaf(w, v.z, acc.z);
-                                        acc.w = fmaf(w, v.w, acc.w);
-                                    }
-                                }
-                            }
-                        }
-                    } else {
-                        for (int ky = 0; ky < nyp; ky++) {
-                            const float wy = yw[ky];
-                            for (int kx = 0; kx < nxp; kx++) {
-                                const float w = wy * xw[kx];
-                                const float4 v = wp[(ky * ww + kx) * QN];
-                                acc.x = fmaf(w, v.x, acc.x);
-                                acc.y = fmaf(w, v.y, acc.y);
-                                acc.z = fmaf(w, v.z, acc.z);
-                                acc.w = fmaf(w, v.w, acc.w);
-                            }
-                        }
-                    }
-                } else {
-                    // taps from global memory, U in flight per lane; the (ky, kx) counters are wave-uniform (gh, gw are per
-                    // ROI), a lane whose bin has fewer pixels on an axis skips the tap
-                    const unsigned o0 = (unsigned)py0 * ystride + (unsigned)px0 * xstride + ch_off;
-                    const int ntap = (gh + 1) * (gw + 1);
-                    int ky = 0, kx = 0;
-                    auto fgroup = [&](auto nu_tag) __attribute__((always_inline)) {
-                        constexpr int NU = decltype(nu_tag)::value;
-                        float4 v[NU];
-                        float w[NU];
-#pragma unroll
-                        for (int u = 0; u < NU; u++) {
-                            // (unconditional: a tap this lane's bin does not have reads the bin's first pixel with weight 0 and is
-                            // then discarded -- a predicated load would break the U-deep pipeline of loads)
-                            const bool ok = ky < nyp && kx < nxp;
-                            w[u] = ok ? yw[ky] * xw[kx] : 0.f;
-                            v[u] = tap(ok ? o0 + (unsigned)ky * ystride + (unsigned)kx * xstride : o0);
-                            if (++kx == gw + 1) {
-                                kx = 0;
-                                ky++;
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < NU; u++) {
-                            if (w[u] != 0.f) {          // (also keeps a non-finite value of an untouched pixel out of the sum)
-                                acc.x = fmaf(w[u], v[u].x, acc.x);
-                                acc.y = fmaf(w[u], v[u].y, acc.y);
-                                acc.z = fmaf(w[u], v[u].z, acc.z);
-                                acc.w = fmaf(w[u], v[u].w, acc.w);
-                            }
-                        }
-                    };
-                    int t0 = 0;
-                    for (; t0 + 8 <= ntap; t0 += 8) fgroup(std::integral_constant<int, 8>{});
-                    const int rem = ntap - t0;
-                    if (rem & 4) fgroup(std::integral_constant<int, 4>{});
-                    if (rem & 2) fgroup(std::integral_constant<int, 2>{});
-                    if (rem & 1) fgroup(std::integral_constant<int, 1>{});
-                }
-            }
-        } else if (bin_ok && c_ok) {
+        if (bin_ok && c_ok) {
             // The gather is latency-bound (taps come from L1 / L2), so the loads of up to U samples are
             // issued back to back before any of them is consumed; the accumulation still runs in sample
             // order (iy outer, ix inner), i.e. the oracle's order.  Groups are sized exactly (ns is
@@ -708,9 +484,9 @@ __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
     __syncthreads();
     const int cn = min(kT2Ch, C - c0);
     float *dst = out + (r * C + c0) * (int64_t)bins;
-    if (LOCOV_T2_STORE16 && (bins & 3) == 0) {
+    if ((bins & 3) == 0) {
         // 16 bytes per lane: four consecutive bins of one channel (a channel's run is a multiple of 4 floats, so a quad never
-        // straddles two channels); (channel, bin) advance incrementally -- no division per element
+        // straddles two channels); (channel, bin quad) advance incrementally -- no division per element
         const int qpc = bins >> 2;                                     // quads per channel
         int c = 0, b4 = threadIdx.x;
         while (b4 >= qpc) {
@@ -731,25 +507,6 @@ __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
         }
         return;
     }
-    if (bins >= kT2Threads / 2) {
-        // 4 bytes per lane, a wave's 256 contiguous bytes per instruction; (channel, bin) advance incrementally
-        int c = 0, bb = threadIdx.x;
-        while (bb >= bins) {
-            bb -= bins;
-            c++;
-        }
-        const int step_c = kT2Threads / bins, step_b = kT2Threads - step_c * bins;
-        while (c < cn) {
-            dst[c * bins + bb] = tile[c * ts + bb];
-            c += step_c;
-            bb += step_b;
-            if (bb >= bins) {
-                bb -= bins;
-                c++;
-            }
-        }
-        return;
-    }
     const float inv_bins = 1.0f / (float)bins;
     for (int idx = threadIdx.x; idx < cn * bins; idx += kT2Threads) {
         const int c = (int)(((float)idx + 0.5f) * inv_bins);       // idx / bins, exact for these sizes (no integer divide)
@@ -760,6 +517,11 @@ __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
 // channel slices per ROI of roi_align_nhwc_kernel: a power of two up to 8 (= one per XCD, see the kernel) that still leaves a
 // slice at least 64 channel quads wide, so that a wave stays inside one bin (wave-uniform pixel loops): 2 048+ channels -> 8,
 // 1 024 -> 4, 512 -> 2, fewer -> 1
+// roi_align_tiles.hip: the LDS-staged form of the contract (mode LOCOV_ROIALIGN_FAST)
+int64_t roi_align_tiles_plan_bytes(int64_t R);
+int launch_roi_align_tiles(const float *feat_nhwc, int N, int H, int W, int C, const float *rois, int64_t R, int PH, int PW,
+                           float scale, int sampling_ratio, int aligned, void *plan_ws, float *out, hipStream_t s);
+
 static int nhwc_slices(int C)
 {
     static const int forced = [] { const char *e = getenv("LOCOV_ROIALIGN_SLICES"); return e ? atoi(e) : 0; }();
@@ -775,9 +537,11 @@ using namespace locov;
 
 extern "C" {
 
+int64_t locov_roi_align_plan_bytes(int64_t R) { return R > 0 ? roi_align_tiles_plan_bytes(R) : 0; }
+
 int locov_roi_align_from_nhwc_fwd_ex(const float *feat_nhwc, int N, int H, int W, int C, const float *rois, int64_t R,
                                      int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, int aligned,
-                                     int mode, float *out, locov_stream_t stream)
+                                     int mode, void *workspace, int64_t workspace_bytes, float *out, locov_stream_t stream)
 {
     LOCOV_REQUIRE(mode == LOCOV_ROIALIGN_EXACT || mode == LOCOV_ROIALIGN_FAST, "locov_roi_align_from_nhwc_fwd: bad mode %d", mode);
     LOCOV_REQUIRE(R >= 0, "locov_roi_align_from_nhwc_fwd: R < 0");
@@ -789,28 +553,23 @@ int locov_roi_align_from_nhwc_fwd_ex(const float *feat_nhwc, int N, int H, int W
     LOCOV_REQUIRE(feat_nhwc && rois && out, "locov_roi_align_from_nhwc_fwd: null pointer");
     LOCOV_REQUIRE(R <= 0x7fffffffLL, "locov_roi_align_from_nhwc_fwd: R too large");
     LOCOV_REQUIRE((int64_t)H * W * C * 4 < 0xffffffffLL, "locov_roi_align_from_nhwc_fwd: one image must stay below 4 GiB");
+    if (mode == LOCOV_ROIALIGN_FAST) {
+        LOCOV_REQUIRE(workspace && workspace_bytes >= locov_roi_align_plan_bytes(R) && (uintptr_t)workspace % 16 == 0,
+                      "locov_roi_align_from_nhwc_fwd: the fast form needs locov_roi_align_plan_bytes(R) bytes of 16-byte aligned workspace");
+        return launch_roi_align_tiles(feat_nhwc, N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, workspace,
+                                      out, as_stream(stream));
+    }
     const int bins = pooled_h * pooled_w, ts = bins | 1;
-    const bool fast = mode == LOCOV_ROIALIGN_FAST;
-    size_t lds = ((size_t)kT2Ch * ts + 4) * sizeof(float);
-    if (fast)
-        lds += (size_t)kT2WinPix * kT2Ch * sizeof(float) + 2 * (size_t)kT2SepBins * kT2SepPitch * sizeof(float) +
-               (4 * (size_t)kT2SepBins + 8) * sizeof(int);
-    else
-        lds += 2 * kT2Axis * sizeof(AxisSampleN);
-    static_assert((size_t)kT2WinPix * kT2Ch * sizeof(float) >= 2 * kT2Axis * sizeof(AxisSampleN), "the window must cover the tables it shares LDS with");
+    const size_t lds = ((size_t)kT2Ch * ts + 4) * sizeof(float) + 2 * kT2Axis * sizeof(AxisSampleN);
     LOCOV_REQUIRE(lds <= 150 * 1024, "locov_roi_align_from_nhwc_fwd: pooled size %dx%d too large for the LDS tile", pooled_h,
                   pooled_w);
-    const void *fn = fast ? reinterpret_cast<const void *>(roi_align_nhwc2nchw_kernel<true>)
-                          : reinterpret_cast<const void *>(roi_align_nhwc2nchw_kernel<false>);
-    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(roi_align_nhwc2nchw_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return set_error(LOCOV_ERR_LAUNCH, "locov_roi_align_from_nhwc_fwd: cannot raise the dynamic LDS limit to %zu bytes", (size_t)lds);
     dim3 grid((unsigned)R, (unsigned)ceil_div(C, kT2Ch));
-    if (fast)
-        hipLaunchKernelGGL(roi_align_nhwc2nchw_kernel<true>, grid, dim3(kT2Threads), lds, as_stream(stream), feat_nhwc, N, H, W, C,
-                           rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, out);
-    else
-        hipLaunchKernelGGL(roi_align_nhwc2nchw_kernel<false>, grid, dim3(kT2Threads), lds, as_stream(stream), feat_nhwc, N, H, W, C,
-                           rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, out);
+    hipLaunchKernelGGL(roi_align_nhwc2nchw_kernel, grid, dim3(kT2Threads), lds, as_stream(stream), feat_nhwc, N, H, W, C,
+                       rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, out);
     return check_launch("locov_roi_align_from_nhwc_fwd");
 }
 
@@ -819,7 +578,7 @@ int locov_roi_align_from_nhwc_fwd(const float *feat_nhwc, int N, int H, int W, i
                                   float *out, locov_stream_t stream)
 {
     return locov_roi_align_from_nhwc_fwd_ex(feat_nhwc, N, H, W, C, rois, R, pooled_h, pooled_w, spatial_scale, sampling_ratio,
-                                            aligned, LOCOV_ROIALIGN_EXACT, out, stream);
+                                            aligned, LOCOV_ROIALIGN_EXACT, nullptr, 0, out, stream);
 }
 
 int locov_nchw_to_nhwc(const float *in, int N, int C, int H, int W, void *out, int out_dtype, locov_stream_t stream)

@@ -87,9 +87,11 @@ class _ROIAlignFn(torch.autograd.Function):
                 nhwc = torch.empty((N, H, W, C), dtype=torch.float32, device=feat.device)
                 check(_lib.load().locov_nchw_to_nhwc(_ptr(feat), N, C, H, W, _ptr(nhwc), F32, _stream(feat)),
                       "locov_nchw_to_nhwc")
-                check(_lib.load().locov_roi_align_from_nhwc_fwd_ex(_ptr(nhwc), N, H, W, C, _ptr(rois), R, ph, pw,
-                                                                   float(scale), int(sampling_ratio), int(aligned), int(mode),
-                                                                   _ptr(out), _stream(feat)),
+                lib = _lib.load()
+                ws = _workspace("roi_plan", feat, int(lib.locov_roi_align_plan_bytes(R))) if mode else None
+                check(lib.locov_roi_align_from_nhwc_fwd_ex(_ptr(nhwc), N, H, W, C, _ptr(rois), R, ph, pw, float(scale),
+                                                           int(sampling_ratio), int(aligned), int(mode), _ptr(ws),
+                                                           ws.numel() if ws is not None else 0, _ptr(out), _stream(feat)),
                       "locov_roi_align_from_nhwc_fwd_ex")
             else:
                 check(_lib.load().locov_roi_align_fwd(_ptr(feat), N, C, H, W, _ptr(rois), R, ph, pw, float(scale),
