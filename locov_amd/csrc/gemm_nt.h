@@ -81,6 +81,13 @@ int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C,
                       const Epilogue &epi, float a_scale, float w_scale, hipStream_t s, const char *what,
                       const Batch &bt = Batch{1, 0, 0, 0}, unsigned *overflow = nullptr, const float *a_scale_dev = nullptr);
 
+// the same on a 256 x 256 tile (gemm_split_big.hip) for launches with BOTH operands pre-split that fill the chip with such tiles
+bool gemm_split_big_applicable(int64_t lda, int64_t ldc, int64_t M, int N, int K, const Epilogue &epi, const Batch &bt,
+                               const float *a_scale_dev);
+int launch_gemm_split_big(const float *A, int64_t lda, const void *Wsplit, float *C, int64_t ldc, int64_t M, int N, int K,
+                          const Epilogue &epi, float a_scale, float w_scale, hipStream_t s, const char *what, const Batch &bt,
+                          unsigned *overflow);
+
 // out[b][N,K] = row_scale[n] * sum_m A_b[m,n] * B_b[m,k]  (gemm_tn.hip: the weight-gradient GEMM; problem b uses
 // A + b*sa, B + b*sb, out + b*so; ws = gemm_tn_workspace_bytes(M, N, K, batch) bytes of device memory)
 int launch_gemm_tn(const float *A, int64_t lda, int64_t sa, const float *B, int64_t ldb, int64_t sb, float *out, int64_t ldo,

@@ -1,0 +1,291 @@
+// The split-operand NT GEMM of gemm_split.hip on a 256x256 tile: y[M,N] = epi(x[M,K] . W[N,K]^T), BOTH operands already in the
+// split (hi, lo) f16 layout (LOCOV_GEMM_A_SPLIT launches: the Winograd-domain batched GEMMs and the 1x1 convolutions behind a
+// Winograd output transform -- roi_emb_heads.py:217-245 as GEMMs).
+//
+// Why a second tile.  On MI355X these launches sit at the 1 400 W package power cap (profiles/r03_power_probe.txt): their time is
+// (dynamic energy) / (cap - idle), and the energy ablation of the 128x128 kernel (profiles/r03_energy_ablation.txt) puts 57 % of
+// the dynamic energy into the MFMAs, 31 % (K = 2048) / 19 % (K = 512) into staging the operand tiles L2 -> LDS, 6 % into the
+// fragment reads.  The MFMA count is fixed; what a kernel can still choose is how often an operand byte crosses L2 -> LDS.
+// A 256x256 tile stages (256 + 256) rows per K-tile for 4x the products of a 128x128 tile's (128 + 128): HALF the staged
+// bytes per product, and a wave's 128x64 sub-tile reads (128 + 64) fragment rows per 96 MFMAs instead of (64 + 64) per 48.
+//
+// Shape of the kernel: ONE workgroup of 8 waves per CU (2 x 4 waves of 128 x 64: acc = 128 VGPRs), two LDS stages of 64 KB, every
+// operand byte by LDS DMA (`buffer_load ... lds`, XOR-swizzled 128-byte rows, as gemm_split.hip).  A K-tile is eight "eighths" of
+// 12 MFMAs -- an A row-block PAIR (32 rows) against a W column-block PAIR (32 columns) -- ordered so that only two A pairs
+// (double buffer) and the two W pairs are ever live: 64 fragment VGPRs, as in the small kernel:
+//
+//     (A0,Bf) (A0,Bg) (A1,Bg) (A1,Bf) (A2,Bf) (A2,Bg) (A3,Bg) | wait DMA(t+1), barrier, issue DMA(t+2) | (A3,Bf)      g = 1 - f
+//
+// The tile ends on Bf, so Bg's registers take the next tile's first W pair behind the barrier and the next tile starts on
+// (A0', Bg'): f flips every tile.  The DMA of tile t+2 goes out right behind the barrier of tile t (all reads of its stage
+// are done by then) -- a full K-tile of matrix work (3 072 cycles per SIMD) ahead of its first use.
+// With one workgroup per CU nothing overlaps the epilogue; under the power cap that costs little (the HBM-bound store phase of one
+// CU runs below the cap while the others compute -- the package budget, not the CU, is what is shared).
+#include "gemm_split_common.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace locov {
+
+namespace {
+
+constexpr int GBM = 256, GBN = 256, GNW = 8, GNT = 64 * GNW;
+constexpr int GTM = 128, GTN = 64;                  // a wave's sub-tile: 8 x 4 blocks of 16 x 16
+constexpr int GSTAGE = (GBM + GBN) * WROWB;         // 64 KB per stage
+constexpr int GEPS = GTN + 4;                       // epilogue staging pitch (floats)
+constexpr int GLDS = 2 * GSTAGE > GNW * 64 * GEPS * 4 ? 2 * GSTAGE : GNW * 64 * GEPS * 4;
+constexpr int GCH = 4;                              // LDS-DMA pieces (8 rows each) per wave, operand and K-tile
+static_assert(GLDS <= 160 * 1024, "one workgroup per CU: all of the LDS, no more");
+
+}  // namespace
+
+__global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
+                                                               float *__restrict__ Cout, int64_t ldc, int64_t M, int N, int K,
+                                                               Epilogue epi, Batch bt, float a_scale, float out_scale,
+                                                               unsigned *overflow)
+{
+    __shared__ u32x4 lds[GLDS / 16];
+    char *const ldsb = reinterpret_cast<char *>(lds);
+
+    const int tiles_n = (N + GBN - 1) / GBN;
+    const int nwg = gridDim.x;
+    int tile = xcd_remap(blockIdx.x, nwg);
+    if (bt.count > 1) {
+        const int per = nwg / bt.count, b = tile / per;
+        tile -= b * per;
+        A += b * bt.sa;
+        B += b * bt.sb;
+        Cout += b * bt.sc;
+    }
+    // M-tile outer / N-tile inner: the workgroups an XCD runs back to back share their A panel in its L2
+    const int64_t m0 = (int64_t)(tile / tiles_n) * GBM;
+    const int n0 = (tile % tiles_n) * GBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 2) * GTM, wn = (wave & 3) * GTN;
+
+    // staging: wave w brings rows 32 w .. 32 w + 31 of both operand tiles, four 1 KB pieces (8 rows) each; lane l supplies row
+    // l / 8 of a piece and fetches the global 16-byte chunk (l % 8) ^ wswz(row): chunk c of row r then sits at slot c ^ wswz(r)
+    const char *a_base = reinterpret_cast<const char *>(A + m0 * lda);
+    const char *b_base = reinterpret_cast<const char *>(B + (int64_t)n0 * K);
+    unsigned a_voff[GCH], b_voff[GCH];
+#pragma unroll
+    for (int i = 0; i < GCH; i++) {
+        const int row = (wave * GCH + i) * 8 + (lane >> 3);
+        const int64_t gm = m0 + row;
+        const int gn = n0 + row;
+        a_voff[i] = (unsigned)((((gm < M ? gm : M - 1) - m0) * lda * 4) + (((lane & 7) ^ wswz(row)) * 16));      // rows past M: clamped (never stored)
+        b_voff[i] = (unsigned)(((int64_t)((gn < N ? gn : N - 1) - n0) * K * 4) + (((lane & 7) ^ wswz(row)) * 16));
+    }
+    auto dma = [&](int stage) {
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a_base), 0, 0xffffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b_base), 0, 0xffffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < GCH; i++) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                ra, (__attribute__((address_space(3))) void *)(ldsb + stage * GSTAGE + (wave * GCH + i) * 8 * WROWB), 16, a_voff[i], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rb, (__attribute__((address_space(3))) void *)(ldsb + stage * GSTAGE + GBM * WROWB + (wave * GCH + i) * 8 * WROWB), 16,
+                b_voff[i], 0, 0, 0);
+        }
+        a_base += BK * 4;
+        b_base += BK * 4;
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragments: lane l holds row l % 16 and the 8 halves of k-group l / 16 of a 16-row block for the whole 32-wide K-tile
+    f16x8 fa[2][2][2];                      // [buffer][block of the pair][hi, lo]
+    f16x8 fb[4][2];                         // [column block][hi, lo]; pairs {0,1} and {2,3}
+    const int l16 = lane & 15, kg = lane >> 4;
+    int bfo[2];
+#pragma unroll
+    for (int hl = 0; hl < 2; hl++) bfo[hl] = l16 * WROWB + (((2 * kg + hl) ^ wswz(l16)) * 16);
+    auto rd_a = [&](int stage, int ap, int buf) {
+        const char *As = ldsb + stage * GSTAGE + (wm + ap * 32) * WROWB;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            fa[buf][i][0] = *reinterpret_cast<const f16x8 *>(As + i * 16 * WROWB + bfo[0]);
+            fa[buf][i][1] = *reinterpret_cast<const f16x8 *>(As + i * 16 * WROWB + bfo[1]);
+        }
+    };
+    auto rd_b = [&](int stage, int bp) {
+        const char *Bs = ldsb + stage * GSTAGE + GBM * WROWB + (wn + bp * 32) * WROWB;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            fb[2 * bp + j][0] = *reinterpret_cast<const f16x8 *>(Bs + j * 16 * WROWB + bfo[0]);
+            fb[2 * bp + j][1] = *reinterpret_cast<const f16x8 *>(Bs + j * 16 * WROWB + bfo[1]);
+        }
+    };
+    // the 12 MFMAs of (A pair ap in buffer buf) x (W pair bp): per 16x16 block hi.hi, hi.lo, lo.hi
+    auto eighth = [&](int ap, int buf, int bp) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const int i = 2 * ap + ii, j = 2 * bp + jj;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ii][0], fb[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ii][0], fb[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ii][1], fb[j][0], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    const int T = K / BK;
+    __builtin_amdgcn_s_setprio(3);
+    dma(0);
+    dma(1);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * GCH));         // vmcnt(8): tile 0 has landed, tile 1's pieces stay in flight
+    __syncthreads();
+    rd_a(0, 0, 0);
+    rd_b(0, 0);
+    __builtin_amdgcn_s_setprio(0);
+
+    // one K-tile computing from LDS stage s; f = the W pair it starts on (= its parity); more: a successor exists
+    auto tile_step = [&](const int s, const bool more, const bool more2) __attribute__((always_inline)) {
+        const int f = s, g = s ^ 1;
+        rd_b(s, g);
+        rd_a(s, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        eighth(0, 0, f);
+        __builtin_amdgcn_sched_barrier(0);
+        eighth(0, 0, g);
+        __builtin_amdgcn_sched_barrier(0);
+        rd_a(s, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        eighth(1, 1, g);
+        __builtin_amdgcn_sched_barrier(0);
+        eighth(1, 1, f);
+        __builtin_amdgcn_sched_barrier(0);
+        rd_a(s, 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        eighth(2, 0, f);
+        __builtin_amdgcn_sched_barrier(0);
+        eighth(2, 0, g);
+        __builtin_amdgcn_sched_barrier(0);
+        eighth(3, 1, g);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the next tile (requested a whole tile ago) has landed
+            __syncthreads();                                // ... for every wave, and every wave is done reading stage s
+            if (more2) dma(s);                              // tile t+2 -> the stage this tile is leaving
+            rd_a(s ^ 1, 0, 0);
+            rd_b(s ^ 1, g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        eighth(3, 1, f);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // T is even (the launcher requires K % 64 == 0): pairs of tiles, ONE straight-line tail -- alternative tails would meet in a
+    // merge of two versions of the 128 accumulator registers, which the register allocator answers with spills
+    for (int t = 0; t + 2 < T; t += 2) {
+        tile_step(0, true, true);
+        tile_step(1, true, true);
+    }
+    tile_step(0, true, false);
+    tile_step(1, false, false);
+
+    // Epilogue: the wave's 128 x 64 sub-tile in two halves of 64 x 64 through its private LDS area (C/D layout of the 16x16 MFMA:
+    // col = lane & 15, row = 4 (lane >> 4) + reg), 16 bytes per lane and row-contiguous from there -- gemm_split.hip's.
+    __builtin_amdgcn_sched_barrier(0);                     // (nothing of the epilogue is hoisted into the last K-tile: it has no registers to spare)
+    __builtin_amdgcn_s_setprio(3);
+    const bool relu = (epi.flags & LOCOV_EPI_RELU) != 0;
+    const bool out_split = (epi.flags & LOCOV_EPI_OUT_SPLIT) != 0, res_split = (epi.flags & LOCOV_EPI_RES_SPLIT) != 0;
+    const bool odd_lane = (lane & 1) != 0;
+    const float inv_a_scale = 1.f / a_scale;
+    float omax = 0.f;
+    constexpr int LPR = GTN / 4, RPI = 64 / LPR, NIT = 64 / RPI;      // 16 lanes per row, 4 rows per instruction, 16 instructions per half
+    const int c4 = (lane % LPR) * 4, rr = lane / LPR;
+    const int n = n0 + wn + c4;
+    const bool n_ok = n < N;
+    const int64_t rows_here = M - m0 < GBM ? M - m0 : GBM;
+    const unsigned nrec = (unsigned)(rows_here * ldc * 4);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(Cout + m0 * ldc, 0, nrec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_res =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(epi.residual ? epi.residual + m0 * ldc : Cout + m0 * ldc), 0, nrec, 0x00020000);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (n_ok && epi.scale) sc = *reinterpret_cast<const f32x4 *>(epi.scale + n);
+    sc *= out_scale;                                       // undo the operand scales
+    if (n_ok && epi.shift) sh = *reinterpret_cast<const f32x4 *>(epi.shift + n);
+    float *ep = reinterpret_cast<float *>(lds) + wave * (64 * GEPS);
+    const unsigned vstep = (unsigned)(RPI * ldc * 4);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        __syncthreads();                                   // (h = 0: every wave has left the K-loop's LDS; h = 1: the area is free again)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) ep[(i * 16 + 4 * kg + r) * GEPS + j * 16 + l16] = acc[4 * h + i][j][r];
+        __syncthreads();
+        if (n_ok) {
+            const unsigned voff = (unsigned)(((int64_t)(wm + 64 * h + rr) * ldc + n) * 4);      // rows past M: outside num_records
+#pragma unroll
+            for (int q4 = 0; q4 < NIT; q4 += 4) {
+                f32x4 res[4];
+                if (epi.residual) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        res[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, voff, (q4 + u) * vstep, 2));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int it = q4 + u;
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(ep + (it * RPI + rr) * GEPS + c4);
+                    v = v * sc + sh;
+                    if (epi.residual) v += res_split ? unsplit4(res[u], odd_lane, inv_a_scale) : res[u];
+                    if (relu) {
+                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                        v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                    }
+                    if (out_split) {
+                        omax = fmaxf(fmaxf(omax, fabsf(v[0])), fabsf(v[1]));
+                        omax = fmaxf(fmaxf(omax, fabsf(v[2])), fabsf(v[3]));
+                        __builtin_amdgcn_raw_buffer_store_b128(split4_pair(v, odd_lane, a_scale), r_out, voff, it * vstep, 2);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, voff, it * vstep, 2);     // nt: streamed once
+                    }
+                }
+            }
+        }
+    }
+    if (out_split && overflow != nullptr && omax * a_scale >= 65504.f) atomicOr(overflow, 1u);
+}
+
+// launches that qualify: pre-split A, no mask / device scale, shapes that fill the chip with 256 x 256 tiles and row pitches
+// whose tile offsets fit 32 bits
+bool gemm_split_big_applicable(int64_t lda, int64_t ldc, int64_t M, int N, int K, const Epilogue &epi, const Batch &bt, const float *a_scale_dev)
+{
+    const char *fe = getenv("LOCOV_SPLIT_BIG");            // developer A/B (read per launch: tools/dbg_bigtile.py flips it): 0 never, 1 whenever legal
+    const int forced = fe ? atoi(fe) : -1;
+    if (forced == 0) return false;
+    if (!(epi.flags & LOCOV_GEMM_A_SPLIT) || epi.mask || epi.amax_out || a_scale_dev) return false;
+    if (K % (2 * BK) != 0 || N % 8 != 0 || (int64_t)GBM * (lda > ldc ? lda : ldc) * 4 > 0x7fffffffLL || (int64_t)GBN * K * 4 > 0x7fffffffLL)
+        return false;
+    const int count = bt.count > 1 ? bt.count : 1;
+    const int64_t tiles = ceil_div(M, GBM) * ceil_div(N, GBN) * count;
+    if (tiles > 0x7fffffffLL) return false;
+    if (forced > 0) return true;
+    // enough tiles for four rounds over 256 CUs, and N a whole number of 256-wide tiles (a half-empty N tile wastes a quarter of the CU)
+    return tiles >= 1024 && N % GBN == 0 && M >= 4 * GBM;
+}
+
+int launch_gemm_split_big(const float *A, int64_t lda, const void *Wsplit, float *C, int64_t ldc, int64_t M, int N, int K,
+                          const Epilogue &epi, float a_scale, float w_scale, hipStream_t s, const char *what, const Batch &bt,
+                          unsigned *overflow)
+{
+    const int count = bt.count > 1 ? bt.count : 1;
+    const int64_t tiles = ceil_div(M, GBM) * ceil_div(N, GBN) * count;
+    const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K * count);     // class 5: split-operand GEMM
+    hipLaunchKernelGGL(gemm_split_big_kernel, dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit), C, ldc,
+                       M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale), overflow);
+    timing_end(trec, s);
+    return check_launch(what);
+}
+
+}  // namespace locov
