@@ -58,9 +58,30 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
         B += b * bt.sb;
         Cout += b * bt.sc;
     }
-    // M-tile outer / N-tile inner: the workgroups an XCD runs back to back share their A panel in its L2
-    const int64_t m0 = (int64_t)(tile / tiles_n) * GBM;
-    const int n0 = (tile % tiles_n) * GBN;
+    // N tiles in groups of NG, inside a group M-tile outer / N-tile inner: the workgroups an XCD runs back to back share their
+    // A panels and stream a W slice (NG x 256 rows x K) that stays in its 4 MB L2 (gemm_split.hip's order)
+    int64_t m0;
+    int n0;
+    {
+#ifndef LOCOV_BIG_NG
+#define LOCOV_BIG_NG 0
+#endif
+        const int NG = LOCOV_BIG_NG > 0 ? LOCOV_BIG_NG : ((int64_t)K * 4 * GBN * 8 <= (2 << 20) ? 8 : 4);
+        const int tiles_m = (int)((bt.count > 1 ? nwg / bt.count : nwg) / tiles_n);
+        const int full = (tiles_n / NG) * NG, per_group = tiles_m * NG;
+        if (tiles_n <= NG) {
+            m0 = (int64_t)(tile / tiles_n) * GBM;
+            n0 = (tile % tiles_n) * GBN;
+        } else if (tile < tiles_m * full) {
+            const int g = tile / per_group, rem = tile - g * per_group;
+            m0 = (int64_t)(rem / NG) * GBM;
+            n0 = (g * NG + rem % NG) * GBN;
+        } else {
+            const int gs = tiles_n - full, rem = tile - tiles_m * full;
+            m0 = (int64_t)(rem / gs) * GBM;
+            n0 = (full + rem % gs) * GBN;
+        }
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave >> 2) * GTM, wn = (wave & 3) * GTN;
