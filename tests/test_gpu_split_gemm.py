@@ -484,3 +484,50 @@ def test_split_layout_output_and_residual(ops, M, N, K):
     ops.linear_split(big, ops.split_pack(torch.ones(N, K).cuda()), out_split=True, x_scale=1.0)   # outputs ~4000*K >> 65504
     assert ops.split_overflow_raised(x.device)
     ops.split_overflow_reset(x.device)
+
+
+def test_big_tile_kernel_is_bit_identical_to_the_128x128_kernel(ops):
+    """gemm_split_big.hip (256 x 256 tile, one 8-wave workgroup per CU; taken by launches with both operands pre-split that are
+    large enough) against gemm_split.hip's 128 x 128 kernel on the same pre-split operands: every accumulator sees the same
+    products in the same order, so the results are BIT-identical -- ragged M and N tiles, K from 64 up, residual (fp32 and
+    split layout), FrozenBN scale / shift, ReLU, split-layout output, and the batched (Winograd-domain) form.
+    LOCOV_SPLIT_BIG is read by the launcher at every call: 1 = whenever legal, 0 = never."""
+    import os
+    rng = np.random.default_rng(808)
+    prev = os.environ.get("LOCOV_SPLIT_BIG")
+    try:
+        for it in range(14):
+            M = int(rng.integers(1, 1500))
+            N = 8 * int(rng.integers(1, 90))
+            K = 64 * int(rng.integers(1, 9))
+            g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+            xs = ops.split_pack(torch.relu(torch.randn(M, K, generator=g)).cuda(), 16.0).data
+            wp = ops.split_pack((torch.randn(N, K, generator=g) * 0.05).cuda())
+            use_res, use_aff, relu, out_split, res_split = (bool(rng.integers(2)) for _ in range(5))
+            if use_res and res_split:
+                N = 32 * max(1, N // 32)                 # (split_pack of the stand-in residual wants whole 32-column groups)
+                wp = ops.split_pack((torch.randn(N, K, generator=g) * 0.05).cuda())
+            res = torch.randn(M, N, generator=g).cuda() if use_res else None
+            if use_res and res_split:
+                res = ops.split_pack(res.abs(), 16.0).data
+            sc = (torch.rand(N, generator=g) + 0.5).cuda() if use_aff else None
+            sh = torch.randn(N, generator=g).cuda() if use_aff else None
+            outs = []
+            for big in ("0", "1"):
+                os.environ["LOCOV_SPLIT_BIG"] = big
+                outs.append(ops.linear_split(xs, wp, sh, scale=sc, residual=res, relu=relu, x_scale=16.0, x_is_split=True,
+                                             out_split=out_split, residual_is_split=use_res and res_split))
+            assert torch.equal(outs[0], outs[1]), (it, M, N, K, use_res, res_split, use_aff, relu, out_split)
+        # the batched launch inside the Winograd-domain convolution
+        x = torch.relu(torch.randn(49 * 37, 64, generator=torch.Generator().manual_seed(4))).cuda()
+        u = ops.split_pack(ops.winograd_pack_weight((torch.randn(96, 64, 3, 3, generator=torch.Generator().manual_seed(5)) * 0.05).cuda()))
+        ys = []
+        for big in ("0", "1"):
+            os.environ["LOCOV_SPLIT_BIG"] = big
+            ys.append(ops.winograd_conv3x3(x, u, relu=True, roi_major=True, in_roi_major=True))
+        assert torch.equal(ys[0], ys[1])
+    finally:
+        if prev is None:
+            os.environ.pop("LOCOV_SPLIT_BIG", None)
+        else:
+            os.environ["LOCOV_SPLIT_BIG"] = prev
