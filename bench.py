@@ -594,11 +594,11 @@ def main():
                 # (2MNK / time) is reported next to it.
                 ns, mss, fls = gemm_split
                 ach = 3.0 * fls / (mss * 1e-3) / 1e12 if mss > 0 else float("nan")
-                roof = {"kernel": "gemm_split_kernel (Res5 1x1 convs, Winograd-domain batched GEMMs; fp32 in/out, f16x2 split "
-                                  "operands on the f16 matrix pipe)",
+                roof = {"kernel": "gemm_split_big_kernel / gemm_split_kernel (Res5 1x1 convs, Winograd-domain batched GEMMs; fp32 in/out, f16x2 "
+                                  "split operands on the f16 matrix pipe; 256x256 tile where both operands arrive pre-split, 128x128 otherwise)",
                         "bound": "mfma", "achieved": ach, "peak": MFMA_16BIT_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / MFMA_16BIT_PEAK_TFLOPS,
-                        "traffic": recorded_traffic(args, "gemm_split_kernel"),
+                        "traffic": recorded_traffic(args, "gemm_split"),
                         "traffic_unit": f"HBM-side bytes per launch, averaged over the launches of all instances of this kernel (PMC, profiles/{TRAFFIC_FILE})",
                         "launches_per_step": ns / args.steps, "avg_launch_ms": mss / max(ns, 1),
                         "share_of_step_time": mss * 1e-3 / dt2,

@@ -423,7 +423,8 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
                  smooth_l1_beta: float = 0.0, box_reg_loss_type: str = "smooth_l1",
                  loss_weight: Union[float, Dict[str, float]] = 1.0, emb_dim: int = 768,
                  embedding_based: bool = True, freeze_emb_pred: bool = True, normalize_emb: bool = False,
-                 standardize_emb: bool = False, detach_cls_predictor: bool = False, sim_gemm_dtype: str = "fp32"):
+                 standardize_emb: bool = False, detach_cls_predictor: bool = False, sim_gemm_dtype: str = "fp32",
+                 fc_dtype: str = "fp32"):
         FastRCNNOutputLayers.__init__(
             self, input_shape, box2box_transform=box2box_transform, num_classes=num_classes,
             test_score_thresh=test_score_thresh, test_nms_thresh=test_nms_thresh,
@@ -433,8 +434,13 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
             input_shape = ShapeSpec(channels=input_shape)
         num_inputs = input_shape.channels * (input_shape.width or 1) * (input_shape.height or 1)
         self.embedding_based = embedding_based
-        assert sim_gemm_dtype in ("fp32", "bf16")
+        assert sim_gemm_dtype in ("fp32", "bf16") and fc_dtype in ("fp32", "f16x2")
         self.sim_gemm_dtype = sim_gemm_dtype
+        # extension: arithmetic of emb_pred and (when SIM_GEMM_DTYPE is "fp32") cls_score in inference -- "f16x2": fp32 in / fp32
+        # out with the products formed from split (hi, lo) f16 operand pairs on the f16 matrix pipe, as Res5's GEMMs under
+        # RES5_DTYPE "f16x2" (csrc/gemm_split.hip: error vs fp64 no larger than the f32 MFMA's); follows RES5_DTYPE
+        self.fc_dtype = fc_dtype
+        self._split_cache = {}
         self._bank_bf16 = None          # packed copy of cls_score.weight for the bf16 MFMA path
         if self.embedding_based:
             self.normalize_emb = normalize_emb
@@ -467,6 +473,9 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
             "detach_cls_predictor": cfg.MODEL.ROI_HEADS.DETACH_CLASS_PREDICTOR,
             "sim_gemm_dtype": box_head.get("SIM_GEMM_DTYPE", "fp32") if hasattr(box_head, "get") else "fp32",
         })
+        res5_dtype = box_head.get("RES5_DTYPE", "f16x2") if hasattr(box_head, "get") else "f16x2"
+        backend = box_head.get("RES5_BACKEND", "hip") if hasattr(box_head, "get") else "hip"
+        ret["fc_dtype"] = "f16x2" if (res5_dtype == "f16x2" and backend == "hip") else "fp32"
         return ret
 
     # ------------------------------------------------------------------ forward (:179-212)
@@ -479,9 +488,31 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
             return ops.NORM_STANDARDIZE
         return ops.NORM_NONE
 
-    def forward(self, x):
+    def _split_weight(self, tag: str, w: torch.Tensor):
+        """Split-operand packing of a weight read at call time (emb_pred.weight is re-assigned by the meta-arch, the bank by
+        set_class_embeddings): re-packed whenever the tensor is replaced or modified in place."""
+        key = (w.data_ptr(), w._version, tuple(w.shape))
+        hit = self._split_cache.get(tag)
+        if hit is None or hit[0] != key:
+            hit = self._split_cache[tag] = (key, ops.split_pack(w.detach().contiguous()))
+        return hit[1]
+
+    def _fc_split_ok(self, x: torch.Tensor) -> bool:
+        return (self.fc_dtype == "f16x2" and x.is_cuda and x.dim() == 2 and x.shape[1] % 32 == 0 and self.emb_dim % 32 == 0
+                and self.cls_score is not None and self.cls_score.weight.shape[0] % 4 == 0)
+
+    @torch.no_grad()
+    def region_embedding(self, x: torch.Tensor, force_fp32: bool = False) -> torch.Tensor:
+        """emb_pred(x) (:206) in the arithmetic forward() uses in inference, before any normalisation: [R, C5] -> [R, D]."""
+        x = x.detach()
+        if self._fc_split_ok(x) and not force_fp32:
+            return ops.linear_split(x, self._split_weight("emb", self.emb_pred.weight), self.emb_pred.bias.detach(), x_scale=16.0)
+        return ops.linear(x, self.emb_pred.weight.detach(), self.emb_pred.bias.detach())
+
+    def forward(self, x, force_fp32: bool = False):
         """x: per-region features [R, ...] (flattened like the reference, :189-190).
-        Returns (scores [R,K+1], proposal_deltas [R,4])."""
+        Returns (scores [R,K+1], proposal_deltas [R,4]).  force_fp32: keep emb_pred / cls_score on the f32 MFMA for this call
+        (the ROI heads' repeat of a call whose activations left the split arithmetic's range)."""
         if x.dim() > 2:
             x = torch.flatten(x, start_dim=1)
         if not self.embedding_based:
@@ -492,6 +523,22 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
             x.requires_grad or self.bbox_pred.weight.requires_grad
             or (not self.detach_cls_predictor and self.emb_pred.weight.requires_grad))
         mode = self._norm_mode()
+        if not needs_grad and mode >= 0 and not force_fp32 and self._fc_split_ok(x):
+            # inference in split arithmetic (3 f16 MFMAs per fp32 product block instead of 16 f32 ones; fp32-level accuracy):
+            # operand scale 16 for the pooled features (their range is Res5's, covered by its range guard), 1 for the
+            # embedding (|emb| < 65504, full 22 bits down to 0.125, absolute floor 3e-8 below: its entries are small)
+            x = x.detach()
+            deltas = ops.linear(x, self.bbox_pred.weight.detach(), self.bbox_pred.bias.detach())
+            emb = self.region_embedding(x)
+            if mode != ops.NORM_NONE:
+                emb = ops.rownorm(emb, mode)
+            if self.sim_gemm_dtype == "bf16":
+                scores = ops.sim_gemm_bf16(ops.to_bf16(emb), self._packed_bank())
+            else:
+                scores = ops.linear_split(emb, self._split_weight("bank", self.cls_score.weight), None, x_scale=1.0)
+            if not self._cls_bias_is_zero():
+                scores = scores + self.cls_score.bias.detach()
+            return scores, deltas
         if not needs_grad and mode >= 0:
             # inference: one C call -> bbox_pred, emb_pred, (norm,) similarity GEMM launches
             x = x.detach()

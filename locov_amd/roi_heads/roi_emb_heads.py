@@ -517,6 +517,14 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
             return fn(predictions, proposals, boxes_validated=True)
         return fn(predictions, proposals)
 
+    def _predict(self, box_features, force_fp32: bool = False):
+        """box_predictor(box_features); force_fp32 reaches predictors that know the keyword (this package's)."""
+        if force_fp32:
+            import inspect
+            if "force_fp32" in inspect.signature(self.box_predictor.forward).parameters:
+                return self.box_predictor(box_features, force_fp32=True)
+        return self.box_predictor(box_features)
+
     def _with_res5_dtype(self, dtype, fn, *args, **kw):
         was, self.res5_dtype = self.res5_dtype, dtype
         try:
@@ -542,7 +550,7 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         if guard is not None and guard.raised():
             self._warn_overflow()
             box_features = self._fused_roi_transform(feats, proposal_boxes, True, "fp32")
-            predictions = self.box_predictor(box_features)
+            predictions = self._predict(box_features, force_fp32=True)
             pred_instances, _ = self.box_predictor.inference(predictions, proposals)
         pred_instances = self.forward_with_given_boxes(features, pred_instances)
         return pred_instances, {}

@@ -337,7 +337,7 @@ def test_full_size_logits_vs_oracle(pkg, oracle, dim, res5_dtype):
         scores16, _ = bp(bf)
     bp.sim_gemm_dtype = "fp32"
     # the bf16-rounded operands the device multiplied: its own fp32 region embedding (same GEMM kernel, same bits) and bank
-    emb_dev = pkg.ops.linear(bf, bp.emb_pred.weight.detach(), bp.emb_pred.bias.detach())
+    emb_dev = bp.region_embedding(bf)          # emb_pred in the predictor's own inference arithmetic (split operands under RES5_DTYPE "f16x2")
     assert np.abs(emb_dev.cpu().numpy() - want_emb).max() <= 2e-5 * np.abs(want_emb).max()
     emb16 = emb_dev.cpu().to(torch.bfloat16).double()
     bank16 = torch.from_numpy(h["cls_w"]).to(torch.bfloat16).double()

@@ -324,8 +324,9 @@ def test_heads_repeat_an_out_of_range_call_on_the_f32_mfma():
     heads._fused_roi_transform = lambda f, b, p, dt: (calls.append(dt), orig(f, b, p, dt))[1]
 
     def run(hd, f):
+        # (the predictor is kept on the f32 MFMA for both heads: what is compared here is the guarded Res5 call)
         with torch.no_grad():
-            return hd.box_predictor(hd._shared_roi_transform([T.dev(f)], [p.proposal_boxes for p in props], pooled=True))[0]
+            return hd.box_predictor(hd._shared_roi_transform([T.dev(f)], [p.proposal_boxes for p in props], pooled=True), force_fp32=True)[0]
 
     with warnings.catch_warnings():
         warnings.simplefilter("error")                     # in range: no warning, one pass
@@ -531,3 +532,39 @@ def test_big_tile_kernel_is_bit_identical_to_the_128x128_kernel(ops):
             os.environ.pop("LOCOV_SPLIT_BIG", None)
         else:
             os.environ["LOCOV_SPLIT_BIG"] = prev
+
+
+def test_predictor_fcs_in_split_arithmetic_match_the_f32_mfma():
+    """EmbeddingFastRCNNOutputLayers in inference under RES5_DTYPE "f16x2": emb_pred and cls_score run as split-operand GEMMs
+    (fc_dtype "f16x2").  Same logits as the f32-MFMA form (force_fp32=True) to well inside the 1e-4 gate, at the config shape
+    (2048 -> 768, 1204-row bank), with and without normalisation; bbox deltas identical (that FC stays on the f32 MFMA); the
+    weights are read at call time (re-assigned emb_pred.weight, swapped bank)."""
+    import locov_amd as pkg
+    from locov_amd.structures import ShapeSpec
+    cfg = pkg.config.get_cfg()
+    cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
+    cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED = True
+    for norm in (False, True):
+        cfg.MODEL.ROI_BOX_HEAD.NORMALIZE_EMB_PRED = norm
+        torch.manual_seed(3)
+        pred = pkg.roi_heads.build_box_predictor(cfg, 2048).cuda().eval()
+        assert pred.fc_dtype == "f16x2"
+        g = torch.Generator().manual_seed(11)
+        bank = torch.randn(1204, 768, generator=g) * 0.05
+        bank[-1] = 0
+        pred.set_class_embeddings(bank)
+        x = (torch.relu(torch.randn(3000, 2048, generator=g)) * 1.5).cuda()
+        with torch.no_grad():
+            s_split, d_split = pred(x)
+            s_f32, d_f32 = pred(x, force_fp32=True)
+        assert torch.equal(d_split, d_f32)
+        assert float((s_split - s_f32).abs().max()) <= 2e-5 * max(1.0, float(s_f32.abs().max()))
+        assert torch.all(s_split[:, -1] == 0)                              # the zero background row stays exactly 0
+        # weights are read at call time
+        with torch.no_grad():
+            pred.emb_pred.weight = torch.nn.Parameter(pred.emb_pred.weight.detach() * 2.0)
+            s2, _ = pred(x)
+            s2_ref, _ = pred(x, force_fp32=True)
+        assert float((s2 - s2_ref).abs().max()) <= 2e-5 * max(1.0, float(s2_ref.abs().max()))
+        if not norm:
+            assert float((s2 - 2.0 * s_split).abs().max()) <= 1e-4 * max(1.0, float(s2.abs().max()))

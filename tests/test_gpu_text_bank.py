@@ -64,7 +64,7 @@ def test_bank_swaps_on_the_device_vs_oracle(pkg, oracle, sim_dtype):
         if sim_dtype == "fp32":
             assert np.abs(scores.cpu().numpy() - want).max() <= 1e-4
         else:
-            emb_dev = pkg.ops.linear(xd, bp.emb_pred.weight.detach(), bp.emb_pred.bias.detach())
+            emb_dev = bp.region_embedding(xd)              # emb_pred in the predictor's own inference arithmetic
             want16 = (emb_dev.cpu().to(torch.bfloat16).double() @ torch.from_numpy(banks[name]).to(torch.bfloat16).double().t()).numpy()
             assert np.abs(scores.cpu().numpy() - want16).max() <= 1e-4
             assert np.abs(scores.cpu().numpy() - want).max() <= 5e-2

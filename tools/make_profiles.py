@@ -57,7 +57,9 @@ util = {"_how": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GU
                 "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE/8): fraction of SIMD-cycles in which the matrix pipe is "
                 "busy (GRBM_GUI_ACTIVE is summed over the 8 XCDs).", "workload": workload, "kernels": {}}
 for k, c in m.items():
-    if "gemm_nt_kernel" not in k and "gemm_split_kernel" not in k:
+    if "gemm_nt_kernel" not in k and "gemm_split" not in k:
+        continue
+    if "pack" in k:
         continue
     avg = lambda n: sum(c[n]) / len(c[n])
     gui = avg("GRBM_GUI_ACTIVE") / 8.0
