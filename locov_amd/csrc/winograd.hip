@@ -22,9 +22,35 @@
 
 #include <cstdlib>
 
+// Cache policy of the transform-domain tensors (A/B: tools/ab_wino.sh, 8 000 ROIs): V is WRITTEN with the default policy
+// (input transform 561 -> 531 us against non-temporal stores), M is READ non-temporally (output transform 556 us against 593)
+#ifndef LOCOV_WINO_NT_STORE
+#define LOCOV_WINO_NT_STORE 0
+#endif
+#ifndef LOCOV_WINO_NT_LOAD
+#define LOCOV_WINO_NT_LOAD 1
+#endif
+#ifndef LOCOV_WINO_THREADS
+#define LOCOV_WINO_THREADS 256
+#endif
+
 namespace locov {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T>
+__device__ __forceinline__ void wino_store(const T &v, T *p)
+{
+    if (LOCOV_WINO_NT_STORE)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+template <typename T>
+__device__ __forceinline__ T wino_load(const T *p)
+{
+    return LOCOV_WINO_NT_LOAD ? __builtin_nontemporal_load(p) : *p;
+}
 
 using wino::AT;
 using wino::BT;
@@ -72,7 +98,7 @@ __device__ __forceinline__ void store_split_pair(float *row, int c, f32x2 v, flo
     const u32x2 out = odd ? u32x2{got, l} : u32x2{h, got};
     // byte offset in the row: group of 8 channels = 32 bytes; hi halves of channels 0-3 | 4-7 at +0 | +8, lo at +16 | +24
     char *p = reinterpret_cast<char *>(row) + (c >> 3) * 32 + ((c >> 2) & 1) * 8 + (odd ? 16 : 0);
-    __builtin_nontemporal_store(out, reinterpret_cast<u32x2 *>(p));
+    wino_store(out, reinterpret_cast<u32x2 *>(p));
 }
 
 // x rows [(y*7+x)*ld_pos + r*ld_roi][C]  ->  V [NF*NF][Rc][C]   (position-major input: ld_pos = R, ld_roi = 1;
@@ -131,7 +157,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
                 store_split_pair(V + r * C + (int64_t)(fy * NF + fx) * fstride, c, a, v_scale);
             } else {
                 amax = fmaxf(fmaxf(amax, fabsf(a[0])), fabsf(a[1]));
-                __builtin_nontemporal_store(a, reinterpret_cast<f32x2 *>(dst + (int64_t)(fy * NF + fx) * fstride));
+                wino_store(a, reinterpret_cast<f32x2 *>(dst + (int64_t)(fy * NF + fx) * fstride));
             }
         }
     }
@@ -172,7 +198,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
         f32x2 m[NF];
 #pragma unroll
         for (int fx = 0; fx < NF; fx++)
-            m[fx] = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(src + (int64_t)(fy * NF + fx) * fstride));
+            m[fx] = wino_load(reinterpret_cast<const f32x2 *>(src + (int64_t)(fy * NF + fx) * fstride));
         f32x2 tx[7];
 #pragma unroll
         for (int xx = 0; xx < 7; xx++) {
