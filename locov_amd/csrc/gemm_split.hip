@@ -719,6 +719,8 @@ int launch_gemm_split_segmean(const float *A, int64_t lda, const void *Wsplit, i
         (epi.scale && (uintptr_t)epi.scale % 16 != 0) || (epi.shift && (uintptr_t)epi.shift % 16 != 0))
         return set_error(LOCOV_ERR_UNSUPPORTED, "%s: N, lda must be multiples of 4 and every pointer 16-byte aligned", what);
     if (!epi.residual) return set_error(LOCOV_ERR_INVALID_ARG, "%s: the residual is required", what);
+    if ((double)M * N * 4 <= 4294967295.0 && gemm_split_big_segmean_applicable(lda, M, N, K, epi, seg))       // 256 x 256 tile (gemm_split_big.hip)
+        return launch_gemm_split_big_segmean(A, lda, Wsplit, M, N, K, epi, seg, a_scale, w_scale, partial, out, s, what, overflow);
     const int64_t tiles_m = ceil_div(M, BM), tiles = tiles_m * ceil_div(N, BN);
     if (tiles > 0x7fffffffLL || (double)M * N * 4 > 4294967295.0 || (int64_t)BM * lda * 4 > 0x7fffffffLL)
         return set_error(LOCOV_ERR_INVALID_ARG, "%s: problem too large for 32-bit residual offsets", what);
@@ -818,7 +820,8 @@ int locov_gemm_nt_f32_split_ex(const float *x, int64_t lda, const void *W_split,
 int64_t locov_gemm_segmean_workspace_bytes(int64_t M, int N)
 {
     if (M <= 0 || N <= 0) return 0;
-    return ceil_div(M, BM) * 4 * (int64_t)N * (int64_t)sizeof(float);
+    const int64_t small = ceil_div(M, BM) * 4 * (int64_t)N * (int64_t)sizeof(float), big = gemm_split_big_segmean_workspace_bytes(M, N);
+    return small > big ? small : big;             // (either kernel may take the launch)
 }
 
 int locov_gemm_nt_f32_split_segmean(const float *x, int64_t lda, const void *W_split, const float *scale, const float *shift,

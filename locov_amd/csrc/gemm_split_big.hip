@@ -40,10 +40,16 @@ static_assert(GLDS <= 160 * 1024, "one workgroup per CU: all of the LDS, no more
 
 }  // namespace
 
+// SEGSUM (the stage's last 1x1 convolution + the spatial mean behind it, roi_emb_heads.py:262,344,356): rows are ROI-major
+// (m = roi * seg + position), the residual too; instead of storing the finished [M, N] values every wave sums them per ROI over
+// each 64-row chunk of its sub-tile: partial[(chunk * 3 + slot) * N + n] with chunk = (global row) / 64 and slot = the ROI's
+// index among the (at most three, seg >= 43) ROIs the chunk touches.  segsum64_finish_kernel adds the one or two chunks of a
+// ROI in a fixed order: deterministic, and the [M, N] tensor is neither written nor re-read.
+template <bool SEGSUM>
 __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                                                                float *__restrict__ Cout, int64_t ldc, int64_t M, int N, int K,
                                                                Epilogue epi, Batch bt, float a_scale, float out_scale,
-                                                               unsigned *overflow)
+                                                               unsigned *overflow, int seg, float *__restrict__ partial)
 {
     __shared__ u32x4 lds[GLDS / 16];
     char *const ldsb = reinterpret_cast<char *>(lds);
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
     const bool n_ok = n < N;
     const int64_t rows_here = M - m0 < GBM ? M - m0 : GBM;
     const unsigned nrec = (unsigned)(rows_here * ldc * 4);
-    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(Cout + m0 * ldc, 0, nrec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(SEGSUM ? const_cast<float *>(epi.residual) + m0 * ldc : Cout + m0 * ldc, 0, nrec, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_res =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(epi.residual ? epi.residual + m0 * ldc : Cout + m0 * ldc), 0, nrec, 0x00020000);
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -264,7 +270,9 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
                         v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
                         v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
                     }
-                    if (out_split) {
+                    if (SEGSUM) {
+                        *reinterpret_cast<f32x4 *>(ep + (it * RPI + rr) * GEPS + c4) = v;        // finished value back in place
+                    } else if (out_split) {
                         omax = fmaxf(fmaxf(omax, fabsf(v[0])), fabsf(v[1]));
                         omax = fmaxf(fmaxf(omax, fabsf(v[2])), fabsf(v[3]));
                         __builtin_amdgcn_raw_buffer_store_b128(split4_pair(v, odd_lane, a_scale), r_out, voff, it * vstep, 2);
@@ -274,8 +282,58 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
                 }
             }
         }
+        if constexpr (SEGSUM) {
+            // per-ROI column sums of this wave's 64 x 64 chunk: lane = column, a walk down the rows (the wave's own LDS area:
+            // its writes above are ordered before these reads, no workgroup barrier needed -- the loop's next one covers re-use)
+            const int64_t grow0 = m0 + wm + 64 * h;
+            const int64_t left = M - grow0;
+            const int rows_valid = left < 0 ? 0 : left < 64 ? (int)left : 64;
+            const int col = n0 + wn + lane;
+            if (rows_valid > 0 && col < N) {
+                const int64_t chunk = grow0 >> 6;
+                int pos = (int)(grow0 % seg), slot = 0;
+                float sum = 0.f;
+                const float *colp = ep + lane;
+                for (int i0 = 0; i0 < 64; i0 += 8) {              // eight LDS reads in flight, then the (order-preserving) adds
+                    float rv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) rv[u] = colp[(i0 + u) * GEPS];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (i0 + u < rows_valid) {
+                            sum += rv[u];
+                            if (++pos == seg) {
+                                partial[(chunk * 3 + slot) * (int64_t)N + col] = sum;
+                                sum = 0.f;
+                                pos = 0;
+                                slot++;
+                            }
+                        }
+                    }
+                }
+                if (pos != 0) partial[(chunk * 3 + slot) * (int64_t)N + col] = sum;
+            }
+        }
     }
-    if (out_split && overflow != nullptr && omax * a_scale >= 65504.f) atomicOr(overflow, 1u);
+    if (!SEGSUM && out_split && overflow != nullptr && omax * a_scale >= 65504.f) atomicOr(overflow, 1u);
+}
+
+// out[q, n] = (the partial sums of ROI q's rows in the one or two 64-row chunks they fall into) / seg, in chunk order
+__global__ __launch_bounds__(256) void segsum64_finish_kernel(const float *__restrict__ partial, int64_t R, int N, int seg, float inv_seg,
+                                                              float *__restrict__ out)
+{
+    const int64_t total = R * (N / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = i / (N / 4);
+        const int n = (int)(i - q * (N / 4)) * 4;
+        const int64_t c0 = (q * seg) >> 6, c1 = (q * seg + seg - 1) >> 6;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t c = c0; c <= c1; c++) {
+            const int64_t slot = q - (c << 6) / seg;                 // ROI q among the ROIs chunk c touches
+            a += *reinterpret_cast<const f32x4 *>(partial + (c * 3 + slot) * N + n);
+        }
+        *reinterpret_cast<f32x4 *>(out + q * N + n) = a * inv_seg;
+    }
 }
 
 // launches that qualify: pre-split A, no mask / device scale, shapes that fill the chip with 256 x 256 tiles and row pitches
@@ -303,9 +361,36 @@ int launch_gemm_split_big(const float *A, int64_t lda, const void *Wsplit, float
     const int count = bt.count > 1 ? bt.count : 1;
     const int64_t tiles = ceil_div(M, GBM) * ceil_div(N, GBN) * count;
     const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K * count);     // class 5: split-operand GEMM
-    hipLaunchKernelGGL(gemm_split_big_kernel, dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit), C, ldc,
-                       M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale), overflow);
+    hipLaunchKernelGGL(gemm_split_big_kernel<false>, dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit), C,
+                       ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale), overflow, 0, static_cast<float *>(nullptr));
     timing_end(trec, s);
+    return check_launch(what);
+}
+
+// the mean-fused form: ROI-major rows and residual, seg rows per ROI (43 <= seg: at most three ROIs per 64-row chunk)
+bool gemm_split_big_segmean_applicable(int64_t lda, int64_t M, int N, int K, const Epilogue &epi, int seg)
+{
+    if (!(epi.flags & LOCOV_SEGMEAN_RES_ROI_MAJOR) || seg < 43) return false;
+    return gemm_split_big_applicable(lda, (int64_t)N, M, N, K, Epilogue{epi.scale, epi.shift, epi.residual, epi.flags & ~(unsigned)LOCOV_SEGMEAN_RES_ROI_MAJOR},
+                                     Batch{1, 0, 0, 0}, nullptr);
+}
+
+int64_t gemm_split_big_segmean_workspace_bytes(int64_t M, int N) { return ceil_div(M, 64) * 3 * (int64_t)N * (int64_t)sizeof(float); }
+
+int launch_gemm_split_big_segmean(const float *A, int64_t lda, const void *Wsplit, int64_t M, int N, int K, const Epilogue &epi, int seg,
+                                  float a_scale, float w_scale, float *partial, float *out, hipStream_t s, const char *what, unsigned *overflow)
+{
+    const int64_t tiles = ceil_div(M, GBM) * ceil_div(N, GBN);
+    const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K);
+    hipLaunchKernelGGL(gemm_split_big_kernel<true>, dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
+                       static_cast<float *>(nullptr), (int64_t)N, M, N, K, epi, Batch{1, 0, 0, 0}, a_scale, 1.f / (a_scale * w_scale), overflow, seg,
+                       partial);
+    timing_end(trec, s);
+    int rc = check_launch(what);
+    if (rc) return rc;
+    const int64_t R = M / seg, total = R * (N / 4);
+    const unsigned blocks = (unsigned)(ceil_div(total, 256) < 65536 ? ceil_div(total, 256) : 65536);
+    hipLaunchKernelGGL(segsum64_finish_kernel, dim3(blocks), dim3(256), 0, s, partial, R, N, seg, 1.f / (float)seg, out);
     return check_launch(what);
 }
 

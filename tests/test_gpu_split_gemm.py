@@ -568,3 +568,46 @@ def test_predictor_fcs_in_split_arithmetic_match_the_f32_mfma():
         assert float((s2 - s2_ref).abs().max()) <= 2e-5 * max(1.0, float(s2_ref.abs().max()))
         if not norm:
             assert float((s2 - 2.0 * s_split).abs().max()) <= 1e-4 * max(1.0, float(s2.abs().max()))
+
+
+def test_big_tile_segmean_matches_the_128x128_form(ops):
+    """The mean-fused last convolution on the 256 x 256 tile (per-64-row-chunk column sums, fixed-order finish) against the
+    128 x 128 form and against GEMM + mean in float64: ROI-major rows and residual (fp32 and split layout), ragged last tile,
+    seg = 49 and 64.  The two kernels group a ROI's rows differently (64-row chunks vs 128-row tiles), so they agree to fp32
+    summation noise, not bit for bit."""
+    import os
+    prev = os.environ.get("LOCOV_SPLIT_BIG")
+    try:
+        for R, seg, N, K, res_split in ((700, 49, 512, 128, False), (1111, 49, 256, 64, True), (300, 64, 264, 192, False), (53, 49, 2048, 512, True)):
+            g = torch.Generator().manual_seed(R + N)
+            M = R * seg
+            x = torch.relu(torch.randn(M, K, generator=g)).cuda()
+            xs = ops.split_pack(x, 16.0).data
+            w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+            wp = ops.split_pack(w)
+            res = torch.relu(torch.randn(M, N, generator=g)).cuda()
+            if res_split:
+                res_arg = ops.split_pack(res, 16.0).data
+                res = ops.split_unpack(res_arg, 16.0)                  # what the kernels add: hi + lo
+            else:
+                res_arg = res
+            sh = torch.randn(N, generator=g).cuda()
+            outs = []
+            for big in ("0", "1"):
+                os.environ["LOCOV_SPLIT_BIG"] = big
+                outs.append(ops.linear_split_segmean(xs, wp, sh, res_arg, seg, relu=True, residual_roi_major=True, x_is_split=True,
+                                                     x_scale=16.0, residual_is_split=res_split))
+            want = torch.relu(x.double() @ w.double().t() + sh.double() + res.double()).view(R, seg, N).mean(dim=1)
+            scale = float(want.abs().max())
+            for o in outs:
+                assert tuple(o.shape) == (R, N)
+                assert float((o.double() - want).abs().max()) <= 4e-6 * scale, (R, seg, N, K, res_split)
+            assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * scale
+            # deterministic
+            assert torch.equal(outs[1], ops.linear_split_segmean(xs, wp, sh, res_arg, seg, relu=True, residual_roi_major=True, x_is_split=True,
+                                                                 x_scale=16.0, residual_is_split=res_split))
+    finally:
+        if prev is None:
+            os.environ.pop("LOCOV_SPLIT_BIG", None)
+        else:
+            os.environ["LOCOV_SPLIT_BIG"] = prev
