@@ -558,6 +558,22 @@ int locov_winograd_conv3x3_f32_split_ex(const float *x, int64_t R, int Cin, cons
 int locov_winograd_wgrad_f32_split(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags,
                                    const float *row_scale, float *dw, unsigned *overflow, void *workspace,
                                    int64_t workspace_bytes, locov_stream_t stream);
+/* A bottleneck's first two convolutions in ONE call (roi_emb_heads.py:217-245: conv1 1x1 + FrozenBN + ReLU, then conv2 3x3 + FrozenBN
+ * + ReLU?) in split arithmetic:  y = locov_winograd_conv3x3_f32_split_ex(relu(x . W1^T * scale1 + shift1), ...)  -- the same bits as
+ * locov_gemm_nt_f32_split (LOCOV_GEMM_A_SPLIT | LOCOV_EPI_RELU) followed by that call, which is what it falls back to.  Where the shapes
+ * fill the chip with 256x256 tiles (both operands pre-split, C % 256 == 0, >= 1 024 tiles) the 1x1 convolution's epilogue applies the
+ * Winograd INPUT transform itself: the [49 R, C] pixel tensor between the two convolutions is never written or re-read.
+ *   x_split [49 R, K] (row pitch ldx): split layout x x_scale, ROI-major rows (r*49 + position); W1_split [C, K] x w1_scale;
+ *   U_split [121, N, C] x u_scale; v_scale: operand scale of the transformed pixels; flags: LOCOV_WINO_IN_ROI_MAJOR (required)
+ *   | LOCOV_WINO_OUT_ROI_MAJOR | LOCOV_EPI_RELU (of the 3x3); y, ldy, y_split_scale as in locov_winograd_conv3x3_f32_split_ex.
+ *   workspace: locov_conv1x1_winograd_workspace_bytes(R, C, N) bytes. */
+int64_t locov_conv1x1_winograd_workspace_bytes(int64_t R, int C, int N);
+int locov_conv1x1_winograd_conv3x3_f32_split(const float *x_split, int64_t ldx, int K, float x_scale, const void *W1_split,
+                                             float w1_scale, const float *scale1, const float *shift1, int64_t R, int C,
+                                             const void *U_split, float u_scale, float v_scale, const float *scale2,
+                                             const float *shift2, float *y, int64_t ldy, int N, unsigned flags,
+                                             float y_split_scale, void *workspace, int64_t workspace_bytes,
+                                             unsigned *overflow, locov_stream_t stream);
 
 int64_t locov_winograd_wgrad_workspace_bytes(int64_t R, int Cin, int N);
 int locov_winograd_wgrad_f32(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags,

@@ -93,6 +93,11 @@ int64_t gemm_split_big_segmean_workspace_bytes(int64_t M, int N);
 int launch_gemm_split_big_segmean(const float *A, int64_t lda, const void *Wsplit, int64_t M, int N, int K, const Epilogue &epi, int seg,
                                   float a_scale, float w_scale, float *partial, float *out, hipStream_t s, const char *what, unsigned *overflow);
 
+// ... with the Winograd input transform of the 3x3 convolution behind it in the epilogue: V [121][M/49][N], split layout x v_scale
+bool gemm_split_big_wino_applicable(int64_t lda, int64_t M, int N, int K, const Epilogue &epi);
+int launch_gemm_split_big_wino(const float *A, int64_t lda, const void *Wsplit, int64_t M, int N, int K, const Epilogue &epi, float a_scale,
+                               float w_scale, float *V, float v_scale, hipStream_t s, const char *what, unsigned *overflow);
+
 // out[b][N,K] = row_scale[n] * sum_m A_b[m,n] * B_b[m,k]  (gemm_tn.hip: the weight-gradient GEMM; problem b uses
 // A + b*sa, B + b*sb, out + b*so; ws = gemm_tn_workspace_bytes(M, N, K, batch) bytes of device memory)
 int launch_gemm_tn(const float *A, int64_t lda, int64_t sa, const float *B, int64_t ldb, int64_t sb, float *out, int64_t ldo,

@@ -22,6 +22,7 @@
 // With one workgroup per CU nothing overlaps the epilogue; under the power cap that costs little (the HBM-bound store phase of one
 // CU runs below the cap while the others compute -- the package budget, not the CU, is what is shared).
 #include "gemm_split_common.h"
+#include "winograd_transform.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -38,6 +39,12 @@ constexpr int GLDS = 2 * GSTAGE > GNW * 64 * GEPS * 4 ? 2 * GSTAGE : GNW * 64 * 
 constexpr int GCH = 4;                              // LDS-DMA pieces (8 rows each) per wave, operand and K-tile
 static_assert(GLDS <= 160 * 1024, "one workgroup per CU: all of the LDS, no more");
 
+constexpr int MODE_PLAIN = 0, MODE_SEGSUM = 1, MODE_WINO = 2;
+// MODE_WINO: an M tile holds the rows of whole ROIs only (5 x 49 = 245 of the 256; the last 11 compute on clamped rows and are dropped)
+constexpr int WSEG = 49, WROIS = GBM / WSEG, WROWS = WROIS * WSEG;
+constexpr int WYP = GBN / 2 + 4;                    // pitch (floats) of the finished half tile [245][128] in LDS
+static_assert(GBM * WYP * 4 <= GLDS, "the finished half tile (all 256 rows: the dump is branch-free) fits the K-loop's LDS");
+
 }  // namespace
 
 // SEGSUM (the stage's last 1x1 convolution + the spatial mean behind it, roi_emb_heads.py:262,344,356): rows are ROI-major
@@ -45,12 +52,21 @@ static_assert(GLDS <= 160 * 1024, "one workgroup per CU: all of the LDS, no more
 // each 64-row chunk of its sub-tile: partial[(chunk * 3 + slot) * N + n] with chunk = (global row) / 64 and slot = the ROI's
 // index among the (at most three, seg >= 43) ROIs the chunk touches.  segsum64_finish_kernel adds the one or two chunks of a
 // ROI in a fixed order: deterministic, and the [M, N] tensor is neither written nor re-read.
-template <bool SEGSUM>
+//
+// MODE_WINO (a bottleneck's first 1x1 convolution + FrozenBN + ReLU, and the input transform of the Winograd-domain 3x3 behind it:
+// roi_emb_heads.py:217-245's conv1 -> conv2): rows are ROI-major with 49 per ROI and an M tile is 5 whole ROIs.  The finished tile
+// never leaves the CU as pixels: half of its columns at a time it is laid out in LDS ([245][128] fp32), and the 8 waves share the
+// (ROI, fy) units of wino_in_fy -- lane = channel pair, the 3-4 patch rows fy needs read from LDS, 11 transform-domain values
+// written straight into V [121][R][N] (`partial`) in the split layout, the bits wino_input_kernel<false, true> would have written
+// from the stored pixels.  Saves the pixel tensor's write and re-read (2 x 0.8 GB per block at 8 000 proposals) and a launch.
+template <int MODE>
 __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                                                                float *__restrict__ Cout, int64_t ldc, int64_t M, int N, int K,
                                                                Epilogue epi, Batch bt, float a_scale, float out_scale,
-                                                               unsigned *overflow, int seg, float *__restrict__ partial)
+                                                               unsigned *overflow, int seg, float *__restrict__ partial, float v_scale)
 {
+    constexpr bool SEGSUM = MODE == MODE_SEGSUM;
+    constexpr int TILE_ROWS = MODE == MODE_WINO ? WROWS : GBM;
     __shared__ u32x4 lds[GLDS / 16];
     char *const ldsb = reinterpret_cast<char *>(lds);
 
@@ -76,15 +92,15 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
         const int tiles_m = (int)((bt.count > 1 ? nwg / bt.count : nwg) / tiles_n);
         const int full = (tiles_n / NG) * NG, per_group = tiles_m * NG;
         if (tiles_n <= NG) {
-            m0 = (int64_t)(tile / tiles_n) * GBM;
+            m0 = (int64_t)(tile / tiles_n) * TILE_ROWS;
             n0 = (tile % tiles_n) * GBN;
         } else if (tile < tiles_m * full) {
             const int g = tile / per_group, rem = tile - g * per_group;
-            m0 = (int64_t)(rem / NG) * GBM;
+            m0 = (int64_t)(rem / NG) * TILE_ROWS;
             n0 = (g * NG + rem % NG) * GBN;
         } else {
             const int gs = tiles_n - full, rem = tile - tiles_m * full;
-            m0 = (int64_t)(rem / gs) * GBM;
+            m0 = (int64_t)(rem / gs) * TILE_ROWS;
             n0 = (full + rem % gs) * GBN;
         }
     }
@@ -102,7 +118,8 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
         const int row = (wave * GCH + i) * 8 + (lane >> 3);
         const int64_t gm = m0 + row;
         const int gn = n0 + row;
-        a_voff[i] = (unsigned)((((gm < M ? gm : M - 1) - m0) * lda * 4) + (((lane & 7) ^ wswz(row)) * 16));      // rows past M: clamped (never stored)
+        const bool a_ok = gm < M && row < TILE_ROWS;            // rows past M (or past the tile's whole ROIs): clamped, never stored
+        a_voff[i] = (unsigned)((((a_ok ? gm : m0) - m0) * lda * 4) + (((lane & 7) ^ wswz(row)) * 16));
         b_voff[i] = (unsigned)(((int64_t)((gn < N ? gn : N - 1) - n0) * K * 4) + (((lane & 7) ^ wswz(row)) * 16));
     }
     auto dma = [&](int stage) {
@@ -150,16 +167,32 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
         }
     };
     // the 12 MFMAs of (A pair ap in buffer buf) x (W pair bp): per 16x16 block hi.hi, hi.lo, lo.hi
+#ifndef LOCOV_BIG_MFMA_ORDER
+#define LOCOV_BIG_MFMA_ORDER 0
+#endif
     auto eighth = [&](int ap, int buf, int bp) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ii = 0; ii < 2; ii++)
+        for (int ii = 0; ii < 2; ii++) {
+            const int i = 2 * ap + ii, j0 = 2 * bp, j1 = 2 * bp + 1;
+            if (LOCOV_BIG_MFMA_ORDER == 1) {
+                // developer A/B: the six products of an A block grouped by A operand (hi x {W0 hi, W0 lo, W1 hi, W1 lo}, lo x {W0 hi, W1 hi}):
+                // every accumulator still sees hi.hi, hi.lo, lo.hi in that order -- same bits, half the A-operand changes
+                acc[i][j0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ii][0], fb[j0][0], acc[i][j0], 0, 0, 0);
+                acc[i][j1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ii][0], fb[j1][0], acc[i][j1], 0, 0, 0);
+                acc[i][j0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ii][0], fb[j0][1], acc[i][j0], 0, 0, 0);
+                acc[i][j1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ii][0], fb[j1][1], acc[i][j1], 0, 0, 0);
+                acc[i][j0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ii][1], fb[j0][0], acc[i][j0], 0, 0, 0);
+                acc[i][j1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ii][1], fb[j1][0], acc[i][j1], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int jj = 0; jj < 2; jj++) {
-                const int i = 2 * ap + ii, j = 2 * bp + jj;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ii][0], fb[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ii][0], fb[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ii][1], fb[j][0], acc[i][j], 0, 0, 0);
+                for (int jj = 0; jj < 2; jj++) {
+                    const int j = 2 * bp + jj;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ii][0], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ii][0], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ii][1], fb[j][0], acc[i][j], 0, 0, 0);
+                }
             }
+        }
     };
 
     const int T = K / BK;
@@ -221,6 +254,75 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
     __builtin_amdgcn_sched_barrier(0);                     // (nothing of the epilogue is hoisted into the last K-tile: it has no registers to spare)
     __builtin_amdgcn_s_setprio(3);
     const bool relu = (epi.flags & LOCOV_EPI_RELU) != 0;
+    if constexpr (MODE == MODE_WINO) {
+        float *yt = reinterpret_cast<float *>(lds);
+        float scj[4], shj[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int nn = n0 + wn + j * 16 + l16;
+            scj[j] = (epi.scale ? epi.scale[nn] : 1.f) * out_scale;
+            shj[j] = epi.shift ? epi.shift[nn] : 0.f;
+        }
+        const int64_t roi0 = m0 / WSEG, Rtot = M / WSEG;
+        const int rois_here = Rtot - roi0 < WROIS ? (int)(Rtot - roi0) : WROIS;
+        const int64_t fstride = Rtot * N;
+        float amax = 0.f;
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            __syncthreads();                               // every wave has left the K-loop's LDS / the previous half's patch rows
+            if (((wave & 3) >> 1) == h) {
+                const int cl = (wave & 1) * GTN;
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int row = wm + i * 16 + 4 * kg + r;
+                            float v = acc[i][j][r] * scj[j] + shj[j];
+                            if (relu) v = fmaxf(v, 0.f);
+                            yt[row * WYP + cl + j * 16 + l16] = v;
+                        }
+            }
+            __syncthreads();
+            const int c = n0 + h * (GBN / 2) + 2 * lane;   // this lane's channel pair
+            const int c_off = split_pair_offset(c);
+#ifndef LOCOV_BIG_WINO_ABLATE
+#define LOCOV_BIG_WINO_ABLATE 0                            // developer timing: 1 = no (ROI, fy) units at all, 2 = units without their stores
+#endif
+            for (int u = wave; u < (LOCOV_BIG_WINO_ABLATE == 1 ? 0 : rois_here * wino::NF); u += GNW) {
+                const int roi = u / wino::NF, fy = u - roi * wino::NF;
+                const float *patch = yt + roi * WSEG * WYP + 2 * lane;
+                // V row (roi0 + roi) of transform-domain plane fy * 11: a buffer whose planes fx are a scalar offset apart
+                const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+                    partial + (roi0 + roi) * N + (int64_t)fy * wino::NF * fstride, 0, 0xffffffff, 0x00020000);
+                const unsigned fbytes = (unsigned)(fstride * 4);
+                auto load = [&](int y, int xx) __attribute__((always_inline)) {
+                    return *reinterpret_cast<const f32x2 *>(patch + (y * 7 + xx) * WYP);
+                };
+                auto emit = [&](int fx, f32x2 a) __attribute__((always_inline)) {
+                    amax = fmaxf(fmaxf(amax, fabsf(a[0])), fabsf(a[1]));
+                    if (LOCOV_BIG_WINO_ABLATE != 2 || a[0] == 1234.5f)
+                        __builtin_amdgcn_raw_buffer_store_b64(split_pair_words(c, a, v_scale), rv, c_off, fx * fbytes, 0);
+                };
+                switch (fy) {
+                case 0: wino_in_fy<false, 0>(load, emit); break;
+                case 1: wino_in_fy<false, 1>(load, emit); break;
+                case 2: wino_in_fy<false, 2>(load, emit); break;
+                case 3: wino_in_fy<false, 3>(load, emit); break;
+                case 4: wino_in_fy<false, 4>(load, emit); break;
+                case 5: wino_in_fy<false, 5>(load, emit); break;
+                case 6: wino_in_fy<false, 6>(load, emit); break;
+                case 7: wino_in_fy<false, 7>(load, emit); break;
+                case 8: wino_in_fy<false, 8>(load, emit); break;
+                case 9: wino_in_fy<false, 9>(load, emit); break;
+                default: wino_in_fy<false, 10>(load, emit); break;
+                }
+            }
+        }
+        if (overflow != nullptr && amax * v_scale >= 65504.f) atomicOr(overflow, 1u);
+        return;
+    }
     const bool out_split = (epi.flags & LOCOV_EPI_OUT_SPLIT) != 0, res_split = (epi.flags & LOCOV_EPI_RES_SPLIT) != 0;
     const bool odd_lane = (lane & 1) != 0;
     const float inv_a_scale = 1.f / a_scale;
@@ -252,6 +354,8 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
         __syncthreads();
         if (n_ok) {
             const unsigned voff = (unsigned)(((int64_t)(wm + 64 * h + rr) * ldc + n) * 4);      // rows past M: outside num_records
+            // (requesting the residual a whole half -- 16 x 16 bytes per lane -- ahead of its use instead of four at a time was tried:
+            //  conv3 2.55 -> 2.53 ms, i.e. nothing; the epilogue is not waiting on memory round trips, the launch is at the power cap)
 #pragma unroll
             for (int q4 = 0; q4 < NIT; q4 += 4) {
                 f32x4 res[4];
@@ -361,8 +465,8 @@ int launch_gemm_split_big(const float *A, int64_t lda, const void *Wsplit, float
     const int count = bt.count > 1 ? bt.count : 1;
     const int64_t tiles = ceil_div(M, GBM) * ceil_div(N, GBN) * count;
     const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K * count);     // class 5: split-operand GEMM
-    hipLaunchKernelGGL(gemm_split_big_kernel<false>, dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit), C,
-                       ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale), overflow, 0, static_cast<float *>(nullptr));
+    hipLaunchKernelGGL(gemm_split_big_kernel<MODE_PLAIN>, dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit), C,
+                       ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale), overflow, 0, static_cast<float *>(nullptr), 0.f);
     timing_end(trec, s);
     return check_launch(what);
 }
@@ -382,15 +486,38 @@ int launch_gemm_split_big_segmean(const float *A, int64_t lda, const void *Wspli
 {
     const int64_t tiles = ceil_div(M, GBM) * ceil_div(N, GBN);
     const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K);
-    hipLaunchKernelGGL(gemm_split_big_kernel<true>, dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
+    hipLaunchKernelGGL(gemm_split_big_kernel<MODE_SEGSUM>, dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
                        static_cast<float *>(nullptr), (int64_t)N, M, N, K, epi, Batch{1, 0, 0, 0}, a_scale, 1.f / (a_scale * w_scale), overflow, seg,
-                       partial);
+                       partial, 0.f);
     timing_end(trec, s);
     int rc = check_launch(what);
     if (rc) return rc;
     const int64_t R = M / seg, total = R * (N / 4);
     const unsigned blocks = (unsigned)(ceil_div(total, 256) < 65536 ? ceil_div(total, 256) : 65536);
     hipLaunchKernelGGL(segsum64_finish_kernel, dim3(blocks), dim3(256), 0, s, partial, R, N, seg, 1.f / (float)seg, out);
+    return check_launch(what);
+}
+
+// the 1x1 convolution whose finished rows go straight into the Winograd domain (MODE_WINO): ROI-major rows, 49 per ROI, N a whole
+// number of 256-wide tiles; V [121][R][N] in the split layout scaled by v_scale
+bool gemm_split_big_wino_applicable(int64_t lda, int64_t M, int N, int K, const Epilogue &epi)
+{
+    const char *fe = getenv("LOCOV_WINO_FUSE");            // developer A/B / tests (read per launch): 0 = never
+    if (fe && atoi(fe) == 0) return false;
+    if (M % WSEG != 0 || N % GBN != 0 || epi.residual || (epi.flags & (LOCOV_EPI_OUT_SPLIT | LOCOV_EPI_RES_SPLIT))) return false;
+    if ((M / WSEG) * (int64_t)N * 4 * wino::NF > 0xffffffffLL) return false;        // (a row of 11 transform-domain planes: 32-bit offsets)
+    return gemm_split_big_applicable(lda, (int64_t)N, M, N, K, epi, Batch{1, 0, 0, 0}, nullptr);
+}
+
+int launch_gemm_split_big_wino(const float *A, int64_t lda, const void *Wsplit, int64_t M, int N, int K, const Epilogue &epi, float a_scale,
+                               float w_scale, float *V, float v_scale, hipStream_t s, const char *what, unsigned *overflow)
+{
+    const int64_t tiles = ceil_div(M / WSEG, WROIS) * ceil_div(N, GBN);
+    const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K);
+    hipLaunchKernelGGL(gemm_split_big_kernel<MODE_WINO>, dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
+                       static_cast<float *>(nullptr), (int64_t)N, M, N, K, epi, Batch{1, 0, 0, 0}, a_scale, 1.f / (a_scale * w_scale), overflow, WSEG,
+                       V, v_scale);
+    timing_end(trec, s);
     return check_launch(what);
 }
 

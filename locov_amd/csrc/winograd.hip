@@ -17,40 +17,15 @@
 //
 // The transforms keep two channels per lane (8-byte accesses, 512 contiguous bytes per wave and
 // row) so that a 7x7 patch (49 x 2 registers) or the 7x7 accumulators fit without spilling.
-#include "gemm_nt.h"
-#include "winograd_tables.h"
+#include "winograd_transform.h"
 
 #include <cstdlib>
 
-// Cache policy of the transform-domain tensors (A/B: tools/ab_wino.sh, 8 000 ROIs): V is WRITTEN with the default policy
-// (input transform 561 -> 531 us against non-temporal stores), M is READ non-temporally (output transform 556 us against 593)
-#ifndef LOCOV_WINO_NT_STORE
-#define LOCOV_WINO_NT_STORE 0
-#endif
-#ifndef LOCOV_WINO_NT_LOAD
-#define LOCOV_WINO_NT_LOAD 1
-#endif
 #ifndef LOCOV_WINO_THREADS
 #define LOCOV_WINO_THREADS 256
 #endif
 
 namespace locov {
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <typename T>
-__device__ __forceinline__ void wino_store(const T &v, T *p)
-{
-    if (LOCOV_WINO_NT_STORE)
-        __builtin_nontemporal_store(v, p);
-    else
-        *p = v;
-}
-template <typename T>
-__device__ __forceinline__ T wino_load(const T *p)
-{
-    return LOCOV_WINO_NT_LOAD ? __builtin_nontemporal_load(p) : *p;
-}
 
 using wino::AT;
 using wino::BT;
@@ -79,35 +54,8 @@ __global__ __launch_bounds__(256) void wino_pack_weight_kernel(const float *__re
     }
 }
 
-// Store the channel pair (c, c+1) of a row in the SPLIT layout of locov_split_f16x2_pack (per 8 channels: 8 hi halves, then 8
-// lo halves of s*v; the row keeps its fp32 size): the split GEMM then stages this tensor by LDS DMA with no conversion of
-// its own (gemm_split.hip, ASPLIT).  A lane owns two channels = 4 bytes of hi and 4 of lo; neighbouring lanes (c and c+2,
-// same group of 8) trade one word so that the even one stores the hi halves of four channels and the odd one their lo
-// halves -- 8 contiguous bytes per lane, a wave's 512-byte row segment fully written by one instruction, as in fp32.
-// Returns max(|v0|, |v1|) for the caller's range guard.
-__device__ __forceinline__ void store_split_pair(float *row, int c, f32x2 v, float s)
-{
-    unsigned h, l;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(v[0]), "v"(s));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(v[1]), "v"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v[0]), "v"(s), "v"(h));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v[1]), "v"(s), "v"(h));
-    const bool odd = (c & 2) != 0;                              // c % 4 == 2: this lane keeps the lo halves
-    const unsigned got = (unsigned)__shfl_xor((int)(odd ? h : l), 1);
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 out = odd ? u32x2{got, l} : u32x2{h, got};
-    // byte offset in the row: group of 8 channels = 32 bytes; hi halves of channels 0-3 | 4-7 at +0 | +8, lo at +16 | +24
-    char *p = reinterpret_cast<char *>(row) + (c >> 3) * 32 + ((c >> 2) & 1) * 8 + (odd ? 16 : 0);
-    wino_store(out, reinterpret_cast<u32x2 *>(p));
-}
-
 // x rows [(y*7+x)*ld_pos + r*ld_roi][C]  ->  V [NF*NF][Rc][C]   (position-major input: ld_pos = R, ld_roi = 1;
 // ROI-major input, row = roi*49 + position: ld_pos = 1, ld_roi = 49)
-// GRAD = true applies A (x) A = (AT (x) AT)^T instead of BT (x) BT: the adjoint of the OUTPUT transform, which maps the
-// gradient of a convolution's output into the transform domain (dM) for the weight gradient (locov_winograd_wgrad_f32).
-template <bool GRAD>
-__device__ __forceinline__ constexpr float in_coef(int f, int y) { return GRAD ? AT[y][f] : BT[f][y]; }
-
 // SPLIT: V is written in the split layout scaled by v_scale (the A operand of the split batched GEMM); a value outside fp16's
 // range raises *overflow (the GEMM no longer sees the fp32 values: the range guard moves here).
 // amax_out (fp32 V only): a 16-byte operand-scale slot whose word 2 receives max |V| (gemm_nt.h, amax_fold) -- the transform of
@@ -135,32 +83,14 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
             d[y][xx] = *reinterpret_cast<const f32x2 *>(src + (int64_t)(y * 7 + xx) * ld_pos * C);
     float *dst = V + r * C + c;
     const int64_t fstride = Rc * C;
-#pragma unroll
-    for (int fy = 0; fy < NF; fy++) {
-        f32x2 wv[7];
-#pragma unroll
-        for (int xx = 0; xx < 7; xx++) {
-            f32x2 a = {0.f, 0.f};
-#pragma unroll
-            for (int y = 0; y < 7; y++)
-                if (in_coef<GRAD>(fy, y) != 0.f) a += in_coef<GRAD>(fy, y) * d[y][xx];
-            wv[xx] = a;
-        }
-#pragma unroll
-        for (int fx = 0; fx < NF; fx++) {
-            f32x2 a = {0.f, 0.f};
-#pragma unroll
-            for (int xx = 0; xx < 7; xx++)
-                if (in_coef<GRAD>(fx, xx) != 0.f) a += in_coef<GRAD>(fx, xx) * wv[xx];
-            if constexpr (SPLIT) {
-                amax = fmaxf(fmaxf(amax, fabsf(a[0])), fabsf(a[1]));
-                store_split_pair(V + r * C + (int64_t)(fy * NF + fx) * fstride, c, a, v_scale);
-            } else {
-                amax = fmaxf(fmaxf(amax, fabsf(a[0])), fabsf(a[1]));
-                wino_store(a, reinterpret_cast<f32x2 *>(dst + (int64_t)(fy * NF + fx) * fstride));
-            }
-        }
-    }
+    wino_in_all<GRAD>([&](int y, int xx) { return d[y][xx]; },
+                      [&](int fy, int fx, f32x2 a) {
+                          amax = fmaxf(fmaxf(amax, fabsf(a[0])), fabsf(a[1]));
+                          if constexpr (SPLIT)
+                              store_split_pair(V + r * C + (int64_t)(fy * NF + fx) * fstride, c, a, v_scale);
+                          else
+                              wino_store(a, reinterpret_cast<f32x2 *>(dst + (int64_t)(fy * NF + fx) * fstride));
+                      });
     }
     if (SPLIT && overflow != nullptr && amax * v_scale >= 65504.f) atomicOr(overflow, 1u);
     if (!SPLIT && amax_out != nullptr) amax_fold(amax_out, amax);
@@ -312,13 +242,26 @@ int locov_winograd_pack_weight(const float *w, int N, int Cin, float *U, locov_s
     return check_launch("locov_winograd_pack_weight");
 }
 
+// the 1x1 convolution (+ FrozenBN + ReLU) in front of the 3x3 one, when both are asked for in one call
+// (locov_conv1x1_winograd_conv3x3_f32_split): its input in the split layout, ROI-major rows; y1 = pixel scratch for the unfused form
+struct PreConv {
+    const float *x;
+    int64_t ldx;
+    int K;
+    float x_scale;
+    const void *W;
+    float w_scale;
+    const float *scale, *shift;
+    float *y1;
+};
+
 // u_scale > 0: U is the split-operand packing of u_scale * U (locov_split_f16x2_pack) and the 121 GEMMs run on the
 // f16 matrix pipe with V scaled by v_scale (gemm_split.hip); u_scale == 0: fp32 U, fp32 MFMA.
 static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
                             const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
                             void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask = nullptr,
                             unsigned *overflow = nullptr, bool v_scale_auto = false, float y_split_scale = 0.f,
-                            float *amax_out = nullptr);
+                            float *amax_out = nullptr, const PreConv *pre = nullptr);
 
 int locov_winograd_conv3x3_f32_ex(const float *x, int64_t R, int Cin, const float *U, const float *scale, const float *shift,
                                   const float *mask, float *y, int64_t ldy, int N, unsigned flags, void *workspace,
@@ -355,15 +298,45 @@ int locov_winograd_conv3x3_f32_split(const float *x, int64_t R, int Cin, const v
                             workspace, workspace_bytes, stream, nullptr, overflow);
 }
 
+int64_t locov_conv1x1_winograd_workspace_bytes(int64_t R, int C, int N)
+{
+    if (R <= 0 || C <= 0 || N <= 0) return 0;
+    return locov_winograd_workspace_bytes(R, C, N) + R * 49 * (int64_t)C * (int64_t)sizeof(float);
+}
+
+int locov_conv1x1_winograd_conv3x3_f32_split(const float *x_split, int64_t ldx, int K, float x_scale, const void *W1_split, float w1_scale,
+                                             const float *scale1, const float *shift1, int64_t R, int C, const void *U_split,
+                                             float u_scale, float v_scale, const float *scale2, const float *shift2, float *y,
+                                             int64_t ldy, int N, unsigned flags, float y_split_scale, void *workspace,
+                                             int64_t workspace_bytes, unsigned *overflow, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(R >= 0 && K > 0 && C > 0 && N > 0, "locov_conv1x1_winograd_conv3x3_f32_split: bad shape");
+    if (R == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(x_split && W1_split && U_split && y && workspace, "locov_conv1x1_winograd_conv3x3_f32_split: null pointer");
+    LOCOV_REQUIRE(x_scale > 0.f && w1_scale > 0.f && u_scale > 0.f && v_scale > 0.f,
+                  "locov_conv1x1_winograd_conv3x3_f32_split: operand scales must be positive");
+    LOCOV_REQUIRE(K % 32 == 0 && ldx >= K && ldx % 4 == 0 && (uintptr_t)x_split % 16 == 0 && (uintptr_t)W1_split % 16 == 0,
+                  "locov_conv1x1_winograd_conv3x3_f32_split: K %% 32, ldx >= K, ldx %% 4 and 16-byte pointers required");
+    LOCOV_REQUIRE((flags & LOCOV_WINO_IN_ROI_MAJOR) != 0, "locov_conv1x1_winograd_conv3x3_f32_split: rows are ROI-major (LOCOV_WINO_IN_ROI_MAJOR)");
+    LOCOV_REQUIRE(chunk_rois(R, C, N) == R, "locov_conv1x1_winograd_conv3x3_f32_split: one pass only (LOCOV_WINO_CHUNK is set)");
+    const int64_t wb = locov_winograd_workspace_bytes(R, C, N);
+    LOCOV_REQUIRE(workspace_bytes >= locov_conv1x1_winograd_workspace_bytes(R, C, N),
+                  "locov_conv1x1_winograd_conv3x3_f32_split: workspace too small (%lld bytes)", (long long)workspace_bytes);
+    PreConv pre{x_split, ldx, K, x_scale, W1_split, w1_scale, scale1, shift1,
+                reinterpret_cast<float *>(static_cast<char *>(workspace) + ((wb + 15) & ~(int64_t)15))};
+    return winograd_conv3x3(nullptr, R, C, static_cast<const float *>(U_split), u_scale, v_scale, scale2, shift2, y, ldy, N, flags, workspace, wb,
+                            stream, nullptr, overflow, false, y_split_scale, nullptr, &pre);
+}
+
 static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
                             const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
                             void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask, unsigned *overflow,
-                            bool v_scale_auto, float y_split_scale, float *amax_out)
+                            bool v_scale_auto, float y_split_scale, float *amax_out, const PreConv *pre)
 {
     LOCOV_REQUIRE(ldy >= N && ldy % 2 == 0, "locov_winograd_conv3x3_f32: ldy must be >= N and even");
     LOCOV_REQUIRE(R >= 0 && Cin > 0 && N > 0, "locov_winograd_conv3x3_f32: bad shape");
     if (R == 0) return LOCOV_OK;
-    LOCOV_REQUIRE(x && U && y && workspace, "locov_winograd_conv3x3_f32: null pointer");
+    LOCOV_REQUIRE((x || pre) && U && y && workspace, "locov_winograd_conv3x3_f32: null pointer");
     LOCOV_REQUIRE(Cin % 32 == 0 && N % 4 == 0, "locov_winograd_conv3x3_f32: Cin %% 32 and N %% 4 must be 0 (got %d, %d)",
                   Cin, N);
     LOCOV_REQUIRE(((uintptr_t)x | (uintptr_t)U | (uintptr_t)y | (uintptr_t)workspace) % 16 == 0,
@@ -385,7 +358,25 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
         const bool in_roi_major = (flags & LOCOV_WINO_IN_ROI_MAJOR) != 0;
         // split GEMM with a scale known up front: V leaves the transform already in the split layout (staged by DMA in the GEMM)
         const bool v_split = u_scale > 0.f && !v_scale_auto;
-        if (v_split)
+        bool v_done = false;
+        if (pre) {
+            // (pre: split arithmetic, fixed v_scale, ROI-major rows, one pass -- checked by the caller)
+            Epilogue e1{pre->scale, pre->shift, nullptr, LOCOV_EPI_RELU | LOCOV_GEMM_A_SPLIT};
+            int rc1;
+            if (gemm_split_big_wino_applicable(pre->ldx, rc * 49, Cin, pre->K, e1)) {
+                rc1 = launch_gemm_split_big_wino(pre->x, pre->ldx, pre->W, rc * 49, Cin, pre->K, e1, pre->x_scale, pre->w_scale, V, v_scale, s,
+                                                 "locov_conv1x1_winograd_conv3x3_f32_split (1x1 + input transform)", overflow);
+                v_done = true;
+            } else {
+                rc1 = launch_gemm_split(pre->x, pre->ldx, pre->W, pre->y1, (int64_t)Cin, rc * 49, Cin, pre->K, e1, pre->x_scale, pre->w_scale, s,
+                                        "locov_conv1x1_winograd_conv3x3_f32_split (1x1)", Batch{1, 0, 0, 0}, overflow);
+                x = pre->y1;
+            }
+            if (rc1) return rc1;
+        }
+        if (v_done)
+            ;
+        else if (v_split)
             hipLaunchKernelGGL((wino_input_kernel<false, true>), dim3((unsigned)ceil_div(tin, 256)), dim3(256), 0, s,
                                x + r0 * (in_roi_major ? 49 : 1) * Cin, in_roi_major ? (int64_t)1 : R,
                                in_roi_major ? (int64_t)49 : (int64_t)1, rc, Cin, V, v_scale, overflow);

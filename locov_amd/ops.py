@@ -384,6 +384,48 @@ def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool =
     return y
 
 
+def conv1x1_winograd_conv3x3(x: torch.Tensor, w1: SplitWeight, b1: Optional[torch.Tensor], U: SplitWeight, *,
+                             scale1: Optional[torch.Tensor] = None, scale2: Optional[torch.Tensor] = None,
+                             shift2: Optional[torch.Tensor] = None, relu: bool = True, x_scale: float = 16.0, v_scale: float = 0.25,
+                             roi_major: bool = True, out_split_scale: Optional[float] = None) -> torch.Tensor:
+    """A bottleneck's conv1 (1x1 + FrozenBN + ReLU) and conv2 (3x3 + FrozenBN + ReLU?) in one call, split arithmetic:
+        winograd_conv3x3(linear_split(x, w1, b1, scale=scale1, relu=True, x_is_split=True), U, in_roi_major=True, ...)
+    and the same bits.  x [49*R, K]: the block input in the split layout (x x_scale), ROI-major rows.  Where the launch fills the
+    chip with 256x256 tiles the pixel tensor between the two convolutions is never written: conv1's epilogue applies the Winograd
+    input transform (gemm_split_big.hip, MODE_WINO)."""
+    x = _rows(x, "x")
+    w1d, Ud = _dev(w1.data, "w1"), _dev(U.data, "U")
+    M, K = x.shape
+    C = w1d.shape[0]
+    if w1d.shape[1] != K or K % 32 or M % 49 or Ud.dim() != 3 or Ud.shape[0] != 121 or Ud.shape[2] != C or C % 32:
+        raise ValueError(f"conv1x1_winograd_conv3x3: x {tuple(x.shape)} w1 {tuple(w1d.shape)} U {tuple(Ud.shape)}")
+    N, R = Ud.shape[1], M // 49
+    if N % 4 or (out_split_scale is not None and N % 32):
+        raise ValueError("conv1x1_winograd_conv3x3: N % 4 == 0 (N % 32 == 0 for a split-layout output)")
+    b1 = _dev(b1, "b1") if b1 is not None else None
+    scale1 = _dev(scale1, "scale1") if scale1 is not None else None
+    scale2 = _dev(scale2, "scale2") if scale2 is not None else None
+    shift2 = _dev(shift2, "shift2") if shift2 is not None else None
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    need = int(lib.locov_conv1x1_winograd_workspace_bytes(R, C, N))
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _WINO_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = None
+        _WINO_WS.pop(key, None)
+        ws = _WINO_WS[key] = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+    wflags = (_lib.EPI_RELU if relu else 0) | (_lib.WINO_OUT_ROI_MAJOR if roi_major else 0) | _lib.WINO_IN_ROI_MAJOR
+    with torch.cuda.device(x.device):
+        check(lib.locov_conv1x1_winograd_conv3x3_f32_split(_ptr(x), x.stride(0) if M else K, K, float(x_scale), _ptr(w1d), w1.scale,
+                                                           _ptr(scale1), _ptr(b1), R, C, _ptr(Ud), U.scale, float(v_scale),
+                                                           _ptr(scale2), _ptr(shift2), _ptr(y), N, N, wflags,
+                                                           float(out_split_scale or 0.0), _ptr(ws), ws.numel(),
+                                                           _ptr(_overflow_word(x)), _stream(x)),
+              "locov_conv1x1_winograd_conv3x3_f32_split")
+    return y
+
+
 def gemm_nt_batched(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """x [B,M,K], w [B,N,K] -> [B,M,N] (fp32, one launch)."""
     x = _dev(x, "x")

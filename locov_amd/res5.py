@@ -30,6 +30,7 @@ import os
 # significant bits, and a row's result has to be the same whichever images share its launch (image sharding over ranks;
 # tests/test_gpu_roi_heads.py::test_full_size_head_properties).  LOCOV_RES5_OUT_SPLIT=0 turns it off.
 _OUT_SPLIT = os.environ.get("LOCOV_RES5_OUT_SPLIT", "1") != "0"
+_FUSE12 = os.environ.get("LOCOV_RES5_FUSE12", "1") != "0"      # developer A/B: conv1 + conv2 through ops.conv1x1_winograd_conv3x3
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -434,10 +435,22 @@ class Res5Stage(nn.Sequential):
                 x = ops.linear_bf16(ops.to_bf16(y), self._bf16(w3), b3, scale=s3, residual=sc, relu=True)
                 continue
             xs_kw = {"x_is_split": True, "x_scale": self.ACT_SPLIT_SCALE} if x_split else {}
-            y = self._linear(split, x, w1, b1, scale=s1, relu=True, **xs_kw)      # 1x1 (+stride via x0) + FBN + ReLU
             use_wino = winograd and H == 7 and W == 7 and c2.in_channels % 32 == 0 and c2.out_channels % 4 == 0
             assert use_wino or not x_split
             rm = not pos_major                     # the Winograd transforms read / write either row order
+            # conv1 and conv2 in one call where the block input is already in the split layout: conv1's epilogue then writes the
+            # Winograd-domain tensor itself (ops.conv1x1_winograd_conv3x3; the same bits as the two calls)
+            fuse12 = _FUSE12 and x_split and use_wino and rm and w1.shape[0] % 32 == 0
+
+            def conv12(**kw):
+                u2, s2, b2 = self._packed(c2, winograd=True)
+                if fuse12:
+                    return ops.conv1x1_winograd_conv3x3(x, self._split(w1), b1, self._split(u2), scale1=s1, scale2=s2, shift2=b2,
+                                                        relu=True, x_scale=self.ACT_SPLIT_SCALE, roi_major=kw["roi_major"],
+                                                        out_split_scale=kw.get("out_split_scale"))
+                return ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True, in_roi_major=rm, **kw)
+
+            y = None if fuse12 else self._linear(split, x, w1, b1, scale=s1, relu=True, **xs_kw)      # 1x1 (+stride via x0) + FBN + ReLU
             if use_wino and bi == 0 and cat is not None and blk.shortcut is not None:
                 u2, s2, b2 = self._packed(c2, winograd=True)
                 ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True,
@@ -448,19 +461,14 @@ class Res5Stage(nn.Sequential):
             last = bi == len(self) - 1
             if (use_wino and pooled and last and split and blk.shortcut is None and w3.shape[1] % 32 == 0 and w3.shape[0] % 4 == 0
                     and x.shape[0] * w3.shape[0] * 4 < 2 ** 32):
-                u2, s2, b2 = self._packed(c2, winograd=True)
                 ysp = self._y2_split_ok(True, c2, w3)
-                y = ops.winograd_conv3x3(y, self._split(u2), scale=s2, shift=b2, relu=True, roi_major=True, in_roi_major=rm,
-                                         out_split_scale=self.ACT_SPLIT_SCALE if ysp else None)
+                y = conv12(roi_major=True, out_split_scale=self.ACT_SPLIT_SCALE if ysp else None)
                 return ops.linear_split_segmean(y, self._split(w3), b3, x, H * W, scale=s3, relu=True, residual_roi_major=rm,
                                                 x_is_split=ysp, x_scale=self.ACT_SPLIT_SCALE, residual_is_split=x_split)
             y_split = False
             if use_wino:
-                u2, s2, b2 = self._packed(c2, winograd=True)
                 y_split = self._y2_split_ok(split, c2, w3)
-                y = ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True,
-                                         roi_major=rm, in_roi_major=rm,
-                                         out_split_scale=self.ACT_SPLIT_SCALE if y_split else None)          # 3x3 + FBN + ReLU
+                y = conv12(roi_major=rm, out_split_scale=self.ACT_SPLIT_SCALE if y_split else None)          # 3x3 + FBN + ReLU
             else:
                 w2, s2, b2 = self._packed(c2)
                 y = ops.conv3x3_nhwc(y, w2, H, W, scale=s2, shift=b2, relu=True, pos_major=pos_major)

@@ -611,3 +611,50 @@ def test_big_tile_segmean_matches_the_128x128_form(ops):
             os.environ.pop("LOCOV_SPLIT_BIG", None)
         else:
             os.environ["LOCOV_SPLIT_BIG"] = prev
+
+
+def test_conv1_with_the_winograd_input_transform_in_its_epilogue_is_bit_identical(ops):
+    """ops.conv1x1_winograd_conv3x3 (a bottleneck's conv1 + FrozenBN + ReLU and conv2 in one call): where the launch qualifies,
+    conv1's epilogue on the 256 x 256 tile applies the Winograd input transform itself (gemm_split_big.hip MODE_WINO: tiles of 5
+    whole ROIs, the finished half tile laid out in LDS, (ROI, fy) units shared by the 8 waves) and the pixel tensor between the
+    two convolutions is never written.  Same BITS as the two separate calls (linear_split -> winograd_conv3x3), with ROI counts
+    that leave a ragged last tile, fp32 and split-layout outputs, both output row orders; the range guard fires in both forms.
+    LOCOV_WINO_FUSE=0 / LOCOV_SPLIT_BIG=1 (read per launch) select the form."""
+    import os
+    prev = {k: os.environ.get(k) for k in ("LOCOV_SPLIT_BIG", "LOCOV_WINO_FUSE")}
+    try:
+        for R, K, C, N, out_split, roi_major in ((1, 64, 256, 64, False, True), (5, 128, 256, 32, True, True), (23, 64, 512, 96, False, False),
+                                                 (64, 192, 256, 64, True, True), (1307, 256, 256, 64, False, True)):
+            g = torch.Generator().manual_seed(R + K)
+            xs = ops.split_pack(torch.relu(torch.randn(49 * R, K, generator=g)).cuda(), 16.0).data
+            w1 = ops.split_pack((torch.randn(C, K, generator=g) * 0.05).cuda())
+            s1, b1 = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+            u = ops.split_pack(ops.winograd_pack_weight((torch.randn(N, C, 3, 3, generator=g) * 0.03).cuda()))
+            s2, b2 = (torch.rand(N, generator=g) + 0.5).cuda(), (torch.randn(N, generator=g) * 0.1).cuda()
+            oss = 16.0 if out_split else None
+            os.environ["LOCOV_SPLIT_BIG"] = "0"
+            y1 = ops.linear_split(xs, w1, b1, scale=s1, relu=True, x_is_split=True, x_scale=16.0)
+            want = ops.winograd_conv3x3(y1, u, scale=s2, shift=b2, relu=True, roi_major=roi_major, in_roi_major=True, out_split_scale=oss)
+            os.environ["LOCOV_SPLIT_BIG"] = "1"
+            got = {}
+            for fuse in ("0", "1"):
+                os.environ["LOCOV_WINO_FUSE"] = fuse
+                got[fuse] = ops.conv1x1_winograd_conv3x3(xs, w1, b1, u, scale1=s1, scale2=s2, shift2=b2, relu=True, x_scale=16.0,
+                                                         roi_major=roi_major, out_split_scale=oss)
+            assert torch.equal(got["0"], want), (R, K, C, N, "unfused form of the one-call entry point")
+            assert torch.equal(got["1"], want), (R, K, C, N, "fused epilogue")
+        # range guard: transform-domain values past fp16's range raise the word in the fused form too
+        ops.split_overflow_reset(xs.device)
+        big = ops.split_pack(torch.full((49 * 5, 64), 60.0).cuda(), 16.0).data
+        wbig = ops.split_pack(torch.ones(256, 64).cuda())
+        u1 = ops.split_pack(ops.winograd_pack_weight((torch.randn(32, 256, 3, 3, generator=torch.Generator().manual_seed(1)) * 0.03).cuda()))
+        os.environ["LOCOV_WINO_FUSE"] = "1"
+        ops.conv1x1_winograd_conv3x3(big, wbig, None, u1, x_scale=16.0, v_scale=16.0)            # pixels 3840, V up to 100x that, x 16
+        assert ops.split_overflow_raised(xs.device)
+        ops.split_overflow_reset(xs.device)
+    finally:
+        for k, v in prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

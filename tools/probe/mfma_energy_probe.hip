@@ -25,7 +25,9 @@ __device__ __forceinline__ h8 frag(unsigned seed)
 }
 
 // arm 0: 16x16x32, 8 x 4 tiles;  arm 1: 32x32x16, 4 x 2 tiles x 2 k-steps;  both 262 144 MACs per (wave, inner pass)
-template <int ARM, int WAVES>
+// ORDER (arm 0 only): 0 = A operand shared by four consecutive MFMAs (the shipped order), 1 = both operands change on every MFMA,
+// 2 = ONE operand pair for all of them (accumulators still differ), 3 = as 0 with all-zero operands (no data toggling)
+template <int ARM, int WAVES, int ORDER = 0>
 __global__ __launch_bounds__(WAVES * 64) void mfma_loop(float *out, int iters)
 {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -34,6 +36,12 @@ __global__ __launch_bounds__(WAVES * 64) void mfma_loop(float *out, int iters)
     for (int i = 0; i < 8; i++) a[i] = frag(t * 31u + i);
 #pragma unroll
     for (int j = 0; j < 4; j++) b[j] = frag(t * 17u + 1000u + j);
+    if (ORDER == 3) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) a[i] = a[i] * (_Float16)(iters < 0 ? 1.f : 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; j++) b[j] = b[j] * (_Float16)(iters < 0 ? 1.f : 0.f);
+    }
     float s = 0.f;
     if (ARM == 0) {
         f4 acc[8][4];
@@ -48,7 +56,9 @@ __global__ __launch_bounds__(WAVES * 64) void mfma_loop(float *out, int iters)
                 for (int i = 0; i < 8; i++)
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(i + p) & 7], b[(j + p) & 3], acc[i][j], 0, 0, 0);
+                        acc[i][j] = ORDER == 1   ? __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(i + j + p) & 7], b[(j + p) & 3], acc[i][j], 0, 0, 0)
+                                    : ORDER == 2 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], acc[i][j], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(i + p) & 7], b[(j + p) & 3], acc[i][j], 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 8; i++)
@@ -83,7 +93,7 @@ __global__ __launch_bounds__(WAVES * 64) void mfma_loop(float *out, int iters)
     if (s == 123.456f) out[t] = s;
 }
 
-template <int ARM, int WAVES>
+template <int ARM, int WAVES, int ORDER = 0>
 static void run(const char *name, double seconds, float *d)
 {
     const int iters = 2000, wgs = 256 * (8 / WAVES) * 4;
@@ -92,15 +102,15 @@ static void run(const char *name, double seconds, float *d)
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const size_t lds = WAVES == 8 ? 0 : 120 * 1024;          // 4-wave arms: one workgroup per CU
-    if (lds) hipFuncSetAttribute((const void *)mfma_loop<ARM, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((mfma_loop<ARM, WAVES>), dim3(wgs), dim3(WAVES * 64), lds, 0, d, iters);
+    if (lds) hipFuncSetAttribute((const void *)mfma_loop<ARM, WAVES, ORDER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((mfma_loop<ARM, WAVES, ORDER>), dim3(wgs), dim3(WAVES * 64), lds, 0, d, iters);
     hipDeviceSynchronize();
     auto t0 = std::chrono::steady_clock::now();
     double last = 0;
     int rounds = 0;
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
         hipEventRecord(e0, 0);
-        for (int i = 0; i < 20; i++) hipLaunchKernelGGL((mfma_loop<ARM, WAVES>), dim3(wgs), dim3(WAVES * 64), lds, 0, d, iters);
+        for (int i = 0; i < 20; i++) hipLaunchKernelGGL((mfma_loop<ARM, WAVES, ORDER>), dim3(wgs), dim3(WAVES * 64), lds, 0, d, iters);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms;
@@ -122,5 +132,8 @@ int main(int argc, char **argv)
     run<1, 8>("v_mfma_f32_32x32x16_f16, 8 waves/CU", seconds, d);
     run<0, 4>("v_mfma_f32_16x16x32_f16, 4 waves/CU", seconds, d);
     run<1, 4>("v_mfma_f32_32x32x16_f16, 4 waves/CU", seconds, d);
+    run<0, 8, 1>("16x16x32, 8 waves, both operands change", seconds, d);
+    run<0, 8, 2>("16x16x32, 8 waves, one operand pair", seconds, d);
+    run<0, 8, 3>("16x16x32, 8 waves, zero operands", seconds, d);
     return 0;
 }
