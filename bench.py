@@ -42,6 +42,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3    # f32-input MFMA peak
 MFMA_16BIT_PEAK_TFLOPS = 2500.0 # dense f16 / bf16 MFMA peak
+SUSTAINED_F16_MFMA_TFLOPS = 1975.0          # measured, not nominal: profiles/r03_mfma_shape_probe.txt (reported beside `frac`, never instead of it)
 
 
 def parse(argv=None):
@@ -607,6 +608,12 @@ def main():
                         "fp32_equivalent_vs_f32_mfma_peak": fls / (mss * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if mss > 0 else None,
                         "f32_mfma_gemms": {"launches_per_step": n0 / args.steps, "share_of_step_time": ms0 * 1e-3 / dt2,
                                            "executed_tflops": achieved},
+                        "power_cap": {"sustained_mfma_only_tflops": SUSTAINED_F16_MFMA_TFLOPS,
+                                      "frac_of_sustained": ach / SUSTAINED_F16_MFMA_TFLOPS,
+                                      "what": "a register-only v_mfma_f32_16x16x32_f16 loop with live operands (no LDS, no memory) is held to "
+                                              "~1.95-2.0 GHz by the 1 400 W package cap and sustains this rate on MI355X "
+                                              "(profiles/r03_mfma_shape_probe.txt); the split GEMM launches run AT the cap "
+                                              "(profiles/r03_power_probe_big_tile.txt), so their time is joules / (cap - idle)"},
                         "note": "achieved counts the f16 MFMA FLOPs the kernel executes (three products per fp32 product); "
                                 "peak is the dense f16/bf16 MFMA peak"}
             if args.res5_dtype == "bf16":
