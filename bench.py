@@ -499,7 +499,8 @@ def main():
         return n.value, ms.value, fl.value
     gemm_plain, gemm_conv = gemm_class(0), gemm_class(1)
     gemm_plain_bf16, gemm_conv_bf16 = gemm_class(3), gemm_class(4)
-    gemm_split = gemm_class(5)
+    gemm_split_plain, gemm_split_wino = gemm_class(5), gemm_class(7)
+    gemm_split = tuple(a + b for a, b in zip(gemm_split_plain, gemm_split_wino))      # every split-operand GEMM launch of the step
     lib.locov_gemm_timing_enable(0)
     # the same job with the Res5 GEMMs on the f32 MFMA (reported beside the headline when that is the split path)
     dt2_f32 = None
@@ -608,6 +609,16 @@ def main():
                         "fp32_equivalent_vs_f32_mfma_peak": fls / (mss * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if mss > 0 else None,
                         "f32_mfma_gemms": {"launches_per_step": n0 / args.steps, "share_of_step_time": ms0 * 1e-3 / dt2,
                                            "executed_tflops": achieved},
+                        "instances": {
+                            "plain_and_mean_fused": {"launches_per_step": gemm_split_plain[0] / args.steps,
+                                                     "avg_launch_ms": gemm_split_plain[1] / max(gemm_split_plain[0], 1),
+                                                     "achieved": 3.0 * gemm_split_plain[2] / (gemm_split_plain[1] * 1e-3) / 1e12 if gemm_split_plain[1] > 0 else None},
+                            "with_winograd_input_transform_in_the_epilogue": {
+                                "launches_per_step": gemm_split_wino[0] / args.steps,
+                                "avg_launch_ms": gemm_split_wino[1] / max(gemm_split_wino[0], 1),
+                                "achieved": 3.0 * gemm_split_wino[2] / (gemm_split_wino[1] * 1e-3) / 1e12 if gemm_split_wino[1] > 0 else None,
+                                "what": "conv1 of blocks 1-2: these launches also write the 2 GB transform-domain tensor a separate HBM-bound "
+                                        "kernel used to write (round 2: outside this number); their MFMA rate alone understates them"}},
                         "power_cap": {"sustained_mfma_only_tflops": SUSTAINED_F16_MFMA_TFLOPS,
                                       "frac_of_sustained": ach / SUSTAINED_F16_MFMA_TFLOPS,
                                       "what": "a register-only v_mfma_f32_16x16x32_f16 loop with live operands (no LDS, no memory) is held to "

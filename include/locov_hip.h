@@ -351,7 +351,8 @@ int locov_gemm_nt_batched_f32_split(const float *x, int64_t lda, int64_t stride_
  * returns, for one kernel class, the number of launches, the sum of their durations (ms) and
  * the FLOPs they executed.  cls: 0 = gemm_nt_kernel<128x128, plain / batched> (1x1 convs, FCs,
  * Winograd-domain GEMMs), 1 = the position-major direct 3x3 conv, 2 = the other tile shapes,
- * 3 / 4 = classes 0 / 1 launched with bf16 operands, 5 = the split-operand GEMM, 6 = the TN (weight-gradient) GEMM.
+ * 3 / 4 = classes 0 / 1 launched with bf16 operands, 5 = the split-operand GEMM, 6 = the TN (weight-gradient) GEMM,
+ * 7 = the split-operand GEMM whose epilogue applies the Winograd input transform (locov_conv1x1_winograd_conv3x3_f32_split).
  * enable(on) clears what was recorded. */
 int locov_gemm_timing_enable(int on);
 int locov_gemm_timing_read(int cls, int64_t *launches, double *ms, double *flops);
@@ -568,6 +569,18 @@ int locov_winograd_wgrad_f32_split(const float *x, const float *g, int64_t R, in
  *   | LOCOV_WINO_OUT_ROI_MAJOR | LOCOV_EPI_RELU (of the 3x3); y, ldy, y_split_scale as in locov_winograd_conv3x3_f32_split_ex.
  *   workspace: locov_conv1x1_winograd_workspace_bytes(R, C, N) bytes. */
 int64_t locov_conv1x1_winograd_workspace_bytes(int64_t R, int C, int N);
+/* The same for block 0, whose 1x1 convolution ran on the feature MAP (ROIAlign is linear): the pooler + FrozenBN + ReLU + conv2 in one
+ * call -- locov_roi_align_nhwc_affine_fwd(bin_stride 2, ROI-major, relu) followed by locov_winograd_conv3x3_f32_split_ex, and those
+ * bits.  With C % 64 == 0 the ROIAlign workgroup (one ROI x 64 channels) keeps its 49 pooled rows in LDS and writes their Winograd
+ * input transform itself; otherwise the two launches.  feat_nhwc: fp32 [Nimg, H, W, C] with pixel pitch feat_ld; pooled: 14 (the
+ * even bins form the 7 x 7 tile); workspace: locov_conv1x1_winograd_workspace_bytes(R, C, N); the other arguments as above. */
+int locov_roi_align_winograd_conv3x3_f32_split(const float *feat_nhwc, int Nimg, int H, int W, int C, int64_t feat_ld,
+                                               const float *rois, int64_t R, int pooled, float spatial_scale,
+                                               int sampling_ratio, int aligned, const float *scale1, const float *shift1,
+                                               const void *U_split, float u_scale, float v_scale, const float *scale2,
+                                               const float *shift2, float *y, int64_t ldy, int N, unsigned flags,
+                                               float y_split_scale, void *workspace, int64_t workspace_bytes,
+                                               unsigned *overflow, locov_stream_t stream);
 int locov_conv1x1_winograd_conv3x3_f32_split(const float *x_split, int64_t ldx, int K, float x_scale, const void *W1_split,
                                              float w1_scale, const float *scale1, const float *shift1, int64_t R, int C,
                                              const void *U_split, float u_scale, float v_scale, const float *scale2,

@@ -98,6 +98,12 @@ bool gemm_split_big_wino_applicable(int64_t lda, int64_t M, int N, int K, const 
 int launch_gemm_split_big_wino(const float *A, int64_t lda, const void *Wsplit, int64_t M, int N, int K, const Epilogue &epi, float a_scale,
                                float w_scale, float *V, float v_scale, hipStream_t s, const char *what, unsigned *overflow);
 
+// ROIAlign (even bins of a 14 x 14 pooler, ROI-major) + per-channel affine + ReLU with the same transform behind it (roi_align_nhwc.hip)
+bool roi_align_nhwc_wino_applicable(int C, int64_t R);
+int launch_roi_align_nhwc_wino(const float *feat, int N, int H, int W, int C, int64_t feat_ld, const float *rois, int64_t R, int pooled,
+                               float spatial_scale, int sampling_ratio, int aligned, const float *ch_scale, const float *ch_shift, int relu,
+                               float *V, float v_scale, unsigned *overflow, hipStream_t s);
+
 // out[b][N,K] = row_scale[n] * sum_m A_b[m,n] * B_b[m,k]  (gemm_tn.hip: the weight-gradient GEMM; problem b uses
 // A + b*sa, B + b*sb, out + b*so; ws = gemm_tn_workspace_bytes(M, N, K, batch) bytes of device memory)
 int launch_gemm_tn(const float *A, int64_t lda, int64_t sa, const float *B, int64_t ldb, int64_t sb, float *out, int64_t ldo,

@@ -11,6 +11,7 @@
 // 1x1 convs of Res5 block 0 (roi_emb_heads.py:217-241) read exactly those positions of the
 // 14x14 tile, so 3/4 of the pooler's output bytes are never produced.
 #include "roi_align_common.h"
+#include "winograd_transform.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -60,13 +61,22 @@ constexpr int kMaxAxisN = 192;     // per-axis LDS table entries (7 x up to 27 s
 // BWD = true is the adjoint with the same sampling geometry: `out` then holds the GRADIENT of the pooled rows (read) and
 // `feat` the gradient of the channels-last map (accumulated with fp32 hardware atomics; the caller zeroes it) -- what
 // autograd needs when the LSM head trains through the even-grid pooler (roi_emb_heads.py:343 under autograd).
-template <typename TIn, typename TOut, bool BWD = false>
-__global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
+//
+// WINO = true (fp32, 7 x 7 strided bins, slices of at most 64 channels): the pooled + FrozenBN + ReLU values are the input of a 3x3
+// convolution evaluated in the Winograd domain (block 0's conv2).  They are kept in LDS ([49][64]) instead of being stored, and
+// the workgroup writes their input transform V [121][R][C] (`out`, split layout x v_scale) itself -- wino_in_fy of
+// winograd_transform.h, the bits wino_input_kernel<false, true> would have produced from the stored rows.
+constexpr int kWinoSliceCh = 64, kWinoPitch = kWinoSliceCh + 4;
+
+template <typename TIn, typename TOut, bool BWD = false, bool WINO = false>
+__global__ __launch_bounds__(kNhwcThreads, WINO ? 6 : 1) void roi_align_nhwc_kernel(
     const TIn *__restrict__ feat, int N, int H, int W, int C, const float *__restrict__ rois, int PH, int PW,
     float scale, int sampling_ratio, int aligned, int bin_stride, int OH, int OW, int pos_major,
     TOut *__restrict__ out, int64_t out_ld, int64_t feat_ld, const float *__restrict__ ch_scale,
-    const float *__restrict__ ch_shift, int relu, int nslices, int64_t R)
+    const float *__restrict__ ch_shift, int relu, int nslices, int64_t R, float v_scale = 1.f, unsigned *overflow = nullptr)
 {
+    __shared__ float wino_tile_s[WINO ? 49 * kWinoPitch : 1];
+    float *const wino_tile = wino_tile_s;
     // feat_ld = elements between consecutive pixels of the map (>= C: the C channels may be a column block
     // of a wider per-pixel vector).  ch_scale / ch_shift / relu: optional per-channel affine + ReLU applied to
     // the pooled value -- ROIAlign is linear, so a 1x1 convolution can run on the MAP (once per pixel instead
@@ -299,9 +309,48 @@ __global__ __launch_bounds__(kNhwcThreads) void roi_align_nhwc_kernel(
         if (relu) {
             acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
         }
-        store4(optr, acc);
+        if constexpr (WINO)
+            *reinterpret_cast<float4 *>(wino_tile + bin * kWinoPitch + 4 * cq) = acc;
+        else
+            store4(optr, acc);
         cq += kNhwcThreads;
         normalise();
+    }
+    if constexpr (WINO && !BWD && std::is_same<TOut, float>::value) {
+        __syncthreads();
+        // wave w takes the rows fy = w, w + 4, w + 8 of the transform; lane = channel pair of the slice (a slice has an even
+        // number of pairs: lanes trade words in pairs)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int npairs = 2 * c4n;
+        float amax = 0.f;
+        if (lane < npairs) {
+            const int c = (q_lo << 2) + 2 * lane;
+            const float *patch = wino_tile + 2 * lane;
+            const int64_t fstride = R * C;
+            float *vrow = reinterpret_cast<float *>(out) + r * C;
+            auto load = [&](int y, int xx) __attribute__((always_inline)) {
+                return *reinterpret_cast<const f32x2 *>(patch + (y * 7 + xx) * kWinoPitch);
+            };
+            auto unit = [&](auto fy_tag) __attribute__((always_inline)) {
+                constexpr int FY = decltype(fy_tag)::value;
+                wino_in_fy<false, FY>(load, [&](int fx, f32x2 a) __attribute__((always_inline)) {
+                    amax = fmaxf(fmaxf(amax, fabsf(a[0])), fabsf(a[1]));
+                    store_split_pair(vrow + (int64_t)(FY * wino::NF + fx) * fstride, c, a, v_scale);
+                });
+                __builtin_amdgcn_sched_barrier(0);             // one row of the transform at a time: ~80 live registers, not 11 rows' worth
+            };
+            using std::integral_constant;
+            if (wave == 0) {
+                unit(integral_constant<int, 0>{}); unit(integral_constant<int, 4>{}); unit(integral_constant<int, 8>{});
+            } else if (wave == 1) {
+                unit(integral_constant<int, 1>{}); unit(integral_constant<int, 5>{}); unit(integral_constant<int, 9>{});
+            } else if (wave == 2) {
+                unit(integral_constant<int, 2>{}); unit(integral_constant<int, 6>{}); unit(integral_constant<int, 10>{});
+            } else {
+                unit(integral_constant<int, 3>{}); unit(integral_constant<int, 7>{});
+            }
+        }
+        if (overflow != nullptr && amax * v_scale >= 65504.f) atomicOr(overflow, 1u);
     }
 }
 
@@ -529,6 +578,25 @@ static int nhwc_slices(int C)
     int n = 1;
     while (n < 8 && (C >> 2) / (2 * n) >= 64) n *= 2;
     return n;
+}
+
+// ROIAlign (even bins of a 14 x 14 pooler = 7 x 7, ROI-major) + per-channel affine + ReLU + Winograd input transform in one launch
+bool roi_align_nhwc_wino_applicable(int C, int64_t R)
+{
+    const char *fe = getenv("LOCOV_WINO_FUSE");            // developer A/B / tests (read per launch): 0 = never
+    if (fe && atoi(fe) == 0) return false;
+    return C % kWinoSliceCh == 0 && R * (C / kWinoSliceCh) <= 0x7fffffffLL;
+}
+
+int launch_roi_align_nhwc_wino(const float *feat, int N, int H, int W, int C, int64_t feat_ld, const float *rois, int64_t R, int pooled,
+                               float spatial_scale, int sampling_ratio, int aligned, const float *ch_scale, const float *ch_shift, int relu,
+                               float *V, float v_scale, unsigned *overflow, hipStream_t s)
+{
+    const int nslices = C / kWinoSliceCh;
+    hipLaunchKernelGGL((roi_align_nhwc_kernel<float, float, false, true>), dim3((unsigned)(R * nslices)), dim3(kNhwcThreads), 0, s, feat, N, H, W, C,
+                       rois, pooled, pooled, spatial_scale, sampling_ratio, aligned, 2, (pooled + 1) / 2, (pooled + 1) / 2, 0, V, (int64_t)C, feat_ld,
+                       ch_scale, ch_shift, relu, nslices, R, v_scale, overflow);
+    return check_launch("locov_roi_align_winograd_conv3x3_f32_split (ROIAlign + input transform)");
 }
 
 }  // namespace locov

@@ -255,13 +255,27 @@ struct PreConv {
     float *y1;
 };
 
+// ... or the pooler in front of it (locov_roi_align_winograd_conv3x3_f32_split: block 0, whose 1x1 convolution ran on the map):
+// even bins of a `pooled` x `pooled` ROIAlign of a channels-last fp32 map + per-channel affine + ReLU, ROI-major rows
+struct PrePool {
+    const float *feat;
+    int N, H, W;
+    int64_t feat_ld;
+    const float *rois;
+    int pooled;
+    float spatial_scale;
+    int sampling_ratio, aligned;
+    const float *scale, *shift;
+    float *y1;
+};
+
 // u_scale > 0: U is the split-operand packing of u_scale * U (locov_split_f16x2_pack) and the 121 GEMMs run on the
 // f16 matrix pipe with V scaled by v_scale (gemm_split.hip); u_scale == 0: fp32 U, fp32 MFMA.
 static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
                             const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
                             void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask = nullptr,
                             unsigned *overflow = nullptr, bool v_scale_auto = false, float y_split_scale = 0.f,
-                            float *amax_out = nullptr, const PreConv *pre = nullptr);
+                            float *amax_out = nullptr, const PreConv *pre = nullptr, const PrePool *pool = nullptr);
 
 int locov_winograd_conv3x3_f32_ex(const float *x, int64_t R, int Cin, const float *U, const float *scale, const float *shift,
                                   const float *mask, float *y, int64_t ldy, int N, unsigned flags, void *workspace,
@@ -298,6 +312,31 @@ int locov_winograd_conv3x3_f32_split(const float *x, int64_t R, int Cin, const v
                             workspace, workspace_bytes, stream, nullptr, overflow);
 }
 
+int locov_roi_align_winograd_conv3x3_f32_split(const float *feat_nhwc, int Nimg, int H, int W, int C, int64_t feat_ld, const float *rois,
+                                               int64_t R, int pooled, float spatial_scale, int sampling_ratio, int aligned,
+                                               const float *scale1, const float *shift1, const void *U_split, float u_scale, float v_scale,
+                                               const float *scale2, const float *shift2, float *y, int64_t ldy, int N, unsigned flags,
+                                               float y_split_scale, void *workspace, int64_t workspace_bytes, unsigned *overflow,
+                                               locov_stream_t stream)
+{
+    LOCOV_REQUIRE(R >= 0 && Nimg > 0 && H > 0 && W > 0 && C > 0 && N > 0, "locov_roi_align_winograd_conv3x3_f32_split: bad shape");
+    if (R == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(feat_nhwc && rois && U_split && y && workspace, "locov_roi_align_winograd_conv3x3_f32_split: null pointer");
+    LOCOV_REQUIRE(pooled == 14 || pooled == 13, "locov_roi_align_winograd_conv3x3_f32_split: the even bins of the pooler must form a 7 x 7 tile");
+    LOCOV_REQUIRE(u_scale > 0.f && v_scale > 0.f && spatial_scale > 0.f, "locov_roi_align_winograd_conv3x3_f32_split: scales must be positive");
+    LOCOV_REQUIRE(feat_ld >= C && feat_ld % 4 == 0 && C % 4 == 0 && (uintptr_t)feat_nhwc % 16 == 0 && (int64_t)H * W * feat_ld * 4 < 0xffffffffLL,
+                  "locov_roi_align_winograd_conv3x3_f32_split: feat_ld >= C, both %% 4, 16-byte pointer, one image below 4 GiB");
+    LOCOV_REQUIRE((flags & LOCOV_WINO_IN_ROI_MAJOR) != 0, "locov_roi_align_winograd_conv3x3_f32_split: rows are ROI-major (LOCOV_WINO_IN_ROI_MAJOR)");
+    LOCOV_REQUIRE(chunk_rois(R, C, N) == R, "locov_roi_align_winograd_conv3x3_f32_split: one pass only (LOCOV_WINO_CHUNK is set)");
+    const int64_t wb = locov_winograd_workspace_bytes(R, C, N);
+    LOCOV_REQUIRE(workspace_bytes >= locov_conv1x1_winograd_workspace_bytes(R, C, N),
+                  "locov_roi_align_winograd_conv3x3_f32_split: workspace too small (%lld bytes)", (long long)workspace_bytes);
+    PrePool pool{feat_nhwc, Nimg, H, W, feat_ld, rois, pooled, spatial_scale, sampling_ratio, aligned, scale1, shift1,
+                 reinterpret_cast<float *>(static_cast<char *>(workspace) + ((wb + 15) & ~(int64_t)15))};
+    return winograd_conv3x3(nullptr, R, C, static_cast<const float *>(U_split), u_scale, v_scale, scale2, shift2, y, ldy, N, flags, workspace, wb,
+                            stream, nullptr, overflow, false, y_split_scale, nullptr, nullptr, &pool);
+}
+
 int64_t locov_conv1x1_winograd_workspace_bytes(int64_t R, int C, int N)
 {
     if (R <= 0 || C <= 0 || N <= 0) return 0;
@@ -331,12 +370,12 @@ int locov_conv1x1_winograd_conv3x3_f32_split(const float *x_split, int64_t ldx, 
 static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, float u_scale, float v_scale,
                             const float *scale, const float *shift, float *y, int64_t ldy, int N, unsigned flags,
                             void *workspace, int64_t workspace_bytes, locov_stream_t stream, const float *mask, unsigned *overflow,
-                            bool v_scale_auto, float y_split_scale, float *amax_out, const PreConv *pre)
+                            bool v_scale_auto, float y_split_scale, float *amax_out, const PreConv *pre, const PrePool *pool)
 {
     LOCOV_REQUIRE(ldy >= N && ldy % 2 == 0, "locov_winograd_conv3x3_f32: ldy must be >= N and even");
     LOCOV_REQUIRE(R >= 0 && Cin > 0 && N > 0, "locov_winograd_conv3x3_f32: bad shape");
     if (R == 0) return LOCOV_OK;
-    LOCOV_REQUIRE((x || pre) && U && y && workspace, "locov_winograd_conv3x3_f32: null pointer");
+    LOCOV_REQUIRE((x || pre || pool) && U && y && workspace, "locov_winograd_conv3x3_f32: null pointer");
     LOCOV_REQUIRE(Cin % 32 == 0 && N % 4 == 0, "locov_winograd_conv3x3_f32: Cin %% 32 and N %% 4 must be 0 (got %d, %d)",
                   Cin, N);
     LOCOV_REQUIRE(((uintptr_t)x | (uintptr_t)U | (uintptr_t)y | (uintptr_t)workspace) % 16 == 0,
@@ -371,6 +410,21 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
                 rc1 = launch_gemm_split(pre->x, pre->ldx, pre->W, pre->y1, (int64_t)Cin, rc * 49, Cin, pre->K, e1, pre->x_scale, pre->w_scale, s,
                                         "locov_conv1x1_winograd_conv3x3_f32_split (1x1)", Batch{1, 0, 0, 0}, overflow);
                 x = pre->y1;
+            }
+            if (rc1) return rc1;
+        }
+        if (pool) {
+            int rc1;
+            if (roi_align_nhwc_wino_applicable(Cin, rc)) {
+                rc1 = launch_roi_align_nhwc_wino(pool->feat, pool->N, pool->H, pool->W, Cin, pool->feat_ld, pool->rois, rc, pool->pooled,
+                                                 pool->spatial_scale, pool->sampling_ratio, pool->aligned, pool->scale, pool->shift, 1, V, v_scale,
+                                                 overflow, s);
+                v_done = true;
+            } else {
+                rc1 = locov_roi_align_nhwc_affine_fwd(pool->feat, LOCOV_F32, pool->N, pool->H, pool->W, Cin, pool->feat_ld, pool->rois, rc,
+                                                      pool->pooled, pool->pooled, pool->spatial_scale, pool->sampling_ratio, pool->aligned, 2, 0,
+                                                      pool->scale, pool->shift, 1, pool->y1, (int64_t)Cin, LOCOV_F32, stream);
+                x = pool->y1;
             }
             if (rc1) return rc1;
         }

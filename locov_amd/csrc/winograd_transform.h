@@ -72,6 +72,7 @@ __device__ __forceinline__ constexpr float in_coef(int f, int y) { return GRAD ?
 template <bool GRAD, int FY, typename Load, typename Emit>
 __device__ __forceinline__ void wino_in_fy(Load &&load, Emit &&emit)
 {
+#pragma clang fp contract(fast)          // the same fused multiply-adds in every translation unit (roi_align_nhwc.hip is built with contraction off)
     f32x2 wv[7];
 #pragma unroll
     for (int xx = 0; xx < 7; xx++) {

@@ -426,6 +426,57 @@ def conv1x1_winograd_conv3x3(x: torch.Tensor, w1: SplitWeight, b1: Optional[torc
     return y
 
 
+def roi_align_winograd_conv3x3(feat: torch.Tensor, rois: torch.Tensor, output_size: int, spatial_scale: float, sampling_ratio: int,
+                               aligned: bool, U: SplitWeight, *, ch_scale: Optional[torch.Tensor] = None,
+                               ch_shift: Optional[torch.Tensor] = None, scale2: Optional[torch.Tensor] = None,
+                               shift2: Optional[torch.Tensor] = None, relu: bool = True, v_scale: float = 0.25,
+                               roi_major: bool = True, out_split_scale: Optional[float] = None) -> torch.Tensor:
+    """Block 0's pooler + FrozenBN + ReLU + conv2 in one call, split arithmetic:
+        winograd_conv3x3(roi_align_nhwc(feat, rois, 14, ..., bin_stride=2, ch_scale, ch_shift, relu=True).view(49 R, C), U,
+                         in_roi_major=True, ...)
+    and the same bits.  feat [N,H,W,C] fp32, possibly a channel slice of a wider channels-last map.  With C % 64 == 0 the pooled
+    rows never leave the ROIAlign workgroup: it writes their Winograd input transform itself (roi_align_nhwc.hip, WINO)."""
+    if not isinstance(feat, torch.Tensor) or feat.dim() != 4 or feat.dtype != torch.float32:
+        raise ValueError("roi_align_winograd_conv3x3: feat must be fp32 [N,H,W,C]")
+    Nimg, H, W, C = feat.shape
+    fld = C
+    if (feat.is_cuda and feat.stride(3) == 1 and feat.stride(2) > C and feat.stride(2) % 4 == 0
+            and feat.stride(1) == W * feat.stride(2) and feat.stride(0) == H * W * feat.stride(2)
+            and feat.data_ptr() % 16 == 0):
+        fld = feat.stride(2)                       # channel slice of a wider map: no copy
+    else:
+        feat = _dev(feat, "feat")
+    rois = _dev(rois, "rois")
+    Ud = _dev(U.data, "U")
+    if Ud.dim() != 3 or Ud.shape[0] != 121 or Ud.shape[2] != C or C % 32 or output_size not in (13, 14):
+        raise ValueError(f"roi_align_winograd_conv3x3: feat {tuple(feat.shape)} U {tuple(Ud.shape)} output_size {output_size}")
+    N, R = Ud.shape[1], rois.shape[0]
+    if N % 4 or (out_split_scale is not None and N % 32):
+        raise ValueError("roi_align_winograd_conv3x3: N % 4 == 0 (N % 32 == 0 for a split-layout output)")
+    ch_scale = _dev(ch_scale, "ch_scale") if ch_scale is not None else None
+    ch_shift = _dev(ch_shift, "ch_shift") if ch_shift is not None else None
+    scale2 = _dev(scale2, "scale2") if scale2 is not None else None
+    shift2 = _dev(shift2, "shift2") if shift2 is not None else None
+    y = torch.empty((49 * R, N), dtype=torch.float32, device=feat.device)
+    lib = _lib.load()
+    need = int(lib.locov_conv1x1_winograd_workspace_bytes(R, C, N))
+    key = (feat.device, torch.cuda.current_stream(feat.device).cuda_stream)
+    ws = _WINO_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = None
+        _WINO_WS.pop(key, None)
+        ws = _WINO_WS[key] = torch.empty(max(need, 16), dtype=torch.uint8, device=feat.device)
+    wflags = (_lib.EPI_RELU if relu else 0) | (_lib.WINO_OUT_ROI_MAJOR if roi_major else 0) | _lib.WINO_IN_ROI_MAJOR
+    with torch.cuda.device(feat.device):
+        check(lib.locov_roi_align_winograd_conv3x3_f32_split(_ptr(feat), Nimg, H, W, C, fld, _ptr(rois), R, int(output_size),
+                                                             float(spatial_scale), int(sampling_ratio), int(aligned), _ptr(ch_scale),
+                                                             _ptr(ch_shift), _ptr(Ud), U.scale, float(v_scale), _ptr(scale2), _ptr(shift2),
+                                                             _ptr(y), N, N, wflags, float(out_split_scale or 0.0), _ptr(ws), ws.numel(),
+                                                             _ptr(_overflow_word(feat)), _stream(feat)),
+              "locov_roi_align_winograd_conv3x3_f32_split")
+    return y
+
+
 def gemm_nt_batched(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """x [B,M,K], w [B,N,K] -> [B,M,N] (fp32, one launch)."""
     x = _dev(x, "x")

@@ -366,26 +366,35 @@ class Res5Stage(nn.Sequential):
         # tap skipping needs) or, with roi_major, ROI-major (r*49 + pos: a ROI's 49 rows are adjacent in memory, which
         # the Winograd transforms and the mean-fused last convolution prefer)
         pm = not (roi_major and not bf16)
-        y = ops.roi_align_nhwc(g[..., :mid], rois, 14, spatial_scale, sampling_ratio, aligned, bin_stride=2,
-                               pos_major=pm, ch_scale=s1, ch_shift=b1, relu=True)            # conv1 + FBN + ReLU, pooled
-        sc = ops.roi_align_nhwc(g[..., mid:], rois, 14, spatial_scale, sampling_ratio, aligned, bin_stride=2,
-                                pos_major=pm)                                                # ss * shortcut, pooled
-        R = rois.shape[0]
-        y, sc = y.view(49 * R, mid), sc.view(49 * R, -1)
         c2 = b0.conv2
         w3, s3, _ = self._packed(b0.conv3)
+        use_wino = winograd and c2.in_channels % 32 == 0 and c2.out_channels % 4 == 0
+        # pooler + FBN + ReLU + conv2 in one call (the pooled rows never leave the ROIAlign workgroup): split Winograd path, ROI-major
+        fuse_pool = _FUSE12 and split and use_wino and not bf16 and not pm and g.dtype == torch.float32
+        R = rois.shape[0]
+        y = None
+        if not fuse_pool:
+            y = ops.roi_align_nhwc(g[..., :mid], rois, 14, spatial_scale, sampling_ratio, aligned, bin_stride=2,
+                                   pos_major=pm, ch_scale=s1, ch_shift=b1, relu=True).view(49 * R, mid)   # conv1 + FBN + ReLU, pooled
+        sc = ops.roi_align_nhwc(g[..., mid:], rois, 14, spatial_scale, sampling_ratio, aligned, bin_stride=2,
+                                pos_major=pm).view(49 * R, -1)                               # ss * shortcut, pooled
         if bf16:
             w2, s2, b2 = self._packed(c2)
             y = ops.conv3x3_nhwc_bf16(ops.to_bf16(y), self._bf16(w2), 7, 7, scale=s2, shift=b2, relu=True, pos_major=True)
             x = ops.linear_bf16(ops.to_bf16(y), self._bf16(w3), shift_tail, scale=s3, residual=sc, relu=True)
             return self.forward_rows(x, 7, 7, pos_major=True, start_block=1, bf16=True)
         y_split = False
-        if winograd and c2.in_channels % 32 == 0 and c2.out_channels % 4 == 0:
+        if use_wino:
             u2, s2, b2 = self._packed(c2, winograd=True)
             y_split = self._y2_split_ok(split, c2, w3)
-            y = ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True,
-                                     roi_major=not pm, in_roi_major=not pm,
-                                     out_split_scale=self.ACT_SPLIT_SCALE if y_split else None)
+            if fuse_pool:
+                y = ops.roi_align_winograd_conv3x3(g[..., :mid], rois, 14, spatial_scale, sampling_ratio, aligned, self._split(u2),
+                                                   ch_scale=s1, ch_shift=b1, scale2=s2, shift2=b2, relu=True, roi_major=True,
+                                                   out_split_scale=self.ACT_SPLIT_SCALE if y_split else None)
+            else:
+                y = ops.winograd_conv3x3(y, self._split(u2) if split else u2, scale=s2, shift=b2, relu=True,
+                                         roi_major=not pm, in_roi_major=not pm,
+                                         out_split_scale=self.ACT_SPLIT_SCALE if y_split else None)
         else:
             w2, s2, b2 = self._packed(c2)
             y = ops.conv3x3_nhwc(y, w2, 7, 7, scale=s2, shift=b2, relu=True, pos_major=pm)

@@ -658,3 +658,39 @@ def test_conv1_with_the_winograd_input_transform_in_its_epilogue_is_bit_identica
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_pooler_with_the_winograd_input_transform_is_bit_identical(ops):
+    """ops.roi_align_winograd_conv3x3 (block 0: even-bin ROIAlign of the conv1-on-the-map channels + FrozenBN + ReLU, then conv2 in
+    the Winograd domain): the ROIAlign workgroup (one ROI x 64 channels) keeps its 49 pooled rows in LDS and writes their input
+    transform itself.  Same BITS as roi_align_nhwc -> winograd_conv3x3 and as the entry point's own two-launch form
+    (LOCOV_WINO_FUSE=0), on a channel slice of a wider map, with boxes that leave the image, adaptive and fixed sampling grids."""
+    import os
+    prev = os.environ.get("LOCOV_WINO_FUSE")
+    try:
+        for Nimg, H, W, C, Cw, R, N2, sr, out_split in ((2, 25, 38, 64, 64, 37, 32, 0, False), (1, 50, 67, 128, 320, 101, 64, 2, True),
+                                                       (3, 19, 23, 512, 2560, 64, 96, 0, False)):
+            g = torch.Generator().manual_seed(Nimg * 100 + C)
+            fmap = torch.randn(Nimg, H, W, Cw, generator=g).cuda()
+            feat = fmap[..., :C]
+            wh = torch.rand(R, 2, generator=g) * torch.tensor([W * 16.0, H * 16.0]) * 0.9 + 4.0
+            xy = torch.rand(R, 2, generator=g) * torch.tensor([W * 16.0, H * 16.0]) - 20.0
+            rois = torch.cat([torch.randint(0, Nimg, (R, 1), generator=g).float(), xy, xy + wh], dim=1).cuda()
+            s1, b1 = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+            u = ops.split_pack(ops.winograd_pack_weight((torch.randn(N2, C, 3, 3, generator=g) * 0.03).cuda()))
+            s2, b2 = (torch.rand(N2, generator=g) + 0.5).cuda(), (torch.randn(N2, generator=g) * 0.1).cuda()
+            oss = 16.0 if out_split else None
+            y1 = ops.roi_align_nhwc(feat, rois, 14, 1.0 / 16, sr, True, bin_stride=2, ch_scale=s1, ch_shift=b1, relu=True).view(49 * R, C)
+            want = ops.winograd_conv3x3(y1, u, scale=s2, shift=b2, relu=True, roi_major=True, in_roi_major=True, out_split_scale=oss)
+            got = {}
+            for fuse in ("0", "1"):
+                os.environ["LOCOV_WINO_FUSE"] = fuse
+                got[fuse] = ops.roi_align_winograd_conv3x3(feat, rois, 14, 1.0 / 16, sr, True, u, ch_scale=s1, ch_shift=b1, scale2=s2,
+                                                           shift2=b2, relu=True, out_split_scale=oss)
+            assert torch.equal(got["0"], want), (C, R, "two-launch form of the one-call entry point")
+            assert torch.equal(got["1"], want), (C, R, "fused")
+    finally:
+        if prev is None:
+            os.environ.pop("LOCOV_WINO_FUSE", None)
+        else:
+            os.environ["LOCOV_WINO_FUSE"] = prev
