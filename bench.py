@@ -499,7 +499,7 @@ def main():
         return n.value, ms.value, fl.value
     gemm_plain, gemm_conv = gemm_class(0), gemm_class(1)
     gemm_plain_bf16, gemm_conv_bf16 = gemm_class(3), gemm_class(4)
-    gemm_split_plain, gemm_split_wino = gemm_class(5), gemm_class(7)
+    gemm_split_plain, gemm_split_wino = gemm_class(5), gemm_class(8)
     gemm_split = tuple(a + b for a, b in zip(gemm_split_plain, gemm_split_wino))      # every split-operand GEMM launch of the step
     lib.locov_gemm_timing_enable(0)
     # the same job with the Res5 GEMMs on the f32 MFMA (reported beside the headline when that is the split path)

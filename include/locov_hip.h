@@ -351,8 +351,9 @@ int locov_gemm_nt_batched_f32_split(const float *x, int64_t lda, int64_t stride_
  * returns, for one kernel class, the number of launches, the sum of their durations (ms) and
  * the FLOPs they executed.  cls: 0 = gemm_nt_kernel<128x128, plain / batched> (1x1 convs, FCs,
  * Winograd-domain GEMMs), 1 = the position-major direct 3x3 conv, 2 = the other tile shapes,
- * 3 / 4 = classes 0 / 1 launched with bf16 operands, 5 = the split-operand GEMM, 6 = the TN (weight-gradient) GEMM,
- * 7 = the split-operand GEMM whose epilogue applies the Winograd input transform (locov_conv1x1_winograd_conv3x3_f32_split).
+ * 3 / 4 = classes 0 / 1 launched with bf16 operands, 5 = the split-operand GEMM, 6 / 7 = the TN (weight-gradient) GEMM on the f32
+ * MFMA / in split arithmetic, 8 = the split-operand GEMM whose epilogue applies the Winograd input transform
+ * (locov_conv1x1_winograd_conv3x3_f32_split).
  * enable(on) clears what was recorded. */
 int locov_gemm_timing_enable(int on);
 int locov_gemm_timing_read(int cls, int64_t *launches, double *ms, double *flops);

@@ -513,7 +513,7 @@ int launch_gemm_split_big_wino(const float *A, int64_t lda, const void *Wsplit, 
                                float w_scale, float *V, float v_scale, hipStream_t s, const char *what, unsigned *overflow)
 {
     const int64_t tiles = ceil_div(M / WSEG, WROIS) * ceil_div(N, GBN);
-    const int trec = timing_begin(s, 7, 2.0 * (double)M * N * K);
+    const int trec = timing_begin(s, 8, 2.0 * (double)M * N * K);
     hipLaunchKernelGGL(gemm_split_big_kernel<MODE_WINO>, dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
                        static_cast<float *>(nullptr), (int64_t)N, M, N, K, epi, Batch{1, 0, 0, 0}, a_scale, 1.f / (a_scale * w_scale), overflow, WSEG,
                        V, v_scale);

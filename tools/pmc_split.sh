@@ -16,11 +16,11 @@ acc = collections.defaultdict(list)
 dur = []
 for f in glob.glob('gpurun_out/pmcsplit*/p_counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        if 'gemm_split' in r['Kernel_Name'] and 'pack' not in r['Kernel_Name']:
+        if os.environ.get('PMC_SPLIT_KERNEL', 'gemm_split') in r['Kernel_Name'] and 'pack' not in r['Kernel_Name']:
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
 for f in glob.glob('gpurun_out/pmcsplit1/p_kernel_trace.csv'):
     for r in csv.DictReader(open(f)):
-        if 'gemm_split' in r['Kernel_Name'] and 'pack' not in r['Kernel_Name']:
+        if os.environ.get('PMC_SPLIT_KERNEL', 'gemm_split') in r['Kernel_Name'] and 'pack' not in r['Kernel_Name']:
             dur.append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
 print('# case', os.environ['PMC_SPLIT_CASE'], ' avg launch (profiled) %.3f ms' % (sum(dur) / max(len(dur), 1) / 1e6))
 for n in sorted(acc):
