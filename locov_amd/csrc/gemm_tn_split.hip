@@ -78,7 +78,9 @@ __global__ __launch_bounds__(SNT, 2) void gemm_tn_split_kernel(const float *__re
 
     // staging: threads 0-127 own operand A (columns n0..), 128-255 operand B (columns k0..); within a half, t % 32 = the
     // group of 4 columns, t / 32 = the group of 8 m
-    const bool is_a = tid < 128;
+    // (waves 0-1 stage A, waves 2-3 stage B: said through readfirstlane so that the operand's base pointer, pitch and buffer
+    //  descriptor live in scalar registers -- with a per-thread `tid < 128` every buffer load became a 12-instruction waterfall loop)
+    const bool is_a = __builtin_amdgcn_readfirstlane(tid >> 6) < 2;
     const int t = tid & 127, cg = t & 31, mg = t >> 5;
     const int ld = (int)(is_a ? lda : ldb);
     const int ncol = is_a ? N : K, c0 = is_a ? n0 : k0;
