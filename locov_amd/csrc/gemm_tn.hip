@@ -16,6 +16,8 @@
 //     wgrad, winograd.hip).
 #include "gemm_nt.h"
 
+#include <cstdlib>
+
 namespace locov {
 
 namespace {
@@ -169,7 +171,8 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__rest
 void tn_split_plan(int64_t M, int N, int K, int batch, int *splits, int64_t *m_chunk)
 {
     const int64_t tiles = ceil_div(N, TBM) * ceil_div(K, TBN) * batch;
-    int64_t s = ceil_div(1024, tiles);
+    static const int64_t target = [] { const char *e = getenv("LOCOV_TN_WGS"); return e && atoll(e) > 0 ? (int64_t)atoll(e) : (int64_t)1024; }();
+    int64_t s = ceil_div(target, tiles);
     const int64_t smax = ceil_div(M, 256);
     if (s > smax) s = smax;
     if (s < 1) s = 1;

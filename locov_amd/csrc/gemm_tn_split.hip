@@ -164,13 +164,33 @@ __global__ __launch_bounds__(SNT, 2) void gemm_tn_split_kernel(const float *__re
     store(0);
     if (steps > 1) load();
     __syncthreads();
-    for (int tt = 0; tt < steps; tt++) {
+#ifndef LOCOV_TNS_INTERLEAVE
+#define LOCOV_TNS_INTERLEAVE 1
+#endif
+    int tt = 0;
+    // steady state: the K-tile's 48 MFMAs and the conversion of the NEXT tile (64 v_fma_mix + 32 max, then 8 LDS writes) in ONE
+    // scheduling region, interleaved 1 : 2 -- the conversion then runs on the vector ALU while the wave's own MFMAs occupy the
+    // matrix pipe, instead of behind them
+    for (; tt + 2 < steps; tt++) {
         const int st = tt & 1;
         compute(st);
-        if (tt + 1 < steps) {
-            store(st ^ 1);
-            if (tt + 2 < steps) load();
+        store(st ^ 1);
+        if (LOCOV_TNS_INTERLEAVE) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // the 16 fragment reads first
+#pragma unroll
+            for (int i = 0; i < 48; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                 // 3 VALU
+            }
         }
+        load();
+        __syncthreads();
+    }
+    for (; tt < steps; tt++) {
+        const int st = tt & 1;
+        compute(st);
+        if (tt + 1 < steps) store(st ^ 1);
         __syncthreads();
     }
     if (overflow != nullptr && amax * scale >= 65504.f) atomicOr(overflow, 1u);
