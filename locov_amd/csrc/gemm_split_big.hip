@@ -354,15 +354,20 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
         __syncthreads();
         if (n_ok) {
             const unsigned voff = (unsigned)(((int64_t)(wm + 64 * h + rr) * ldc + n) * 4);      // rows past M: outside num_records
-            // (requesting the residual a whole half -- 16 x 16 bytes per lane -- ahead of its use instead of four at a time was tried:
-            //  conv3 2.55 -> 2.53 ms, i.e. nothing; the epilogue is not waiting on memory round trips, the launch is at the power cap)
+            // (requesting the residual a whole half -- 16 x 16 bytes per lane -- ahead of its use instead of four at a time was tried
+            //  twice: conv3 2.55 -> 2.53 / 2.58 -> 2.64 ms, i.e. nothing.  Without the residual loads the launch is 0.5 ms shorter
+            //  (LOCOV_BIG_EPI_ABLATE=1: 2.58 -> 2.08 ms) -- the 3.2 GB they read are what costs, not the round trips)
 #pragma unroll
             for (int q4 = 0; q4 < NIT; q4 += 4) {
                 f32x4 res[4];
+#ifndef LOCOV_BIG_EPI_ABLATE
+#define LOCOV_BIG_EPI_ABLATE 0                             // developer timing: 1 = no residual loads, 2 = no per-ROI column walk (SEGSUM), 3 = both
+#endif
                 if (epi.residual) {
 #pragma unroll
                     for (int u = 0; u < 4; u++)
-                        res[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, voff, (q4 + u) * vstep, 2));
+                        res[u] = (LOCOV_BIG_EPI_ABLATE & 1) ? f32x4{0.f, 0.f, 0.f, 0.f}
+                                                            : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, voff, (q4 + u) * vstep, 2));
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
             const int64_t left = M - grow0;
             const int rows_valid = left < 0 ? 0 : left < 64 ? (int)left : 64;
             const int col = n0 + wn + lane;
-            if (rows_valid > 0 && col < N) {
+            if (rows_valid > 0 && col < N && !(LOCOV_BIG_EPI_ABLATE & 2)) {
                 const int64_t chunk = grow0 >> 6;
                 int pos = (int)(grow0 % seg), slot = 0;
                 float sum = 0.f;
