@@ -196,6 +196,16 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
     };
 
     const int T = K / BK;
+#ifndef LOCOV_BIG_STAGGER
+#define LOCOV_BIG_STAGGER 0
+#endif
+    if (LOCOV_BIG_STAGGER && blockIdx.x < 256u) {
+        // developer experiment: the first workgroup of every CU starts up to one tile-time late (golden-ratio spread), so that the
+        // CUs -- whose tiles all take the same time -- do not reach their HBM-bound epilogues together
+        const unsigned frac = (blockIdx.x * 0x9E3779B9u) >> 24;                 // 0..255
+        const int units = (int)((frac * (unsigned)(T * LOCOV_BIG_STAGGER + 160)) >> 8);      // in 64-clock s_sleep units: ~T*48 clocks per K-tile + epilogue
+        for (int i = 0; i < units; i += 64) __builtin_amdgcn_s_sleep(64);
+    }
     __builtin_amdgcn_s_setprio(3);
     dma(0);
     dma(1);
