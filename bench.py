@@ -524,7 +524,7 @@ def main():
         tw = TrainWorkload(args, device, backend, world, data_seed=1992 + rank, config=config)
         n_sampled = tw.step()
         steps = max(args.steps // 2, 3)
-        dtt = timed(tw.step, steps, 2)
+        dtt = timed(tw.step, steps, max(args.warmup, 5))      # (the first steps still grow the allocator's pools and pick the operand scales)
         del tw
         torch.cuda.empty_cache()
         return {"sampled_proposals_per_s": n_sampled * world * steps / dtt, "ms_per_step": dtt / steps * 1e3,
