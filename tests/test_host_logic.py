@@ -363,3 +363,25 @@ def test_batched_nms_per_class_fallback_equals_the_single_launch(monkeypatch):
     per_class = beh.batched_nms(boxes, scores, idxs, 0.5)
     assert torch.equal(one, per_class)
     assert beh._PER_CLASS_NMS_ABOVE == 100
+
+
+def test_bench_refuses_a_pmc_traffic_record_taken_on_other_sources(monkeypatch):
+    """bench.py's `roofline.traffic` comes from a committed PMC pass (counters cannot be collected inside the timed run).  The record
+    names the kernel sources it was taken on; for the committed tree it must be current, and for a library built from any other
+    sources -- or another workload -- it reads as None, never as a stale number."""
+    import importlib, json, sys, types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    from locov_amd import build
+    rec = json.load(open(os.path.join(root, "profiles", bench.TRAFFIC_FILE)))
+    wl = rec["workload"]
+    args = types.SimpleNamespace(**{k: wl[k] for k in ("images", "proposals", "classes", "dim", "res5", "conv3x3", "block0", "res5_dtype")})
+    if rec.get("source_fingerprint") == build.source_fingerprint():       # (a tree whose kernels changed after the last PMC pass: already None)
+        got = bench.recorded_traffic(args, "gemm_split")
+        assert got is not None and 1e9 < got < 2e10
+    monkeypatch.setattr(build, "source_fingerprint", lambda: "some other tree")
+    assert bench.recorded_traffic(args, "gemm_split") is None
+    monkeypatch.undo()
+    args.proposals = wl["proposals"] + 1
+    assert bench.recorded_traffic(args, "gemm_split") is None
