@@ -20,20 +20,37 @@ from .structures import Boxes, boxes_tensor
 __all__ = ["ROIPooler", "convert_boxes_to_pooler_format", "assign_boxes_to_levels"]
 
 
+_BATCH_INDEX_COLUMNS = {}
+
+
+def _batch_index_column(lens, dev) -> torch.Tensor:
+    """[R,1] fp32 column of image indices for per-image row counts `lens` (host-side shapes): built once per (device, counts) by
+    fill kernels -- no host-to-device copy, no sync -- and re-used: a detector sees the same proposal counts call after call."""
+    key = (dev, lens)
+    col = _BATCH_INDEX_COLUMNS.get(key)
+    if col is None:
+        if len(_BATCH_INDEX_COLUMNS) >= 16:
+            _BATCH_INDEX_COLUMNS.pop(next(iter(_BATCH_INDEX_COLUMNS)))
+        col = torch.empty((sum(lens), 1), dtype=torch.float32, device=dev)
+        r0 = 0
+        for i, n in enumerate(lens):
+            col[r0:r0 + n] = float(i)
+            r0 += n
+        _BATCH_INDEX_COLUMNS[key] = col
+    return col
+
+
 def convert_boxes_to_pooler_format(box_lists: Sequence[Union[Boxes, torch.Tensor]]) -> torch.Tensor:
-    """per-image [Ri,4] boxes -> [R,5] rows (batch_index, x0, y0, x1, y1)."""
+    """per-image [Ri,4] boxes -> [R,5] rows (batch_index, x0, y0, x1, y1).  Two launches whatever the number of images (the boxes
+    concatenated, then joined to the cached index column) instead of two per image."""
     tensors = [boxes_tensor(b) for b in box_lists]
     if len(tensors) == 0:
         return torch.zeros((0, 5), dtype=torch.float32)
     dev = tensors[0].device
-    # (batch indices by fill kernels: the row counts are host-side shapes -- no host-to-device copy, no sync, capturable)
-    out = torch.empty((sum(t.shape[0] for t in tensors), 5), dtype=torch.float32, device=dev)
-    r0 = 0
-    for i, t in enumerate(tensors):
-        out[r0:r0 + t.shape[0], 0] = float(i)
-        out[r0:r0 + t.shape[0], 1:] = t
-        r0 += t.shape[0]
-    return out
+    boxes = torch.cat(tensors, dim=0) if len(tensors) > 1 else tensors[0]
+    if boxes.dtype != torch.float32:
+        boxes = boxes.to(torch.float32)
+    return torch.cat([_batch_index_column(tuple(int(t.shape[0]) for t in tensors), dev), boxes], dim=1)
 
 
 def assign_boxes_to_levels(box_lists, min_level: int, max_level: int, canonical_box_size: int,
