@@ -19,8 +19,10 @@
 // The tile ends on Bf, so Bg's registers take the next tile's first W pair behind the barrier and the next tile starts on
 // (A0', Bg'): f flips every tile.  The DMA of tile t+2 goes out right behind the barrier of tile t (all reads of its stage
 // are done by then) -- a full K-tile of matrix work (3 072 cycles per SIMD) ahead of its first use.
-// With one workgroup per CU nothing overlaps the epilogue; under the power cap that costs little (the HBM-bound store phase of one
-// CU runs below the cap while the others compute -- the package budget, not the CU, is what is shared).
+// With one workgroup per CU nothing overlaps a tile's prologue and epilogue: 10.5-11.4 us per tile whatever K (tools/dbg_big_fixed_cost.py),
+// a fifth of a K = 512 tile.  Resident workgroups, a staggered start and an earlier residual request were each measured and bought
+// nothing: hiding it takes matrix work running beside the epilogue, which 160 KB of LDS and 512 VGPRs
+// per SIMD do not leave room for at this tile size.
 #include "gemm_split_common.h"
 #include "winograd_transform.h"
 
@@ -42,7 +44,7 @@ static_assert(GLDS <= 160 * 1024, "one workgroup per CU: all of the LDS, no more
 constexpr int MODE_PLAIN = 0, MODE_SEGSUM = 1, MODE_WINO = 2;
 // MODE_WINO: an M tile holds the rows of whole ROIs only (5 x 49 = 245 of the 256; the last 11 compute on clamped rows and are dropped)
 constexpr int WSEG = 49, WROIS = GBM / WSEG, WROWS = WROIS * WSEG;
-constexpr int WYP = GBN / 2 + 4;                    // pitch (floats) of the finished half tile [245][128] in LDS
+constexpr int WYP = GBN / 2 + 4;                    // pitch (floats) of the finished half tile [256][128] in LDS
 static_assert(GBM * WYP * 4 <= GLDS, "the finished half tile (all 256 rows: the dump is branch-free) fits the K-loop's LDS");
 
 }  // namespace
@@ -55,7 +57,7 @@ static_assert(GBM * WYP * 4 <= GLDS, "the finished half tile (all 256 rows: the 
 //
 // MODE_WINO (a bottleneck's first 1x1 convolution + FrozenBN + ReLU, and the input transform of the Winograd-domain 3x3 behind it:
 // roi_emb_heads.py:217-245's conv1 -> conv2): rows are ROI-major with 49 per ROI and an M tile is 5 whole ROIs.  The finished tile
-// never leaves the CU as pixels: half of its columns at a time it is laid out in LDS ([245][128] fp32), and the 8 waves share the
+// never leaves the CU as pixels: half of its columns at a time it is laid out in LDS ([256][128] fp32, pitch 132), and the 8 waves share the
 // (ROI, fy) units of wino_in_fy -- lane = channel pair, the 3-4 patch rows fy needs read from LDS, 11 transform-domain values
 // written straight into V [121][R][N] (`partial`) in the split layout, the bits wino_input_kernel<false, true> would have written
 // from the stored pixels.  Saves the pixel tensor's write and re-read (2 x 0.8 GB per block at 8 000 proposals) and a launch.
