@@ -24,6 +24,13 @@
 #ifndef LOCOV_WINO_THREADS
 #define LOCOV_WINO_THREADS 256
 #endif
+// minimum waves per SIMD asked of the register allocator for the output / input transforms (second __launch_bounds__ argument)
+#ifndef LOCOV_WINO_OUT_MINW
+#define LOCOV_WINO_OUT_MINW 1
+#endif
+#ifndef LOCOV_WINO_IN_MINW
+#define LOCOV_WINO_IN_MINW 1
+#endif
 
 namespace locov {
 
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(256) void wino_pack_weight_kernel(const float *__re
 // amax_out (fp32 V only): a 16-byte operand-scale slot whose word 2 receives max |V| (gemm_nt.h, amax_fold) -- the transform of
 // a gradient has no a-priori range, the GEMM that reads V derives its operand scale from that word.
 template <bool GRAD, bool SPLIT = false>
-__global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, int64_t ld_pos, int64_t ld_roi, int64_t Rc, int C,
+__global__ __launch_bounds__(256, LOCOV_WINO_IN_MINW) void wino_input_kernel(const float *__restrict__ x, int64_t ld_pos, int64_t ld_roi, int64_t Rc, int C,
                                                          float *__restrict__ V, float v_scale = 1.f, unsigned *overflow = nullptr,
                                                          float *amax_out = nullptr)
 {
@@ -100,8 +107,14 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
 // position-major output: ld_pos = R, ld_roi = 1; ROI-major output (row = roi*49 + position): ld_pos = 1, ld_roi = 49
 // SPLIT: y is written in the split layout scaled by y_scale (it is then the pre-split A operand of the 1x1 convolution that
 // follows); a finished value outside fp16's range raises *overflow.
-template <bool SPLIT = false>
-__global__ __launch_bounds__(256) void wino_output_kernel(const float *__restrict__ Mv, int64_t ld_pos, int64_t ld_roi, int64_t Rc, int N,
+// WIDE = false (the launcher's choice whenever the 11 planes of a row of M and the 49 rows of a ROI's output stay within 32-bit byte
+// offsets): every access goes through a buffer descriptor with the plane / position as a SCALAR offset and the lane's (ROI, channel
+// pair) as one 32-bit vector offset.  As flat accesses the kernel carried 121 + 49 64-bit addresses in VGPRs: 256 + 20 registers, one
+// wave per SIMD on a kernel that lives on memory-level parallelism; now 254 and two (8 000 ROIs, 512 channels: 540 -> 485 us).  The
+// compiler still issues all 121 loads before the first add -- scheduling fences between the rows of planes and a lower register budget
+// (LOCOV_WINO_OUT_MINW) only turn the loaded values into scratch traffic -- which at two waves per SIMD is what keeps HBM busy.
+template <bool SPLIT = false, bool WIDE = false>
+__global__ __launch_bounds__(256, LOCOV_WINO_OUT_MINW) void wino_output_kernel(const float *__restrict__ Mv, int64_t ld_pos, int64_t ld_roi, int64_t Rc, int N,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, int relu,
                                                           float *__restrict__ y, int64_t ldy, const float *__restrict__ mask,
@@ -118,6 +131,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
     const int n = (int)(t - r * n2) * 2;
     const float *src = Mv + r * N + n;
     const int64_t fstride = Rc * N;
+    const unsigned lane_off = (unsigned)((r * N + n) * 4), fbytes = (unsigned)(fstride * 4);
     f32x2 acc[7][7];
 #pragma unroll
     for (int yy = 0; yy < 7; yy++)
@@ -126,9 +140,16 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
 #pragma unroll
     for (int fy = 0; fy < NF; fy++) {
         f32x2 m[NF];
+        if constexpr (!WIDE) {
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Mv + (int64_t)fy * NF * fstride), 0, 0xffffffff, 0x00020000);
 #pragma unroll
-        for (int fx = 0; fx < NF; fx++)
-            m[fx] = wino_load(reinterpret_cast<const f32x2 *>(src + (int64_t)(fy * NF + fx) * fstride));
+            for (int fx = 0; fx < NF; fx++)
+                m[fx] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, lane_off, (unsigned)fx * fbytes, LOCOV_WINO_NT_LOAD ? 2 : 0));
+        } else {
+#pragma unroll
+            for (int fx = 0; fx < NF; fx++)
+                m[fx] = wino_load(reinterpret_cast<const f32x2 *>(src + (int64_t)(fy * NF + fx) * fstride));
+        }
         f32x2 tx[7];
 #pragma unroll
         for (int xx = 0; xx < 7; xx++) {
@@ -150,8 +171,13 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
     if (shift) sh = *reinterpret_cast<const f32x2 *>(shift + n);
     float *dst = y + r * ld_roi * ldy + n;
     const float *msk = mask ? mask + r * ld_roi * ldy + n : nullptr;
+    // narrow form: the ROI's row block as the vector offset, the position as a scalar one
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(mask ? mask : y), 0, 0xffffffff, 0x00020000);
+    const unsigned row_off = (unsigned)(r * ld_roi * ldy * 4), pos_bytes = (unsigned)(ld_pos * ldy * 4);
+    const unsigned y_off = row_off + (SPLIT ? (unsigned)split_pair_offset(n) : (unsigned)n * 4u);
 #pragma unroll
-    for (int yy = 0; yy < 7; yy++)
+    for (int yy = 0; yy < 7; yy++) {
 #pragma unroll
         for (int xx = 0; xx < 7; xx++) {
             f32x2 v = acc[yy][xx] * sc + sh;
@@ -159,19 +185,28 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
                 v[0] = fmaxf(v[0], 0.f);
                 v[1] = fmaxf(v[1], 0.f);
             }
-            if (msk) {
-                const f32x2 mk = *reinterpret_cast<const f32x2 *>(msk + (int64_t)(yy * 7 + xx) * ld_pos * ldy);
+            if (!SPLIT && msk) {                                   // (a split-layout output takes no mask: locov_winograd_conv3x3_f32_split_ex)
+                const f32x2 mk = WIDE ? *reinterpret_cast<const f32x2 *>(msk + (int64_t)(yy * 7 + xx) * ld_pos * ldy)
+                                      : __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rk, row_off + (unsigned)n * 4u,
+                                                                                                       (unsigned)(yy * 7 + xx) * pos_bytes, 0));
                 v[0] = mk[0] > 0.f ? v[0] : 0.f;
                 v[1] = mk[1] > 0.f ? v[1] : 0.f;
             }
+            amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
             if constexpr (SPLIT) {
-                amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
-                store_split_pair(y + r * ld_roi * ldy + (int64_t)(yy * 7 + xx) * ld_pos * ldy, n, v, y_scale);
+                if constexpr (WIDE)
+                    store_split_pair(y + r * ld_roi * ldy + (int64_t)(yy * 7 + xx) * ld_pos * ldy, n, v, y_scale);
+                else
+                    __builtin_amdgcn_raw_buffer_store_b64(split_pair_words(n, v, y_scale), ry, y_off, (unsigned)(yy * 7 + xx) * pos_bytes,
+                                                          LOCOV_WINO_NT_STORE ? 2 : 0);
             } else {
-                amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
-                *reinterpret_cast<f32x2 *>(dst + (int64_t)(yy * 7 + xx) * ld_pos * ldy) = v;
+                if constexpr (WIDE)
+                    *reinterpret_cast<f32x2 *>(dst + (int64_t)(yy * 7 + xx) * ld_pos * ldy) = v;
+                else
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wino_u32x2, v), ry, y_off, (unsigned)(yy * 7 + xx) * pos_bytes, 0);
             }
         }
+    }
     }
     if (SPLIT && overflow != nullptr && amax * y_scale >= 65504.f) atomicOr(overflow, 1u);
     if (!SPLIT && amax_out != nullptr) amax_fold(amax_out, amax);
@@ -460,15 +495,22 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
                                                  Batch{NF * NF, rc * Cin, (int64_t)N * Cin, rc * N});
         if (rcode) return rcode;
         const bool roi_major = (flags & LOCOV_WINO_OUT_ROI_MAJOR) != 0;
-        if (y_split_scale > 0.f)
-            hipLaunchKernelGGL((wino_output_kernel<true>), dim3((unsigned)ceil_div(tout, 256)), dim3(256), 0, s, Mv, roi_major ? (int64_t)1 : R,
-                               roi_major ? (int64_t)49 : (int64_t)1, rc, N, scale, shift, (flags & LOCOV_EPI_RELU) ? 1 : 0,
-                               y + r0 * (roi_major ? 49 : 1) * ldy, ldy, static_cast<const float *>(nullptr), y_split_scale, overflow);
-        else
-            hipLaunchKernelGGL((wino_output_kernel<false>), dim3((unsigned)ceil_div(tout, 256)), dim3(256), 0, s, Mv, roi_major ? (int64_t)1 : R,
-                               roi_major ? (int64_t)49 : (int64_t)1, rc, N, scale, shift, (flags & LOCOV_EPI_RELU) ? 1 : 0,
-                               y + r0 * (roi_major ? 49 : 1) * ldy, ldy, mask ? mask + r0 * (roi_major ? 49 : 1) * ldy : nullptr, 1.f,
-                               static_cast<unsigned *>(nullptr), amax_out);
+        // 32-bit byte offsets suffice for a row of 11 planes of M and for the 49 rows of every ROI of y (else the flat-address instance)
+        const bool wide = (uint64_t)rc * N * 4u * NF > 0xffffffffull || (uint64_t)rc * 49u * (uint64_t)ldy * 4u > 0xffffffffull;
+        const int64_t lp = roi_major ? (int64_t)1 : R, lr = roi_major ? (int64_t)49 : (int64_t)1;
+        float *yo = y + r0 * (roi_major ? 49 : 1) * ldy;
+        const float *mo = mask ? mask + r0 * (roi_major ? 49 : 1) * ldy : nullptr;
+        const int relu_i = (flags & LOCOV_EPI_RELU) ? 1 : 0;
+        const dim3 og((unsigned)ceil_div(tout, 256));
+#define LOCOV_WINO_OUT(SP, WD, ...) hipLaunchKernelGGL((wino_output_kernel<SP, WD>), og, dim3(256), 0, s, Mv, lp, lr, rc, N, scale, shift, relu_i, yo, ldy, __VA_ARGS__)
+        if (y_split_scale > 0.f) {
+            if (wide) LOCOV_WINO_OUT(true, true, static_cast<const float *>(nullptr), y_split_scale, overflow, static_cast<float *>(nullptr));
+            else LOCOV_WINO_OUT(true, false, static_cast<const float *>(nullptr), y_split_scale, overflow, static_cast<float *>(nullptr));
+        } else {
+            if (wide) LOCOV_WINO_OUT(false, true, mo, 1.f, static_cast<unsigned *>(nullptr), amax_out);
+            else LOCOV_WINO_OUT(false, false, mo, 1.f, static_cast<unsigned *>(nullptr), amax_out);
+        }
+#undef LOCOV_WINO_OUT
         rcode = check_launch("locov_winograd_conv3x3_f32 (output transform)");
         if (rcode) return rcode;
     }
