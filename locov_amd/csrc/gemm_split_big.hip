@@ -356,14 +356,22 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
     const unsigned vstep = (unsigned)(RPI * ldc * 4);
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        __syncthreads();                                   // (h = 0: every wave has left the K-loop's LDS; h = 1: the area is free again)
+#ifndef LOCOV_BIG_EPI_FEWBAR
+#define LOCOV_BIG_EPI_FEWBAR 1                             // 0 = a workgroup barrier around every dump (the round's first form: conv3 +1 %, conv1 +1.5 %)
+#endif
+        // ONE workgroup barrier: every wave has left the K-loop's LDS.  From there on a wave only touches its own staging area, and the
+        // LDS executes a wave's instructions in order: the dump of half 1 cannot pass the reads of half 0, the reads of a half cannot
+        // pass its dump.  (The compiler is held to the program order by the memory clobbers.)
+        if (h == 0 || !LOCOV_BIG_EPI_FEWBAR) __syncthreads();
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) ep[(i * 16 + 4 * kg + r) * GEPS + j * 16 + l16] = acc[4 * h + i][j][r];
-        __syncthreads();
+        if (!LOCOV_BIG_EPI_FEWBAR) __syncthreads();
+        asm volatile("" ::: "memory");
         if (n_ok) {
             const unsigned voff = (unsigned)(((int64_t)(wm + 64 * h + rr) * ldc + n) * 4);      // rows past M: outside num_records
             // (requesting the residual a whole half -- 16 x 16 bytes per lane -- ahead of its use instead of four at a time was tried
