@@ -346,7 +346,8 @@ def recorded_traffic(args, kernel_key: str):
         from locov_amd import build as _build
         if rec.get("source_fingerprint") != _build.source_fingerprint():
             return None
-        hits = [v for name, v in rec["kernels"].items() if kernel_key in name]      # every template instance of the kernel
+        keys = (kernel_key,) if isinstance(kernel_key, str) else tuple(kernel_key)
+        hits = [v for name, v in rec["kernels"].items() if any(k in name for k in keys)]      # every matching template instance
         n = sum(v["launches_sampled"] for v in hits)
         if n:
             return sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in hits) / n
@@ -494,13 +495,25 @@ def main():
 
     def gemm_class(cls):
         import ctypes
-        n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
-        _lib.check(lib.locov_gemm_timing_read(cls, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)))
-        return n.value, ms.value, fl.value
-    gemm_plain, gemm_conv = gemm_class(0), gemm_class(1)
-    gemm_plain_bf16, gemm_conv_bf16 = gemm_class(3), gemm_class(4)
-    gemm_split_plain, gemm_split_wino = gemm_class(5), gemm_class(8)
-    gemm_split = tuple(a + b for a, b in zip(gemm_split_plain, gemm_split_wino))      # every split-operand GEMM launch of the step
+        n, ms, fl, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(lib.locov_gemm_timing_read_ex(cls, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
+        return n.value, ms.value, fl.value, by.value
+    gemm_plain, gemm_conv = gemm_class(0)[:3], gemm_class(1)[:3]
+    gemm_plain_bf16, gemm_conv_bf16 = gemm_class(3)[:3], gemm_class(4)[:3]
+    # the split-operand GEMM by launch kind (include/locov_hip.h, locov_gemm_timing_*): kind -> (timing class, kernel-name key of
+    # the profiler output, what it is)
+    SPLIT_KINDS = {
+        "winograd_domain_batched": (10, "gemm_split_big_kernel<0, true>", "the 121 Winograd-domain GEMMs [R,512]x[512,512]^T of a 3x3 convolution, one launch"),
+        "conv3": (9, "gemm_split_big_kernel<0, false>", "conv3 of blocks 0-1: [49R,512]x[2048,512]^T + residual, block output written in the split layout"),
+        "conv3_mean_fused": (11, "gemm_split_big_kernel<1, false>", "conv3 of block 2 with the spatial mean in the epilogue (no [49R,2048] result)"),
+        "conv1_with_winograd_input_transform": (8, "gemm_split_big_kernel<2, false>", "conv1 of blocks 1-2: [49R,2048]x[512,2048]^T, the epilogue writes "
+                                                "the transform-domain tensor V instead of the pixels"),
+        "tile_128x128": (5, "gemm_split_kernel<", "the launches below 1 024 tiles of 256x256: block 0's 1x1 convolutions on the map, emb_pred, cls_score"),
+    }
+    split_kinds = {k: gemm_class(c) for k, (c, _, _) in SPLIT_KINDS.items()}
+    big_kinds = [k for k in SPLIT_KINDS if k != "tile_128x128"]
+    gemm_split_big = tuple(sum(split_kinds[k][i] for k in big_kinds) for i in range(4))     # the dominant kernel: every 256x256 launch
+    gemm_split = tuple(a + b for a, b in zip(gemm_split_big, split_kinds["tile_128x128"]))  # every split-operand GEMM launch of the step
     lib.locov_gemm_timing_enable(0)
     # the same job with the Res5 GEMMs on the f32 MFMA (reported beside the headline when that is the split path)
     dt2_f32 = None
@@ -571,12 +584,12 @@ def main():
             # and the three 121-problem Winograd-domain batched GEMMs; always emb_pred and the similarity GEMM.
             n0, ms0, fl0 = gemm_plain
             n1, ms1, fl1 = gemm_conv
-            achieved = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else float("nan")
+            achieved = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else None
             survey_res5_flops = 2.0 * 732.2e6 * R_local * args.steps          # 732.2 M MAC per ROI
             roof = {"kernel": "gemm_nt_kernel<float,float,128,128,2,2,2,CONV=0,false,8> (Res5 1x1 convs, "
                               "Winograd-domain batched GEMMs, emb_pred, similarity GEMM)",
                     "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                    "frac": achieved / MFMA_F32_PEAK_TFLOPS if achieved else None,
                     "traffic": recorded_traffic(args, "gemm_nt_kernel<float, float, 128, 128, 2, 2, 2, 0, false, 8"),
                     "traffic_unit": f"HBM-side bytes per launch, averaged over the launches of all instances of this kernel (PMC, profiles/{TRAFFIC_FILE})",
                     "launches_per_step": n0 / args.steps, "avg_launch_ms": ms0 / max(n0, 1),
@@ -594,31 +607,46 @@ def main():
                 # Winograd-domain batched GEMMs.  It executes three f16 MFMAs per fp32 product block, so it is priced
                 # against the dense f16 MFMA peak on the f16 FLOPs it executes (3 x 2MNK); the fp32-equivalent rate
                 # (2MNK / time) is reported next to it.
-                ns, mss, fls = gemm_split
+                ns, mss, fls, bys = gemm_split_big
+                if not ns:            # a workload whose launches all stay below the 256x256 threshold: the 128x128 kernel is the dominant one
+                    ns, mss, fls, bys = gemm_split
                 ach = 3.0 * fls / (mss * 1e-3) / 1e12 if mss > 0 else float("nan")
-                roof = {"kernel": "gemm_split_big_kernel / gemm_split_kernel (Res5 1x1 convs, Winograd-domain batched GEMMs; fp32 in/out, f16x2 "
-                                  "split operands on the f16 matrix pipe; 256x256 tile where both operands arrive pre-split, 128x128 otherwise)",
+                na, msa, fla, _ = gemm_split
+
+                def instance(kind):
+                    n_, ms_, fl_, by_ = split_kinds[kind]
+                    _, key, what = SPLIT_KINDS[kind]
+                    if not n_:
+                        return None
+                    tr = recorded_traffic(args, key)
+                    a_ = 3.0 * fl_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else None
+                    return {"what": what, "kernel": key.rstrip("<"), "launches_per_step": n_ / args.steps, "avg_launch_ms": ms_ / n_,
+                            "achieved": a_, "frac": a_ / MFMA_16BIT_PEAK_TFLOPS if a_ else None,
+                            "algorithmic_bytes": by_ / n_, "traffic": tr,
+                            "traffic_over_algorithmic": tr / (by_ / n_) if tr and by_ else None}
+                roof = {"kernel": "gemm_split_big_kernel (csrc/gemm_split_big.hip): the split-operand NT GEMM on its 256x256 tile -- Res5's 1x1 "
+                                  "convolutions on pooled rows and the Winograd-domain batched GEMMs; fp32 in / fp32 out, products formed from "
+                                  "f16x2 split operands on the f16 matrix pipe",
                         "bound": "mfma", "achieved": ach, "peak": MFMA_16BIT_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / MFMA_16BIT_PEAK_TFLOPS,
-                        "traffic": recorded_traffic(args, "gemm_split"),
-                        "traffic_unit": f"HBM-side bytes per launch, averaged over the launches of all instances of this kernel (PMC, profiles/{TRAFFIC_FILE})",
+                        "traffic": recorded_traffic(args, "gemm_split_big_kernel"),
+                        "algorithmic_bytes": bys / max(ns, 1),
+                        "traffic_unit": f"HBM-side bytes per launch (memory side of L2: FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes; "
+                                        f"separate rocprofv3 --pmc passes, profiles/{TRAFFIC_FILE}), averaged over this kernel's launches; "
+                                        "`algorithmic_bytes` = every operand read once and every result written once, same average; per launch "
+                                        "kind under `instances`",
                         "launches_per_step": ns / args.steps, "avg_launch_ms": mss / max(ns, 1),
                         "share_of_step_time": mss * 1e-3 / dt2,
                         "executed_f16_flops_per_step": 3.0 * fls / args.steps,
                         "fp32_equivalent_tflops": fls / (mss * 1e-3) / 1e12 if mss > 0 else None,
                         "fp32_equivalent_vs_f32_mfma_peak": fls / (mss * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if mss > 0 else None,
+                        "all_split_gemm_launches": {"launches_per_step": na / args.steps, "share_of_step_time": msa * 1e-3 / dt2,
+                                                    "achieved": 3.0 * fla / (msa * 1e-3) / 1e12 if msa > 0 else None,
+                                                    "what": "the dominant kernel's launches plus the 128x128-tile launches of the same arithmetic "
+                                                            "(round 3's lumped figure)"},
                         "f32_mfma_gemms": {"launches_per_step": n0 / args.steps, "share_of_step_time": ms0 * 1e-3 / dt2,
                                            "executed_tflops": achieved},
-                        "instances": {
-                            "plain_and_mean_fused": {"launches_per_step": gemm_split_plain[0] / args.steps,
-                                                     "avg_launch_ms": gemm_split_plain[1] / max(gemm_split_plain[0], 1),
-                                                     "achieved": 3.0 * gemm_split_plain[2] / (gemm_split_plain[1] * 1e-3) / 1e12 if gemm_split_plain[1] > 0 else None},
-                            "with_winograd_input_transform_in_the_epilogue": {
-                                "launches_per_step": gemm_split_wino[0] / args.steps,
-                                "avg_launch_ms": gemm_split_wino[1] / max(gemm_split_wino[0], 1),
-                                "achieved": 3.0 * gemm_split_wino[2] / (gemm_split_wino[1] * 1e-3) / 1e12 if gemm_split_wino[1] > 0 else None,
-                                "what": "conv1 of blocks 1-2: these launches also write the 2 GB transform-domain tensor a separate HBM-bound "
-                                        "kernel used to write (round 2: outside this number); their MFMA rate alone understates them"}},
+                        "instances": {k: instance(k) for k in SPLIT_KINDS},
                         "power_cap": {"sustained_mfma_only_tflops": SUSTAINED_F16_MFMA_TFLOPS,
                                       "frac_of_sustained": ach / SUSTAINED_F16_MFMA_TFLOPS,
                                       "what": "a register-only v_mfma_f32_16x16x32_f16 loop with live operands (no LDS, no memory) is held to "

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LOCOV_ABI_VERSION 3
+#define LOCOV_ABI_VERSION 4
 
 #define LOCOV_OK 0
 #define LOCOV_ERR_INVALID_ARG (-1)
@@ -351,12 +351,17 @@ int locov_gemm_nt_batched_f32_split(const float *x, int64_t lda, int64_t stride_
  * returns, for one kernel class, the number of launches, the sum of their durations (ms) and
  * the FLOPs they executed.  cls: 0 = gemm_nt_kernel<128x128, plain / batched> (1x1 convs, FCs,
  * Winograd-domain GEMMs), 1 = the position-major direct 3x3 conv, 2 = the other tile shapes,
- * 3 / 4 = classes 0 / 1 launched with bf16 operands, 5 = the split-operand GEMM, 6 / 7 = the TN (weight-gradient) GEMM on the f32
- * MFMA / in split arithmetic, 8 = the split-operand GEMM whose epilogue applies the Winograd input transform
- * (locov_conv1x1_winograd_conv3x3_f32_split).
+ * 3 / 4 = classes 0 / 1 launched with bf16 operands, 5 = the split-operand GEMM on its 128x128 tile (gemm_split_kernel, every
+ * form), 6 / 7 = the TN (weight-gradient) GEMM on the f32 MFMA / in split arithmetic; the split-operand GEMM on its 256x256 tile
+ * (gemm_split_big_kernel) by launch kind: 8 = with the Winograd input transform in the epilogue
+ * (locov_conv1x1_winograd_conv3x3_f32_split), 9 = one problem (the 1x1 convolutions), 10 = batched (the Winograd-domain GEMMs),
+ * 11 = mean-fused (locov_gemm_nt_f32_split_segmean).
+ * read_ex() also returns the ALGORITHMIC HBM bytes of those launches (every operand read once, every result written once;
+ * stated for classes 5 and 8-11, 0 elsewhere); bytes may be null.
  * enable(on) clears what was recorded. */
 int locov_gemm_timing_enable(int on);
 int locov_gemm_timing_read(int cls, int64_t *launches, double *ms, double *flops);
+int locov_gemm_timing_read_ex(int cls, int64_t *launches, double *ms, double *flops, double *bytes);
 
 int locov_frozen_bn_fold(const float *weight, const float *bias, const float *running_mean,
                          const float *running_var, float eps, int C, float *scale, float *shift,
@@ -568,13 +573,18 @@ int locov_winograd_wgrad_f32_split(const float *x, const float *g, int64_t R, in
  *   x_split [49 R, K] (row pitch ldx): split layout x x_scale, ROI-major rows (r*49 + position); W1_split [C, K] x w1_scale;
  *   U_split [121, N, C] x u_scale; v_scale: operand scale of the transformed pixels; flags: LOCOV_WINO_IN_ROI_MAJOR (required)
  *   | LOCOV_WINO_OUT_ROI_MAJOR | LOCOV_EPI_RELU (of the 3x3); y, ldy, y_split_scale as in locov_winograd_conv3x3_f32_split_ex.
- *   workspace: locov_conv1x1_winograd_workspace_bytes(R, C, N) bytes. */
+ *   workspace: locov_conv1x1_winograd_workspace_bytes_for(R, K, C, N, ldx) bytes -- the transform-domain workspace, plus the
+ *   [49 R, C] pixel scratch only when these shapes take the two-launch fallback; locov_conv1x1_winograd_workspace_bytes(R, C, N)
+ *   is the upper bound over both forms (always sufficient). */
 int64_t locov_conv1x1_winograd_workspace_bytes(int64_t R, int C, int N);
+int64_t locov_conv1x1_winograd_workspace_bytes_for(int64_t R, int K, int C, int N, int64_t ldx);
 /* The same for block 0, whose 1x1 convolution ran on the feature MAP (ROIAlign is linear): the pooler + FrozenBN + ReLU + conv2 in one
  * call -- locov_roi_align_nhwc_affine_fwd(bin_stride 2, ROI-major, relu) followed by locov_winograd_conv3x3_f32_split_ex, and those
  * bits.  With C % 64 == 0 the ROIAlign workgroup (one ROI x 64 channels) keeps its 49 pooled rows in LDS and writes their Winograd
  * input transform itself; otherwise the two launches.  feat_nhwc: fp32 [Nimg, H, W, C] with pixel pitch feat_ld; pooled: 14 (the
- * even bins form the 7 x 7 tile); workspace: locov_conv1x1_winograd_workspace_bytes(R, C, N); the other arguments as above. */
+ * even bins form the 7 x 7 tile); workspace: locov_roi_align_winograd_workspace_bytes(R, C, N) (the pixel scratch only for the
+ * two-launch fallback; locov_conv1x1_winograd_workspace_bytes is the upper bound); the other arguments as above. */
+int64_t locov_roi_align_winograd_workspace_bytes(int64_t R, int C, int N);
 int locov_roi_align_winograd_conv3x3_f32_split(const float *feat_nhwc, int Nimg, int H, int W, int C, int64_t feat_ld,
                                                const float *rois, int64_t R, int pooled, float spatial_scale,
                                                int sampling_ratio, int aligned, const float *scale1, const float *shift1,
@@ -602,6 +612,17 @@ int locov_im2col3x3_nhwc(const float *x, int64_t R, int H, int W, int C, float *
 int locov_conv3x3_wgrad_unpack(const float *dw_packed, int N, int Cin, const float *row_scale, float *dw,
                                locov_stream_t stream);
 int locov_relu_mask(const float *g, const float *act, int64_t n, float *out, float *amax_out, locov_stream_t stream);
+/* locov_zero_if_raised : the GradScaler-style skip of a backward pass in split arithmetic, decided ON THE DEVICE.  `flag` is the
+ *                          pass's range-guard word (Res5RowsFn.backward -- the gradients of roi_emb_heads.py:323,343-347's Res5
+ *                          calls, which the reference's cuDNN autograd computes in fp32 and cannot overflow): when it is non-zero
+ *                          each of the n_tensors (<= LOCOV_ZERO_LIST_MAX) fp32 gradient tensors (`tensors[i]`, `counts[i]` elements;
+ *                          host arrays of device pointers / counts) is zero-filled, so that no inf / NaN produced beyond fp16's range
+ *                          reaches an optimizer step or DDP's all-reduce; when it is zero nothing is read or written.  One launch,
+ *                          no host read -- the caller learns of the skip from the word whenever it next reads it. */
+#define LOCOV_ZERO_LIST_MAX 24
+int locov_zero_if_raised(float *const *tensors, const int64_t *counts, int n_tensors, const unsigned *flag,
+                         locov_stream_t stream);
+
 int locov_spatial_mean_bwd(const float *g, const float *act, int64_t R, int C, int HW, float *out,
                            float *amax_out, locov_stream_t stream);
 int locov_rows_stride2(const float *src, int N, int H, int W, int C, int forward, float *dst,

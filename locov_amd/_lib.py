@@ -24,7 +24,8 @@ GEMM_A_SPLIT = 0x1000
 EPI_OUT_SPLIT = 0x2000
 EPI_RES_SPLIT = 0x4000
 MAX_LEVELS = 8
-ABI_VERSION = 3
+ZERO_LIST_MAX = 24
+ABI_VERSION = 4
 
 _p = c_void_p  # device pointer
 
@@ -67,6 +68,7 @@ SIGNATURES = {
                                           c_int, c_int, _p]),
     "locov_gemm_timing_enable": (c_int, [c_int]),
     "locov_gemm_timing_read": (c_int, [c_int, _p, _p, _p]),
+    "locov_gemm_timing_read_ex": (c_int, [c_int, _p, _p, _p, _p]),
     "locov_frozen_bn_fold": (c_int, [_p, _p, _p, _p, c_float, c_int, _p, _p, _p]),
     "locov_nms_workspace_bytes": (c_int64, [c_int64]),
     "locov_nms_sorted": (c_int, [_p, c_int64, c_float, _p, _p, _p, _p]),
@@ -107,6 +109,8 @@ SIGNATURES = {
                                                     c_uint, c_float, _p, c_int64, _p, _p, _p]),
     "locov_winograd_wgrad_f32_split": (c_int, [_p, _p, c_int64, c_int, c_int, c_uint, _p, _p, _p, _p, c_int64, _p]),
     "locov_conv1x1_winograd_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "locov_conv1x1_winograd_workspace_bytes_for": (c_int64, [c_int64, c_int, c_int, c_int, c_int64]),
+    "locov_roi_align_winograd_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
     "locov_roi_align_winograd_conv3x3_f32_split": (c_int, [_p, c_int, c_int, c_int, c_int, c_int64, _p, c_int64, c_int, c_float, c_int, c_int,
                                                            _p, _p, _p, c_float, c_float, _p, _p, _p, c_int64, c_int, c_uint, c_float, _p, c_int64,
                                                            _p, _p]),
@@ -119,6 +123,7 @@ SIGNATURES = {
     "locov_im2col3x3_nhwc": (c_int, [_p, c_int64, c_int, c_int, c_int, _p, _p]),
     "locov_conv3x3_wgrad_unpack": (c_int, [_p, c_int, c_int, _p, _p, _p]),
     "locov_relu_mask": (c_int, [_p, _p, c_int64, _p, _p, _p]),
+    "locov_zero_if_raised": (c_int, [POINTER(c_void_p), POINTER(c_int64), c_int, _p, _p]),
     "locov_spatial_mean_bwd": (c_int, [_p, _p, c_int64, c_int, c_int, _p, _p, _p]),
     "locov_rows_stride2": (c_int, [_p, c_int, c_int, c_int, c_int, c_int, _p, _p]),
     "locov_roi_align_nhwc_bwd": (c_int, [_p, c_int64, c_int, c_int, c_int, c_int, _p, c_int64, c_int, c_int, c_float, c_int, c_int,

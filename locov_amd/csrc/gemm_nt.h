@@ -70,8 +70,9 @@ int launch_gemm_nt(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C, in
                    const Batch &bt = Batch{1, 0, 0, 0});
 
 // Per-launch timing hooks of locov_gemm_timing_* (gemm_nt.hip): begin() returns a record index or -1 when timing is
-// off; cls = kernel class (include/locov_hip.h), flops = what the launch executes.
-int timing_begin(hipStream_t s, int cls, double flops);
+// off; cls = kernel class (include/locov_hip.h), flops = what the launch executes, bytes = its ALGORITHMIC HBM bytes (every operand
+// read once, every result written once; 0 = not stated).
+int timing_begin(hipStream_t s, int cls, double flops, double bytes = 0.0);
 void timing_end(int idx, hipStream_t s);
 
 // y[M,N] = epi(A[M,K] . W[N,K]^T) with fp32 A split on the fly (scaled by a_scale) and W pre-split into f16 (hi, lo)

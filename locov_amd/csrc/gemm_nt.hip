@@ -51,19 +51,19 @@ namespace locov {
 struct TimingRec {
     hipEvent_t e0, e1;
     int cls;
-    double flops;
+    double flops, bytes;
 };
 static std::mutex g_timing_mutex;
 static bool g_timing_on = false;
 static std::vector<TimingRec> g_timing;
 
-int timing_begin(hipStream_t s, int cls, double flops)
+int timing_begin(hipStream_t s, int cls, double flops, double bytes)
 {
     std::lock_guard<std::mutex> lock(g_timing_mutex);
     if (!g_timing_on) return -1;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return -1;   // never inside a graph capture
-    TimingRec r{nullptr, nullptr, cls, flops};
+    TimingRec r{nullptr, nullptr, cls, flops, bytes};
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
     (void)hipEventRecord(r.e0, s);
     g_timing.push_back(r);
@@ -900,13 +900,14 @@ int locov_gemm_timing_enable(int on)
     return LOCOV_OK;
 }
 
-int locov_gemm_timing_read(int cls, int64_t *launches, double *ms, double *flops)
+int locov_gemm_timing_read_ex(int cls, int64_t *launches, double *ms, double *flops, double *bytes)
 {
     LOCOV_REQUIRE(launches && ms && flops, "locov_gemm_timing_read: null pointer");
     std::lock_guard<std::mutex> lock(g_timing_mutex);
     *launches = 0;
     *ms = 0.0;
     *flops = 0.0;
+    if (bytes) *bytes = 0.0;
     for (auto &r : g_timing) {
         if (r.cls != cls) continue;
         float t = 0.f;
@@ -915,8 +916,14 @@ int locov_gemm_timing_read(int cls, int64_t *launches, double *ms, double *flops
         *launches += 1;
         *ms += (double)t;
         *flops += r.flops;
+        if (bytes) *bytes += r.bytes;
     }
     return LOCOV_OK;
+}
+
+int locov_gemm_timing_read(int cls, int64_t *launches, double *ms, double *flops)
+{
+    return locov_gemm_timing_read_ex(cls, launches, ms, flops, nullptr);
 }
 
 int locov_conv3x3_nhwc_f32(const float *x, int64_t R, int H, int W, int Cin, int pos_major, const float *w_packed,

@@ -670,7 +670,8 @@ int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C,
     if (tiles > 0x7fffffffLL) return set_error(LOCOV_ERR_INVALID_ARG, "%s: problem too large", what);
     if ((int64_t)bm * (lda > ldc ? lda : ldc) * 4 > 0x7fffffffLL)
         return set_error(LOCOV_ERR_INVALID_ARG, "%s: row pitch too large for 32-bit tile offsets", what);
-    const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K * count);     // class 5: split-operand GEMM
+    const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K * count,       // class 5: the 128x128 split-operand GEMM
+                                  4.0 * count * ((double)M * K + (double)N * K + (double)M * N * (epi.residual ? 2.0 : 1.0)));
     const float os = 1.f / (a_scale * w_scale);
     const float *Bw = reinterpret_cast<const float *>(Wsplit);
     const SegSum ss0{0, 0, nullptr};
@@ -678,7 +679,9 @@ int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C,
     hipLaunchKernelGGL((gemm_split_kernel<false, EM, AS, WMV>), dim3((unsigned)tiles), dim3(64 * WMV * WN), 0, s, A, lda, Bw, C, \
                        ldc, M, N, K, epi, bt, a_scale, os, ss0, overflow, a_scale_dev)
     if (epi.flags & LOCOV_GEMM_A_SPLIT) {
-        if (epi.mask || a_scale_dev) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: pre-split A takes no mask / device scale", what);
+        // (amax_out too: the pre-split instance carries no fold, a silently untouched slot would read as scale 1 downstream)
+        if (epi.mask || a_scale_dev || epi.amax_out)
+            return set_error(LOCOV_ERR_UNSUPPORTED, "%s: pre-split A takes no mask / device scale / amax_out", what);
         LOCOV_LAUNCH_SPLIT(false, true, 2);
     } else if (epi.mask || epi.amax_out)
         LOCOV_LAUNCH_SPLIT(true, false, 2);
@@ -724,7 +727,7 @@ int launch_gemm_split_segmean(const float *A, int64_t lda, const void *Wsplit, i
     const int64_t tiles_m = ceil_div(M, BM), tiles = tiles_m * ceil_div(N, BN);
     if (tiles > 0x7fffffffLL || (double)M * N * 4 > 4294967295.0 || (int64_t)BM * lda * 4 > 0x7fffffffLL)
         return set_error(LOCOV_ERR_INVALID_ARG, "%s: problem too large for 32-bit residual offsets", what);
-    const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K);
+    const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     if (epi.flags & LOCOV_GEMM_A_SPLIT)
         hipLaunchKernelGGL((gemm_split_kernel<true, false, true>), dim3((unsigned)tiles), dim3(NT), 0, s, A, lda,
                            reinterpret_cast<const float *>(Wsplit), static_cast<float *>(nullptr), (int64_t)N, M, N, K, epi, Batch{1, 0, 0, 0},

@@ -61,7 +61,9 @@ static_assert(GBM * WYP * 4 <= GLDS, "the finished half tile (all 256 rows: the 
 // (ROI, fy) units of wino_in_fy -- lane = channel pair, the 3-4 patch rows fy needs read from LDS, 11 transform-domain values
 // written straight into V [121][R][N] (`partial`) in the split layout, the bits wino_input_kernel<false, true> would have written
 // from the stored pixels.  Saves the pixel tensor's write and re-read (2 x 0.8 GB per block at 8 000 proposals) and a launch.
-template <int MODE>
+// BATCHED: bt.count problems of the same shape in one grid (the 121 Winograd-domain GEMMs) -- a template parameter only so that the
+// two launch kinds of MODE_PLAIN carry different kernel names in profiler output (per-kind traffic / duration, bench.py `instances`)
+template <int MODE, bool BATCHED = false>
 __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                                                                float *__restrict__ Cout, int64_t ldc, int64_t M, int N, int K,
                                                                Epilogue epi, Batch bt, float a_scale, float out_scale,
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
     const int tiles_n = (N + GBN - 1) / GBN;
     const int nwg = gridDim.x;
     int tile = xcd_remap(blockIdx.x, nwg);
-    if (bt.count > 1) {
+    if (BATCHED) {
         const int per = nwg / bt.count, b = tile / per;
         tile -= b * per;
         A += b * bt.sa;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
 #define LOCOV_BIG_NG 0
 #endif
         const int NG = LOCOV_BIG_NG > 0 ? LOCOV_BIG_NG : ((int64_t)K * 4 * GBN * 8 <= (2 << 20) ? 8 : 4);
-        const int tiles_m = (int)((bt.count > 1 ? nwg / bt.count : nwg) / tiles_n);
+        const int tiles_m = (int)((BATCHED ? nwg / bt.count : nwg) / tiles_n);
         const int full = (tiles_n / NG) * NG, per_group = tiles_m * NG;
         if (tiles_n <= NG) {
             m0 = (int64_t)(tile / tiles_n) * TILE_ROWS;
@@ -489,9 +491,16 @@ int launch_gemm_split_big(const float *A, int64_t lda, const void *Wsplit, float
 {
     const int count = bt.count > 1 ? bt.count : 1;
     const int64_t tiles = ceil_div(M, GBM) * ceil_div(N, GBN) * count;
-    const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K * count);     // class 5: split-operand GEMM
-    hipLaunchKernelGGL(gemm_split_big_kernel<MODE_PLAIN>, dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit), C,
-                       ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale), overflow, 0, static_cast<float *>(nullptr), 0.f);
+    // classes 9 / 10: the 256x256 split GEMM, one problem (the 1x1 convolutions) / batched (the Winograd-domain GEMMs).
+    // algorithmic bytes: A and W once, the result once, the residual once
+    const double abytes = 4.0 * count * ((double)M * K + (double)N * K + (double)M * N * (epi.residual ? 2.0 : 1.0));
+    const int trec = timing_begin(s, count > 1 ? 10 : 9, 2.0 * (double)M * N * K * count, abytes);
+    if (count > 1)
+        hipLaunchKernelGGL((gemm_split_big_kernel<MODE_PLAIN, true>), dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit), C,
+                           ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale), overflow, 0, static_cast<float *>(nullptr), 0.f);
+    else
+        hipLaunchKernelGGL((gemm_split_big_kernel<MODE_PLAIN, false>), dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit), C,
+                           ldc, M, N, K, epi, bt, a_scale, 1.f / (a_scale * w_scale), overflow, 0, static_cast<float *>(nullptr), 0.f);
     timing_end(trec, s);
     return check_launch(what);
 }
@@ -510,8 +519,10 @@ int launch_gemm_split_big_segmean(const float *A, int64_t lda, const void *Wspli
                                   float a_scale, float w_scale, float *partial, float *out, hipStream_t s, const char *what, unsigned *overflow)
 {
     const int64_t tiles = ceil_div(M, GBM) * ceil_div(N, GBN);
-    const int trec = timing_begin(s, 5, 2.0 * (double)M * N * K);
-    hipLaunchKernelGGL(gemm_split_big_kernel<MODE_SEGSUM>, dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
+    // class 11: the mean-fused form -- A, W and the residual once; the per-chunk column sums instead of the [M, N] result
+    const int trec = timing_begin(s, 11, 2.0 * (double)M * N * K,
+                                  4.0 * ((double)M * K + (double)N * K + (double)M * N) + (double)gemm_split_big_segmean_workspace_bytes(M, N));
+    hipLaunchKernelGGL((gemm_split_big_kernel<MODE_SEGSUM, false>), dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
                        static_cast<float *>(nullptr), (int64_t)N, M, N, K, epi, Batch{1, 0, 0, 0}, a_scale, 1.f / (a_scale * w_scale), overflow, seg,
                        partial, 0.f);
     timing_end(trec, s);
@@ -538,8 +549,9 @@ int launch_gemm_split_big_wino(const float *A, int64_t lda, const void *Wsplit, 
                                float w_scale, float *V, float v_scale, hipStream_t s, const char *what, unsigned *overflow)
 {
     const int64_t tiles = ceil_div(M / WSEG, WROIS) * ceil_div(N, GBN);
-    const int trec = timing_begin(s, 8, 2.0 * (double)M * N * K);
-    hipLaunchKernelGGL(gemm_split_big_kernel<MODE_WINO>, dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
+    // class 8: A and W once, the transform-domain tensor V [121][M / 49][N] instead of the [M, N] pixels
+    const int trec = timing_begin(s, 8, 2.0 * (double)M * N * K, 4.0 * ((double)M * K + (double)N * K + 121.0 * (double)(M / WSEG) * N));
+    hipLaunchKernelGGL((gemm_split_big_kernel<MODE_WINO, false>), dim3((unsigned)tiles), dim3(GNT), 0, s, A, lda, reinterpret_cast<const float *>(Wsplit),
                        static_cast<float *>(nullptr), (int64_t)N, M, N, K, epi, Batch{1, 0, 0, 0}, a_scale, 1.f / (a_scale * w_scale), overflow, WSEG,
                        V, v_scale);
     timing_end(trec, s);

@@ -150,6 +150,30 @@ __global__ __launch_bounds__(256) void rows_stride2_kernel(const float *__restri
     }
 }
 
+// GradScaler-style skip ON THE DEVICE (locov_zero_if_raised): when the range-guard word of a backward pass in split arithmetic is
+// set, the gradients that pass wrote may hold inf / NaN -- they are zero-filled before anything downstream (an optimizer, DDP's
+// all-reduce) can consume them.  With the word clear every workgroup leaves after one scalar load: nothing is read or written.
+struct ZeroList {
+    float *p[LOCOV_ZERO_LIST_MAX];
+    int64_t n[LOCOV_ZERO_LIST_MAX];
+};
+
+__global__ __launch_bounds__(256) void zero_if_raised_kernel(ZeroList list, const unsigned *__restrict__ flag)
+{
+    if (*flag == 0u) return;
+    float *p = list.p[blockIdx.y];
+    const int64_t n = list.n[blockIdx.y];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = t0; i < n4; i += stride) reinterpret_cast<float4 *>(p)[i] = float4{0.f, 0.f, 0.f, 0.f};
+        for (int64_t i = (n4 << 2) + t0; i < n; i += stride) p[i] = 0.f;
+    } else {
+        for (int64_t i = t0; i < n; i += stride) p[i] = 0.f;
+    }
+}
+
+
 static unsigned grid_for(int64_t total) { return (unsigned)(ceil_div(total, 256) < 16384 ? ceil_div(total, 256) : 16384); }
 
 }  // namespace locov
@@ -227,6 +251,26 @@ int locov_rows_stride2(const float *src, int N, int H, int W, int C, int forward
         hipLaunchKernelGGL(rows_stride2_kernel<false>, dim3(grid_for((int64_t)N * H * W * (C / 4))), dim3(256), 0, as_stream(stream), src, N, H,
                            W, C, dst);
     return check_launch("locov_rows_stride2");
+}
+
+int locov_zero_if_raised(float *const *tensors, const int64_t *counts, int n_tensors, const unsigned *flag, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(n_tensors >= 0 && n_tensors <= LOCOV_ZERO_LIST_MAX, "locov_zero_if_raised: 0..%d tensors per call", LOCOV_ZERO_LIST_MAX);
+    if (n_tensors == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(tensors && counts && flag, "locov_zero_if_raised: null pointer");
+    ZeroList list{};
+    int used = 0;
+    for (int i = 0; i < n_tensors; i++) {
+        LOCOV_REQUIRE(counts[i] >= 0, "locov_zero_if_raised: negative element count");
+        if (counts[i] == 0) continue;
+        LOCOV_REQUIRE(tensors[i] && (uintptr_t)tensors[i] % 4 == 0, "locov_zero_if_raised: null or misaligned tensor %d", i);
+        list.p[used] = tensors[i];
+        list.n[used] = counts[i];
+        used++;
+    }
+    if (used == 0) return LOCOV_OK;
+    hipLaunchKernelGGL(zero_if_raised_kernel, dim3(64, used), dim3(256), 0, as_stream(stream), list, flag);
+    return check_launch("locov_zero_if_raised");
 }
 
 }  // extern "C"

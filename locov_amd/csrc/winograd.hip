@@ -364,7 +364,7 @@ int locov_roi_align_winograd_conv3x3_f32_split(const float *feat_nhwc, int Nimg,
     LOCOV_REQUIRE((flags & LOCOV_WINO_IN_ROI_MAJOR) != 0, "locov_roi_align_winograd_conv3x3_f32_split: rows are ROI-major (LOCOV_WINO_IN_ROI_MAJOR)");
     LOCOV_REQUIRE(chunk_rois(R, C, N) == R, "locov_roi_align_winograd_conv3x3_f32_split: one pass only (LOCOV_WINO_CHUNK is set)");
     const int64_t wb = locov_winograd_workspace_bytes(R, C, N);
-    LOCOV_REQUIRE(workspace_bytes >= locov_conv1x1_winograd_workspace_bytes(R, C, N),
+    LOCOV_REQUIRE(workspace_bytes >= locov_roi_align_winograd_workspace_bytes(R, C, N),
                   "locov_roi_align_winograd_conv3x3_f32_split: workspace too small (%lld bytes)", (long long)workspace_bytes);
     PrePool pool{feat_nhwc, Nimg, H, W, feat_ld, rois, pooled, spatial_scale, sampling_ratio, aligned, scale1, shift1,
                  reinterpret_cast<float *>(static_cast<char *>(workspace) + ((wb + 15) & ~(int64_t)15))};
@@ -376,6 +376,28 @@ int64_t locov_conv1x1_winograd_workspace_bytes(int64_t R, int C, int N)
 {
     if (R <= 0 || C <= 0 || N <= 0) return 0;
     return locov_winograd_workspace_bytes(R, C, N) + R * 49 * (int64_t)C * (int64_t)sizeof(float);
+}
+
+// What the two fused calls need for THESE shapes: the [49 R, C] pixel scratch behind the transform-domain workspace exists only
+// for the two-launch fallback -- where the producer writes the Winograd input transform itself nothing ever touches it
+// (0.8 GB at 8 000 ROIs that a cached workspace would otherwise hold for good).
+static bool conv1x1_wino_fused(int64_t R, int K, int C, int64_t ldx)
+{
+    return gemm_split_big_wino_applicable(ldx, R * 49, C, K, Epilogue{nullptr, nullptr, nullptr, LOCOV_EPI_RELU | LOCOV_GEMM_A_SPLIT});
+}
+
+int64_t locov_conv1x1_winograd_workspace_bytes_for(int64_t R, int K, int C, int N, int64_t ldx)
+{
+    if (R <= 0 || C <= 0 || N <= 0 || K <= 0) return 0;
+    const int64_t wb = locov_winograd_workspace_bytes(R, C, N);
+    return chunk_rois(R, C, N) == R && conv1x1_wino_fused(R, K, C, ldx) ? wb : locov_conv1x1_winograd_workspace_bytes(R, C, N);
+}
+
+int64_t locov_roi_align_winograd_workspace_bytes(int64_t R, int C, int N)
+{
+    if (R <= 0 || C <= 0 || N <= 0) return 0;
+    const int64_t wb = locov_winograd_workspace_bytes(R, C, N);
+    return chunk_rois(R, C, N) == R && roi_align_nhwc_wino_applicable(C, R) ? wb : locov_conv1x1_winograd_workspace_bytes(R, C, N);
 }
 
 int locov_conv1x1_winograd_conv3x3_f32_split(const float *x_split, int64_t ldx, int K, float x_scale, const void *W1_split, float w1_scale,
@@ -394,7 +416,7 @@ int locov_conv1x1_winograd_conv3x3_f32_split(const float *x_split, int64_t ldx, 
     LOCOV_REQUIRE((flags & LOCOV_WINO_IN_ROI_MAJOR) != 0, "locov_conv1x1_winograd_conv3x3_f32_split: rows are ROI-major (LOCOV_WINO_IN_ROI_MAJOR)");
     LOCOV_REQUIRE(chunk_rois(R, C, N) == R, "locov_conv1x1_winograd_conv3x3_f32_split: one pass only (LOCOV_WINO_CHUNK is set)");
     const int64_t wb = locov_winograd_workspace_bytes(R, C, N);
-    LOCOV_REQUIRE(workspace_bytes >= locov_conv1x1_winograd_workspace_bytes(R, C, N),
+    LOCOV_REQUIRE(workspace_bytes >= locov_conv1x1_winograd_workspace_bytes_for(R, K, C, N, ldx),
                   "locov_conv1x1_winograd_conv3x3_f32_split: workspace too small (%lld bytes)", (long long)workspace_bytes);
     PreConv pre{x_split, ldx, K, x_scale, W1_split, w1_scale, scale1, shift1,
                 reinterpret_cast<float *>(static_cast<char *>(workspace) + ((wb + 15) & ~(int64_t)15))};
@@ -496,7 +518,9 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
         if (rcode) return rcode;
         const bool roi_major = (flags & LOCOV_WINO_OUT_ROI_MAJOR) != 0;
         // 32-bit byte offsets suffice for a row of 11 planes of M and for the 49 rows of every ROI of y (else the flat-address instance)
-        const bool wide = (uint64_t)rc * N * 4u * NF > 0xffffffffull || (uint64_t)rc * 49u * (uint64_t)ldy * 4u > 0xffffffffull;
+        // (position-major y: a position's rows are R -- the whole call's ROI count, not this chunk's rc -- apart)
+        const bool wide = (uint64_t)rc * N * 4u * NF > 0xffffffffull ||
+                          (uint64_t)(roi_major ? rc : R) * 49u * (uint64_t)ldy * 4u > 0xffffffffull;
         const int64_t lp = roi_major ? (int64_t)1 : R, lr = roi_major ? (int64_t)49 : (int64_t)1;
         float *yo = y + r0 * (roi_major ? 49 : 1) * ldy;
         const float *mo = mask ? mask + r0 * (roi_major ? 49 : 1) * ldy : nullptr;

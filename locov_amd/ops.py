@@ -408,7 +408,7 @@ def conv1x1_winograd_conv3x3(x: torch.Tensor, w1: SplitWeight, b1: Optional[torc
     shift2 = _dev(shift2, "shift2") if shift2 is not None else None
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    need = int(lib.locov_conv1x1_winograd_workspace_bytes(R, C, N))
+    need = int(lib.locov_conv1x1_winograd_workspace_bytes_for(R, K, C, N, x.stride(0) if M else K))     # no pixel scratch for the fused form
     key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
     ws = _WINO_WS.get(key)
     if ws is None or ws.numel() < need:
@@ -459,7 +459,7 @@ def roi_align_winograd_conv3x3(feat: torch.Tensor, rois: torch.Tensor, output_si
     shift2 = _dev(shift2, "shift2") if shift2 is not None else None
     y = torch.empty((49 * R, N), dtype=torch.float32, device=feat.device)
     lib = _lib.load()
-    need = int(lib.locov_conv1x1_winograd_workspace_bytes(R, C, N))
+    need = int(lib.locov_roi_align_winograd_workspace_bytes(R, C, N))       # no pixel scratch for the fused form
     key = (feat.device, torch.cuda.current_stream(feat.device).cuda_stream)
     ws = _WINO_WS.get(key)
     if ws is None or ws.numel() < need:
@@ -896,9 +896,9 @@ _SCALE_SLOTS = {}
 
 def _scale_slot(ref: torch.Tensor, lazy: bool = False) -> torch.Tensor:
     """16 bytes for a device-chosen operand scale, from a per-(device, stream) ring of 2048 zeroed slots.  The reduction kernel
-    (split_scale_from_amax) leaves its scratch words zero again; a `lazy` slot (scale_slot: producers fold their max into
-    word 2, consumers derive the scale) stays dirty, so a ring that handed one out is zeroed when it wraps -- one fill per 2048
-    uses, enqueued behind every GEMM that read the old contents (same stream; a training step takes ~40 slots)."""
+    (split_scale_from_amax) leaves {s, 1/s, 0, 0} behind; a `lazy` slot (scale_slot: producers fold their max into
+    word 2, consumers derive the scale while word 0 is zero) stays dirty too, so the ring is zeroed every time it wraps -- one
+    fill per 2048 uses, enqueued behind every GEMM that read the old contents (same stream; a training step takes ~40 slots)."""
     key = (ref.device, torch.cuda.current_stream(ref.device).cuda_stream)
     ring = _SCALE_SLOTS.get(key)
     if ring is None:
@@ -908,7 +908,10 @@ def _scale_slot(ref: torch.Tensor, lazy: bool = False) -> torch.Tensor:
         ring[0].zero_()
         ring[2] = False
     ring[1] = (i + 1) % ring[0].shape[0]
-    ring[2] = ring[2] or lazy
+    # every hand-out dirties the ring: the reduction kernel leaves {s, 1/s, 0, 0} behind, and a LAZY consumer derives the scale
+    # from word 2 only while word 0 is zero -- a slot that carried a reduced scale in the previous cycle must not be handed out
+    # lazily with that stale s in it
+    ring[2] = True
     return ring[0][i]
 
 
@@ -1051,6 +1054,24 @@ def relu_mask(g: torch.Tensor, act: torch.Tensor, amax_out: Optional[torch.Tenso
     with torch.cuda.device(g.device):
         check(_lib.load().locov_relu_mask(_ptr(g), _ptr(act), g.numel(), _ptr(out), _ptr(amax_out), _stream(g)), "locov_relu_mask")
     return out
+
+
+def zero_if_raised(tensors, word: torch.Tensor) -> None:
+    """Zero-fill every tensor of `tensors` (contiguous fp32 device tensors, None entries skipped) ON THE DEVICE when the
+    range-guard word `word` is set; a no-op launch otherwise.  No host read (locov_zero_if_raised)."""
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    if not ts:
+        return
+    for t in ts:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise LocovError("zero_if_raised: contiguous fp32 device tensors only")
+    lib = _lib.load()
+    with torch.cuda.device(word.device):
+        for i in range(0, len(ts), _lib.ZERO_LIST_MAX):
+            chunk = ts[i:i + _lib.ZERO_LIST_MAX]
+            ptrs = (ctypes.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])
+            counts = (ctypes.c_int64 * len(chunk))(*[t.numel() for t in chunk])
+            check(lib.locov_zero_if_raised(ptrs, counts, len(chunk), _ptr(word), _stream(word)), "locov_zero_if_raised")
 
 
 def spatial_mean_bwd(g: torch.Tensor, act: Optional[torch.Tensor], hw: int, amax_out: Optional[torch.Tensor] = None) -> torch.Tensor:

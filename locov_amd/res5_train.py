@@ -124,11 +124,17 @@ class Res5RowsFn(torch.autograd.Function):
         # operand scale is chosen on the device from its own max |g|.  Only a REMEMBERED weight scale (Res5Stage._split: chosen
         # afresh every 64 packings, 8x headroom) that stopped covering a weight could trip the guard -- the pack kernel
         # raises it.  That is recorded in the stage's "bwd" guard and nothing is read inside autograd (a host read here would
-        # stall DDP's overlapped all-reduce): the ROI heads look at the word together with the ONE host read of the next
-        # step's labelling (SampleAllROIHeads.label_and_sample_proposals) and then drop the remembered scales with a warning;
-        # `stage.backward_guard_raised()` reads it on demand.
-        with ops.range_guard(ctx.stage.range_guard("bwd", grad_out.device)):
-            return Res5RowsFn._backward(ctx, grad_out, True)
+        # stall DDP's overlapped all-reduce).  Instead the pass ends with a GradScaler-style skip decided ON THE DEVICE: when the
+        # word is set every gradient this pass produced (stage input and all convolution weights) is zero-filled
+        # (locov_zero_if_raised: one launch that exits after a scalar load when the word is clear), so no inf / NaN can reach
+        # the optimizer or the all-reduce whether or not another step follows.  The ROI heads look at the word together with
+        # the ONE host read of the next step's labelling (SampleAllROIHeads.label_and_sample_proposals), warn, and drop the
+        # remembered scales; `stage.backward_guard_raised()` reads it on demand (e.g. next to a trainer's loss logging).
+        guard = ctx.stage.range_guard("bwd", grad_out.device)
+        with ops.range_guard(guard):
+            grads = Res5RowsFn._backward(ctx, grad_out, True)
+        ops.zero_if_raised(grads, guard.word)          # (every gradient here is a freshly written contiguous tensor or a view of one)
+        return grads
 
     @staticmethod
     def _backward(ctx, grad_out, sp):

@@ -491,11 +491,13 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
     def _split_weight(self, tag: str, w: torch.Tensor):
         """Split-operand packing of a weight read at call time (emb_pred.weight is re-assigned by the meta-arch, the bank by
         set_class_embeddings): re-packed whenever the tensor is replaced or modified in place."""
-        key = (w.data_ptr(), w._version, tuple(w.shape))
+        # The entry KEEPS the tensor and compares by identity: a (data_ptr, _version) key alone can match a different tensor --
+        # every bank swap builds a fresh nn.Linear (version 0 again) and the caching allocator may hand the freed bank's address
+        # to the next one of the same shape (Res5Stage._split does the same).
         hit = self._split_cache.get(tag)
-        if hit is None or hit[0] != key:
-            hit = self._split_cache[tag] = (key, ops.split_pack(w.detach().contiguous()))
-        return hit[1]
+        if hit is None or hit[0] is not w or hit[1] != w._version:
+            hit = self._split_cache[tag] = (w, w._version, ops.split_pack(w.detach().contiguous()))
+        return hit[2]
 
     def _fc_split_ok(self, x: torch.Tensor) -> bool:
         return (self.fc_dtype == "f16x2" and x.is_cuda and x.dim() == 2 and x.shape[1] % 32 == 0 and self.emb_dim % 32 == 0
@@ -576,8 +578,9 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
         return hip_linear(x, self.cls_score)
 
     def _bank_key(self):
+        # (the tensor object itself is part of the key -- held, so its id cannot be recycled -- next to its version: see _split_weight)
         w = self.cls_score.weight
-        return (w.data_ptr(), w._version, tuple(w.shape), w.device)
+        return (w, w._version)
 
     def _packed_bank(self):
         """bf16 copy of the bank for the bf16 MFMA similarity GEMM, re-packed whenever cls_score.weight is re-assigned,
@@ -585,7 +588,8 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
         if self.sim_gemm_dtype != "bf16":
             return None
         key = self._bank_key()
-        if self._bank_bf16 is None or getattr(self, "_bank_bf16_key", None) != key:
+        have = getattr(self, "_bank_bf16_key", None)
+        if self._bank_bf16 is None or have is None or have[0] is not key[0] or have[1] != key[1]:
             self._bank_bf16 = ops.to_bf16(self.cls_score.weight.detach())
             self._bank_bf16_key = key
         return self._bank_bf16
@@ -628,6 +632,9 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
         self.cls_score.weight.requires_grad = False
         self.cls_score.bias.requires_grad = False
         self._bank_bf16 = None
+        self._bank_bf16_key = None
+        self._split_cache.pop("bank", None)           # the packed (hi, lo) copy belongs to the bank that was just replaced
+        self._bias_zero_key = None
 
 
 def _rownorm(x: torch.Tensor, mode: int) -> torch.Tensor:

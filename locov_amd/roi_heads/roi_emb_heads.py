@@ -327,14 +327,49 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
     def _build_res5_block(cls, cfg):
         return build_res5_block(cfg)
 
-    def _rows_path_ok(self, features: List[torch.Tensor]) -> bool:
-        """The channels-last hand-written path: one feature level, FrozenBN Res5 whose block 0 strides in its
-        1x1 convs, even pooler resolution."""
-        if self.res5_backend != "hip" or len(features) != 1:
-            return False
+    def _rows_path_reason(self, features: List[torch.Tensor]) -> Optional[str]:
+        """None when the channels-last hand-written path applies (one feature level, FrozenBN Res5 whose block 0 strides in
+        its 1x1 convs, ungrouped 3x3, even pooler resolution, channels a multiple of 32, device tensors) -- else the first
+        condition that fails, in words (the text of the fallback warning)."""
+        if self.res5_backend != "hip":
+            return f"MODEL.ROI_BOX_HEAD.RES5_BACKEND is {self.res5_backend!r}"
+        if len(features) != 1:
+            return f"{len(features)} feature levels (the hand-written Res5 path takes one)"
         ph, pw = self.pooler.output_size
-        return (hasattr(self.res5, "forward_rows") and self.res5.supports_rows_path() and self.res5[0].stride == 2
-                and ph == pw and ph % 2 == 0 and features[0].shape[1] % 32 == 0 and features[0].is_cuda)
+        if not hasattr(self.res5, "forward_rows"):
+            return f"res5 is a {type(self.res5).__name__}, not locov_amd.res5.Res5Stage"
+        if not self.res5.supports_rows_path():
+            return "Res5 needs FrozenBN on every convolution, STRIDE_IN_1X1 and ungrouped 3x3 convolutions"
+        if self.res5[0].stride != 2:
+            return f"block 0 has stride {self.res5[0].stride} (the even-grid pooler assumes 2)"
+        if ph != pw or ph % 2:
+            return f"pooler resolution {ph}x{pw} is not square and even"
+        if features[0].shape[1] % 32:
+            return f"{features[0].shape[1]} input channels (a multiple of 32 is needed)"
+        if not features[0].is_cuda:
+            return f"the feature map is on {features[0].device}"
+        return None
+
+    def _rows_path_ok(self, features: List[torch.Tensor]) -> bool:
+        return self._rows_path_reason(features) is None
+
+    def _warn_stock_fallback(self, where: str, features: List[torch.Tensor]) -> None:
+        """RES5_BACKEND "hip" was asked for and this call runs Res5 as torch.conv2d (MIOpen) instead: say so, once per call
+        site and reason.  ("miopen" as the configured backend is a choice, not a fallback: silent.)"""
+        if self.res5_backend != "hip":
+            return
+        reason = self._rows_path_reason(features)
+        if reason is None and self._needs_graph(features) and self.res5_dtype not in ("fp32", "f16x2"):
+            reason = f"RES5_DTYPE {self.res5_dtype!r} has no backward on the hand-written kernels (fp32 and f16x2 do)"
+        if reason is None:
+            return
+        seen = self.__dict__.setdefault("_fallback_warned", set())
+        if (where, reason) in seen:
+            return
+        seen.add((where, reason))
+        import warnings
+        warnings.warn(f"{type(self).__name__}.{where}: RES5_BACKEND is 'hip' but this call runs Res5 on torch.conv2d (the stock "
+                      f"library path, ~8x slower): {reason}", RuntimeWarning, stacklevel=3)
 
     def _needs_graph(self, features: List[torch.Tensor]) -> bool:
         return torch.is_grad_enabled() and (features[0].requires_grad or any(p.requires_grad for p in self.res5.parameters()))
@@ -350,6 +385,7 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
     def _res5_grid(self, feature: torch.Tensor, nhwc: Optional[torch.Tensor] = None) -> torch.Tensor:
         """roi_emb_heads.py:323: self.res5(features) on the whole res4 grid -> [N, C5, H/2, W/2]."""
         if not self._train_path_ok([feature]):
+            self._warn_stock_fallback("_res5_grid", [feature])
             return self.res5(feature)
         from .. import res5_train
         if nhwc is None:
@@ -381,6 +417,7 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
                                      overflow_check=self.res5_overflow_check, on_overflow=self._warn_overflow)
             return y if pooled else y.view(R, o, o, y.shape[1]).permute(0, 3, 1, 2)
         if not self._fused_path_ok(features):
+            self._warn_stock_fallback("_shared_roi_transform", features)
             x = self.pooler(features, boxes)                 # :244
             x = self.res5(x)                                 # :245
             return self._pooled_mean(x) if pooled else x
@@ -420,8 +457,9 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         import warnings
         self.res5.backward_guard_tripped()
         warnings.warn("a remembered split-operand weight scale stopped covering its weight during the previous step's Res5 backward "
-                      "(weights grew 8x within 64 steps): that step's Res5 weight gradients may hold inf / NaN; the scales are "
-                      "chosen afresh from here on", RuntimeWarning, stacklevel=3)
+                      "(weights grew 8x within 64 steps): that backward's Res5 gradients were ZEROED on the device (the step was "
+                      "skipped for the Res5 weights and the feature map, GradScaler-style; no inf / NaN was applied); the scales "
+                      "are chosen afresh from here on", RuntimeWarning, stacklevel=3)
 
     def _warn_overflow(self):
         if hasattr(self.res5, "_scales"):

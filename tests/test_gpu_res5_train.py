@@ -315,6 +315,67 @@ def test_res5_rows_gradients_vs_float64(pkg, oracle, dims, R, split):
     assert max(errs.values()) < 1e-4, errs
 
 
+def test_a_stale_backward_weight_scale_never_reaches_the_parameters(pkg, oracle):
+    """the split-arithmetic backward re-uses remembered power-of-two weight scales; when one stops covering its
+    (grown) weight the pack kernel raises the stage's "bwd" range-guard word and the GEMMs behind it produce inf / NaN.  Nothing
+    reads the word inside autograd -- so the pass itself must keep those values from an optimizer: every gradient it produced
+    is zero-filled on the device (locov_zero_if_raised), the word stays set for the next host read, and the step after that
+    (scales chosen afresh) is correct again."""
+    from locov_amd import res5_train
+    R, (in_ch, mid, out_ch) = 21, (128, 64, 256)
+    res5, params = _stage(pkg, oracle, in_ch, mid, out_ch, seed=5)
+    gen = torch.Generator().manual_seed(23)
+    x0 = torch.randn(R * 49, in_ch, generator=gen).cuda()
+    gy = torch.randn(R, out_ch, generator=gen).cuda()
+    named = dict(res5.named_parameters())
+    keys = _weight_keys(params)
+
+    def step():
+        res5.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        (res5_train.res5_rows(res5, x, R, 7, 7, pooled=True, split=True) * gy).sum().backward()
+        torch.cuda.synchronize()
+        return x.grad.clone(), {k: named[k].grad.clone() for k in keys}
+
+    gx_ref, gw_ref = step()
+    assert not res5.backward_guard_raised(x0.device) and float(gx_ref.abs().max()) > 0 and all(float(g.abs().max()) > 0 for g in gw_ref.values())
+    # an "optimizer step" (every weight's version moves: all packings are redone) and remembered BACKWARD scales 2^14 too large
+    with torch.no_grad():
+        for k in keys:
+            named[k].add_(0.0)
+    poisoned = 0
+    for key, (scale, _) in list(res5._scales.items()):
+        if isinstance(key[1], str):                              # (id(conv), "t" / "uflip" / "flip9"): the backward's operands
+            res5._scales[key] = (scale * 2.0 ** 14, 0)
+            poisoned += 1
+    assert poisoned >= 9
+    gx, gw = step()
+    for name, g in [("x0", gx)] + list(gw.items()):
+        assert bool(torch.isfinite(g).all()), name
+        assert float(g.abs().max()) == 0.0, f"{name}: the skipped pass must leave zeros, not partial gradients"
+    assert res5.backward_guard_raised(x0.device)                    # ... and says so at the next host read (which drops the scales)
+    assert not res5.backward_guard_raised(x0.device)
+    gx2, gw2 = step()
+    assert torch.equal(gx2, gx_ref) and all(torch.equal(gw2[k], gw_ref[k]) for k in keys)
+    assert not res5.backward_guard_raised(x0.device)
+
+
+def test_zero_if_raised(pkg):
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(3)
+    ts = [torch.randn(n, generator=g).cuda() for n in (1, 3, 4, 1000, 70001)] + [None, torch.zeros(0, device="cuda")]
+    ts.append(torch.randn(16, 37, generator=g).cuda()[1:])       # not 16-byte aligned
+    keep = [t.clone() if t is not None else None for t in ts]
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.zero_if_raised(ts, word)
+    assert all(t is None or torch.equal(t, k) for t, k in zip(ts, keep))
+    word.fill_(1)
+    ops.zero_if_raised(ts + [torch.randn(5, generator=g).cuda() for _ in range(30)], word)       # more than one launch's list
+    assert all(t is None or float(t.abs().sum()) == 0.0 for t in ts)
+    with pytest.raises(Exception):
+        ops.zero_if_raised([torch.zeros(4, 4, device="cuda").t()], word)
+
+
 @pytest.mark.parametrize("split", [False, True], ids=["f32mfma", "f16x2"])
 @pytest.mark.parametrize("dims,N,H,W", [((128, 64, 256), 2, 26, 43), ((1024, 512, 2048), 2, 50, 84)])
 def test_res5_grid_gradients_vs_float64(pkg, oracle, dims, N, H, W, split):

@@ -348,6 +348,75 @@ def test_full_size_logits_vs_oracle(pkg, oracle, dim, res5_dtype):
     assert dev16 <= 5e-2, dev16                                                          # reported deviation from pure fp32
 
 
+def test_bench_kernel_mix_vs_oracle(pkg, oracle):
+    """the kernels the bench line is timed on, against the oracle.  At 1 x 1000 proposals
+    (test_full_size_logits_vs_oracle) conv1 and the Winograd-domain GEMMs stay below the 1 024-tile threshold and run the 128x128
+    kernel; here 4 x 1000 proposals of 1333x800 images, 1203-class bank, default arithmetic, put every launch kind of
+    gemm_split_big_kernel (plain / batched / mean-fused / with the Winograd input transform: timing classes 9 / 10 / 11 / 8,
+    include/locov_hip.h) on the path -- asserted -- and the logits must still be within north_star's 1e-4 of
+    oracle.roi_head_forward's pieces (ROIAlign 14x14 -> Res5 -> mean -> FCs -> similarity; ~15 s of host time)."""
+    import ctypes
+    from locov_amd import _lib
+    from locov_amd.structures import Boxes, ShapeSpec
+    n_img, R = 4, 1000
+    rng = np.random.default_rng(404)
+    feat = rng.standard_normal((n_img, 1024, 50, 84)).astype(np.float32)
+    boxes = [oracle.synth_boxes(rng, R) for _ in range(n_img)]
+    params = oracle.make_res5_params(404)
+    bfs = []
+    for i in range(n_img):                                   # one image at a time: the [1000,1024,14,14] intermediate is 0.8 GB
+        pooled = oracle.roi_pooler([feat[i:i + 1]], [boxes[i]], 14, (1.0 / 16,), 0)
+        bfs.append(oracle.spatial_mean(oracle.res5_stage(pooled, params).numpy()))
+        del pooled
+    box_features = np.concatenate(bfs)
+    cfg = pkg.config.get_cfg()
+    cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
+    cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED = True
+    cfg.MODEL.ROI_HEADS.NAME = "EmbeddingProposalsRes5ROIHeads"
+    heads = pkg.build_roi_heads(cfg, {"res4": ShapeSpec(channels=1024, stride=16)})
+    assert heads.res5_dtype == "f16x2" and heads.res5_backend == "hip"          # the bench's default arithmetic
+    heads.res5.load_state_dict(params)
+    h = oracle.synth_head(np.random.default_rng(405), 2048, 768, 1203)
+    bp = heads.box_predictor
+    with torch.no_grad():
+        bp.emb_pred.weight.copy_(torch.from_numpy(h["emb_w"]))
+        bp.emb_pred.bias.copy_(torch.from_numpy(h["emb_b"]))
+        bp.bbox_pred.weight.copy_(torch.from_numpy(h["bbox_w"]))
+        bp.bbox_pred.bias.copy_(torch.from_numpy(h["bbox_b"]))
+    heads = heads.cuda().eval()
+    bp.set_class_embeddings(h["cls_w"])
+    heads.num_classes = bp.num_classes
+    want_scores, want_deltas, _ = oracle.box_predictor_forward(box_features, h["emb_w"], h["emb_b"], h["bbox_w"], h["bbox_b"], h["cls_w"])
+    lib = _lib.load()
+    featd = dev(feat)
+    bx = [Boxes(torch.from_numpy(b).cuda()) for b in boxes]
+    lib.locov_gemm_timing_enable(1)
+    try:
+        with torch.no_grad():
+            bf = heads._shared_roi_transform([featd], bx, pooled=True)          # roi_emb_heads.py:355-356, as bench.py's step_s2
+            scores, deltas = bp(bf)                                             # :357
+        torch.cuda.synchronize()
+        launches = {}
+        for cls in (5, 8, 9, 10, 11, 0):
+            n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+            _lib.check(lib.locov_gemm_timing_read(cls, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)))
+            launches[cls] = n.value
+    finally:
+        lib.locov_gemm_timing_enable(0)
+    # the bench's mix: 2 x conv1 + input transform (8), conv3 of blocks 0-1 (9), 3 Winograd-domain batched launches (10), the
+    # mean-fused conv3 (11) on the 256x256 tile; map GEMM + the two predictor GEMMs on the 128x128 one (5); nothing on the f32 MFMA
+    # but bbox_pred (N = 4)
+    assert launches[8] == 2 and launches[9] == 2 and launches[10] == 3 and launches[11] == 1, launches
+    assert launches[5] == 3, launches
+    assert tuple(scores.shape) == (n_img * R, 1204)
+    ferr = np.abs(bf.cpu().numpy() - box_features).max() / np.abs(box_features).max()
+    assert ferr <= 2e-5, ferr
+    err = np.abs(scores.cpu().numpy() - want_scores).max()
+    assert err <= 1e-4, err                                                     # north_star gate
+    np.testing.assert_allclose(deltas.cpu().numpy(), want_deltas, atol=1e-5)
+    assert np.all(scores.cpu().numpy()[:, -1] == 0)
+
+
 def test_full_size_head_properties(pkg, oracle):
     """BASELINE.json's full size (1333x800 map, 4 x 1000 proposals, Res5 1024 -> 2048, 1203-class bank): the
     size-independent properties of the path (the oracle comparison at 1 x 1000 is test_full_size_logits_vs_oracle):

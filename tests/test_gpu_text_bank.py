@@ -99,6 +99,34 @@ def test_packed_bank_follows_the_weight_and_bias_is_honoured(pkg, oracle):
         assert (s4 - ref).abs().max() <= 1e-6
 
 
+def test_same_size_bank_swaps_never_score_against_the_previous_bank(pkg, oracle):
+    """every swap builds a fresh nn.Linear (version 0) and the freed bank's address can be handed to the next
+    bank of the same shape -- a (data_ptr, _version) cache key then matches a different tensor.  Two different banks with the
+    same K swapped back and forth, on the split-operand similarity GEMM (the cached packing) and the bf16 one."""
+    rng = np.random.default_rng(14)
+    for sim_dtype in ("fp32", "bf16"):
+        bp = _predictor(pkg, sim_dtype)
+        assert bp.fc_dtype == "f16x2"
+        banks = [_bank(rng, 47), _bank(rng, 47)]
+        x = rng.standard_normal((96, 256)).astype(np.float32)
+        xd = torch.from_numpy(x).cuda()
+        w = {k: v.detach().cpu().numpy() for k, v in bp.state_dict().items()}
+        seen_ptrs = set()
+        for i in range(6):
+            m = banks[i % 2]
+            bp.set_class_embeddings(m)                       # the previous cls_score (and its weight) is dropped here
+            torch.cuda.synchronize()
+            seen_ptrs.add(bp.cls_score.weight.data_ptr())
+            with torch.no_grad():
+                scores, _ = bp(xd)
+            want, _, _ = oracle.box_predictor_forward(x, w["emb_pred.weight"], w["emb_pred.bias"], w["bbox_pred.weight"],
+                                                      w["bbox_pred.bias"], m)
+            tol = 1e-4 if sim_dtype == "fp32" else 5e-2
+            assert np.abs(scores.cpu().numpy() - want).max() <= tol, (sim_dtype, i)
+        # (the allocator did recycle addresses in this loop on the test box: the stale-key failure was reachable)
+        assert len(seen_ptrs) <= 6
+
+
 def test_nms_per_class_fallback_on_the_device(pkg, monkeypatch):
     from locov_amd.roi_heads import box_emb_head as beh
     g = torch.Generator().manual_seed(21)

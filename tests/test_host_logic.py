@@ -385,3 +385,38 @@ def test_bench_refuses_a_pmc_traffic_record_taken_on_other_sources(monkeypatch):
     monkeypatch.undo()
     args.proposals = wl["proposals"] + 1
     assert bench.recorded_traffic(args, "gemm_split") is None
+
+
+def test_stock_library_fallback_is_announced_once_with_the_failed_condition(lsm_cfg):
+    """with RES5_BACKEND "hip" a call that cannot take the hand-written Res5 path (odd pooler size,
+    non-FrozenBN, grouped 3x3, channels not a multiple of 32, host tensors, a dtype without a backward) runs torch.conv2d --
+    that must be said once, naming the condition; "miopen" as the configured backend is a choice and stays silent."""
+    import warnings
+    heads = locov_amd.build_roi_heads(lsm_cfg, {"res4": ShapeSpec(channels=1024, stride=16)})
+    feat = torch.zeros(1, 1024, 8, 8)
+    assert heads._rows_path_reason([feat]) == "the feature map is on cpu"
+    with pytest.warns(RuntimeWarning, match=r"_shared_roi_transform: RES5_BACKEND is 'hip' but .*the feature map is on cpu"):
+        heads._warn_stock_fallback("_shared_roi_transform", [feat])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                   # the second time: nothing
+        heads._warn_stock_fallback("_shared_roi_transform", [feat])
+    with pytest.warns(RuntimeWarning, match="_res5_grid"):               # another call site is its own announcement
+        heads._warn_stock_fallback("_res5_grid", [feat])
+    assert "1000 input channels" in heads._rows_path_reason([torch.zeros(1, 1000, 8, 8)])
+    assert "2 feature levels" in heads._rows_path_reason([feat, feat])
+    heads.pooler.output_size = (7, 7)
+    assert "7x7 is not square and even" in heads._rows_path_reason([feat])
+    heads.pooler.output_size = (14, 14)
+    heads.res5[1].conv2.groups = 2
+    assert "ungrouped" in heads._rows_path_reason([feat])
+    heads.res5[1].conv2.groups = 1
+    heads.res5_backend = "miopen"
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        heads._warn_stock_fallback("forward", [feat])
+    # and the call site really warns before it takes the stock path (the pooler then refuses host tensors: no CPU fallback below it)
+    heads.res5_backend = "hip"
+    heads.__dict__.pop("_fallback_warned", None)
+    with pytest.warns(RuntimeWarning, match="stock library path"):
+        with pytest.raises(Exception):
+            heads._shared_roi_transform([feat], [Boxes(torch.tensor([[0.0, 0.0, 32.0, 32.0]]))])
