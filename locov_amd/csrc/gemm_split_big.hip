@@ -36,8 +36,17 @@ namespace {
 constexpr int GBM = 256, GBN = 256, GNW = 8, GNT = 64 * GNW;
 constexpr int GTM = 128, GTN = 64;                  // a wave's sub-tile: 8 x 4 blocks of 16 x 16
 constexpr int GSTAGE = (GBM + GBN) * WROWB;         // 64 KB per stage
-constexpr int GEPS = GTN + 4;                       // epilogue staging pitch (floats)
-constexpr int GLDS = 2 * GSTAGE > GNW * 64 * GEPS * 4 ? 2 * GSTAGE : GNW * 64 * GEPS * 4;
+// Epilogue staging: a wave's 64 x 64 half in its private LDS area, UNPADDED rows of 64 floats with the 16-float column blocks of
+// rows 4..7 (mod 8) swapped pairwise (column ^ 16): the accumulator dump (ds_write_b32; lanes 0-15 / 16-31 of a service group hold
+// rows 4 apart) and the row reads (ds_read_b128; a 16-lane service group -- lanes {0-3, 12-15, 20-27} -- spans two adjacent rows
+// of one 4-row group) are then both bank-conflict-free.  The padded pitch of 68 floats this replaces made every one of those reads
+// 2-way conflicted on 4 banks (rows r and r + 1 shifted by 4 banks: SQ_LDS_BANK_CONFLICT = tiles x 8 waves x 32 reads x 4 =
+// 12.5 M per conv3 launch, profiles/r03_pmc_mfma_util.json; the Winograd-input form, which does not use this staging, showed 0).
+constexpr int GEPS = GTN;                           // epilogue staging pitch (floats)
+__device__ __forceinline__ int eps_swz(int row) { return ((row >> 2) & 1) * 16; }
+constexpr int GLDS_WINO = GBM * (GBN / 2 + 4) * 4;   // MODE_WINO's finished half tile [256][128 + 4] (below)
+constexpr int GLDS_KE = 2 * GSTAGE > GNW * 64 * GEPS * 4 ? 2 * GSTAGE : GNW * 64 * GEPS * 4;
+constexpr int GLDS = GLDS_KE > GLDS_WINO ? GLDS_KE : GLDS_WINO;
 constexpr int GCH = 4;                              // LDS-DMA pieces (8 rows each) per wave, operand and K-tile
 static_assert(GLDS <= 160 * 1024, "one workgroup per CU: all of the LDS, no more");
 
@@ -126,16 +135,22 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
         a_voff[i] = (unsigned)((((a_ok ? gm : m0) - m0) * lda * 4) + (((lane & 7) ^ wswz(row)) * 16));
         b_voff[i] = (unsigned)(((int64_t)((gn < N ? gn : N - 1) - n0) * K * 4) + (((lane & 7) ^ wswz(row)) * 16));
     }
+#ifndef LOCOV_BIG_A_AUX
+#define LOCOV_BIG_A_AUX 0                                  // developer A/B: cache policy bits of the operand DMAs (2 = nt)
+#endif
+#ifndef LOCOV_BIG_B_AUX
+#define LOCOV_BIG_B_AUX 0
+#endif
     auto dma = [&](int stage) {
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a_base), 0, 0xffffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b_base), 0, 0xffffffff, 0x00020000);
 #pragma unroll
         for (int i = 0; i < GCH; i++) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                ra, (__attribute__((address_space(3))) void *)(ldsb + stage * GSTAGE + (wave * GCH + i) * 8 * WROWB), 16, a_voff[i], 0, 0, 0);
+                ra, (__attribute__((address_space(3))) void *)(ldsb + stage * GSTAGE + (wave * GCH + i) * 8 * WROWB), 16, a_voff[i], 0, 0, LOCOV_BIG_A_AUX);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                 rb, (__attribute__((address_space(3))) void *)(ldsb + stage * GSTAGE + GBM * WROWB + (wave * GCH + i) * 8 * WROWB), 16,
-                b_voff[i], 0, 0, 0);
+                b_voff[i], 0, 0, LOCOV_BIG_B_AUX);
         }
         a_base += BK * 4;
         b_base += BK * 4;
@@ -342,6 +357,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
     const float inv_a_scale = 1.f / a_scale;
     float omax = 0.f;
     constexpr int LPR = GTN / 4, RPI = 64 / LPR, NIT = 64 / RPI;      // 16 lanes per row, 4 rows per instruction, 16 instructions per half
+    static_assert(RPI == 4, "eps_swz: one read instruction covers one 4-row group (a uniform column swap per instruction)");
     const int c4 = (lane % LPR) * 4, rr = lane / LPR;
     const int n = n0 + wn + c4;
     const bool n_ok = n < N;
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) ep[(i * 16 + 4 * kg + r) * GEPS + j * 16 + l16] = acc[4 * h + i][j][r];
+                for (int r = 0; r < 4; r++) ep[(i * 16 + 4 * kg + r) * GEPS + ((j * 16 + l16) ^ eps_swz(4 * kg))] = acc[4 * h + i][j][r];
         if (!LOCOV_BIG_EPI_FEWBAR) __syncthreads();
         asm volatile("" ::: "memory");
         if (n_ok) {
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int it = q4 + u;
-                    f32x4 v = *reinterpret_cast<const f32x4 *>(ep + (it * RPI + rr) * GEPS + c4);
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(ep + (it * RPI + rr) * GEPS + (c4 ^ eps_swz(it * RPI)));
                     v = v * sc + sh;
                     if (epi.residual) v += res_split ? unsplit4(res[u], odd_lane, inv_a_scale) : res[u];
                     if (relu) {
@@ -402,7 +418,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
                         v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
                     }
                     if (SEGSUM) {
-                        *reinterpret_cast<f32x4 *>(ep + (it * RPI + rr) * GEPS + c4) = v;        // finished value back in place
+                        *reinterpret_cast<f32x4 *>(ep + (it * RPI + rr) * GEPS + (c4 ^ eps_swz(it * RPI))) = v;        // finished value back in place
                     } else if (out_split) {
                         omax = fmaxf(fmaxf(omax, fabsf(v[0])), fabsf(v[1]));
                         omax = fmaxf(fmaxf(omax, fabsf(v[2])), fabsf(v[3]));
@@ -424,11 +440,10 @@ __global__ __launch_bounds__(GNT, 1) void gemm_split_big_kernel(const float *__r
                 const int64_t chunk = grow0 >> 6;
                 int pos = (int)(grow0 % seg), slot = 0;
                 float sum = 0.f;
-                const float *colp = ep + lane;
                 for (int i0 = 0; i0 < 64; i0 += 8) {              // eight LDS reads in flight, then the (order-preserving) adds
                     float rv[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) rv[u] = colp[(i0 + u) * GEPS];
+                    for (int u = 0; u < 8; u++) rv[u] = ep[(i0 + u) * GEPS + (lane ^ eps_swz(u))];        // (i0 is a multiple of 8)
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         if (i0 + u < rows_valid) {

@@ -494,9 +494,10 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
         # The entry KEEPS the tensor and compares by identity: a (data_ptr, _version) key alone can match a different tensor --
         # every bank swap builds a fresh nn.Linear (version 0 again) and the caching allocator may hand the freed bank's address
         # to the next one of the same shape (Res5Stage._split does the same).
+        # (... and the storage address stays in the key: `w.data = other` swaps the storage under the SAME object and version)
         hit = self._split_cache.get(tag)
-        if hit is None or hit[0] is not w or hit[1] != w._version:
-            hit = self._split_cache[tag] = (w, w._version, ops.split_pack(w.detach().contiguous()))
+        if hit is None or hit[0] is not w or hit[1] != (w._version, w.data_ptr()):
+            hit = self._split_cache[tag] = (w, (w._version, w.data_ptr()), ops.split_pack(w.detach().contiguous()))
         return hit[2]
 
     def _fc_split_ok(self, x: torch.Tensor) -> bool:
@@ -580,7 +581,7 @@ class EmbeddingFastRCNNOutputLayers(FastRCNNOutputLayers):
     def _bank_key(self):
         # (the tensor object itself is part of the key -- held, so its id cannot be recycled -- next to its version: see _split_weight)
         w = self.cls_score.weight
-        return (w, w._version)
+        return (w, (w._version, w.data_ptr()))
 
     def _packed_bank(self):
         """bf16 copy of the bank for the bf16 MFMA similarity GEMM, re-packed whenever cls_score.weight is re-assigned,

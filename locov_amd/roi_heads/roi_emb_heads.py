@@ -232,10 +232,9 @@ class SampleAllROIHeads(ROIHeads):
     def _backward_guard_tripped(self) -> None:
         pass
 
-    @torch.no_grad()
-    def label_and_sample_proposals(self, proposals: List[Instances], targets: List[Instances]) -> List[Instances]:
-        if self.proposal_append_gt:
-            proposals = add_ground_truth_to_proposals(targets, proposals)
+    def _label_and_sample_per_image(self, proposals: List[Instances], targets: List[Instances]) -> List[Instances]:
+        """The per-image form of label_and_sample_proposals (any matcher object: one that asserts a non-negative quality matrix
+        cannot take the batch form's -1 mask).  Same results, ~4x the launches."""
         sampled, bg_counts, totals = [], [], []
         matched = [self._match_one_image(props, tgt) for props, tgt in zip(proposals, targets)]     # no host value needed
         # ONE host read for the whole batch: population sizes, the reference's two validity asserts, and -- it costs nothing
@@ -265,6 +264,133 @@ class SampleAllROIHeads(ROIHeads):
             storage = get_event_storage()
             storage.put_scalar("roi_head/num_fg_samples", float(np.mean(tot - bg)))
             storage.put_scalar("roi_head/num_bg_samples", float(np.mean(bg)))
+        return sampled
+
+
+    def _match_batch(self, proposals: List[Instances], targets: List[Instances]):
+        """The device half of labelling a whole BATCH in one set of launches (what _match_one_image does per image: the batch of
+        a training step is 4 images x ~60 small launches -- a third of the step's launch count): IoU of every ground-truth box
+        with every proposal of the batch, pairs from different images masked to -1 so that they can never be the maximum
+        (the same argmax, hence the same matches and labels, as the per-image form), the reference's class labels, ONE pair
+        of sorts for the sampling orders (key = image * 4 + [not in the population] * 2 + U[0,1): image-major, population
+        first, uniformly random inside it), per-image population sizes and the two validity bits.
+        Returns (gt_index [global], labels, pos_order, neg_order, rows [B,4] = n_pos, n_neg, bad IoU, degenerate fg box)."""
+        dev = proposals[0].proposal_boxes.tensor.device
+        n_r = [len(p) for p in proposals]
+        n_g = [len(t) for t in targets]
+        B = len(proposals)
+        box = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+        img_r = torch.cat([torch.full((n,), i, dtype=torch.int64, device=dev) for i, n in enumerate(n_r)])
+        counts_dtype = torch.int64
+        if sum(n_g) > 0:
+            gtb = torch.cat([t.gt_boxes.tensor for t in targets], dim=0)
+            gtc = torch.cat([t.gt_classes for t in targets], dim=0)
+            img_g = torch.cat([torch.full((n,), i, dtype=torch.int64, device=dev) for i, n in enumerate(n_g)])
+            iou = pairwise_iou(Boxes(gtb), Boxes(box))                         # [sum M, sum R]
+            same = img_g[:, None] == img_r[None, :]
+            bad_iou = (~(iou >= 0) & same).any()
+            quality = torch.where(same, iou, torch.full((), -1.0, dtype=iou.dtype, device=dev))
+            matcher = self.proposal_matcher
+            was, matcher.check_quality = getattr(matcher, "check_quality", True), False
+            try:
+                gt_index, match_label = matcher(quality)                       # gt_index: row of the CONCATENATED targets
+            finally:
+                matcher.check_quality = was
+            labels = gtc[gt_index]                                              # ROIHeads._sample_proposals' labelling
+            labels[match_label == 0] = self.num_classes
+            labels[match_label == -1] = -1
+        else:
+            gt_index = torch.zeros(box.shape[0], dtype=torch.int64, device=dev)
+            labels = torch.zeros_like(gt_index) + self.num_classes
+            bad_iou = torch.zeros((), dtype=torch.bool, device=dev)
+        pos = (labels != -1) & (labels != self.num_classes)
+        neg = labels == self.num_classes
+        k = torch.rand((2, box.shape[0]), device=dev, dtype=torch.float64)      # (float64: the image term must not cost the draw its bits)
+        base = img_r.to(k.dtype) * 4.0
+        pos_order = torch.argsort(k[0] + (~pos).to(k.dtype) * 2.0 + base)
+        neg_order = torch.argsort(k[1] + (~neg).to(k.dtype) * 2.0 + base)
+        degenerate = ~(((box[:, 2] - box[:, 0]) > 0) & ((box[:, 3] - box[:, 1]) > 0)) & pos      # (NaN counts as invalid, as upstream)
+        per_image = torch.zeros((3, B), dtype=counts_dtype, device=dev)
+        per_image.index_add_(1, img_r, torch.stack([pos, neg, degenerate]).to(counts_dtype))
+        rows = torch.cat([per_image[:2], bad_iou.to(counts_dtype).expand(1, B), per_image[2:]], dim=0).t().contiguous()
+        return gt_index, labels, pos_order, neg_order, rows
+
+    @staticmethod
+    def _gather_split(values, index: torch.Tensor, sizes: List[int]):
+        """values: one field of every image (tensors or Boxes-like objects with `.tensor`) -> that field of the sampled
+        instances: ONE concatenation and ONE gather for the batch, handed out as per-image views."""
+        v0 = values[0]
+        boxes_like = not isinstance(v0, torch.Tensor) and hasattr(v0, "tensor")
+        flat = torch.cat([v.tensor if boxes_like else v for v in values], dim=0)[index]
+        parts = torch.split(flat, sizes, dim=0)
+        return [type(v0)(p) for p in parts] if boxes_like else list(parts)
+
+    @torch.no_grad()
+    def label_and_sample_proposals(self, proposals: List[Instances], targets: List[Instances]) -> List[Instances]:
+        if self.proposal_append_gt:
+            proposals = add_ground_truth_to_proposals(targets, proposals)
+        if not proposals:
+            return []
+        if type(self.proposal_matcher) is not Matcher:
+            return self._label_and_sample_per_image(proposals, targets)
+        gt_index, labels, pos_order, neg_order, rows = self._match_batch(proposals, targets)        # no host value needed
+        # ONE host read for the whole batch: population sizes, the reference's two validity asserts, and -- it costs nothing
+        # here -- the range-guard words the previous step's Res5 backward may have raised (res5_train.Res5RowsFn.backward)
+        words = self._backward_guard_words(rows.device)
+        if words:
+            flat = torch.cat([rows.reshape(-1), torch.stack([w.reshape(()) for w in words]).to(rows.dtype)]).cpu()
+            rows_h, guard_h = flat[:rows.numel()].view(rows.shape), flat[rows.numel():]
+            if bool(guard_h.any()):
+                self._backward_guard_tripped()
+        else:
+            rows_h = rows.cpu()
+        assert not bool(rows_h[:, 2].any()), "Matcher: the match quality matrix has negative entries"
+        assert not bool(rows_h[:, 3].any()), "Input boxes to Box2BoxTransform are not valid!"
+        avail = rows_h[:, :2].tolist()
+        # subsample_labels' counts per image, then ONE gather per field for the batch (the sampled rows of image i are a slice of
+        # the two image-major orders: its foreground draws sit at the head of its segment of pos_order, likewise neg_order)
+        n_r = [len(p) for p in proposals]
+        n_g = [len(t) for t in targets]
+        off_r = np.concatenate([[0], np.cumsum(n_r)]).tolist()
+        off_g = np.concatenate([[0], np.cumsum(n_g)]).tolist()
+        pieces, sizes, bg_counts = [], [], []
+        for i, (n_pos_avail, n_neg_avail) in enumerate(avail):
+            num_pos = min(int(n_pos_avail), int(self.batch_size_per_image * self.positive_fraction))
+            num_neg = min(int(n_neg_avail), self.batch_size_per_image - num_pos)
+            pieces += [pos_order[off_r[i]:off_r[i] + num_pos], neg_order[off_r[i]:off_r[i] + num_neg]]
+            sizes.append(num_pos + num_neg)
+            bg_counts.append(num_neg)
+        picked = torch.cat(pieces, dim=0)                                       # rows of the concatenated proposals
+        classes = torch.split(labels[picked], sizes)
+        src_global = gt_index[picked]
+        prop_fields = list(proposals[0].get_fields().keys())
+        sampled = [type(p)(p.image_size) for p in proposals]
+        for name in prop_fields:
+            for out, part in zip(sampled, self._gather_split([p.get(name) for p in proposals], picked, sizes)):
+                out.set(name, part)
+        for out, cls in zip(sampled, classes):
+            out.gt_classes = cls
+        # every field of the matched target (:97-100) -- images without ground truth carry none
+        with_gt = [i for i in range(len(targets)) if n_g[i] > 0]
+        if with_gt:
+            tgt_fields = [k for k in targets[with_gt[0]].get_fields() if not sampled[with_gt[0]].has(k)]
+            if len(with_gt) == len(targets):
+                for name in tgt_fields:
+                    for out, part in zip(sampled, self._gather_split([t.get(name) for t in targets], src_global, sizes)):
+                        out.set(name, part)
+            else:
+                src_parts = torch.split(src_global, sizes)
+                for i in with_gt:
+                    src = src_parts[i] - off_g[i]
+                    for name in tgt_fields:
+                        sampled[i].set(name, targets[i].get(name)[src])
+        for out, cls in zip(sampled, classes):
+            out.set("fg_proposal", (cls != self.num_classes).to(cls.dtype))
+        bg = np.asarray(bg_counts, dtype=np.float64)
+        tot = np.asarray(sizes, dtype=np.float64)
+        storage = get_event_storage()
+        storage.put_scalar("roi_head/num_fg_samples", float(np.mean(tot - bg)))
+        storage.put_scalar("roi_head/num_bg_samples", float(np.mean(bg)))
         return sampled
 
 

@@ -190,3 +190,29 @@ def test_box_reg_loss_ignores_non_finite_background_predictions():
     assert torch.isfinite(got) and float(got) == float(want)
     assert torch.isfinite(dirty.grad).all() and torch.equal(dirty.grad, clean.grad)
     assert not dirty.grad[[1, 2, 4, 5, 7, 8, 9, 11]].any()
+
+
+def test_batched_labelling_equals_the_per_image_form(oracle):
+    """label_and_sample_proposals labels the whole batch in one set of launches (IoU of all targets x all proposals, pairs of
+    different images masked out).  With a budget that takes EVERY candidate the draw is no longer random, so the batch form and
+    the per-image form must return the same sets: rows, classes, foreground flags and every copied target field."""
+    heads = _heads(True, 10 ** 6, 1.0, "cpu")
+    rng = np.random.default_rng(11)
+    props, targets, _ = _batch(oracle, rng, "cpu", n_img=4, r=90, n_gt=5)
+    for t in targets:                                            # an extra target field must travel too (:97-100)
+        t.set("gt_tag", torch.arange(len(t), dtype=torch.float32) + 0.5)
+    a = heads.label_and_sample_proposals(props, targets)
+    from locov_amd.roi_heads.roi_emb_heads import add_ground_truth_to_proposals
+    b = heads._label_and_sample_per_image(add_ground_truth_to_proposals(targets, props), targets)
+
+    def canon(inst):
+        order = np.lexsort(inst.proposal_boxes.tensor.numpy().T[::-1])
+        return {k: (v.tensor if hasattr(v, "tensor") else v).numpy()[order] for k, v in inst.get_fields().items()}
+    for x, y, t in zip(a, b, targets):
+        cx, cy = canon(x), canon(y)
+        assert set(cx) == set(cy) and len(x) == len(y)
+        for k in cx:
+            if len(t) == 0 and k in ("gt_boxes", "gt_tag"):
+                continue
+            np.testing.assert_array_equal(cx[k], cy[k], err_msg=k)
+    assert not a[1].has("gt_boxes") and not b[1].has("gt_boxes")          # the image without ground truth carries no target fields
