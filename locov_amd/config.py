@@ -128,6 +128,7 @@ def get_cfg() -> CfgNode:
                 # extension: with "f16x2" every split launch ORs a range-guard word when an activation left fp16's range; the
                 # heads read it once per call and repeat the call on the f32 MFMA (with a warning) if it is set
                 "RES5_OVERFLOW_CHECK": True,
+                "RES5_TRAIN_GUARD": "deferred",      # training forwards: act on the range guard on the device ("sync": read it every step)
             },
             "RESNETS": {
                 "NUM_GROUPS": 1, "WIDTH_PER_GROUP": 64, "RES2_OUT_CHANNELS": 256,

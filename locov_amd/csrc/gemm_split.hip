@@ -38,7 +38,7 @@
 #define LOCOV_SPLIT_MINWG 2   // launch-bounds occupancy hint of the 128x128 tile: 2 workgroups per CU (3: a 168-register budget, see DESIGN)
 #endif
 #ifndef LOCOV_SPLIT_ABLATE
-#define LOCOV_SPLIT_ABLATE 0  // ENERGY-ablation builds only (tools/dbg_power.py; results are wrong on purpose): 1 no staging DMA in the
+#define LOCOV_SPLIT_ABLATE 0  // ENERGY-ablation builds only (tools/attic/dbg_power.py; results are wrong on purpose): 1 no staging DMA in the
 #endif                        // K-loop, 2 no fragment reads in the K-loop, 4 no MFMAs, 8 no epilogue; operands stay real data
 #ifndef LOCOV_STORE_AUX
 #define LOCOV_STORE_AUX 2     // cache policy bits of the epilogue's stores: 2 = nt (A/B: tools/make_variant.py ... -DLOCOV_STORE_AUX=0)
@@ -74,7 +74,7 @@ struct SegSum {
 // it then needs no conversion and takes W's road -- LDS DMA into unpadded, XOR-swizzled 128-byte rows -- instead of
 // buffer loads, 8 v_fma_mix + 2 v_max3 and two 8-byte LDS stores per 16-byte chunk.
 // LOCOV_KTRACE (tools/make_variant.py ktrace gemm_split.hip -DLOCOV_KTRACE=1; never the product): s_memtime stamps inside the
-// K-tile step of a few workgroups of the ASPLIT form, read back by tools/dbg_ktrace.py
+// K-tile step of a few workgroups of the ASPLIT form, read back by tools/attic/dbg_ktrace.py
 #ifdef LOCOV_KTRACE
 __device__ unsigned long long g_ktrace[4 * 16];
 #define KSTAMP(i) asm volatile("s_memtime %0" : "=s"(kt_[i]))

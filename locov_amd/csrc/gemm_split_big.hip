@@ -19,7 +19,7 @@
 // The tile ends on Bf, so Bg's registers take the next tile's first W pair behind the barrier and the next tile starts on
 // (A0', Bg'): f flips every tile.  The DMA of tile t+2 goes out right behind the barrier of tile t (all reads of its stage
 // are done by then) -- a full K-tile of matrix work (3 072 cycles per SIMD) ahead of its first use.
-// With one workgroup per CU nothing overlaps a tile's prologue and epilogue: 10.5-11.4 us per tile whatever K (tools/dbg_big_fixed_cost.py),
+// With one workgroup per CU nothing overlaps a tile's prologue and epilogue: 10.5-11.4 us per tile whatever K (tools/attic/dbg_big_fixed_cost.py),
 // a fifth of a K = 512 tile.  Resident workgroups, a staggered start and an earlier residual request were each measured and bought
 // nothing: hiding it takes matrix work running beside the epilogue, which 160 KB of LDS and 512 VGPRs
 // per SIMD do not leave room for at this tile size.
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void segsum64_finish_kernel(const float *__res
 // whose tile offsets fit 32 bits
 bool gemm_split_big_applicable(int64_t lda, int64_t ldc, int64_t M, int N, int K, const Epilogue &epi, const Batch &bt, const float *a_scale_dev)
 {
-    const char *fe = getenv("LOCOV_SPLIT_BIG");            // developer A/B (read per launch: tools/dbg_bigtile.py flips it): 0 never, 1 whenever legal
+    const char *fe = getenv("LOCOV_SPLIT_BIG");            // developer A/B (read per launch: tools/attic/dbg_bigtile.py flips it): 0 never, 1 whenever legal
     const int forced = fe ? atoi(fe) : -1;
     if (forced == 0) return false;
     if (!(epi.flags & LOCOV_GEMM_A_SPLIT) || epi.mask || epi.amax_out || a_scale_dev) return false;

@@ -27,12 +27,28 @@ __device__ __forceinline__ float4 load4(const __bf16 *p)
     return float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
 __device__ __forceinline__ void store4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
+// The pooled rows are consumed by a LATER kernel (GBs of other traffic in between), while the map slice they were gathered from
+// is re-read by every ROI of the image: `sc1` stores leave no copy of the written line in the XCD's L2 (MI355X_MICROARCH.md,
+// stores of each flavour), so the 3.2 GB of output no longer push the 2-4 MB map slice out of it.
+#ifndef LOCOV_POOL_STORE_AUX
+#define LOCOV_POOL_STORE_AUX 16                            // 0 = plain, 2 = nt, 16 = sc1, 17 = sc0 sc1 (developer A/B)
+#endif
+__device__ __forceinline__ void store4_out(float *p, const float4 &v)
+{
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const f32x4_t d = {v.x, v.y, v.z, v.w};
+    if (LOCOV_POOL_STORE_AUX == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+    else if (LOCOV_POOL_STORE_AUX == 17) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+    else if (LOCOV_POOL_STORE_AUX == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
+    else *reinterpret_cast<float4 *>(p) = v;
+}
 __device__ __forceinline__ void store4(__bf16 *p, const float4 &v)
 {
     bf16x4 o;
     o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
     *reinterpret_cast<bf16x4 *>(p) = o;
 }
+__device__ __forceinline__ void store4_out(__bf16 *p, const float4 &v) { store4(p, v); }
 
 // one tap = 4 consecutive channels through a raw buffer descriptor (byte offset in a VGPR, base in SGPRs)
 __device__ __forceinline__ float4 tap4(__amdgpu_buffer_rsrc_t r, unsigned off, float *)
@@ -84,8 +100,13 @@ __global__ __launch_bounds__(kNhwcThreads, WINO ? 6 : 1) void roi_align_nhwc_ker
     __shared__ AxisSampleN ytab[kMaxAxisN];
     __shared__ AxisSampleN xtab[kMaxAxisN];
 
-    const int slice = (int)(blockIdx.x % (unsigned)nslices);
-    const int64_t r = blockIdx.x / (unsigned)nslices;
+    // up to 8 slices: blockIdx % nslices = the slice = (round-robin dispatch) the XCD.  More than 8 (developer A/B,
+    // LOCOV_ROIALIGN_SLICES): passes of 8 slices, every ROI of pass p before any of pass p + 1, so that an XCD still works on ONE
+    // slice at a time
+    const unsigned per = nslices > 8 ? 8u : (unsigned)nslices, per_pass = per * (unsigned)R;
+    const unsigned pass = blockIdx.x / per_pass, rem = blockIdx.x - pass * per_pass;
+    const int slice = (int)(rem % per + pass * per);
+    const int64_t r = rem / per;
     const float *roi = rois + r * 5;
     const int b = (int)roi[0];
 
@@ -312,7 +333,7 @@ __global__ __launch_bounds__(kNhwcThreads, WINO ? 6 : 1) void roi_align_nhwc_ker
         if constexpr (WINO)
             *reinterpret_cast<float4 *>(wino_tile + bin * kWinoPitch + 4 * cq) = acc;
         else
-            store4(optr, acc);
+            store4_out(optr, acc);
         cq += kNhwcThreads;
         normalise();
     }

@@ -503,11 +503,15 @@ class RangeGuard:
     A guard belongs to ONE caller (a module and a stream): nothing else clears or reads it, so a reset enqueued by another
     module, stream or thread cannot hide a flag raised for this caller."""
 
-    def __init__(self, device):
+    def __init__(self, device, deferred: bool = False):
         self.device = torch.device(device)
         self.word = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.event = None
+        # deferred: nobody reads this word before the results are used -- whoever holds the guard zero-fills what the guarded
+        # launches produced ON THE DEVICE when it is set (zero_if_raised) and reads the word whenever it next talks to the host
+        # (the training forward: res5_train.Res5RowsFn / EmbeddingProposalsRes5ROIHeads.forward)
+        self.deferred = deferred
 
     def reset(self) -> None:
         self.word.zero_()

@@ -134,13 +134,21 @@ class Res5Stage(nn.Sequential):
         key = (kind, torch.device(device), torch.cuda.current_stream(device).cuda_stream)
         g = self._guards.get(key)
         if g is None:
-            g = self._guards[key] = ops.RangeGuard(device)
+            g = self._guards[key] = ops.RangeGuard(device, deferred=kind in self.DEFERRED_KINDS)
         return g
+
+    # guards nobody reads where they are raised: "bwd" (Res5RowsFn.backward) and "fwd_train" (the training forward of the ROI
+    # heads) -- the pass zero-fills its results on the device when the word is set, the word is read with the NEXT host read
+    DEFERRED_KINDS = ("bwd", "fwd_train")
+
+    def deferred_guards(self, device):
+        """[(kind, guard)] of every deferred guard of `device` (their words are read together with another host read)."""
+        dev = torch.device(device)
+        return [(kind, g) for (kind, d, _), g in self._guards.items() if kind in self.DEFERRED_KINDS and d == dev]
 
     def backward_guard_words(self, device):
         """Device words of every "bwd" guard of `device` (to be read together with another host read)."""
-        dev = torch.device(device)
-        return [g.word for (kind, d, _), g in self._guards.items() if kind == "bwd" and d == dev]
+        return [g.word for kind, g in self.deferred_guards(device) if kind == "bwd"]
 
     def backward_guard_tripped(self) -> None:
         """A remembered weight scale stopped covering its weight during a backward: forget the scales (they are chosen

@@ -109,6 +109,11 @@ class Res5RowsFn(torch.autograd.Function):
             saved, meta, out = Res5RowsFn._blocks(stage, x, H, W, False)
         ctx.stage, ctx.meta, ctx.geom, ctx.pooled = stage, meta, (R, H, W), pooled
         ctx.split = bool(split) and not _BWD_F32
+        # a DEFERRED guard held by the caller (the ROI heads' training forward): nothing reads it before the backward runs, so
+        # the backward must not turn the inf / NaN activations of an out-of-range forward into gradients -- it zero-fills them
+        # on the device when that word is set (the caller does the same with this forward's outputs)
+        active = ops.active_guard(x.device) if split else None
+        ctx.skip_words = [active.word] if active is not None and getattr(active, "deferred", False) else []
         ctx.nw = len(weights)
         ctx.save_for_backward(*saved)
         if pooled:
@@ -118,7 +123,10 @@ class Res5RowsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         if not ctx.split:
-            return Res5RowsFn._backward(ctx, grad_out, False)
+            grads = Res5RowsFn._backward(ctx, grad_out, False)
+            for w in ctx.skip_words:
+                ops.zero_if_raised(grads, w)
+            return grads
         # Split arithmetic.  What can leave fp16's range here is not data: the activations passed the forward's guard (the
         # weight-gradient GEMMs and the Winograd transforms see the same tensors at the same scales) and every gradient's
         # operand scale is chosen on the device from its own max |g|.  Only a REMEMBERED weight scale (Res5Stage._split: chosen
@@ -134,6 +142,8 @@ class Res5RowsFn(torch.autograd.Function):
         with ops.range_guard(guard):
             grads = Res5RowsFn._backward(ctx, grad_out, True)
         ops.zero_if_raised(grads, guard.word)          # (every gradient here is a freshly written contiguous tensor or a view of one)
+        for w in ctx.skip_words:
+            ops.zero_if_raised(grads, w)
         return grads
 
     @staticmethod

@@ -11,6 +11,7 @@ add_ground_truth_to_proposals, _sample_proposals, from_config).
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -232,6 +233,13 @@ class SampleAllROIHeads(ROIHeads):
     def _backward_guard_tripped(self) -> None:
         pass
 
+    def _deferred_guards(self, device):
+        """[(kind, RangeGuard)] whose words travel with the labelling read (none in the base class)."""
+        return []
+
+    def _deferred_guards_tripped(self, kinds) -> None:
+        pass
+
     def _label_and_sample_per_image(self, proposals: List[Instances], targets: List[Instances]) -> List[Instances]:
         """The per-image form of label_and_sample_proposals (any matcher object: one that asserts a non-negative quality matrix
         cannot take the batch form's -1 mask).  Same results, ~4x the launches."""
@@ -242,12 +250,13 @@ class SampleAllROIHeads(ROIHeads):
         avail = []
         if matched:
             rows = torch.stack([m[-1] for m in matched])
-            words = self._backward_guard_words(rows.device)
-            if words:
-                flat = torch.cat([rows.reshape(-1), torch.stack([w.reshape(()) for w in words]).to(rows.dtype)]).cpu()
+            guards = self._deferred_guards(rows.device)
+            if guards:
+                flat = torch.cat([rows.reshape(-1), torch.stack([g.word.reshape(()) for _, g in guards]).to(rows.dtype)]).cpu()
                 rows_h, guard_h = flat[:rows.numel()].view(rows.shape), flat[rows.numel():]
-                if bool(guard_h.any()):
-                    self._backward_guard_tripped()
+                tripped = {kind for (kind, _), v in zip(guards, guard_h.tolist()) if v}
+                if tripped:
+                    self._deferred_guards_tripped(tripped)
             else:
                 rows_h = rows.cpu()
             assert not bool(rows_h[:, 2].any()), "Matcher: the match quality matrix has negative entries"
@@ -327,23 +336,54 @@ class SampleAllROIHeads(ROIHeads):
 
     @torch.no_grad()
     def label_and_sample_proposals(self, proposals: List[Instances], targets: List[Instances]) -> List[Instances]:
+        return self._label_finish(self._label_begin(proposals, targets))
+
+    @torch.no_grad()
+    def _label_begin(self, proposals: List[Instances], targets: List[Instances]):
+        """The device half of label_and_sample_proposals: everything is enqueued, the few integers the host needs are on their
+        way to pinned memory behind an event -- and NOTHING waits.  A caller with independent device work (the whole-grid Res5
+        call of EmbeddingProposalsRes5ROIHeads.forward) enqueues it between _label_begin and _label_finish: the host then waits
+        for the labelling kernels only, with that work still queued behind them, instead of draining the GPU once per step."""
         if self.proposal_append_gt:
             proposals = add_ground_truth_to_proposals(targets, proposals)
         if not proposals:
-            return []
+            return {"done": []}
         if type(self.proposal_matcher) is not Matcher:
-            return self._label_and_sample_per_image(proposals, targets)
+            return {"done": self._label_and_sample_per_image(proposals, targets)}
         gt_index, labels, pos_order, neg_order, rows = self._match_batch(proposals, targets)        # no host value needed
         # ONE host read for the whole batch: population sizes, the reference's two validity asserts, and -- it costs nothing
-        # here -- the range-guard words the previous step's Res5 backward may have raised (res5_train.Res5RowsFn.backward)
-        words = self._backward_guard_words(rows.device)
-        if words:
-            flat = torch.cat([rows.reshape(-1), torch.stack([w.reshape(()) for w in words]).to(rows.dtype)]).cpu()
-            rows_h, guard_h = flat[:rows.numel()].view(rows.shape), flat[rows.numel():]
-            if bool(guard_h.any()):
-                self._backward_guard_tripped()
+        # here -- the deferred range-guard words of the previous step (Res5's backward, the training forward)
+        guards = self._deferred_guards(rows.device)
+        flat = rows.reshape(-1)
+        if guards:
+            flat = torch.cat([flat, torch.stack([g.word.reshape(()) for _, g in guards]).to(rows.dtype)])
+        event = None
+        if flat.is_cuda:
+            host = self.__dict__.get("_label_pinned")
+            if host is None or host.numel() < flat.numel() or host.dtype != flat.dtype:
+                host = self.__dict__["_label_pinned"] = torch.empty(max(flat.numel(), 256), dtype=flat.dtype).pin_memory()
+            host = host[:flat.numel()]
+            host.copy_(flat, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record(torch.cuda.current_stream(flat.device))
         else:
-            rows_h = rows.cpu()
+            host = flat
+        return {"proposals": proposals, "targets": targets, "gt_index": gt_index, "labels": labels, "pos_order": pos_order,
+                "neg_order": neg_order, "rows_shape": tuple(rows.shape), "host": host, "event": event, "guards": guards}
+
+    def _label_finish(self, st) -> List[Instances]:
+        if "done" in st:
+            return st["done"]
+        proposals, targets = st["proposals"], st["targets"]
+        gt_index, labels, pos_order, neg_order = st["gt_index"], st["labels"], st["pos_order"], st["neg_order"]
+        if st["event"] is not None:
+            st["event"].synchronize()                       # the step's one host wait: for the labelling kernels only
+        n_rows = st["rows_shape"][0] * st["rows_shape"][1]
+        flat = st["host"].clone() if st["event"] is not None else st["host"].cpu()
+        rows_h, guard_h = flat[:n_rows].view(st["rows_shape"]), flat[n_rows:]
+        tripped = {kind for (kind, _), v in zip(st["guards"], guard_h.tolist()) if v}
+        if tripped:
+            self._deferred_guards_tripped(tripped)
         assert not bool(rows_h[:, 2].any()), "Matcher: the match quality matrix has negative entries"
         assert not bool(rows_h[:, 3].any()), "Input boxes to Box2BoxTransform are not valid!"
         avail = rows_h[:, :2].tolist()
@@ -402,7 +442,7 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
     def __init__(self, *, in_features: List[str], pooler: ROIPooler, res5: nn.Module, box_predictor: nn.Module,
                  mask_head: Optional[nn.Module] = None, output_shape: Optional[int] = 0,
                  res5_backend: str = "hip", res5_conv3x3: str = "winograd", res5_dtype: str = "f16x2",
-                 res5_overflow_check: bool = True, **kwargs):
+                 res5_overflow_check: bool = True, res5_train_guard: str = "deferred", **kwargs):
         super().__init__(**kwargs)
         assert res5_backend in ("hip", "miopen") and res5_conv3x3 in ("winograd", "direct") and res5_dtype in ("fp32", "f16x2", "bf16")
         # extension: "f16x2" = fp32 GEMMs formed from split f16 operand pairs on the f16 matrix pipe (fp32-level
@@ -411,6 +451,10 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         # the split arithmetic's range guard: read the device flag once per call and, if an activation left fp16's range
         # (|x| >= 4094 at the activation scale), repeat the call on the f32 MFMA
         self.res5_overflow_check = res5_overflow_check
+        # training forwards: "deferred" = the guard is acted on on the device and read with the next step's labelling (no host
+        # wait inside the step); "sync" = read behind the Res5 forward, an out-of-range forward is repeated on the f32 MFMA
+        assert res5_train_guard in ("deferred", "sync")
+        self.res5_train_guard = os.environ.get("LOCOV_RES5_TRAIN_GUARD", res5_train_guard)
         self._overflow_warned = False
         self.res5_backend = res5_backend      # extension: how the Res5 convolutions run (see res5.py)
         self.res5_conv3x3 = res5_conv3x3      # extension: form of the 3x3 convolutions on the hip backend
@@ -447,6 +491,7 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         ret["res5_conv3x3"] = box_head.get("RES5_CONV3X3", "winograd") if hasattr(box_head, "get") else "winograd"
         ret["res5_dtype"] = box_head.get("RES5_DTYPE", "f16x2") if hasattr(box_head, "get") else "f16x2"
         ret["res5_overflow_check"] = bool(box_head.get("RES5_OVERFLOW_CHECK", True)) if hasattr(box_head, "get") else True
+        ret["res5_train_guard"] = box_head.get("RES5_TRAIN_GUARD", "deferred") if hasattr(box_head, "get") else "deferred"
         return ret
 
     @classmethod
@@ -579,6 +624,39 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
     def _backward_guard_words(self, device):
         return self.res5.backward_guard_words(device) if hasattr(self.res5, "backward_guard_words") else []
 
+    def _deferred_guards(self, device):
+        return self.res5.deferred_guards(device) if hasattr(self.res5, "deferred_guards") else []
+
+    def _deferred_guards_tripped(self, kinds) -> None:
+        if "bwd" in kinds:
+            self._backward_guard_tripped()
+        if "fwd_train" in kinds:
+            import warnings
+            for kind, g in self.res5.deferred_guards(next(self.res5.parameters()).device):
+                if kind == "fwd_train":
+                    g.reset()
+            if hasattr(self.res5, "_scales"):
+                self.res5._scales.clear()
+                self.res5._cache.clear()
+            self.res5_dtype = "fp32"
+            warnings.warn("Res5 activations left the range of the f16x2 split arithmetic (|x| >= 4094) during the previous training "
+                          "step: that step's Res5 outputs and gradients were ZEROED on the device (no inf / NaN reached the losses "
+                          "or the optimizer; the step was skipped for the ROI-head path), and RES5_DTYPE is 'fp32' (the f32 MFMA) "
+                          "from this step on.  MODEL.ROI_BOX_HEAD.RES5_TRAIN_GUARD 'sync' reads the guard inside every step and "
+                          "repeats an out-of-range forward instead", RuntimeWarning, stacklevel=4)
+
+    def _train_guard(self, feats: List[torch.Tensor]):
+        """The DEFERRED range guard of a training forward (RES5_TRAIN_GUARD "deferred", the default): never read inside the
+        step -- a host read behind the Res5 forward drains the GPU in front of the step's ~200 small launches (predictor,
+        losses, grounding head) -- but acted on ON THE DEVICE: the forward's outputs and the backward's gradients are
+        zero-filled when the word is set (ops.zero_if_raised), and the word travels with the next step's labelling read."""
+        if not (self.res5_dtype == "f16x2" and self.res5_overflow_check and self.res5_train_guard == "deferred"
+                and self._train_path_ok(feats) and self._needs_graph(feats) and hasattr(self.res5, "range_guard")):
+            return None
+        if ops.active_guard(feats[0].device) is not None:
+            return None                                      # an outer caller already holds one
+        return self.res5.range_guard("fwd_train", feats[0].device)
+
     def _backward_guard_tripped(self) -> None:
         import warnings
         self.res5.backward_guard_tripped()
@@ -661,10 +739,13 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
             return self._detect(features, proposals)
         proposal_boxes = [x.proposal_boxes for x in proposals]
         feats = [features[f] for f in self.in_features]
-        guard = self._deferred_guard(feats)
-        with ops.range_guard(guard):
+        tguard = self._train_guard(feats)
+        guard = None if tguard is not None else self._deferred_guard(feats)
+        with ops.range_guard(tguard if tguard is not None else guard):
             box_features = self._shared_roi_transform(feats, proposal_boxes, pooled=True)
-        if guard is not None and guard.raised():             # the step's one range-guard read
+        if tguard is not None:
+            ops.zero_if_raised([box_features], tguard.word)   # (a fresh contiguous tensor: zeroed in place, no host read)
+        elif guard is not None and guard.raised():           # RES5_TRAIN_GUARD "sync": the step's range-guard read
             self._warn_overflow()
             box_features = self._with_res5_dtype("fp32", self._shared_roi_transform, feats, proposal_boxes, pooled=True)
         predictions = self.box_predictor(box_features)       # (:261-262: the mean is all the predictor sees)
@@ -735,22 +816,35 @@ class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
         del images
         if targets is None:                              # keyed on targets, not self.training (:316)
             return self.inference_detection(features, proposals)
-        proposals = self.label_and_sample_proposals(proposals, targets)
+        # (:318 labels first, :323 then runs Res5 on the whole grid: the two are independent, so the labelling's kernels are
+        # enqueued, the grid call is enqueued BEHIND them, and only then does the host wait for the labelling's few integers --
+        # with the grid call's work still queued the GPU does not drain while the host samples and launches the ROI path)
+        pending = self._label_begin(proposals, targets)
         del targets
         feats = [features[f] for f in self.in_features]
         nhwc = None
         if self._train_path_ok(feats) and self._needs_graph(feats):
             from .. import res5_train
             nhwc = res5_train.to_nhwc(feats[0])          # one channels-last copy (and one gradient transpose) for both calls
-        proposal_boxes = [x.proposal_boxes for x in proposals]
-        boxes_per_image = [len(x) for x in proposals]
-        # ONE range-guard read for both Res5 calls of the step (the whole grid and the sampled proposals); a step that left
-        # the split arithmetic's range repeats both on the f32 MFMA (the graph of the first attempt is simply dropped)
-        guard = self._deferred_guard(feats)
-        with ops.range_guard(guard):
+        # ONE range guard for both Res5 calls of the step (the whole grid and the sampled proposals).  Training ("deferred"):
+        # acted on on the device, read with the next step's labelling.  "sync": one read behind both calls; a step that left the
+        # split arithmetic's range repeats both on the f32 MFMA (the graph of the first attempt is simply dropped)
+        tguard = self._train_guard(feats)
+        guard = None if tguard is not None else self._deferred_guard(feats)
+        dtype_was = self.res5_dtype
+        with ops.range_guard(tguard if tguard is not None else guard):
             visual_grid_features = self._res5_grid(feats[0], nhwc)               # :323
+            proposals = self._label_finish(pending)                              # :318 (the step's one host wait)
+            if self.res5_dtype != dtype_was:
+                # that read found the PREVIOUS step's deferred guard set: RES5_DTYPE is "fp32" from here on, and the grid call
+                # enqueued above (still in split arithmetic, on data that may again be out of range) is redone
+                visual_grid_features = self._res5_grid(feats[0], nhwc)
+            proposal_boxes = [x.proposal_boxes for x in proposals]
+            boxes_per_image = [len(x) for x in proposals]
             box_features = self._shared_roi_transform(feats, proposal_boxes, pooled=True, nhwc=nhwc)   # :343-344
-        if guard is not None and guard.raised():
+        if tguard is not None:
+            ops.zero_if_raised([visual_grid_features, box_features], tguard.word)
+        elif guard is not None and guard.raised():
             self._warn_overflow()
             del visual_grid_features, box_features
             visual_grid_features = self._with_res5_dtype("fp32", self._res5_grid, feats[0], nhwc)

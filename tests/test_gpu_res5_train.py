@@ -488,6 +488,60 @@ def test_training_forward_backward_matches_the_stock_library_path(pkg, oracle, d
     assert worst[0] < 5e-3, worst
 
 
+@pytest.mark.parametrize("mode", ["deferred", "sync"])
+def test_training_forward_out_of_range_never_reaches_the_losses_or_the_parameters(pkg, oracle, mode, monkeypatch):
+    """A training forward whose activations leave the split arithmetic's range (|x| >= 4094).  RES5_TRAIN_GUARD "deferred"
+    (default): no host read inside the step -- the forward's outputs and the backward's Res5 gradients are zero-filled on
+    the device, the next step's labelling read reports it (one RuntimeWarning) and the module runs on the f32 MFMA from
+    then on, where the same input gives the f32 path's results.  "sync": the forward is repeated on the f32 MFMA at once."""
+    import warnings
+    monkeypatch.setenv("LOCOV_RES5_TRAIN_GUARD", mode)
+    heads, c_in = _train_heads(pkg, oracle, "hip", "f16x2")
+    assert heads.res5_train_guard == mode
+    ref, _ = _train_heads(pkg, oracle, "hip", "fp32")
+    gen = torch.Generator().manual_seed(6)
+    base = torch.randn(2, c_in, 50, 84, generator=gen).cuda()
+    props, targets = _train_batch(pkg, oracle, 2, 60, 5, seed=32)
+
+    def step(h, scale, seed):
+        h.zero_grad()
+        feat = (base * scale).requires_grad_(True)
+        torch.manual_seed(seed)
+        grid, box_feats, sampled, losses = h(None, {"res4": feat}, props, targets)
+        (sum(losses.values()) + grid.mean() + sum(b.sum() for b in box_feats) * 1e-3).backward()
+        torch.cuda.synchronize()
+        return grid, box_feats, losses, feat.grad, {k: p.grad for k, p in h.named_parameters() if p.grad is not None}
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        step(heads, 1.0, 1)                                              # in range: nothing is reported, nothing zeroed
+        assert heads.res5_dtype == "f16x2"
+    big = 3.0e4                                                          # a res4 map of ~1e5: far outside fp16 at the activation scale
+    want = step(ref, big, 2)
+    if mode == "sync":
+        with pytest.warns(RuntimeWarning, match="repeated"):
+            got = step(heads, big, 2)
+        assert rel_err(got[0], want[0]) < 1e-6 and rel_err(got[3], want[3]) < 1e-5
+        return
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)                   # deferred: silent inside the step ...
+        grid, box_feats, losses, gfeat, gparams = step(heads, big, 2)
+    assert float(grid.abs().max()) == 0.0 and all(float(b.abs().max()) == 0.0 for b in box_feats)
+    assert all(bool(torch.isfinite(v).all()) for v in losses.values())
+    assert bool(torch.isfinite(gfeat).all()) and float(gfeat.abs().max()) == 0.0
+    for k, g in gparams.items():
+        assert bool(torch.isfinite(g).all()), k
+        if k.startswith("res5."):
+            assert float(g.abs().max()) == 0.0, k
+    with pytest.warns(RuntimeWarning, match="ZEROED on the device"):     # ... and reported by the next step's one host read
+        got = step(heads, big, 2)
+    assert heads.res5_dtype == "fp32"
+    assert rel_err(got[0], want[0]) < 1e-6 and rel_err(got[3], want[3]) < 1e-5
+    for k in want[4]:
+        if k.startswith("res5."):
+            assert rel_err(got[4][k], want[4][k]) < 1e-5, k
+
+
 def test_training_step_at_config_sizes_runs_on_the_hip_kernels(pkg, oracle):
     """configs/coco_lsm.yaml sizes (Res5 1024 -> 512 -> 2048, 200 sampled proposals per image): one forward + backward
     on the hand-written path; finite gradients for every Res5 convolution and the res4 map."""

@@ -4,6 +4,6 @@
 # 2.37 / 2.01 / 2.18 / 1.79 ms, conv3 with split-layout residual and output 2.58 / 2.08 ms.
 for lib in product segabl1 segabl2 segabl3; do
   if [ $lib = product ]; then unset LOCOV_HIP_LIB; else export LOCOV_HIP_LIB=tools/liblocov_$lib.so; fi
-  echo "== $lib"; timeout 200 python tools/dbg_segmean_big.py 2>&1 | grep "big = 1" | tail -2
-  timeout 200 python tools/dbg_outsplit.py 2>&1 | grep "split res -> split out" | tail -1
+  echo "== $lib"; timeout 200 python tools/attic/dbg_segmean_big.py 2>&1 | grep "big = 1" | tail -2
+  timeout 200 python tools/attic/dbg_outsplit.py 2>&1 | grep "split res -> split out" | tail -1
 done

@@ -1,7 +1,7 @@
 """Developer experiment: the same GEMM launch writing into DIFFERENT freshly allocated output / residual buffers (held alive, so
 each is a new hipMalloc): is the launch time a property of the buffer (physical placement / page fragments)?"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops, _lib
 from locov_amd.ops import _ptr, _stream, _overflow_word, check

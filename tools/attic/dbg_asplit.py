@@ -1,6 +1,6 @@
 """Developer aid: split GEMM with A converted in the kernel vs A pre-split (staged by LDS DMA)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops
 g = torch.Generator().manual_seed(0)

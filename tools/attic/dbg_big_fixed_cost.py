@@ -1,6 +1,6 @@
 """Developer timing: per-tile fixed cost (workgroup turnover + prologue + epilogue) of the 256x256 split GEMM: time over K at fixed M, N."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops
 M = 392000

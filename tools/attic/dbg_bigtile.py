@@ -1,7 +1,7 @@
 """Developer aid: 128x128 (two workgroups per CU) vs 256x256 (gemm_split_big.hip: one 8-wave workgroup per CU) tile of the split GEMM
 on launches with both operands pre-split, same process, alternating arms.  LOCOV_SPLIT_BIG is read by the launcher at every call."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops
 g = torch.Generator().manual_seed(0)

@@ -1,7 +1,7 @@
 """Developer timing: a bottleneck's conv1 + conv2 as two calls (linear_split -> winograd_conv3x3) against the one-call form whose
 conv1 epilogue applies the Winograd input transform (ops.conv1x1_winograd_conv3x3), at the Res5 shape, 8 000 proposals."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8000

@@ -1,7 +1,7 @@
 """Developer timing: block 0's pooler + conv2 as two calls (roi_align_nhwc -> winograd_conv3x3) against ops.roi_align_winograd_conv3x3
 (the ROIAlign workgroup writes the Winograd input transform itself), 8 images x 1000 proposals, 512 of 2560 map channels."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops
 g = torch.Generator().manual_seed(0)

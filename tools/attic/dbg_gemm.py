@@ -1,7 +1,7 @@
 """Per-shape timing of the hand-written NT GEMM against hipBLASLt (torch) at the Res5 shapes, interleaved rounds in
 one process after a long warm-up (first-run timings are clock-ramp biased)."""
 import sys, os, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from locov_amd import _lib, ops

@@ -1,7 +1,7 @@
 """Developer aid: where a wave of gemm_split_kernel<ASPLIT> spends a K-tile (LOCOV_HIP_LIB=tools/liblocov_ktrace.so, built by
 `python tools/make_variant.py ktrace gemm_split.hip -DLOCOV_KTRACE=1`).  Segments between the s_memtime stamps of tile_step."""
 import ctypes, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops, _lib
 lib = _lib.lib() if hasattr(_lib, "lib") else ctypes.CDLL(os.environ["LOCOV_HIP_LIB"])

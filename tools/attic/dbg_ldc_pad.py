@@ -2,7 +2,7 @@
 (L2 / HBM channel mapping of the epilogue's traffic)?  One arena allocated once; views carved at chosen offsets; every
 configuration measured twice in shuffled order."""
 import os, sys, time, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops, _lib
 from locov_amd.ops import _ptr, _stream, _overflow_word, check

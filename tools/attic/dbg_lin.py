@@ -1,6 +1,6 @@
 """Developer check of the GEMM epilogue paths (flag 0x800 forces the general path)."""
 import sys, os, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import _lib
 lib = _lib.load()

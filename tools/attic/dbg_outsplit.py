@@ -1,6 +1,6 @@
 """Developer aid: cost of the split-layout epilogue (LOCOV_EPI_OUT_SPLIT / RES_SPLIT) on conv3's shape, and the conv1 it speeds up."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops
 g = torch.Generator().manual_seed(0)

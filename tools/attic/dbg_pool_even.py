@@ -1,6 +1,6 @@
 """Developer timing: the even-grid channels-last ROIAlign (block 0's pooler on the map GEMM's output) at 512 and 2048 channels, 8 000 proposals."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops
 g = torch.Generator().manual_seed(0)

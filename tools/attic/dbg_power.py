@@ -1,7 +1,7 @@
 """Developer aid: shader clock and package power (rocm-smi / amd-smi, whichever answers) sampled while one kernel runs back to back:
 is the split GEMM power-limited?  Arms: the shipped conv1 / conv3 launches, the f32-MFMA GEMM, an HBM-bound transform, idle."""
 import os, subprocess, sys, threading, time, re
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops
 

@@ -1,6 +1,6 @@
 """Developer aid: element placement of gemm_split_pp_kernel's epilogue (A = 0, so the output must equal relu-less residual)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops
 M, N, K = 196000, 2048, 512

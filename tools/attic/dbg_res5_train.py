@@ -1,6 +1,6 @@
 """Developer aid: per-tensor gradient errors of the Res5 rows path against float64 autograd (run on the GPU box)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import lsm_oracle as oracle
 import tests.test_gpu_res5_train as T

@@ -1,6 +1,6 @@
 """Developer timing: the split-arithmetic weight-gradient (TN) GEMM at the training step's shapes (M = 39 200 ROI rows)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops
 M = 39200

@@ -1,6 +1,6 @@
 """Developer aid: the wave-specialised split GEMM against the plain one (run twice: LOCOV_SPLIT_WS=0 / 1) and float64."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from locov_amd import ops

@@ -1,6 +1,6 @@
 """Developer aid: barrier-wait cycles per role of the wave-specialised split GEMM (LOCOV_HIP_LIB=tools/liblocov_wsdbg.so)."""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops, _lib
 g = torch.Generator().manual_seed(0)

@@ -3,12 +3,12 @@
 // arithmetic) -- the shapes Res5 spends most of its launches on: the three Winograd-domain batched GEMMs [R,512]x[512,512]
 // and the last 1x1 convolution of blocks 0-1 [49R,512]x[2048,512] + residual (roi_emb_heads.py:217-245 as GEMMs).
 //
-// Why.  In-kernel stamps of gemm_split_kernel (tools/dbg_ktrace.py) put a K = 512 tile at 44 k cycles of K-loop, 10.5-12 k
+// Why.  In-kernel stamps of gemm_split_kernel (tools/attic/dbg_ktrace.py) put a K = 512 tile at 44 k cycles of K-loop, 10.5-12 k
 // cycles of epilogue (64 KB of stores per workgroup, store-issue bound) and 1.3-1.6 k before the first DMA: a fifth of every
 // workgroup slot is spent with that workgroup's MFMAs stopped, and what the K-loop itself could still give up is returned
 // as a lower clock by the power-limited chip, while an epilogue saving is not.  A wave-specialised
 // kernel that moved the epilogue to other waves lost more than it gained (one MFMA wave per SIMD cannot hide its LDS
-// latency: tools/experiments/).  This kernel keeps what works -- two independent 4-wave workgroups per CU, every wave doing
+// latency: tools/attic/experiments/).  This kernel keeps what works -- two independent 4-wave workgroups per CU, every wave doing
 // the whole K-tile step -- and changes only WHEN the epilogue happens:
 //   * workgroups are persistent (2 per CU) and walk the tile list in the hardware dispatcher's order; the operand stream is
 //     continuous across tiles (the last K-tile step of tile t requests K-tile 0 of tile t+1);
@@ -19,7 +19,7 @@
 //     PER K-TILE STEP of the next tile (K = 512 has exactly 16 steps), each block's residual / scale / shift requested a step
 //     ahead.  Per step and wave that is three 16-byte loads, ~12 vector-ALU instructions and one 16-byte store beside 48
 //     MFMAs; the MFMAs never stop for an epilogue.
-// Results are bit-identical to gemm_split_kernel<false, false, true> (tools/dbg_asplit.py, tests/test_gpu_split_gemm.py).
+// Results are bit-identical to gemm_split_kernel<false, false, true> (tools/attic/dbg_asplit.py, tests/test_gpu_split_gemm.py).
 #include "gemm_nt.h"
 
 #include <type_traits>

@@ -10,7 +10,7 @@
 // the kernel was slower than the plain one: measured with in-kernel cycle stamps, its four staging waves needed ~1 500 cycles
 // per K-tile (4 LDS DMAs 330, 4 buffer loads 170, the split of 4 chunks + 8 LDS stores 560-680, waiting for A 200-400)
 // against 768 cycles of MFMA work -- the plain kernel is bound by the same staging instruction stream, spread over eight waves
-// (tools/experiments/).  With A pre-split the staging of a K-tile is eight LDS DMAs per wave and nothing else, and the roles
+// (tools/attic/experiments/).  With A pre-split the staging of a K-tile is eight LDS DMAs per wave and nothing else, and the roles
 // separate cleanly.
 //
 // ONE 768-thread workgroup per CU stays resident and walks over its tiles; its 12 waves have fixed roles (waves w, w+4, w+8

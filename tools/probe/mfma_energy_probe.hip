@@ -1,7 +1,7 @@
 // Developer probe: f16 MFMA throughput of a register-only loop, per instruction shape, at the package power cap.
 //   hipcc -O3 --offload-arch=gfx950 mfma_energy_probe.hip -o mfma_energy_probe ;  ./mfma_energy_probe [seconds per arm]
 // The split GEMM runs at the 1 400 W cap (profiles/r03_power_probe.txt), so what a shape sustains HERE -- no LDS, no memory, the same
-// 128x64 wave tile and register footprint as gemm_split_big.hip -- is a direct reading of its energy per FLOP.  tools/dbg_mfma_energy.py
+// 128x64 wave tile and register footprint as gemm_split_big.hip -- is a direct reading of its energy per FLOP.  tools/attic/dbg_mfma_energy.py
 // samples power and clock beside it.
 #include <hip/hip_runtime.h>
 #include <chrono>
