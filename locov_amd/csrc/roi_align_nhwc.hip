@@ -30,18 +30,28 @@ __device__ __forceinline__ void store4(float *p, const float4 &v) { *reinterpret
 // The pooled rows are consumed by a LATER kernel (GBs of other traffic in between), while the map slice they were gathered from
 // is re-read by every ROI of the image: `sc1` stores leave no copy of the written line in the XCD's L2 (MI355X_MICROARCH.md,
 // stores of each flavour), so the 3.2 GB of output no longer push the 2-4 MB map slice out of it.
+// Measured on the 2 048-channel launch of block 0's shortcut (8 x 1000 proposals; tools/ab_pool.sh, docs/experiments.md R4):
+// plain stores 1.17 ms with 3.9 GB of fabric reads for a 0.28 GB map; `sc1` 1.18 ms / 1.6 GB; `nt` 1.06 ms / 1.8 GB -- nt it is.
 #ifndef LOCOV_POOL_STORE_AUX
-#define LOCOV_POOL_STORE_AUX 16                            // 0 = plain, 2 = nt, 16 = sc1, 17 = sc0 sc1 (developer A/B)
+#define LOCOV_POOL_STORE_AUX 2                             // 0 = plain, 2 = nt, 16 = sc1, 17 = sc0 sc1 (developer A/B)
 #endif
-__device__ __forceinline__ void store4_out(float *p, const float4 &v)
+#ifndef LOCOV_T2_STORE_AUX
+#define LOCOV_T2_STORE_AUX 2                               // the pooler-contract kernel's NCHW stores: nt 2.88 ms, plain 2.94, sc1 2.98 (tools/ab_t2.py)
+#endif
+#ifndef LOCOV_POOLWINO_NT
+#define LOCOV_POOLWINO_NT 0                                // the WINO pooler's transform-domain stores (developer A/B)
+#endif
+template <int AUX>
+__device__ __forceinline__ void store4_policy(float *p, const float4 &v)
 {
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
     const f32x4_t d = {v.x, v.y, v.z, v.w};
-    if (LOCOV_POOL_STORE_AUX == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
-    else if (LOCOV_POOL_STORE_AUX == 17) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
-    else if (LOCOV_POOL_STORE_AUX == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
+    if (AUX == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+    else if (AUX == 17) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+    else if (AUX == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
     else *reinterpret_cast<float4 *>(p) = v;
 }
+__device__ __forceinline__ void store4_out(float *p, const float4 &v) { store4_policy<LOCOV_POOL_STORE_AUX>(p, v); }
 __device__ __forceinline__ void store4(__bf16 *p, const float4 &v)
 {
     bf16x4 o;
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(kNhwcThreads, WINO ? 6 : 1) void roi_align_nhwc_ker
                 constexpr int FY = decltype(fy_tag)::value;
                 wino_in_fy<false, FY>(load, [&](int fx, f32x2 a) __attribute__((always_inline)) {
                     amax = fmaxf(fmaxf(amax, fabsf(a[0])), fabsf(a[1]));
-                    store_split_pair(vrow + (int64_t)(FY * wino::NF + fx) * fstride, c, a, v_scale);
+                    store_split_pair_policy<LOCOV_POOLWINO_NT != 0>(vrow + (int64_t)(FY * wino::NF + fx) * fstride, c, a, v_scale);
                 });
                 __builtin_amdgcn_sched_barrier(0);             // one row of the transform at a time: ~80 live registers, not 11 rows' worth
             };
@@ -567,7 +577,7 @@ __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
         while (c < cn) {
             const float *t = tile + c * ts + 4 * b4;
             const float4 v = {t[0], t[1], t[2], t[3]};
-            *reinterpret_cast<float4 *>(dst + (c * bins + 4 * b4)) = v;
+            store4_policy<LOCOV_T2_STORE_AUX>(dst + (c * bins + 4 * b4), v);
             c += step_c;
             b4 += step_b;
             if (b4 >= qpc) {

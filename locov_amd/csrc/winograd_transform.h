@@ -61,6 +61,17 @@ __device__ __forceinline__ void store_split_pair(float *row, int c, f32x2 v, flo
 {
     wino_store(split_pair_words(c, v, s), reinterpret_cast<wino_u32x2 *>(reinterpret_cast<char *>(row) + split_pair_offset(c)));
 }
+// ... with the store's cache policy chosen by the caller (the pooler that also gathers from a map slice it wants to keep in L2)
+template <bool NT>
+__device__ __forceinline__ void store_split_pair_policy(float *row, int c, f32x2 v, float s)
+{
+    wino_u32x2 *p = reinterpret_cast<wino_u32x2 *>(reinterpret_cast<char *>(row) + split_pair_offset(c));
+    const wino_u32x2 w = split_pair_words(c, v, s);
+    if (NT)
+        __builtin_nontemporal_store(w, p);
+    else
+        wino_store(w, p);
+}
 
 // GRAD = true applies A (x) A = (AT (x) AT)^T instead of BT (x) BT: the adjoint of the OUTPUT transform, which maps the
 // gradient of a convolution's output into the transform domain (dM) for the weight gradient (locov_winograd_wgrad_f32).
