@@ -393,6 +393,27 @@ int locov_sim_gemm_bf16(const uint16_t *emb, const uint16_t *bank, int64_t R, in
                         float *logits, int64_t ldc, locov_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * a-11  proposal labelling of a whole batch in one launch: the device half of SampleAllROIHeads.label_and_sample_proposals
+ * (ovr/modeling/roi_heads/roi_emb_heads.py:25-118) -- [D2-upstream] pairwise_iou of every proposal with ITS image's ground truth,
+ * Matcher (intervals [thr_lo[k], thr_hi[k]) -> thr_label[k] in {-1, 0, 1}; the first maximum wins, as torch.max), the class
+ * labels of ROIHeads._sample_proposals (matched class / num_classes for background / -1 for ignored), the sort keys of the
+ * sampler (rnd [2, total] uniform doubles: key = rnd + 2 [not in the population] + 4 image -- image-major, population first,
+ * uniformly random inside it) and, per image, rows[i] = {foreground count, background count, entries of the quality matrix that
+ * fail `>= 0` (the Matcher's assert), foreground boxes without positive width and height (Box2BoxTransform's assert)}.
+ *   boxes [total, 4] / gt_boxes [sum M, 4] XYXY fp32 and gt_classes [sum M] int64 on the device, concatenated over the images;
+ *   prop_offsets / gt_offsets: n_images + 1 HOST ints (rows of image i: [off[i], off[i+1])); rows [n_images, 4] int64, ZEROED by
+ *   the caller; gt_index [total] int64 = matched row of the CONCATENATED ground truth (0 for an image without any);
+ *   labels [total] int64; key_pos / key_neg [total] double.  At most LOCOV_LABEL_MAX_IMAGES images, LOCOV_LABEL_MAX_THRESHOLDS
+ *   intervals.  Bit-identical to the torch-op form (tests/test_gpu_roi_heads.py).
+ * ------------------------------------------------------------------------------------- */
+#define LOCOV_LABEL_MAX_IMAGES 64
+#define LOCOV_LABEL_MAX_THRESHOLDS 6
+int locov_label_proposals(const float *boxes, const int *prop_offsets, const float *gt_boxes, const int64_t *gt_classes,
+                          const int *gt_offsets, int n_images, const float *thr_lo, const float *thr_hi, const int *thr_label,
+                          int n_thresholds, int64_t num_classes, const double *rnd, int64_t *gt_index, int64_t *labels,
+                          double *key_pos, double *key_neg, int64_t *rows, locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * a-10  greedy NMS on the device.  Replaces [D2-upstream] torchvision.ops.nms as reached from
  * box_predictor.inference -> fast_rcnn_inference -> batched_nms
  * (ovr/modeling/roi_heads/roi_emb_heads.py:280,357).

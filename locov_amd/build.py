@@ -30,6 +30,7 @@ FILE_FLAGS = {
     "roi_align.hip": ["-ffp-contract=off"],
     "roi_align_nhwc.hip": ["-ffp-contract=off"],
     "roi_align_tiles.hip": ["-ffp-contract=off"],
+    "label.hip": ["-ffp-contract=off"],          # (IoU values must be the torch ops', rounded step by step)
 }
 
 

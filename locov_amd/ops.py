@@ -8,6 +8,7 @@ CPU path: tensors must live on a ROCm device.
 from __future__ import annotations
 
 import ctypes
+import itertools
 import math
 import threading
 from typing import NamedTuple, Optional, Sequence, Tuple
@@ -1058,6 +1059,40 @@ def relu_mask(g: torch.Tensor, act: torch.Tensor, amax_out: Optional[torch.Tenso
     with torch.cuda.device(g.device):
         check(_lib.load().locov_relu_mask(_ptr(g), _ptr(act), g.numel(), _ptr(out), _ptr(amax_out), _stream(g)), "locov_relu_mask")
     return out
+
+
+LABEL_MAX_IMAGES, LABEL_MAX_THRESHOLDS = _lib.LABEL_MAX_IMAGES, _lib.LABEL_MAX_THRESHOLDS
+
+
+def label_proposals(boxes: torch.Tensor, n_props, gt_boxes: torch.Tensor, gt_classes: torch.Tensor, n_gt, thresholds, labels_of,
+                    num_classes: int, rnd: torch.Tensor):
+    """Labelling of a whole batch in one launch (locov_label_proposals; roi_emb_heads.py:25-118's device half).
+    boxes [sum R, 4] / gt_boxes [sum M, 4] fp32 and gt_classes [sum M] int64, concatenated over the images; n_props / n_gt: per-image
+    counts (host ints); thresholds: the Matcher's [-inf, t1, ..., inf]; labels_of: its interval labels; rnd [2, sum R] float64 in [0, 1).
+    Returns (gt_index, labels, key_pos, key_neg, rows [B, 4] int64) -- see include/locov_hip.h."""
+    boxes = _dev(boxes, "boxes")
+    B, total = len(n_props), int(sum(n_props))
+    if B > _lib.LABEL_MAX_IMAGES or len(labels_of) > _lib.LABEL_MAX_THRESHOLDS or boxes.shape[0] != total:
+        raise ValueError("label_proposals: too many images / matcher intervals, or counts that do not add up")
+    dev = boxes.device
+    gt_boxes = _dev(gt_boxes, "gt_boxes") if sum(n_gt) else None
+    gt_classes = _dev(gt_classes, "gt_classes", torch.int64) if sum(n_gt) else None
+    rnd = _dev(rnd, "rnd", torch.float64)
+    gt_index = torch.empty(total, dtype=torch.int64, device=dev)
+    labels = torch.empty(total, dtype=torch.int64, device=dev)
+    keys = torch.empty((2, total), dtype=torch.float64, device=dev)
+    rows = torch.zeros((B, 4), dtype=torch.int64, device=dev)
+    roff = (ctypes.c_int * (B + 1))(*([0] + list(itertools.accumulate(int(n) for n in n_props))))
+    goff = (ctypes.c_int * (B + 1))(*([0] + list(itertools.accumulate(int(n) for n in n_gt))))
+    nt = len(labels_of)
+    lo = (ctypes.c_float * max(nt, 1))(*[float(v) for v in thresholds[:-1]])
+    hi = (ctypes.c_float * max(nt, 1))(*[float(v) for v in thresholds[1:]])
+    lab = (ctypes.c_int * max(nt, 1))(*[int(v) for v in labels_of])
+    with torch.cuda.device(dev):
+        check(_lib.load().locov_label_proposals(_ptr(boxes), roff, _ptr(gt_boxes), _ptr(gt_classes), goff, B, lo, hi, lab, nt,
+                                                int(num_classes), _ptr(rnd), _ptr(gt_index), _ptr(labels), _ptr(keys[0]), _ptr(keys[1]),
+                                                _ptr(rows), _stream(boxes)), "locov_label_proposals")
+    return gt_index, labels, keys[0], keys[1], rows
 
 
 def zero_if_raised(tensors, word: torch.Tensor) -> None:

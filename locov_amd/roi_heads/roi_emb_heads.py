@@ -289,6 +289,20 @@ class SampleAllROIHeads(ROIHeads):
         n_g = [len(t) for t in targets]
         B = len(proposals)
         box = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+        matcher = self.proposal_matcher
+        if (box.is_cuda and box.dtype == torch.float32 and 0 < B <= ops.LABEL_MAX_IMAGES and len(matcher.labels) <= ops.LABEL_MAX_THRESHOLDS
+                and not matcher.allow_low_quality_matches and box.shape[0] > 0):
+            # ONE kernel for IoU / matching / labels / sort keys / counts (locov_label_proposals: the torch ops below, bit for bit,
+            # without the [sum M, sum R] matrix and ~80 small launches), then the two sorts
+            if sum(n_g) > 0:
+                gtb = torch.cat([t.gt_boxes.tensor for t in targets], dim=0).to(torch.float32)
+                gtc = torch.cat([t.gt_classes for t in targets], dim=0).to(torch.int64)
+            else:
+                gtb = gtc = None
+            k = torch.rand((2, box.shape[0]), device=dev, dtype=torch.float64)
+            gt_index, labels, key_pos, key_neg, rows = ops.label_proposals(box, n_r, gtb, gtc, n_g, matcher.thresholds, matcher.labels,
+                                                                           self.num_classes, k)
+            return gt_index, labels, torch.argsort(key_pos), torch.argsort(key_neg), rows
         img_r = torch.cat([torch.full((n,), i, dtype=torch.int64, device=dev) for i, n in enumerate(n_r)])
         counts_dtype = torch.int64
         if sum(n_g) > 0:

@@ -216,3 +216,34 @@ def test_batched_labelling_equals_the_per_image_form(oracle):
                 continue
             np.testing.assert_array_equal(cx[k], cy[k], err_msg=k)
     assert not a[1].has("gt_boxes") and not b[1].has("gt_boxes")          # the image without ground truth carries no target fields
+
+
+@pytest.mark.gpu
+def test_label_kernel_equals_the_torch_ops_on_the_device(oracle, monkeypatch):
+    """locov_label_proposals (one launch per batch) against the torch-op form of SampleAllROIHeads._match_batch on the same draw:
+    matched ground truth, labels, both sampling orders and the per-image rows -- equal element for element, incl. an image without
+    ground truth, a NaN proposal, a zero-width foreground candidate and exact ties."""
+    from locov_amd import ops
+    heads = _heads(True, 64, 0.5, "cuda")
+    rng = np.random.default_rng(21)
+    props, targets, raw = _batch(oracle, rng, "cuda", n_img=5, r=300, n_gt=7)
+    b0 = props[0].proposal_boxes.tensor.clone()
+    b0[11, 1] = float("nan")                                                  # NaN coordinate: IoU 0 by the `inter > 0` rule
+    b0[12] = targets[0].gt_boxes.tensor[2]                                    # an exact copy of a ground-truth box: IoU 1
+    b0[13] = targets[0].gt_boxes.tensor[2]
+    b0[13, 2] = b0[13, 0]                                                     # ... and a zero-width one
+    b0[14] = torch.tensor([0.0, 0.0, 1.0, 1.0])                               # touches nothing: every IoU is 0 (a tie: first row wins)
+    props[0].proposal_boxes = Boxes(b0)
+    from locov_amd.roi_heads.roi_emb_heads import add_ground_truth_to_proposals
+    props = add_ground_truth_to_proposals(targets, props)
+    outs = []
+    for use_kernel in (True, False):
+        monkeypatch.setattr(ops, "LABEL_MAX_IMAGES", 64 if use_kernel else 0)
+        torch.manual_seed(9)
+        outs.append(heads._match_batch(props, targets))
+    (gi_k, lab_k, po_k, no_k, rows_k), (gi_t, lab_t, po_t, no_t, rows_t) = outs
+    assert torch.equal(lab_k, lab_t) and torch.equal(gi_k, gi_t)
+    assert torch.equal(po_k, po_t) and torch.equal(no_k, no_t)
+    assert torch.equal(rows_k[:, :2], rows_t[:, :2])
+    assert torch.equal(rows_k[:, 2:] > 0, rows_t[:, 2:] > 0)
+    assert int((lab_k == 80).sum()) > 0 and int(((lab_k >= 0) & (lab_k < 80)).sum()) > 0
