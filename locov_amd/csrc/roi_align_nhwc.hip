@@ -92,15 +92,17 @@ constexpr int kMaxAxisN = 192;     // per-axis LDS table entries (7 x up to 27 s
 // convolution evaluated in the Winograd domain (block 0's conv2).  They are kept in LDS ([49][64]) instead of being stored, and
 // the workgroup writes their input transform V [121][R][C] (`out`, split layout x v_scale) itself -- wino_in_fy of
 // winograd_transform.h, the bits wino_input_kernel<false, true> would have produced from the stored rows.
-constexpr int kWinoSliceCh = 64, kWinoPitch = kWinoSliceCh + 4;
-
-template <typename TIn, typename TOut, bool BWD = false, bool WINO = false>
-__global__ __launch_bounds__(kNhwcThreads, WINO ? 6 : 1) void roi_align_nhwc_kernel(
+// WINO = the slice width in channels (0: not the WINO form).  128 where C allows it: the transform phase's lane = channel pair then
+// fills its waves (64 pairs), a wave's store is a 512-byte run, and a 512-channel map makes 4 slices (two XCDs share one: 2.15 MB per
+// image, still inside L2) -- block 0's pooler + conv2 2.73 -> 2.60 ms at 8 000 proposals (tools/attic/dbg_fuse_pool.py); 64 otherwise.
+template <typename TIn, typename TOut, bool BWD = false, int WINO = 0>
+__global__ __launch_bounds__(kNhwcThreads, WINO == 64 ? 6 : WINO ? 4 : 1) void roi_align_nhwc_kernel(
     const TIn *__restrict__ feat, int N, int H, int W, int C, const float *__restrict__ rois, int PH, int PW,
     float scale, int sampling_ratio, int aligned, int bin_stride, int OH, int OW, int pos_major,
     TOut *__restrict__ out, int64_t out_ld, int64_t feat_ld, const float *__restrict__ ch_scale,
     const float *__restrict__ ch_shift, int relu, int nslices, int64_t R, float v_scale = 1.f, unsigned *overflow = nullptr)
 {
+    constexpr int kWinoPitch = WINO + 4;
     __shared__ float wino_tile_s[WINO ? 49 * kWinoPitch : 1];
     float *const wino_tile = wino_tile_s;
     // feat_ld = elements between consecutive pixels of the map (>= C: the C channels may be a column block
@@ -616,17 +618,25 @@ bool roi_align_nhwc_wino_applicable(int C, int64_t R)
 {
     const char *fe = getenv("LOCOV_WINO_FUSE");            // developer A/B / tests (read per launch): 0 = never
     if (fe && atoi(fe) == 0) return false;
-    return C % kWinoSliceCh == 0 && R * (C / kWinoSliceCh) <= 0x7fffffffLL;
+    return C % 64 == 0 && R * (C / 64) <= 0x7fffffffLL;
 }
 
 int launch_roi_align_nhwc_wino(const float *feat, int N, int H, int W, int C, int64_t feat_ld, const float *rois, int64_t R, int pooled,
                                float spatial_scale, int sampling_ratio, int aligned, const float *ch_scale, const float *ch_shift, int relu,
                                float *V, float v_scale, unsigned *overflow, hipStream_t s)
 {
-    const int nslices = C / kWinoSliceCh;
-    hipLaunchKernelGGL((roi_align_nhwc_kernel<float, float, false, true>), dim3((unsigned)(R * nslices)), dim3(kNhwcThreads), 0, s, feat, N, H, W, C,
-                       rois, pooled, pooled, spatial_scale, sampling_ratio, aligned, 2, (pooled + 1) / 2, (pooled + 1) / 2, 0, V, (int64_t)C, feat_ld,
-                       ch_scale, ch_shift, relu, nslices, R, v_scale, overflow);
+    // (LOCOV_WINO_SLICE_CH: developer A/B of the slice width)
+    static const int forced = [] { const char *e = getenv("LOCOV_WINO_SLICE_CH"); return e ? atoi(e) : 0; }();
+    const int width = forced == 64 || forced == 128 ? (C % forced == 0 ? forced : 64) : (C % 128 == 0 ? 128 : 64);
+    const int nslices = C / width;
+    if (width == 128)
+        hipLaunchKernelGGL((roi_align_nhwc_kernel<float, float, false, 128>), dim3((unsigned)(R * nslices)), dim3(kNhwcThreads), 0, s, feat, N, H, W, C,
+                           rois, pooled, pooled, spatial_scale, sampling_ratio, aligned, 2, (pooled + 1) / 2, (pooled + 1) / 2, 0, V, (int64_t)C, feat_ld,
+                           ch_scale, ch_shift, relu, nslices, R, v_scale, overflow);
+    else
+        hipLaunchKernelGGL((roi_align_nhwc_kernel<float, float, false, 64>), dim3((unsigned)(R * nslices)), dim3(kNhwcThreads), 0, s, feat, N, H, W, C,
+                           rois, pooled, pooled, spatial_scale, sampling_ratio, aligned, 2, (pooled + 1) / 2, (pooled + 1) / 2, 0, V, (int64_t)C, feat_ld,
+                           ch_scale, ch_shift, relu, nslices, R, v_scale, overflow);
     return check_launch("locov_roi_align_winograd_conv3x3_f32_split (ROIAlign + input transform)");
 }
 
