@@ -327,7 +327,7 @@ class TrainWorkload:
         return n_sampled
 
 
-TRAFFIC_FILE = "r03_pmc_traffic.json"
+TRAFFIC_FILE = "r04_pmc_traffic.json"
 
 
 def recorded_traffic(args, kernel_key: str):

@@ -385,6 +385,7 @@ class SampleAllROIHeads(ROIHeads):
         return {"proposals": proposals, "targets": targets, "gt_index": gt_index, "labels": labels, "pos_order": pos_order,
                 "neg_order": neg_order, "rows_shape": tuple(rows.shape), "host": host, "event": event, "guards": guards}
 
+    @torch.no_grad()
     def _label_finish(self, st) -> List[Instances]:
         if "done" in st:
             return st["done"]

@@ -70,4 +70,10 @@ for k, c in m.items():
                                 "SQ_LDS_BANK_CONFLICT": avg("SQ_LDS_BANK_CONFLICT"),
                                 "SQ_WAIT_ANY_over_WAVE_CYCLES": avg("SQ_WAIT_ANY") / avg("SQ_WAVE_CYCLES")}
 json.dump(util, open(dst("pmc_mfma_util.json"), "w"), indent=1)
-print("wrote", [os.path.basename(dst(n)) for n in ("bench.json", "bench_kernel_stats.csv", "pmc_traffic.json", "pmc_mfma_util.json")])
+extra = []
+for src, name in ((os.path.join(SRC, "find_syncs.txt"), "find_syncs.txt"), (os.path.join(SRC, "train_timeline.txt"), "train_timeline.txt"),
+                  (os.path.join(ROOT, "gpurun_out", "prof_train", "stats", "s_kernel_stats.csv"), "train_kernel_stats.csv")):
+    if os.path.exists(src):
+        shutil.copy(src, dst(name))
+        extra.append(os.path.basename(dst(name)))
+print("wrote", [os.path.basename(dst(n)) for n in ("bench.json", "bench_kernel_stats.csv", "pmc_traffic.json", "pmc_mfma_util.json")] + extra)
