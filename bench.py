@@ -523,6 +523,19 @@ def main():
         wl.heads.res5_dtype = "f16x2"
     dom_ms = float(np.mean([a.elapsed_time(b) for a, b in wl.ev])) if wl.ev else float("nan")
     dt1 = timed(wl.step_s1, args.steps, args.warmup) if not args.skip_s1 else float("nan")
+    # S1's dominant kernel on its own: the pooler-contract ROIAlign ([R,1024,14,14] out of the NCHW map, incl. its channels-last copy)
+    s1_roi = None
+    if not args.skip_s1:
+        with torch.no_grad():
+            dtr = timed(lambda: wl.ops.roi_align(wl.features["res4"], wl.rois, 14, 1.0 / 16, 0, True), max(args.steps // 2, 3), 2)
+        R_all = args.images * args.proposals
+        roi_bytes = args.images * 1024 * 50 * 84 * 4 + R_all * 5 * 4 + R_all * 1024 * 14 * 14 * 4      # map + rois read, pooled written
+        ms_roi = dtr / max(args.steps // 2, 3) * 1e3
+        s1_roi = {"kernel": "roi_align_nhwc2nchw_kernel (+ nchw_to_nhwc_kernel): bit-exact pooler-contract ROIAlign", "bound": "hbm",
+                  "ms_per_call": ms_roi, "algorithmic_bytes": roi_bytes, "achieved": roi_bytes / (ms_roi * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                  "unit": "GB/s", "frac": roi_bytes / (ms_roi * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "what": "write-dominated; the gather runs at the texture path's rate (taps in torchvision's per-sample order, ~77 GB through "
+                          "the vector L1 per call), not at HBM's: docs/experiments.md R4.5"}
     # north_star's 1024-d bank, fp32 and bf16 similarity GEMM (config 3): the same job with another predictor / bank
     variants = {}
     if not args.skip_variants:
@@ -706,7 +719,7 @@ def main():
             "rccl_ranks": rccl_ranks,
             "scopes": {"S2_full_head_proposals_per_s": props_per_step * args.steps / dt2,
                        "S1_handwritten_kernels_proposals_per_s": None if args.skip_s1 else props_per_step * args.steps / dt1,
-                       "S1_ms_per_step": None if args.skip_s1 else dt1 / args.steps * 1e3, **variants},
+                       "S1_ms_per_step": None if args.skip_s1 else dt1 / args.steps * 1e3, "S1_roi_align_roofline": s1_roi, **variants},
             "roofline": roof,
         }
         if dt2_f32 is not None:
