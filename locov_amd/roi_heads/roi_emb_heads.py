@@ -344,6 +344,10 @@ class SampleAllROIHeads(ROIHeads):
         instances: ONE concatenation and ONE gather for the batch, handed out as per-image views."""
         v0 = values[0]
         boxes_like = not isinstance(v0, torch.Tensor) and hasattr(v0, "tensor")
+        if not boxes_like and not isinstance(v0, torch.Tensor):
+            # any other indexable field type (lists, masks, ...): index image by image with the image's own row numbers
+            offs = np.concatenate([[0], np.cumsum([len(v) for v in values])]).tolist()
+            return [v[idx - off] for v, idx, off in zip(values, torch.split(index, sizes), offs)]
         flat = torch.cat([v.tensor if boxes_like else v for v in values], dim=0)[index]
         parts = torch.split(flat, sizes, dim=0)
         return [type(v0)(p) for p in parts] if boxes_like else list(parts)
