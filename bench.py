@@ -621,6 +621,7 @@ def main():
                 # against the dense f16 MFMA peak on the f16 FLOPs it executes (3 x 2MNK); the fp32-equivalent rate
                 # (2MNK / time) is reported next to it.
                 ns, mss, fls, bys = gemm_split_big
+                big_tile = bool(ns)
                 if not ns:            # a workload whose launches all stay below the 256x256 threshold: the 128x128 kernel is the dominant one
                     ns, mss, fls, bys = gemm_split
                 ach = 3.0 * fls / (mss * 1e-3) / 1e12 if mss > 0 else float("nan")
@@ -637,9 +638,11 @@ def main():
                             "achieved": a_, "frac": a_ / MFMA_16BIT_PEAK_TFLOPS if a_ else None,
                             "algorithmic_bytes": by_ / n_, "traffic": tr,
                             "traffic_over_algorithmic": tr / (by_ / n_) if tr and by_ else None}
-                roof = {"kernel": "gemm_split_big_kernel (csrc/gemm_split_big.hip): the split-operand NT GEMM on its 256x256 tile -- Res5's 1x1 "
-                                  "convolutions on pooled rows and the Winograd-domain batched GEMMs; fp32 in / fp32 out, products formed from "
-                                  "f16x2 split operands on the f16 matrix pipe",
+                roof = {"kernel": ("gemm_split_big_kernel (csrc/gemm_split_big.hip): the split-operand NT GEMM on its 256x256 tile -- Res5's 1x1 "
+                                   "convolutions on pooled rows and the Winograd-domain batched GEMMs; fp32 in / fp32 out, products formed from "
+                                   "f16x2 split operands on the f16 matrix pipe") if big_tile else
+                                  ("gemm_split_kernel (csrc/gemm_split.hip): the split-operand NT GEMM on its 128x128 tile (this workload has no "
+                                   "launch with the 1 024 tiles of 256x256 the big-tile kernel asks for)"),
                         "bound": "mfma", "achieved": ach, "peak": MFMA_16BIT_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / MFMA_16BIT_PEAK_TFLOPS,
                         "traffic": recorded_traffic(args, "gemm_split_big_kernel"),
