@@ -427,6 +427,207 @@ constexpr int kT2Threads = 256;
 constexpr int kT2Ch = 32;          // channels per workgroup (one 128-byte line per tap; ~25 KiB LDS tile)
 constexpr int kT2Axis = 256;       // per-axis LDS table entries (larger sampling grids: computed on the fly)
 
+// ---- small proposals: the whole footprint in LDS (roi_align_win_kernel) --------------------------------------------------
+// A proposal of up to ~11 x 11 map pixels (side <= ~180 image pixels: 6 of 10 bench proposals) touches at most 14 x 14 pixels, and
+// the [32 ch][bins] transpose tile is 25 KB = 197 pixels x 128 B.  For those ROIs the workgroup fetches the pixel rectangle ONCE
+// (<= 7 loads per thread, all in flight: one memory latency instead of one per pass of 32 bins), takes every tap from LDS -- the
+// same values in the same per-sample order: bit-identical -- keeps its 7 results per thread in registers and only then re-uses
+// the same LDS bytes as the transpose tile.  LDS per workgroup and waves per CU are those of the direct form (what sank round 3's
+// LDS-staged kernel and round 4's pipelined one was occupancy).  roi_window_rect decides per workgroup, from the proposal's coordinates
+// alone, which path it takes.
+constexpr int kWinPitch = 4 * kT2Ch;                      // bytes per pixel of the window (32 channels)
+constexpr int kWinMaxPasses = 7;                          // results per thread kept in registers: bins <= 7 * 32
+#ifndef LOCOV_ROIALIGN_WINDOW
+#define LOCOV_ROIALIGN_WINDOW 1                           // developer A/B: 0 = every proposal takes the direct form
+#endif
+
+// conservative pixel rectangle of every tap of the ROI: one pixel of margin on each side absorbs the difference between this
+// estimate's rounding and axis_sample_n's.  Returns false when it does not fit `cap` pixels (or the ROI cannot use the window).
+__device__ __forceinline__ bool roi_window_rect(float start_h, float start_w, float bin_h, float bin_w, int gh, int gw, int PH, int PW, int H,
+                                                int W, int cap, bool valid_b, int &y0, int &x0, int &wh, int &ww)
+{
+    if (!LOCOV_ROIALIGN_WINDOW || !valid_b || gh <= 0 || gw <= 0 || PH * PW > kWinMaxPasses * (kT2Threads / (kT2Ch / 4)) || PH * gh > kT2Axis ||
+        PW * gw > kT2Axis)
+        return false;
+    // every sample lies between the ROI's two edges (an inverted ROI under a forced sampling ratio runs from the far edge back)
+    const float ya_ = start_h, yb_ = start_h + (float)PH * bin_h, xa_ = start_w, xb_ = start_w + (float)PW * bin_w;
+    const float yf = fminf(ya_, yb_), yl = fmaxf(ya_, yb_), xf = fminf(xa_, xb_), xl = fmaxf(xa_, xb_);
+    if (!(yl - yf < 64.f) || !(xl - xf < 64.f) || !(yf > -1.0e6f) || !(xf > -1.0e6f) || !(yl < 1.0e6f) || !(xl < 1.0e6f)) return false;   // (also rejects NaN)
+    const int ya = max((int)floorf(fmaxf(yf, 0.f)) - 1, 0), yb = min((int)floorf(fmaxf(yl, 0.f)) + 2, H - 1);
+    const int xa = max((int)floorf(fmaxf(xf, 0.f)) - 1, 0), xb = min((int)floorf(fmaxf(xl, 0.f)) + 2, W - 1);
+    y0 = min(ya, H - 1);
+    x0 = min(xa, W - 1);
+    wh = max(yb - y0 + 1, 1);
+    ww = max(xb - x0 + 1, 1);
+    return wh * ww <= cap;
+}
+
+// (a device function of roi_align_nhwc2nchw_kernel, not a launch of its own: as two launches the direct form's texture-bound large
+//  proposals and the window form's store-bound small ones ran one after the other instead of beside each other -- 3.05 ms against
+//  2.84; the two paths share the kernel's register allocation, the larger of the two)
+__device__ __forceinline__ void roi_align_window_path(
+    const float *__restrict__ feat, int N, int H, int W, int C, const float *__restrict__ rois, int PH, int PW,
+    float scale, int sampling_ratio, int aligned, float *__restrict__ out, float *smem, int y0, int x0, int wh, int ww)
+{
+    const int bins = PH * PW;
+    const int ts = bins | 1;                                  // odd row stride of the transpose tile
+    float *tile = smem;                                       // [kT2Ch][ts] -- first the pixel window, then the tile
+    char *win = reinterpret_cast<char *>(smem);
+    AxisSampleN *ytab = reinterpret_cast<AxisSampleN *>(smem + kT2Ch * ts + (4 - (kT2Ch * ts) % 4) % 4);
+    AxisSampleN *xtab = ytab + kT2Axis;
+
+    const int64_t r = blockIdx.x;
+    const int c0 = blockIdx.y * kT2Ch;
+    const float *roi = rois + r * 5;
+    const int b = (int)roi[0];
+    const float off = aligned ? 0.5f : 0.0f;
+    const float start_w = roi[1] * scale - off, start_h = roi[2] * scale - off;
+    const float end_w = roi[3] * scale - off, end_h = roi[4] * scale - off;
+    float rw = end_w - start_w, rh = end_h - start_h;
+    if (!aligned) {
+        rw = fmaxf(rw, 1.f);
+        rh = fmaxf(rh, 1.f);
+    }
+    const float bin_h = rh / (float)PH, bin_w = rw / (float)PW;
+    const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(bin_h);
+    const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(bin_w);
+    const int prod = gh * gw;
+    const float count = (float)(prod > 1 ? prod : 1);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int QN = kT2Ch / 4;                             // lanes (channel quads) per bin / per pixel
+    constexpr int BPW = 64 / QN;                              // bins per wave instruction
+    constexpr int PPP = kT2Threads / QN;                      // pixels (and bins) per pass of the workgroup
+    const int q = lane % QN, sub = lane / QN;
+    const int cq = c0 + 4 * q;
+    const bool c_ok = cq < C;                                 // C % 4 == 0: a quad is all-in or all-out
+    const unsigned ystride = (unsigned)W * C * (unsigned)sizeof(float), xstride = (unsigned)C * (unsigned)sizeof(float);
+    const float *img = feat + (int64_t)b * H * W * C;
+    const __amdgpu_buffer_rsrc_t img_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(img), 0, (unsigned)H * ystride, 0x00020000);
+
+    // 1. the window's pixels, every load of this thread in flight: pixel p = (row p / ww, column p % ww), its 128 bytes by 8 lanes
+    const int npx = wh * ww;
+    const float inv_ww = 1.0f / (float)ww;
+    const int p0 = threadIdx.x / QN, qq = threadIdx.x % QN;
+    const unsigned qoff = (unsigned)(c0 + 4 * qq < C ? c0 + 4 * qq : 0) * (unsigned)sizeof(float);
+    float4 stage[kWinMaxPasses];
+#pragma unroll
+    for (int i = 0; i < kWinMaxPasses; i++) {
+        const int p = p0 + i * PPP;
+        stage[i] = float4{0.f, 0.f, 0.f, 0.f};
+        if (p < npx) {
+            const int wr = (int)(((float)p + 0.5f) * inv_ww), wc = p - wr * ww;         // exact for these small integers
+            stage[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      img_rsrc, (unsigned)(y0 + wr) * ystride + (unsigned)(x0 + wc) * xstride + qoff, 0, 0));
+        }
+    }
+    // 2. (under those loads) the sampling tables, with WINDOW byte offsets: row offset for y, pixel offset for x.  A sample outside
+    // [-1, size] has weights 0 and points at the window's first row / column (0 * finite = 0, as in the direct form)
+    const int ny = PH * gh, nx = PW * gw;
+    for (int t = threadIdx.x; t < ny; t += kT2Threads) {
+        AxisSampleN a = axis_sample_n(start_h, bin_h, t / gh, t % gh, gh, H);
+        a.lo = min(max(a.lo - y0, 0), wh - 1) * (ww * kWinPitch);
+        a.hi = min(max(a.hi - y0, 0), wh - 1) * (ww * kWinPitch);
+        ytab[t] = a;
+    }
+    for (int t = threadIdx.x; t < nx; t += kT2Threads) {
+        AxisSampleN a = axis_sample_n(start_w, bin_w, t / gw, t % gw, gw, W);
+        a.lo = min(max(a.lo - x0, 0), ww - 1) * kWinPitch;
+        a.hi = min(max(a.hi - x0, 0), ww - 1) * kWinPitch;
+        xtab[t] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < kWinMaxPasses; i++) {
+        const int p = p0 + i * PPP;
+        if (p < npx) *reinterpret_cast<float4 *>(win + p * kWinPitch + qq * 16) = stage[i];
+    }
+    __syncthreads();
+
+    // 3. every bin of this thread out of the window, torchvision's sample order, un-fused: the arithmetic of the direct form
+    const int ns = gh * gw;
+    const float inv_pw = 1.0f / (float)PW;
+    const int icount = prod > 1 ? prod : 1;
+    const bool count_pow2 = (icount & (icount - 1)) == 0;     // wave-uniform
+    const float inv_count = 1.0f / count;                     // exact when count is a power of two
+    const char *wq = win + q * 16;
+    float4 res[kWinMaxPasses];
+#pragma unroll
+    for (int k = 0; k < kWinMaxPasses; k++) {
+        const int bin = k * PPP + wave * BPW + sub;
+        const bool bin_ok = bin < bins;
+        const int ph = bin_ok ? (int)(((float)bin + 0.5f) * inv_pw) : 0, pw = bin_ok ? bin - ph * PW : 0;
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (bin_ok && c_ok) {
+            int iy = 0, ix = 0;
+            for (int sidx = 0; sidx < ns; sidx++) {
+                const AxisSampleN ys = ytab[ph * gh + iy], xs = xtab[pw * gw + ix];
+                const float w1 = ys.wh * xs.wh, w2 = ys.wh * xs.wl, w3 = ys.wl * xs.wh, w4 = ys.wl * xs.wl;
+                const float4 v1 = *reinterpret_cast<const float4 *>(wq + ys.lo + xs.lo);
+                const float4 v2 = *reinterpret_cast<const float4 *>(wq + ys.lo + xs.hi);
+                const float4 v3 = *reinterpret_cast<const float4 *>(wq + ys.hi + xs.lo);
+                const float4 v4 = *reinterpret_cast<const float4 *>(wq + ys.hi + xs.hi);
+                // ((w1*v1 + w2*v2) + w3*v3) + w4*v4, then accumulate -- un-fused (file built with -ffp-contract=off)
+                acc.x = acc.x + (((w1 * v1.x + w2 * v2.x) + w3 * v3.x) + w4 * v4.x);
+                acc.y = acc.y + (((w1 * v1.y + w2 * v2.y) + w3 * v3.y) + w4 * v4.y);
+                acc.z = acc.z + (((w1 * v1.z + w2 * v2.z) + w3 * v3.z) + w4 * v4.z);
+                acc.w = acc.w + (((w1 * v1.w + w2 * v2.w) + w3 * v3.w) + w4 * v4.w);
+                if (++ix == gw) {
+                    ix = 0;
+                    iy++;
+                }
+            }
+        }
+        if (count_pow2) {              // x / 2^k == x * 2^-k bit for bit (both are the correctly rounded quotient)
+            acc.x *= inv_count; acc.y *= inv_count; acc.z *= inv_count; acc.w *= inv_count;
+        } else {
+            acc.x /= count; acc.y /= count; acc.z /= count; acc.w /= count;
+        }
+        res[k] = acc;
+    }
+    __syncthreads();                                          // every tap has been read: the window's bytes become the tile
+#pragma unroll
+    for (int k = 0; k < kWinMaxPasses; k++) {
+        const int bin = k * PPP + wave * BPW + sub;
+        if (bin < bins) {
+            float *t = tile + (4 * q) * ts + bin;
+            t[0] = res[k].x;
+            t[ts] = res[k].y;
+            t[2 * ts] = res[k].z;
+            t[3 * ts] = res[k].w;
+        }
+    }
+    __syncthreads();
+    const int cn = min(kT2Ch, C - c0);
+    float *dst = out + (r * C + c0) * (int64_t)bins;
+    if ((bins & 3) == 0) {
+        const int qpc = bins >> 2;                                     // quads per channel
+        int c = 0, b4 = threadIdx.x;
+        while (b4 >= qpc) {
+            b4 -= qpc;
+            c++;
+        }
+        const int step_c = kT2Threads / qpc, step_b = kT2Threads - step_c * qpc;
+        while (c < cn) {
+            const float *t = tile + c * ts + 4 * b4;
+            const float4 v = {t[0], t[1], t[2], t[3]};
+            store4_policy<LOCOV_T2_STORE_AUX>(dst + (c * bins + 4 * b4), v);
+            c += step_c;
+            b4 += step_b;
+            if (b4 >= qpc) {
+                b4 -= qpc;
+                c++;
+            }
+        }
+        return;
+    }
+    const float inv_bins = 1.0f / (float)bins;
+    for (int idx = threadIdx.x; idx < cn * bins; idx += kT2Threads) {
+        const int c = (int)(((float)idx + 0.5f) * inv_bins);       // idx / bins, exact for these sizes (no integer divide)
+        dst[idx] = tile[c * ts + (idx - c * bins)];
+    }
+}
+
 __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
     const float *__restrict__ feat, int N, int H, int W, int C, const float *__restrict__ rois, int PH, int PW,
     float scale, int sampling_ratio, int aligned, float *__restrict__ out)
@@ -456,6 +657,14 @@ __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
     const int prod = gh * gw;
     const float count = (float)(prod > 1 ? prod : 1);
     const bool valid_b = b >= 0 && b < N;
+    {
+        // a proposal whose pixel rectangle fits the LDS window takes every tap from there (roi_align_window_path)
+        int wy0, wx0, wwh, www;
+        if (roi_window_rect(start_h, start_w, bin_h, bin_w, gh, gw, PH, PW, H, W, (kT2Ch * (bins | 1) * 4) / kWinPitch, valid_b, wy0, wx0, wwh, www)) {
+            roi_align_window_path(feat, N, H, W, C, rois, PH, PW, scale, sampling_ratio, aligned, out, smem, wy0, wx0, wwh, www);
+            return;
+        }
+    }
     gh = (gh > 0 && valid_b) ? gh : 0;
     gw = (gw > 0 && valid_b) ? gw : 0;
     const int ny = PH * gh, nx = PW * gw;
