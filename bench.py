@@ -534,8 +534,9 @@ def main():
         s1_roi = {"kernel": "roi_align_nhwc2nchw_kernel (+ nchw_to_nhwc_kernel): bit-exact pooler-contract ROIAlign", "bound": "hbm",
                   "ms_per_call": ms_roi, "algorithmic_bytes": roi_bytes, "achieved": roi_bytes / (ms_roi * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                   "unit": "GB/s", "frac": roi_bytes / (ms_roi * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                  "what": "write-dominated; the gather runs at the texture path's rate (taps in torchvision's per-sample order, ~77 GB through "
-                          "the vector L1 per call), not at HBM's: docs/experiments.md R4.5"}
+                  "what": "write-dominated; proposals up to ~180 px take their taps from an LDS window (the transpose tile's bytes), larger ones "
+                          "gather at the texture path's rate (torchvision's per-sample order: 9-16 samples per bin), not at HBM's: "
+                          "docs/experiments.md R4.5, R4.7"}
     # north_star's 1024-d bank, fp32 and bf16 similarity GEMM (config 3): the same job with another predictor / bank
     variants = {}
     if not args.skip_variants:
