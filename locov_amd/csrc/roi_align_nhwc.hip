@@ -628,7 +628,10 @@ __device__ __forceinline__ void roi_align_window_path(
     }
 }
 
-__global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
+#ifndef LOCOV_T2_MINW
+#define LOCOV_T2_MINW 4                                    // four waves per SIMD = four workgroups per CU (the register allocator's budget: 128)
+#endif
+__global__ __launch_bounds__(kT2Threads, LOCOV_T2_MINW) void roi_align_nhwc2nchw_kernel(
     const float *__restrict__ feat, int N, int H, int W, int C, const float *__restrict__ rois, int PH, int PW,
     float scale, int sampling_ratio, int aligned, float *__restrict__ out)
 {
@@ -699,7 +702,10 @@ __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(img_rsrc, off, 0, 0));
     };
     const int ns = gh * gw;                                   // samples per bin
-    constexpr int U = 4;                                      // samples in flight per lane (16 x 16-byte loads)
+#ifndef LOCOV_T2_U
+#define LOCOV_T2_U 2                                       // (4 until the row form took the 2-4-sample rows: 2 leaves it the registers -- mix 2.62 -> 2.50 ms)
+#endif
+    constexpr int U = LOCOV_T2_U;                             // samples in flight per lane on the plain path (4 x 16-byte loads each)
     const float inv_pw = 1.0f / (float)PW;
     const int icount = prod > 1 ? prod : 1;
     const bool count_pow2 = (icount & (icount - 1)) == 0;     // wave-uniform
@@ -748,13 +754,86 @@ __global__ __launch_bounds__(kT2Threads) void roi_align_nhwc2nchw_kernel(
                     acc.w = acc.w + (((w[u][0] * v[u][0].w + w[u][1] * v[u][1].w) + w[u][2] * v[u][2].w) + w[u][3] * v[u][3].w);
                 }
             };
-            int s0 = 0;
-            for (; s0 + U <= ns; s0 += U) group(std::integral_constant<int, U>{});
-            switch (ns - s0) {                                   // wave-uniform remainder, 0..U-1 samples
-            case 3: group(std::integral_constant<int, 3>{}); break;
-            case 2: group(std::integral_constant<int, 2>{}); break;
-            case 1: group(std::integral_constant<int, 1>{}); break;
-            default: break;
+            // Rows of 2-4 samples: consecutive samples of a bin row are at most one pixel apart (grid = ceil(bin size)), so sample
+            // ix + 1 re-uses one of sample ix's two pixel columns -- its left column IS the previous left or the previous right one.
+            // A row of GW samples then needs GW + 1 columns x 2 rows of loads instead of 4 GW taps (6 / 8 / 10 instead of 8 / 12 / 16):
+            // a quarter to three eighths fewer bytes through the texture path, which is what bounds the large proposals.  Which column is
+            // re-used differs per lane group (= per bin): a select on already loaded registers, the SAME values in the same sample
+            // order -- bit-identical.  Checked per row from the tables alone (all lanes must be able to re-use); otherwise the row
+            // takes the four taps per sample.
+            auto row_group = [&](auto gw_tag, auto rp_tag) __attribute__((always_inline)) {
+                constexpr int GW = decltype(gw_tag)::value, RP = decltype(rp_tag)::value;
+                AxisSampleN xs[GW];
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < GW; i++) {
+                    xs[i] = xtab[pw * gw + i];
+                    if (i > 0) ok = ok && (xs[i].lo == xs[i - 1].lo || xs[i].lo == xs[i - 1].hi);
+                }
+                if (!__all(ok)) {                              // (wave-uniform: a lane group whose samples jump takes the plain form with it)
+                    for (int t = 0; t < RP * GW; t++) group(std::integral_constant<int, 1>{});
+                    return;
+                }
+                float4 L[RP][GW + 1], Hh[RP][GW + 1];
+                AxisSampleN ys[RP];
+#pragma unroll
+                for (int r = 0; r < RP; r++) {
+                    ys[r] = ytab[ph * gh + iy + r];
+                    const unsigned ylo = (unsigned)ys[r].lo + ch_off, yhi = (unsigned)ys[r].hi + ch_off;
+                    L[r][0] = tap(ylo + (unsigned)xs[0].lo);
+                    Hh[r][0] = tap(yhi + (unsigned)xs[0].lo);
+#pragma unroll
+                    for (int i = 0; i < GW; i++) {
+                        L[r][i + 1] = tap(ylo + (unsigned)xs[i].hi);
+                        Hh[r][i + 1] = tap(yhi + (unsigned)xs[i].hi);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RP; r++) {
+                    float4 a0 = L[r][0], a2 = Hh[r][0], a1 = L[r][1], a3 = Hh[r][1];
+#pragma unroll
+                    for (int i = 0; i < GW; i++) {
+                        if (i > 0) {
+                            const bool same = xs[i].lo == xs[i - 1].lo;      // else the previous right column
+                            a0.x = same ? a0.x : a1.x; a0.y = same ? a0.y : a1.y; a0.z = same ? a0.z : a1.z; a0.w = same ? a0.w : a1.w;
+                            a2.x = same ? a2.x : a3.x; a2.y = same ? a2.y : a3.y; a2.z = same ? a2.z : a3.z; a2.w = same ? a2.w : a3.w;
+                            a1 = L[r][i + 1];
+                            a3 = Hh[r][i + 1];
+                        }
+                        const float w0 = ys[r].wh * xs[i].wh, w1 = ys[r].wh * xs[i].wl, w2 = ys[r].wl * xs[i].wh, w3 = ys[r].wl * xs[i].wl;
+                        acc.x = acc.x + (((w0 * a0.x + w1 * a1.x) + w2 * a2.x) + w3 * a3.x);
+                        acc.y = acc.y + (((w0 * a0.y + w1 * a1.y) + w2 * a2.y) + w3 * a3.y);
+                        acc.z = acc.z + (((w0 * a0.z + w1 * a1.z) + w2 * a2.z) + w3 * a3.z);
+                        acc.w = acc.w + (((w0 * a0.w + w1 * a1.w) + w2 * a2.w) + w3 * a3.w);
+                    }
+                }
+                iy += RP;                                      // (ix stays 0: whole rows)
+            };
+#ifndef LOCOV_T2_DEDUPE
+#define LOCOV_T2_DEDUPE 1                                  // developer A/B: 0 = four taps per sample everywhere
+#endif
+            using std::integral_constant;
+            if (LOCOV_T2_DEDUPE && use_lds && gw >= 2 && gw <= 4) {
+                while (iy < gh) {
+                    // (two rows in flight only at GW = 2: 12 loads; three samples x two rows asked for 140 registers = a wave per SIMD less)
+                    if (gw == 2) {
+                        if (iy + 1 < gh) row_group(integral_constant<int, 2>{}, integral_constant<int, 2>{});
+                        else row_group(integral_constant<int, 2>{}, integral_constant<int, 1>{});
+                    } else if (gw == 3) {
+                        row_group(integral_constant<int, 3>{}, integral_constant<int, 1>{});
+                    } else {
+                        row_group(integral_constant<int, 4>{}, integral_constant<int, 1>{});
+                    }
+                }
+            } else {
+                int s0 = 0;
+                for (; s0 + U <= ns; s0 += U) group(std::integral_constant<int, U>{});
+                switch (ns - s0) {                                   // wave-uniform remainder, 0..U-1 samples
+                case 3: group(std::integral_constant<int, (U > 3 ? 3 : 1)>{}); break;
+                case 2: group(std::integral_constant<int, (U > 2 ? 2 : 1)>{}); break;
+                case 1: group(std::integral_constant<int, 1>{}); break;
+                default: break;
+                }
             }
         }
         if (bin_ok) {
