@@ -809,6 +809,8 @@ __global__ __launch_bounds__(kT2Threads, LOCOV_T2_MINW) void roi_align_nhwc2nchw
                 }
                 iy += RP;                                      // (ix stays 0: whole rows)
             };
+            // (Sharing a pixel ROW between two consecutive sample rows the same way -- 3 (GW + 1) loads per row pair instead of
+            //  4 (GW + 1) -- was built too: bit-identical and 15-40 % SLOWER, 22 spilled registers at four waves per SIMD; R4.8.)
 #ifndef LOCOV_T2_DEDUPE
 #define LOCOV_T2_DEDUPE 1                                  // developer A/B: 0 = four taps per sample everywhere
 #endif
