@@ -459,7 +459,8 @@ __device__ __forceinline__ bool roi_window_rect(float start_h, float start_w, fl
     x0 = min(xa, W - 1);
     wh = max(yb - y0 + 1, 1);
     ww = max(xb - x0 + 1, 1);
-    return wh * ww <= cap;
+    // (the window path stages at most kWinMaxPasses pixels per thread group: a tile of more than 224 floats per channel row could hold more)
+    return wh * ww <= min(cap, kWinMaxPasses * (kT2Threads / (kT2Ch / 4)));
 }
 
 // (a device function of roi_align_nhwc2nchw_kernel, not a launch of its own: as two launches the direct form's texture-bound large

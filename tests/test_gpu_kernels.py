@@ -349,6 +349,24 @@ def test_roi_align_nhwc_random_configurations(ops, oracle):
                                    err_msg=str((N, C, H, W, P, scale, ratio, aligned, stride)))
 
 
+@pytest.mark.parametrize("P", [(14, 16), (16, 14), (15, 15), (13, 17), (2, 3)])
+def test_roi_align_nchw_bit_exact_at_the_window_limits(ops, oracle, P):
+    """Pooled sizes around the LDS-window path's limits (7 passes x 32 bins = 224 bins; the window is the transpose tile's bytes,
+    32 x (bins | 1) floats): proposals of every size, many of them small enough for the window, on a map with few and with many channels."""
+    rng = np.random.default_rng(P[0] * 31 + P[1])
+    for C in (8, 64, 36):
+        N, H, W = 2, 30, 44
+        feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        rois = _rois(oracle, rng, N, 48, W, H, wild=6)
+        small = rng.uniform(8, 200, (24, 2)).astype(np.float32)                # sides of 0.5 .. 12 map pixels: the window's proposals
+        xy = rng.uniform(-20, [W * 16.0, H * 16.0], (24, 2)).astype(np.float32)
+        rois[:24, 1:3], rois[:24, 3:5] = xy, xy + small
+        for sr in (0, 2):
+            want = oracle.roi_align(feat, rois, P, 1 / 16, sr, True)
+            got = ops.roi_align(dev(feat), dev(rois), P, 1 / 16, sr, True).cpu().numpy()
+            np.testing.assert_array_equal(got, want, err_msg=str((P, C, sr)))
+
+
 def test_roi_align_nchw_bit_exact_random_configurations(ops, oracle):
     """Bit-exactness of the contract kernel over random configurations (both gather kernels: C % 4 == 0 or not)."""
     rng = np.random.default_rng(515)
