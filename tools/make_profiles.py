@@ -72,6 +72,7 @@ for k, c in m.items():
 json.dump(util, open(dst("pmc_mfma_util.json"), "w"), indent=1)
 extra = []
 for src, name in ((os.path.join(SRC, "find_syncs.txt"), "find_syncs.txt"), (os.path.join(SRC, "train_timeline.txt"), "train_timeline.txt"),
+                  (os.path.join(SRC, "power_step.txt"), "power_step.txt"),
                   (os.path.join(ROOT, "gpurun_out", "prof_train", "stats", "s_kernel_stats.csv"), "train_kernel_stats.csv")):
     if os.path.exists(src):
         shutil.copy(src, dst(name))

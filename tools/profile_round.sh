@@ -2,6 +2,7 @@
 #   1. bench.py JSON line                       -> gpurun_out/prof/bench.json
 #   2. rocprofv3 --kernel-trace --stats         -> gpurun_out/prof/stats/
 #   3. separate --pmc passes (no trace domains) -> gpurun_out/prof/pmc_{fetch,write,mfma}/
+#   5. package power / shader clock while the step runs (tools/power_step.py) -> gpurun_out/prof/power_step.txt
 #   4. the training step: kernel stats + trace  -> gpurun_out/prof_train/ (tools/profile_train.sh), host syncs -> gpurun_out/prof/find_syncs.txt
 # then tools/make_profiles.py <tag> turns them into profiles/<tag>_* (run locally).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -16,5 +17,6 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACT
 for m in infer lsm stt; do python3 tools/find_syncs.py $m 2>/dev/null | grep -v "^/"; done > $OUT/find_syncs.txt
 bash tools/profile_train.sh > $OUT/profile_train.txt 2>&1
 python3 tools/train_timeline.py > $OUT/train_timeline.txt 2>/dev/null
+timeout 300 python3 tools/power_step.py > $OUT/power_step.txt 2>/dev/null      # package power / clock of the step and its launch kinds
 ls -R $OUT | head -40
 tail -c 600 $OUT/bench.json
