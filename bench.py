@@ -468,9 +468,16 @@ def main():
     def timed(fn, steps, warmup, on_start=None, key=None, **kw):
         """K steps between barrier + synchronize on both sides; the time is hipEventElapsedTime between two events recorded
         on the launch stream inside that bracket, max over ranks; the host wall clock of the same bracket is
-        kept beside it (wall[key])."""
+        kept beside it (wall[key]).  The interpreter's full garbage-collection pass is taken HERE, after the warm-up and before the
+        bracket, and the objects alive at that point are frozen (gc.freeze): with a quarter of a million tracked objects a
+        generation-2 pass takes ~90 ms, and one landing at a random step inside a 10-step training window moved
+        `train.lsm.ms_per_step` between 14.5 and 24 ms from run to run (tools/ab_fused_losses.py).  Collections of the younger
+        generations keep running inside the bracket."""
+        import gc
         for _ in range(warmup):
             fn()
+        gc.collect()
+        gc.freeze()
         barrier()
         if on_start is not None:
             on_start()
@@ -702,7 +709,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt2 / args.steps * 1e3,
             "timing": {"how": "hipEventElapsedTime between two events on the launch stream around the K timed steps, inside the "
-                              "barrier + synchronize bracket, max over ranks", "wall_ms_per_step": wall["s2"] / args.steps * 1e3},
+                              "barrier + synchronize bracket, max over ranks; the interpreter's full garbage-collection pass is "
+                              "taken between warm-up and bracket (gc.collect + gc.freeze), not at a random step inside it",
+                       "wall_ms_per_step": wall["s2"] / args.steps * 1e3},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16 operands / f32 accumulate in Res5 (opt-in reduced precision, not the parity configuration)"
                       if args.res5_dtype == "bf16" else

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LOCOV_ABI_VERSION 4
+#define LOCOV_ABI_VERSION 5
 
 #define LOCOV_OK 0
 #define LOCOV_ERR_INVALID_ARG (-1)
@@ -414,6 +414,21 @@ int locov_label_proposals(const float *boxes, const int *prop_offsets, const flo
                           double *key_pos, double *key_neg, int64_t *rows, locov_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * a-11  the box-regression loss of the training heads in ONE launch.  Replaces the torch-op chain of [D2-upstream]
+ * FastRCNNOutputLayers.box_reg_loss as the reference configures it (ovr/modeling/roi_heads/box_emb_grounding_head.py:278-279,
+ * 370-374: "smooth_l1", SMOOTH_L1_BETA; Box2BoxTransform weights :368) -- get_deltas(proposal, matched ground truth) of the
+ * foreground rows (0 <= gt_classes < num_classes), smooth-L1 (plain L1 below beta 1e-5) against the predicted deltas, summed in a
+ * fixed order and divided by max(R, 1) -- and d loss / d pred_deltas from the same launch.
+ *   proposal_boxes / gt_boxes [R, 4] XYXY fp32 (16-byte aligned), pred_deltas [R, ld] with ld = 4 (class-agnostic) or
+ *   4 * num_classes, gt_classes [R] int64; loss [1]; dpred [R, ld] or NULL: written completely when ld == 4, otherwise only the four
+ *   columns of a foreground row's class (the caller zeroes it).  Foreground boxes must have positive width and height (the
+ *   labelling's validity bit, locov_label_proposals' rows[:, 3]).
+ * ------------------------------------------------------------------------------------- */
+int locov_box_reg_loss(const float *proposal_boxes, const float *gt_boxes, const float *pred_deltas, int64_t ld,
+                       const int64_t *gt_classes, int64_t R, int64_t num_classes, float wx, float wy, float ww, float wh,
+                       float smooth_l1_beta, float *loss, float *dpred, locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * a-10  greedy NMS on the device.  Replaces [D2-upstream] torchvision.ops.nms as reached from
  * box_predictor.inference -> fast_rcnn_inference -> batched_nms
  * (ovr/modeling/roi_heads/roi_emb_heads.py:280,357).
@@ -447,6 +462,22 @@ int locov_grounding_fwd(const float *S, int B, int T, int NR, const float *capti
 int locov_grounding_bwd(const float *S, int B, int T, int NR, const float *caption_mask,
                         const float *region_mask, float temperature, const float *grad_w2r,
                         const float *grad_r2w, float *grad_S, locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a-12  the cross-entropy tail of GroundingHead.forward on the [B, B] caption x image costs of locov_grounding_fwd, in ONE launch
+ * (ovr/modeling/mmss_heads/grounding_head.py:239-251: pairs with neither words nor regions get max(cost) + 100; :273-290
+ * diag(-log_softmax(-cost, dim 0 | 1)).mean(); :357-377 (cost.argmin(dim 0 | 1) == arange).mean()).
+ *   cost_w2r / cost_r2w [B, B] (either may be NULL: ALIGN_WORDS_TO_REGIONS / ALIGN_REGIONS_TO_WORDS off), caption_mask [B, T],
+ *   region_mask [B, NR] fp32; out8 = {CE choose caption, CE choose image, accuracy choose caption, accuracy choose image} for w2r,
+ *   then for r2w.  _bwd: g_* = device scalars d L / d (each of the four CE values) or NULL (= 0); dcost_* [B, B].
+ *   B <= LOCOV_GROUNDING_CE_MAX_B.
+ * ------------------------------------------------------------------------------------- */
+#define LOCOV_GROUNDING_CE_MAX_B 64
+int locov_grounding_ce_fwd(const float *cost_w2r, const float *cost_r2w, const float *caption_mask, const float *region_mask, int B,
+                           int T, int NR, float *out8, locov_stream_t stream);
+int locov_grounding_ce_bwd(const float *cost_w2r, const float *cost_r2w, const float *caption_mask, const float *region_mask, int B,
+                           int T, int NR, const float *g_w2r_caption, const float *g_w2r_image, const float *g_r2w_caption,
+                           const float *g_r2w_image, float *dcost_w2r, float *dcost_r2w, locov_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Backward of the predictor's dense layers under autograd (locov_pool_fc_bwd, locov_sim_gemm_bwd; the

@@ -24,6 +24,8 @@ from __future__ import annotations
 
 from typing import Dict
 
+import os
+
 import torch
 from torch import nn
 
@@ -67,8 +69,6 @@ class GroundingHead(nn.Module):
         region_mask = input_image["region_mask"].to(torch.float32)
         B, NR, V = region_features.shape
         T = caption_mask.shape[1]
-        num_words = caption_mask.sum(dim=1)
-        num_regions = region_mask.sum(dim=1)
 
         # :111 image_emb = v2l_projection(region_features); weights read at call time (tied to emb_pred)
         image_emb = ops.linear_autograd(region_features.reshape(B * NR, V).contiguous().float(),
@@ -79,12 +79,28 @@ class GroundingHead(nn.Module):
         # :147 all B^2 caption x image token-region similarities as one NT GEMM
         S = ops.linear_autograd(cap, image_emb, None)                                 # [B*T, B*NR]
         if not self._fused:
-            return self._general(S, cap.view(B, T, -1), image_emb.view(B, NR, -1), caption_mask, region_mask, num_words, num_regions)
+            return self._general(S, cap.view(B, T, -1), image_emb.view(B, NR, -1), caption_mask, region_mask, caption_mask.sum(dim=1),
+                                 region_mask.sum(dim=1))
         # :150-228 temperature, masked softmax both ways, aligned-local distances -> [caption, image] costs
         cost_w2r, cost_r2w = ops.grounding_costs(S, caption_mask, region_mask, self.temperature)
-        # :232-243 pairs with neither words nor regions get (max + 100)
-        ok = (num_words[:, None] > 0) | (num_regions[None, :] > 0)
         losses, other_info = {}, {}
+        if not self.return_dist and S.is_cuda and B <= ops.GROUNDING_CE_MAX_B and os.environ.get("LOCOV_FUSED_LOSSES", "1") != "0":
+            # :239-290, :357-377 in one launch (ops.grounding_ce = locov_grounding_ce_fwd / _bwd): the (max + 100) replacement, both
+            # log-softmaxes, the diagonal means and the batch accuracies of both alignments
+            vals = ops.grounding_ce(cost_w2r if self.align_words else None, cost_r2w if self.align_regions else None, caption_mask,
+                                    region_mask)
+            for k, (on, tag) in enumerate(((self.align_words, "Words"), (self.align_regions, "Regions"))):
+                if not on:
+                    continue
+                losses[f"CE_loss (Align {tag}, Choose Caption)"] = vals[4 * k]
+                losses[f"CE_loss (Align {tag}, Choose Image)"] = vals[4 * k + 1]
+                other_info[f"Batch Accuracy (Align {tag}, Choose Caption)"] = vals[4 * k + 2]
+                other_info[f"Batch Accuracy (Align {tag}, Choose Image)"] = vals[4 * k + 3]
+            self.log_info = {**losses, **other_info}
+            return other_info, losses
+        # :232-243 pairs with neither words nor regions get (max + 100)
+        num_words, num_regions = caption_mask.sum(dim=1), region_mask.sum(dim=1)
+        ok = (num_words[:, None] > 0) | (num_regions[None, :] > 0)
         eye = torch.arange(B, device=S.device)
         pw = {}
         for on, tag, cost in ((self.align_words, "Words", cost_w2r), (self.align_regions, "Regions", cost_r2w)):

@@ -1238,6 +1238,92 @@ def grounding_costs(S: torch.Tensor, caption_mask: torch.Tensor, region_mask: to
                               float(temperature))
 
 
+GROUNDING_CE_MAX_B = 64        # LOCOV_GROUNDING_CE_MAX_B
+
+
+class _GroundingCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cost_w2r, cost_r2w, cmask, rmask):
+        ref = cost_w2r if cost_w2r is not None else cost_r2w
+        c0 = _dev(cost_w2r, "cost_w2r") if cost_w2r is not None else None
+        c1 = _dev(cost_r2w, "cost_r2w") if cost_r2w is not None else None
+        cmask, rmask = _dev(cmask, "caption_mask"), _dev(rmask, "region_mask")
+        B, T, NR = ref.shape[0], cmask.shape[1], rmask.shape[1]
+        out = torch.zeros(8, dtype=torch.float32, device=ref.device) if (c0 is None or c1 is None) else \
+            torch.empty(8, dtype=torch.float32, device=ref.device)
+        with torch.cuda.device(ref.device):
+            check(_lib.load().locov_grounding_ce_fwd(_ptr(c0), _ptr(c1), _ptr(cmask), _ptr(rmask), B, T, NR, _ptr(out), _stream(ref)),
+                  "locov_grounding_ce_fwd")
+        ctx.save_for_backward(*(t for t in (c0, c1) if t is not None), cmask, rmask)
+        ctx.have = (c0 is not None, c1 is not None)
+        vals = out.unbind(0)
+        ctx.mark_non_differentiable(vals[2], vals[3], vals[6], vals[7])
+        return vals
+
+    @staticmethod
+    def backward(ctx, *g):
+        saved = list(ctx.saved_tensors)
+        c0 = saved.pop(0) if ctx.have[0] else None
+        c1 = saved.pop(0) if ctx.have[1] else None
+        cmask, rmask = saved
+        ref = c0 if c0 is not None else c1
+        B, T, NR = ref.shape[0], cmask.shape[1], rmask.shape[1]
+        ups = [(_dev(g[i].reshape(1), "grad") if g[i] is not None else None) for i in (0, 1, 4, 5)]
+        d0 = torch.empty_like(c0) if c0 is not None else None
+        d1 = torch.empty_like(c1) if c1 is not None else None
+        with torch.cuda.device(ref.device):
+            check(_lib.load().locov_grounding_ce_bwd(_ptr(c0), _ptr(c1), _ptr(cmask), _ptr(rmask), B, T, NR, *(_ptr(u) for u in ups),
+                                                     _ptr(d0), _ptr(d1), _stream(ref)), "locov_grounding_ce_bwd")
+        return d0, d1, None, None
+
+
+def grounding_ce(cost_w2r: Optional[torch.Tensor], cost_r2w: Optional[torch.Tensor], caption_mask: torch.Tensor,
+                 region_mask: torch.Tensor) -> Tuple[torch.Tensor, ...]:
+    """The cross-entropy tail of GroundingHead.forward (grounding_head.py:239-290,357-377) on the [B, B] costs of grounding_costs, one
+    launch (and one in backward): returns 8 scalars -- for w2r, then r2w: CE choose caption, CE choose image, batch accuracy choose
+    caption, batch accuracy choose image (zeros for a cost that is None).  Differentiable in the costs."""
+    ref = cost_w2r if cost_w2r is not None else cost_r2w
+    if ref is None or ref.dim() != 2 or ref.shape[0] != ref.shape[1] or ref.shape[0] > GROUNDING_CE_MAX_B:
+        raise ValueError(f"grounding_ce: costs must be [B, B] with B <= {GROUNDING_CE_MAX_B}")
+    return _GroundingCEFn.apply(cost_w2r, cost_r2w, caption_mask.to(torch.float32), region_mask.to(torch.float32))
+
+
+class _BoxRegLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, proposal_boxes, gt_boxes, gt_classes, num_classes, weights, beta):
+        pred = _dev(pred, "pred_deltas")
+        pb, gb = _dev(proposal_boxes.detach().float(), "proposal_boxes"), _dev(gt_boxes.detach().float(), "gt_boxes")
+        cls = _dev(gt_classes, "gt_classes", torch.int64)
+        R, ld = pred.shape
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        need = ctx.needs_input_grad[0]
+        dpred = None
+        if need:
+            dpred = torch.empty_like(pred) if ld == 4 else torch.zeros_like(pred)
+        with torch.cuda.device(pred.device):
+            check(_lib.load().locov_box_reg_loss(_ptr(pb), _ptr(gb), _ptr(pred), ld, _ptr(cls), R, int(num_classes),
+                                                 *(float(w) for w in weights), float(beta), _ptr(loss), _ptr(dpred), _stream(pred)),
+                  "locov_box_reg_loss")
+        ctx.dpred = dpred
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.dpred * g if ctx.dpred is not None else None), None, None, None, None, None, None
+
+
+def box_reg_loss(pred_deltas: torch.Tensor, proposal_boxes: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.Tensor,
+                 num_classes: int, weights, smooth_l1_beta: float) -> torch.Tensor:
+    """[D2-upstream] FastRCNNOutputLayers.box_reg_loss ("smooth_l1") in one launch: get_deltas of the foreground rows
+    (0 <= gt_classes < num_classes), smooth-L1 against pred_deltas [R, 4] or [R, 4 * num_classes], sum / max(R, 1).  The foreground
+    boxes must already be known to have positive width and height.  Differentiable in pred_deltas."""
+    R = pred_deltas.shape[0]
+    if pred_deltas.dim() != 2 or pred_deltas.shape[1] not in (4, 4 * num_classes) or tuple(proposal_boxes.shape) != (R, 4) \
+            or tuple(gt_boxes.shape) != (R, 4) or tuple(gt_classes.shape) != (R,) or gt_classes.dtype != torch.int64:
+        raise ValueError("box_reg_loss: pred_deltas [R, 4 | 4K], boxes [R, 4], gt_classes [R] int64")
+    return _BoxRegLossFn.apply(pred_deltas.float(), proposal_boxes, gt_boxes, gt_classes, num_classes, tuple(weights), smooth_l1_beta)
+
+
 def rownorm(x: torch.Tensor, mode: int, eps: float = 1e-12) -> torch.Tensor:
     x = _dev(x, "x")
     R, D = x.shape

@@ -15,6 +15,7 @@ predict_probs; Box2BoxTransform; fast_rcnn_inference).
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Tuple, Union
 
 import numpy as np
@@ -30,6 +31,7 @@ __all__ = ["Box2BoxTransform", "FastRCNNOutputLayers", "EmbeddingFastRCNNOutputL
            "fast_rcnn_inference", "batched_nms"]
 
 _DEFAULT_SCALE_CLAMP = math.log(1000.0 / 16)
+_FUSED_BOX_LOSS = os.environ.get("LOCOV_FUSED_LOSSES", "1") != "0"          # (developer A/B switch: tools/ab_fused_losses.py)
 
 
 class Box2BoxTransform:
@@ -369,14 +371,20 @@ class FastRCNNOutputLayers(nn.Module):
         mask instead of `nonzero` indices (a data-dependent size = a host sync): background rows get a unit box as source and
         target (zero deltas, finite everywhere) and weight 0 in the sum -- same value, same gradients."""
         box_dim = proposal_boxes.shape[1]
+        if self.box_reg_loss_type != "smooth_l1":
+            raise ValueError(f"Invalid bbox reg loss type '{self.box_reg_loss_type}'")
+        if (_FUSED_BOX_LOSS and boxes_validated and pred_deltas.is_cuda and box_dim == 4 and pred_deltas.dtype == torch.float32
+                and type(self.box2box_transform) is Box2BoxTransform and gt_classes.numel() > 0):
+            # one launch (ops.box_reg_loss = locov_box_reg_loss): the chain below, fused -- same foreground rule, same deltas, same
+            # normalisation; the gradient of the predictions comes out of the same launch
+            return ops.box_reg_loss(pred_deltas, proposal_boxes, gt_boxes, gt_classes, self.num_classes,
+                                    self.box2box_transform.weights, self.smooth_l1_beta)
         fg = (gt_classes >= 0) & (gt_classes < self.num_classes)
         if pred_deltas.shape[1] == box_dim:
             pred = pred_deltas
         else:
             rows = torch.arange(gt_classes.shape[0], device=gt_classes.device)
             pred = pred_deltas.view(-1, self.num_classes, box_dim)[rows, gt_classes.clamp(0, self.num_classes - 1)]
-        if self.box_reg_loss_type != "smooth_l1":
-            raise ValueError(f"Invalid bbox reg loss type '{self.box_reg_loss_type}'")
         unit = torch.cat([proposal_boxes.new_zeros(box_dim // 2), proposal_boxes.new_ones(box_dim - box_dim // 2)])   # [0, 0, 1, 1], built on the device
         src_boxes = torch.where(fg[:, None], proposal_boxes, unit)        # (background rows may be degenerate boxes: they
         target_boxes = torch.where(fg[:, None], gt_boxes, unit)           # never reach get_deltas' validity check upstream)

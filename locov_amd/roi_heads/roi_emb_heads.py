@@ -132,7 +132,7 @@ def add_ground_truth_to_proposals(targets: List[Instances], proposals: List[Inst
         gt_proposal = inst_cls(prop_i.image_size)
         gt_proposal.proposal_boxes = gt_boxes
         if prop_i.has("objectness_logits"):
-            gt_proposal.objectness_logits = gt_logit_value * torch.ones(len(gt_boxes), device=device)
+            gt_proposal.objectness_logits = torch.full((len(gt_boxes),), gt_logit_value, device=device)   # (= value * ones, one launch)
         keep = inst_cls(prop_i.image_size)
         for k in gt_proposal.get_fields():
             keep.set(k, prop_i.get(k))
@@ -420,7 +420,9 @@ class SampleAllROIHeads(ROIHeads):
             sizes.append(num_pos + num_neg)
             bg_counts.append(num_neg)
         picked = torch.cat(pieces, dim=0)                                       # rows of the concatenated proposals
-        classes = torch.split(labels[picked], sizes)
+        picked_labels = labels[picked]
+        classes = torch.split(picked_labels, sizes)
+        fg_flags = torch.split((picked_labels != self.num_classes).to(picked_labels.dtype), sizes)     # (one launch pair for the batch)
         src_global = gt_index[picked]
         prop_fields = list(proposals[0].get_fields().keys())
         sampled = [type(p)(p.image_size) for p in proposals]
@@ -443,8 +445,8 @@ class SampleAllROIHeads(ROIHeads):
                     src = src_parts[i] - off_g[i]
                     for name in tgt_fields:
                         sampled[i].set(name, targets[i].get(name)[src])
-        for out, cls in zip(sampled, classes):
-            out.set("fg_proposal", (cls != self.num_classes).to(cls.dtype))
+        for out, flag in zip(sampled, fg_flags):
+            out.set("fg_proposal", flag)
         bg = np.asarray(bg_counts, dtype=np.float64)
         tot = np.asarray(sizes, dtype=np.float64)
         storage = get_event_storage()

@@ -118,19 +118,20 @@ def _torch_reference(region, rmask, cap, cmask, w, b, temp):
     return loss, w2r, r2w
 
 
+@pytest.mark.parametrize("distill", [True, False])            # False: the cross-entropy tail in one launch (ops.grounding_ce)
 @pytest.mark.parametrize("empty_case", [False, True])
-def test_gradients_match_float64_reference(gh_mod, empty_case):
+def test_gradients_match_float64_reference(gh_mod, empty_case, distill):
     rng = np.random.default_rng(7)
     B, NR, T, V, L = 3, 19, 11, 64, 32
     d = _synth(rng, B, NR, T, V, L)
     if empty_case:
         d["region_mask"][2, :] = 0              # an image without regions: uniform-attention branch
         d["attention_mask"][1, :] = 0           # a caption without words
-    head = gh_mod.GroundingHead(_cfg(), V, L).cuda()
+    head = gh_mod.GroundingHead(_cfg(distill), V, L).cuda()
     img, cap = _inputs(d)
     img["region_features"].requires_grad_(True)
     cap["input_embeddings"].requires_grad_(True)
-    info, losses, dist = head(img, cap)
+    info, losses = head(img, cap)[:2]
     total = sum(losses.values())
     total.backward()
     # float64 reference on the CPU
@@ -243,3 +244,53 @@ def test_random_alignments_and_error_behaviour(gh_mod):
         gh_mod.GroundingHead(_variant_cfg(dict(GLOBAL_METRIC="emd"), False), 64, 32).cuda()(*_inputs(d))
     with pytest.raises(Exception, match="Matching loss is not defined"):
         gh_mod.GroundingHead(_variant_cfg(dict(LOSS="matching"), False), 64, 32).cuda()(*_inputs(d))
+
+
+@pytest.mark.parametrize("words,regions", [(True, True), (True, False), (False, True)])
+def test_one_launch_ce_tail_equals_the_torch_ops(gh_mod, golden_dir, words, regions):
+    """GroundingHead without the distillation outputs runs grounding_head.py:239-290,357-377 as ONE launch (ops.grounding_ce =
+    locov_grounding_ce_fwd / _bwd); with them it keeps the torch ops.  Same names in the same order, same values, same gradients --
+    both alignments, either one alone, a caption without words next to an image without regions (the max + 100 pairs), and the
+    reference's own vectors."""
+    rng = np.random.default_rng(11)
+    B, NR, T, V, L = 6, 23, 9, 48, 32
+    d = _synth(rng, B, NR, T, V, L)
+    d["attention_mask"][:, :4] = 1
+    d["special_tokens_mask"][:, 1:4] = 0
+    d["region_mask"][4, :] = 0
+    d["attention_mask"][3, :] = 0
+    outs = []
+    for distill in (True, False):
+        cfg = _cfg(distill)
+        cfg.MODEL.MMSS_HEAD.GROUNDING.ALIGN_WORDS_TO_REGIONS = words
+        cfg.MODEL.MMSS_HEAD.GROUNDING.ALIGN_REGIONS_TO_WORDS = regions
+        torch.manual_seed(5)
+        head = gh_mod.GroundingHead(cfg, V, L).cuda()
+        img, cap = _inputs(d)
+        img["region_features"].requires_grad_(True)
+        cap["input_embeddings"].requires_grad_(True)
+        info, losses = head(img, cap)[:2]
+        w = torch.linspace(0.5, 2.0, len(losses)).tolist()
+        sum(v * k for v, k in zip(losses.values(), w)).backward()
+        outs.append((info, losses, img["region_features"].grad, cap["input_embeddings"].grad, head.v2l_projection.weight.grad))
+    (ia, la, ga, ca, wa), (ib, lb, gb, cb, wb) = outs
+    assert list(la) == list(lb) and list(ia) == list(ib) and len(la) == 2 * (words + regions)
+    for k in la:
+        assert abs(float(la[k]) - float(lb[k])) <= 1e-6 * max(1.0, abs(float(la[k]))), k
+    for k in ia:
+        assert float(ia[k]) == float(ib[k]), k
+    for x, y in ((ga, gb), (ca, cb), (wa, wb)):
+        torch.testing.assert_close(y, x, rtol=1e-4, atol=1e-8)
+    if words and regions:
+        g = np.load(os.path.join(golden_dir, "g4_grounding_head.npz"))
+        head = gh_mod.GroundingHead(_cfg(False), 256, 96).cuda()
+        with torch.no_grad():
+            head.v2l_projection.weight.copy_(torch.from_numpy(g["v2l_w"]))
+            head.v2l_projection.bias.copy_(torch.from_numpy(g["v2l_b"]))
+            for Bg in (1, 2, 4):
+                p = f"b{Bg}_"
+                info, losses = head(*_inputs(g, p))
+                assert list(losses.keys()) == [str(n) for n in g[p + "loss_names"]]
+                assert list(info.keys()) == [str(n) for n in g[p + "info_names"]]
+                np.testing.assert_allclose([float(v) for v in losses.values()], g[p + "losses"], atol=2e-5)
+                np.testing.assert_array_equal([float(v) for v in info.values()], g[p + "info"])

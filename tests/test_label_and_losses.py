@@ -247,3 +247,44 @@ def test_label_kernel_equals_the_torch_ops_on_the_device(oracle, monkeypatch):
     assert torch.equal(rows_k[:, :2], rows_t[:, :2])
     assert torch.equal(rows_k[:, 2:] > 0, rows_t[:, 2:] > 0)
     assert int((lab_k == 80).sum()) > 0 and int(((lab_k >= 0) & (lab_k < 80)).sum()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agnostic", [True, False])
+@pytest.mark.parametrize("beta", [0.0, 0.5])
+def test_one_launch_box_reg_loss_equals_the_torch_chain(agnostic, beta):
+    """ops.box_reg_loss (locov_box_reg_loss: deltas, smooth-L1, masked sum, normalisation and the gradient in one launch) against the
+    torch-op chain of box_reg_loss it replaces when the labelling has validated the boxes: value and gradient, class-agnostic and
+    per-class predictions, L1 and smooth-L1, non-finite predictions in background / ignored rows."""
+    heads = _heads(False, 16, 0.5, "cuda")
+    bp = heads.box_predictor
+    bp.smooth_l1_beta = beta
+    g = torch.Generator().manual_seed(3)
+    n, K = 700, bp.num_classes
+    boxes = torch.rand(n, 4, generator=g) * 600
+    boxes[:, 2:] = boxes[:, :2] + 4 + torch.rand(n, 2, generator=g) * 300
+    gt = boxes + torch.randn(n, 4, generator=g) * 6
+    gt[:, 2:] = torch.maximum(gt[:, 2:], gt[:, :2] + 1)
+    cls = torch.randint(0, K, (n,), generator=g)
+    cls[torch.rand(n, generator=g) < 0.5] = K                       # background
+    cls[torch.rand(n, generator=g) < 0.05] = -1                     # ignored
+    pred = torch.randn(n, 4 if agnostic else 4 * K, generator=g) * 0.3
+    bad = (cls == K).nonzero()[:3, 0]
+    pred[bad[0]] = float("inf"); pred[bad[1]] = float("nan"); pred[bad[2], 1] = -float("inf")
+    boxes, gt, cls = boxes.cuda(), gt.cuda(), cls.cuda()
+    a = pred.clone().cuda().requires_grad_(True)
+    b = pred.clone().cuda().requires_grad_(True)
+    want = bp.box_reg_loss(boxes, gt, a, cls, boxes_validated=False)          # the torch-op chain
+    got = bp.box_reg_loss(boxes, gt, b, cls, boxes_validated=True)            # one launch
+    assert got.shape == want.shape and torch.isfinite(got)
+    (want * 3.0).backward()
+    (got * 3.0).backward()
+    assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want))
+    assert torch.isfinite(b.grad).all()
+    torch.testing.assert_close(b.grad, a.grad, rtol=1e-6, atol=1e-9)
+    assert torch.equal(b.grad != 0, a.grad != 0)                               # exactly the foreground rows' (class) columns
+    # an all-background batch: zero loss, zero gradient
+    c = pred.clone().cuda().requires_grad_(True)
+    z = bp.box_reg_loss(boxes, gt, c, torch.full_like(cls, K), boxes_validated=True)
+    z.backward()
+    assert float(z) == 0.0 and not c.grad.any()
