@@ -75,6 +75,8 @@ def parse(argv=None):
                         "sampled); stt = configs/coco_stt.yaml fine-tune step (EmbeddingRes5ROIHeads, 48 classes, emb_pred frozen, "
                         "3 img x 512 sampled)")
     p.add_argument("--train-backends", default="hip,miopen", help="--mode train: which Res5 backends to time (profile runs: hip)")
+    p.add_argument("--unfrozen-steps", type=int, default=-1,
+                   help="training steps timed WITHOUT gc.freeze() for train.*.ms_per_step_unfrozen_heap (-1: max(5 x steps/2, 50); 0: skip)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--skip-f32-reference", action="store_true",
                    help="do not also time the f32-MFMA form of the Res5 GEMMs (profile runs)")
@@ -454,7 +456,7 @@ def main():
             raise SystemExit(f"all_reduce over {world} ranks returned {rccl_ranks}")
 
     from locov_amd import _lib
-    from locov_amd.sharding import max_over_ranks
+    from locov_amd.sharding import all_ranks, max_over_ranks
     lib = _lib.load()
     wl = Workload(args, device)
 
@@ -464,20 +466,24 @@ def main():
         torch.cuda.synchronize()
 
     wall = {}
+    per_rank = {}                               # key -> every rank's ms per step of that bracket (rank order)
 
-    def timed(fn, steps, warmup, on_start=None, key=None, **kw):
+    def timed(fn, steps, warmup, on_start=None, key=None, freeze=True, **kw):
         """K steps between barrier + synchronize on both sides; the time is hipEventElapsedTime between two events recorded
         on the launch stream inside that bracket, max over ranks; the host wall clock of the same bracket is
         kept beside it (wall[key]).  The interpreter's full garbage-collection pass is taken HERE, after the warm-up and before the
         bracket, and the objects alive at that point are frozen (gc.freeze): with a quarter of a million tracked objects a
         generation-2 pass takes ~90 ms, and one landing at a random step inside a 10-step training window moved
         `train.lsm.ms_per_step` between 14.5 and 24 ms from run to run (tools/ab_fused_losses.py).  Collections of the younger
-        generations keep running inside the bracket."""
+        generations keep running inside the bracket, and the heap is un-frozen behind it (a frozen object is never collected:
+        freezing per phase would pin every earlier workload's tensors).  freeze=False: nothing of that -- the interpreter's
+        collector runs as it does under an unchanged train_ovnet.py (`train.*.ms_per_step_unfrozen_heap`)."""
         import gc
         for _ in range(warmup):
             fn()
-        gc.collect()
-        gc.freeze()
+        if freeze:
+            gc.collect()
+            gc.freeze()
         barrier()
         if on_start is not None:
             on_start()
@@ -489,9 +495,12 @@ def main():
         e1.record()
         barrier()
         dt_wall = time.perf_counter() - t0
+        if freeze:
+            gc.unfreeze()
         dt = e0.elapsed_time(e1) * 1e-3
         if key is not None:
             wall[key] = max_over_ranks(dt_wall, device if args.dist_backend == "nccl" else None)
+            per_rank[key] = [t / steps * 1e3 for t in all_ranks(dt, device if args.dist_backend == "nccl" else None)]
         # the slowest rank defines the job's time
         return max_over_ranks(dt, device if args.dist_backend == "nccl" else None)
 
@@ -558,11 +567,22 @@ def main():
         tw = TrainWorkload(args, device, backend, world, data_seed=1992 + rank, config=config)
         n_sampled = tw.step()
         steps = max(args.steps // 2, 3)
-        dtt = timed(tw.step, steps, max(args.warmup, 5))      # (the first steps still grow the allocator's pools and pick the operand scales)
+        dtt = timed(tw.step, steps, max(args.warmup, 5), key="train_" + config)      # (the first steps still grow the allocator's pools and pick the operand scales)
+        # the same step with the interpreter's collector left alone (no collect / freeze in front of the bracket): what a trainer
+        # that does not freeze its heap gets.  A full collection of torch's ~250 k tracked objects takes ~90 ms and comes every few
+        # dozen steps, so this figure is taken over enough steps to hold its share of them
+        steps_u = max(5 * steps, 50) if args.unfrozen_steps < 0 else args.unfrozen_steps
+        out = {"sampled_proposals_per_s": n_sampled * world * steps / dtt, "ms_per_step": dtt / steps * 1e3,
+               "per_rank_ms_per_step": per_rank["train_" + config], "sampled_proposals_per_step_per_gpu": n_sampled}
+        if steps_u > 0:
+            import gc
+            full0 = gc.get_stats()[2]["collections"]
+            dtu = timed(tw.step, steps_u, 0, freeze=False)
+            out.update(ms_per_step_unfrozen_heap=dtu / steps_u * 1e3, unfrozen_heap_steps=steps_u,
+                       unfrozen_heap_full_collections=gc.get_stats()[2]["collections"] - full0)
         del tw
         torch.cuda.empty_cache()
-        return {"sampled_proposals_per_s": n_sampled * world * steps / dtt, "ms_per_step": dtt / steps * 1e3,
-                "sampled_proposals_per_step_per_gpu": n_sampled}
+        return out
 
     train = None
     if args.mode == "infer" and not args.skip_train and args.res5 == "hip" and args.res5_dtype in ("f16x2", "fp32"):
@@ -708,9 +728,12 @@ def main():
             "unit": "proposals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt2 / args.steps * 1e3,
+            "per_rank_ms_per_step": per_rank["s2"],
             "timing": {"how": "hipEventElapsedTime between two events on the launch stream around the K timed steps, inside the "
-                              "barrier + synchronize bracket, max over ranks; the interpreter's full garbage-collection pass is "
-                              "taken between warm-up and bracket (gc.collect + gc.freeze), not at a random step inside it",
+                              "barrier + synchronize bracket, max over ranks (per_rank_ms_per_step lists every rank's); the interpreter's full "
+                              "garbage-collection pass is taken between warm-up and bracket (gc.collect + gc.freeze, un-frozen "
+                              "behind it), not at a random step inside it; train.*.ms_per_step_unfrozen_heap is the same step "
+                              "with the collector left alone",
                        "wall_ms_per_step": wall["s2"] / args.steps * 1e3},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16 operands / f32 accumulate in Res5 (opt-in reduced precision, not the parity configuration)"

@@ -330,8 +330,11 @@ int locov_gemm_nt_f32_split(const float *x, int64_t lda, const void *W_split, co
  * and the [M, N] result is never written.  Per M-tile and ROI the kernel leaves column
  * sums in `workspace` (locov_gemm_segmean_workspace_bytes), a second small kernel adds the one or two partials of
  * each ROI in a fixed order (deterministic).  43 <= seg <= 128 (a 128-row tile holds at most four ROIs; Res5's 7x7
- * positions give 49), M % seg == 0, M * N * 4 < 2^32, otherwise as
- * locov_gemm_nt_f32_split. */
+ * positions give 49), M % seg == 0, otherwise as locov_gemm_nt_f32_split.  M * N * 4 may pass 2^32 where the launch
+ * takes the 256 x 256 tile (pre-split x, ROI-major residual, >= 1 024 tiles: the Res5 call of thousands of proposals); the
+ * 128 x 128 form needs M * N * 4 < 2^32.  locov_gemm_segmean_supported says (1 / 0) whether a shape can be launched at
+ * all -- the caller of roi_emb_heads.py:262,344,356 falls back to the unfused convolution + locov_spatial_mean_fwd. */
+int locov_gemm_segmean_supported(int64_t lda, int64_t M, int N, int K, int seg, unsigned flags);
 int64_t locov_gemm_segmean_workspace_bytes(int64_t M, int N);
 int locov_gemm_nt_f32_split_segmean(const float *x, int64_t lda, const void *W_split, const float *scale,
                                     const float *shift, const float *residual, float *out, int64_t M,

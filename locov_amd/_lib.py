@@ -93,6 +93,7 @@ SIGNATURES = {
     "locov_split_f16x2_pack": (c_int, [_p, c_int64, c_int, c_int64, c_float, _p, _p, _p]),
     "locov_gemm_nt_f32_split": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, c_float,
                                         c_float, _p, _p]),
+    "locov_gemm_segmean_supported": (c_int, [c_int64, c_int64, c_int, c_int, c_int, c_uint]),
     "locov_gemm_segmean_workspace_bytes": (c_int64, [c_int64, c_int]),
     "locov_gemm_nt_f32_split_segmean": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, c_int64, c_int, c_int, c_int, c_uint, c_float,
                                                 c_float, _p, c_int64, _p, _p]),

@@ -128,7 +128,10 @@ def get_cfg() -> CfgNode:
                 # extension: with "f16x2" every split launch ORs a range-guard word when an activation left fp16's range; the
                 # heads read it once per call and repeat the call on the f32 MFMA (with a warning) if it is set
                 "RES5_OVERFLOW_CHECK": True,
-                "RES5_TRAIN_GUARD": "deferred",      # training forwards: act on the range guard on the device ("sync": read it every step)
+                # training forwards: "sync" = the guard word is looked at at the end of the ROI heads' forward (an event wait behind
+                # the Res5 calls that leaves the predictor's launches queued) and an out-of-range forward is repeated on the f32
+                # MFMA; "deferred" = never read inside the step, acted on on the device (a skipped step), read with the next labelling
+                "RES5_TRAIN_GUARD": "sync",
             },
             "RESNETS": {
                 "NUM_GROUPS": 1, "WIDTH_PER_GROUP": 64, "RES2_OUT_CHANNELS": 256,

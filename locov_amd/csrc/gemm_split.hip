@@ -756,7 +756,9 @@ int launch_gemm_split_segmean(const float *A, int64_t lda, const void *Wsplit, i
         (epi.scale && (uintptr_t)epi.scale % 16 != 0) || (epi.shift && (uintptr_t)epi.shift % 16 != 0))
         return set_error(LOCOV_ERR_UNSUPPORTED, "%s: N, lda must be multiples of 4 and every pointer 16-byte aligned", what);
     if (!epi.residual) return set_error(LOCOV_ERR_INVALID_ARG, "%s: the residual is required", what);
-    if ((double)M * N * 4 <= 4294967295.0 && gemm_split_big_segmean_applicable(lda, M, N, K, epi, seg))       // 256 x 256 tile (gemm_split_big.hip)
+    // 256 x 256 tile (gemm_split_big.hip): every tile addresses A, the residual and its partial sums from a 64-bit tile base, so
+    // M * N * 4 may pass 2^32 (12 000 proposals: 4.8 GB); the 128 x 128 form below keeps 32-bit residual offsets
+    if (gemm_split_big_segmean_applicable(lda, M, N, K, epi, seg))
         return launch_gemm_split_big_segmean(A, lda, Wsplit, M, N, K, epi, seg, a_scale, w_scale, partial, out, s, what, overflow);
     const int64_t tiles_m = ceil_div(M, BM), tiles = tiles_m * ceil_div(N, BN);
     if (tiles > 0x7fffffffLL || (double)M * N * 4 > 4294967295.0 || (int64_t)BM * lda * 4 > 0x7fffffffLL)
@@ -859,6 +861,15 @@ int locov_gemm_nt_f32_split_ex(const float *x, int64_t lda, const void *W_split,
     Epilogue epi{scale, shift, residual, flags, mask, amax_out};
     return launch_gemm_split(x, lda, W_split, y, ldc, M, N, K, epi, x_scale, w_scale, as_stream(stream),
                              "locov_gemm_nt_f32_split_ex", Batch{1, 0, 0, 0}, overflow, x_scale_dev);
+}
+
+int locov_gemm_segmean_supported(int64_t lda, int64_t M, int N, int K, int seg, unsigned flags)
+{
+    if (M <= 0 || N <= 0 || K < BK || K % BK != 0 || seg < 43 || seg > BM || M % seg != 0 || N % 4 != 0 || lda % 4 != 0 || lda < K) return 0;
+    const Epilogue epi{nullptr, nullptr, reinterpret_cast<const float *>(16), flags};
+    if (gemm_split_big_segmean_applicable(lda, M, N, K, epi, seg)) return 1;
+    const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
+    return !(tiles > 0x7fffffffLL || (double)M * N * 4 > 4294967295.0 || (int64_t)BM * lda * 4 > 0x7fffffffLL);
 }
 
 int64_t locov_gemm_segmean_workspace_bytes(int64_t M, int N)

@@ -61,8 +61,10 @@ __global__ __launch_bounds__(256) void label_proposals_kernel(const float4 *__re
     for (int k = 0; k < g.n_thr; k++)
         if (best >= g.lo[k] && best < g.hi[k]) ml = g.lab[k];
     int64_t label;
-    if (g.goff[g.n_img] == 0)
-        label = num_classes;                               // no ground truth in the whole batch (the torch form's else branch)
+    if (g.goff[img + 1] == g.goff[img])
+        label = num_classes;                               // an image without ground truth: ROIHeads._sample_proposals' has_gt == False
+                                                           // branch labels EVERY proposal background, whatever the Matcher said
+                                                           // (with IOU_LABELS[0] == -1 the threshold label of "no match" is "ignore")
     else
         label = ml == 0 ? num_classes : ml == -1 ? (int64_t)-1 : gt_classes[best_j];
     const bool pos = label != -1 && label != num_classes, neg = label == num_classes;

@@ -115,10 +115,13 @@ __global__ __launch_bounds__(kNhwcThreads, WINO == 64 ? 6 : WINO ? 4 : 1) void r
     // up to 8 slices: blockIdx % nslices = the slice = (round-robin dispatch) the XCD.  More than 8 (developer A/B,
     // LOCOV_ROIALIGN_SLICES): passes of 8 slices, every ROI of pass p before any of pass p + 1, so that an XCD still works on ONE
     // slice at a time
+    // slice at a time.  The LAST pass may be ragged (nslices = 9, 12, ...: C = 576, 1536 on 64- / 128-channel slices): it holds
+    // the remaining nslices - 8 * pass slices, every ROI of each
     const unsigned per = nslices > 8 ? 8u : (unsigned)nslices, per_pass = per * (unsigned)R;
     const unsigned pass = blockIdx.x / per_pass, rem = blockIdx.x - pass * per_pass;
-    const int slice = (int)(rem % per + pass * per);
-    const int64_t r = rem / per;
+    const unsigned left = (unsigned)nslices - pass * per, per_here = left < per ? left : per;
+    const int slice = (int)(rem % per_here + pass * per);
+    const int64_t r = rem / per_here;
     const float *roi = rois + r * 5;
     const int b = (int)roi[0];
 

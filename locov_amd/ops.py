@@ -662,6 +662,14 @@ def split_unpack(t: torch.Tensor, scale: float) -> torch.Tensor:
 _SEGMEAN_WS = {}
 
 
+def segmean_supported(M: int, N: int, K: int, seg: int, lda: Optional[int] = None, *, residual_roi_major: bool = False,
+                      x_is_split: bool = False, residual_is_split: bool = False) -> bool:
+    """Can linear_split_segmean launch this shape?  (The 256 x 256 tile takes any M; the 128 x 128 one needs M * N * 4 < 2^32.)"""
+    flags = ((_lib.SEGMEAN_RES_ROI_MAJOR if residual_roi_major else 0) | (_lib.GEMM_A_SPLIT if x_is_split else 0)
+             | (_lib.EPI_RES_SPLIT if residual_is_split else 0) | _lib.EPI_RELU)
+    return bool(_lib.load().locov_gemm_segmean_supported(int(K if lda is None else lda), int(M), int(N), int(K), int(seg), flags))
+
+
 def linear_split_segmean(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tensor], residual: torch.Tensor, seg: int, *,
                          scale: Optional[torch.Tensor] = None, relu: bool = True, x_scale: float = 16.0,
                          residual_roi_major: bool = False, x_is_split: bool = False,

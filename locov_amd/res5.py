@@ -305,6 +305,13 @@ class Res5Stage(nn.Sequential):
             kw.pop(k, None)
         return ops.linear(x, w, bias, **kw)
 
+    def _warn_once(self, key: str, text: str) -> None:
+        seen = self.__dict__.setdefault("_warned", set())
+        if key not in seen:
+            seen.add(key)
+            import warnings
+            warnings.warn(text, RuntimeWarning, stacklevel=3)
+
     ACT_SPLIT_SCALE = 16.0       # operand scale of activations (|x| < 4094), also used when a producer writes them pre-split
 
     def _y2_split_ok(self, split: bool, c2, w3) -> bool:
@@ -476,9 +483,19 @@ class Res5Stage(nn.Sequential):
                 x = self._linear(split, cat, wcat, bcat, relu=True)               # conv3 + shortcut + add + ReLU, K-concatenated
                 continue
             last = bi == len(self) - 1
-            if (use_wino and pooled and last and split and blk.shortcut is None and w3.shape[1] % 32 == 0 and w3.shape[0] % 4 == 0
-                    and x.shape[0] * w3.shape[0] * 4 < 2 ** 32):
+            if use_wino and pooled and last and split and blk.shortcut is None and w3.shape[1] % 32 == 0 and w3.shape[0] % 4 == 0:
                 ysp = self._y2_split_ok(True, c2, w3)
+                if not ops.segmean_supported(x.shape[0], w3.shape[0], w3.shape[1], H * W, residual_roi_major=rm, x_is_split=ysp,
+                                             residual_is_split=x_split):
+                    # (the 128 x 128 form of the mean-fused convolution addresses its residual with 32-bit offsets; the 256 x 256
+                    # form, which every call of thousands of proposals takes, does not)
+                    self._warn_once("segmean", f"Res5Stage.forward_rows: the spatial mean is NOT fused into the last convolution for "
+                                    f"{x.shape[0]} rows x {w3.shape[0]} channels (too large for the 128x128 mean-fused kernel and not a "
+                                    "256x256 launch): the [rows, channels] tensor is written and read once more (~10 % slower)")
+                    ysp = None
+            else:
+                ysp = None
+            if ysp is not None:
                 y = conv12(roi_major=True, out_split_scale=self.ACT_SPLIT_SCALE if ysp else None)
                 return ops.linear_split_segmean(y, self._split(w3), b3, x, H * W, scale=s3, relu=True, residual_roi_major=rm,
                                                 x_is_split=ysp, x_scale=self.ACT_SPLIT_SCALE, residual_is_split=x_split)

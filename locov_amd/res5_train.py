@@ -112,8 +112,10 @@ class Res5RowsFn(torch.autograd.Function):
         # a DEFERRED guard held by the caller (the ROI heads' training forward): nothing reads it before the backward runs, so
         # the backward must not turn the inf / NaN activations of an out-of-range forward into gradients -- it zero-fills them
         # on the device when that word is set (the caller does the same with this forward's outputs)
+        # (its per-forward copy `step_word`, which the caller fills at the end of ITS forward: a later forward's labelling read
+        # may clear the guard's own word before this backward runs)
         active = ops.active_guard(x.device) if split else None
-        ctx.skip_words = [active.word] if active is not None and getattr(active, "deferred", False) else []
+        ctx.skip_words = [getattr(active, "step_word", active.word)] if active is not None and getattr(active, "deferred", False) else []
         ctx.nw = len(weights)
         ctx.save_for_backward(*saved)
         if pooled:

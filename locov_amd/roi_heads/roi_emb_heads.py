@@ -322,6 +322,11 @@ class SampleAllROIHeads(ROIHeads):
             labels = gtc[gt_index]                                              # ROIHeads._sample_proposals' labelling
             labels[match_label == 0] = self.num_classes
             labels[match_label == -1] = -1
+            if min(n_g) == 0:
+                # an image without ground truth inside a batch that has some: _sample_proposals' has_gt == False branch labels all
+                # of its proposals background, whatever the Matcher's "no match" label is (IOU_LABELS[0] may be -1)
+                no_gt = torch.tensor([n == 0 for n in n_g], device=dev)[img_r]
+                labels[no_gt] = self.num_classes
         else:
             gt_index = torch.zeros(box.shape[0], dtype=torch.int64, device=dev)
             labels = torch.zeros_like(gt_index) + self.num_classes
@@ -463,7 +468,7 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
     def __init__(self, *, in_features: List[str], pooler: ROIPooler, res5: nn.Module, box_predictor: nn.Module,
                  mask_head: Optional[nn.Module] = None, output_shape: Optional[int] = 0,
                  res5_backend: str = "hip", res5_conv3x3: str = "winograd", res5_dtype: str = "f16x2",
-                 res5_overflow_check: bool = True, res5_train_guard: str = "deferred", **kwargs):
+                 res5_overflow_check: bool = True, res5_train_guard: str = "sync", **kwargs):
         super().__init__(**kwargs)
         assert res5_backend in ("hip", "miopen") and res5_conv3x3 in ("winograd", "direct") and res5_dtype in ("fp32", "f16x2", "bf16")
         # extension: "f16x2" = fp32 GEMMs formed from split f16 operand pairs on the f16 matrix pipe (fp32-level
@@ -472,10 +477,14 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         # the split arithmetic's range guard: read the device flag once per call and, if an activation left fp16's range
         # (|x| >= 4094 at the activation scale), repeat the call on the f32 MFMA
         self.res5_overflow_check = res5_overflow_check
-        # training forwards: "deferred" = the guard is acted on on the device and read with the next step's labelling (no host
-        # wait inside the step); "sync" = read behind the Res5 forward, an out-of-range forward is repeated on the f32 MFMA
-        assert res5_train_guard in ("deferred", "sync")
-        self.res5_train_guard = os.environ.get("LOCOV_RES5_TRAIN_GUARD", res5_train_guard)
+        # training forwards: "sync" (default) = the word is copied to pinned memory behind the Res5 calls and looked at at the END
+        # of this module's forward, behind the predictor's and the losses' launches (an event wait that leaves them queued: the
+        # GPU does not drain); an out-of-range forward is repeated on the f32 MFMA, i.e. every step has the reference's values.
+        # "deferred" = never read inside the step: acted on on the device (outputs, this module's losses and the backward's
+        # gradients are zeroed: a skipped step) and read with the next step's labelling
+        mode = os.environ.get("LOCOV_RES5_TRAIN_GUARD", res5_train_guard)      # (developer A/B override, validated like the key)
+        assert mode in ("deferred", "sync"), f"RES5_TRAIN_GUARD / LOCOV_RES5_TRAIN_GUARD must be 'deferred' or 'sync', got {mode!r}"
+        self.res5_train_guard = mode
         self._overflow_warned = False
         self.res5_backend = res5_backend      # extension: how the Res5 convolutions run (see res5.py)
         self.res5_conv3x3 = res5_conv3x3      # extension: form of the 3x3 convolutions on the hip backend
@@ -512,7 +521,7 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         ret["res5_conv3x3"] = box_head.get("RES5_CONV3X3", "winograd") if hasattr(box_head, "get") else "winograd"
         ret["res5_dtype"] = box_head.get("RES5_DTYPE", "f16x2") if hasattr(box_head, "get") else "f16x2"
         ret["res5_overflow_check"] = bool(box_head.get("RES5_OVERFLOW_CHECK", True)) if hasattr(box_head, "get") else True
-        ret["res5_train_guard"] = box_head.get("RES5_TRAIN_GUARD", "deferred") if hasattr(box_head, "get") else "deferred"
+        ret["res5_train_guard"] = box_head.get("RES5_TRAIN_GUARD", "sync") if hasattr(box_head, "get") else "sync"
         return ret
 
     @classmethod
@@ -676,7 +685,21 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
             return None
         if ops.active_guard(feats[0].device) is not None:
             return None                                      # an outer caller already holds one
-        return self.res5.range_guard("fwd_train", feats[0].device)
+        g = self.res5.range_guard("fwd_train", feats[0].device)
+        # THIS forward's copy of the word (filled by _close_train_guard at the end of the forward): what the backward of this
+        # forward looks at -- a later forward's labelling read may clear the guard's own word before that backward runs
+        # (gradient accumulation), it cannot reach this tensor
+        g.step_word = torch.zeros(1, dtype=torch.int32, device=feats[0].device)
+        return g
+
+    @staticmethod
+    def _close_train_guard(tguard, outputs, losses=None):
+        """End of a forward under a DEFERRED guard: freeze the word for this forward, zero-fill the Res5 outputs when it is
+        set, and return the factor (1 / 0, a device scalar) that turns this module's losses -- and with them every gradient
+        they send into the predictor -- into a skipped step."""
+        tguard.step_word.copy_(tguard.word)
+        ops.zero_if_raised(list(outputs), tguard.step_word)    # (fresh contiguous tensors: zeroed in place, no host read)
+        return (tguard.step_word == 0).to(torch.float32).reshape(())
 
     def _backward_guard_tripped(self) -> None:
         import warnings
@@ -764,14 +787,22 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         guard = None if tguard is not None else self._deferred_guard(feats)
         with ops.range_guard(tguard if tguard is not None else guard):
             box_features = self._shared_roi_transform(feats, proposal_boxes, pooled=True)
+        keep = None
         if tguard is not None:
-            ops.zero_if_raised([box_features], tguard.word)   # (a fresh contiguous tensor: zeroed in place, no host read)
-        elif guard is not None and guard.raised():           # RES5_TRAIN_GUARD "sync": the step's range-guard read
-            self._warn_overflow()
-            box_features = self._with_res5_dtype("fp32", self._shared_roi_transform, feats, proposal_boxes, pooled=True)
+            keep = self._close_train_guard(tguard, [box_features])
+        elif guard is not None:
+            guard.snapshot()                                 # 4 bytes to pinned memory + an event, behind the Res5 launches
         predictions = self.box_predictor(box_features)       # (:261-262: the mean is all the predictor sees)
-        del features
         losses = self._predictor_losses(predictions, proposals)
+        if keep is not None:
+            losses = {k: v * keep for k, v in losses.items()}
+        elif guard is not None and guard.raised():           # RES5_TRAIN_GUARD "sync": waits for the event only -- the predictor's
+            self._warn_overflow()                            # and the losses' launches stay queued behind it
+            del box_features, predictions, losses
+            box_features = self._with_res5_dtype("fp32", self._shared_roi_transform, feats, proposal_boxes, pooled=True)
+            predictions = self.box_predictor(box_features)
+            losses = self._predictor_losses(predictions, proposals)
+        del features
         return [], losses
 
     def _predictor_losses(self, predictions, proposals):
@@ -863,18 +894,27 @@ class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
             proposal_boxes = [x.proposal_boxes for x in proposals]
             boxes_per_image = [len(x) for x in proposals]
             box_features = self._shared_roi_transform(feats, proposal_boxes, pooled=True, nhwc=nhwc)   # :343-344
+        keep = None
         if tguard is not None:
-            ops.zero_if_raised([visual_grid_features, box_features], tguard.word)
+            keep = self._close_train_guard(tguard, [visual_grid_features, box_features])
+        elif guard is not None:
+            guard.snapshot()                                 # 4 bytes to pinned memory + an event, behind both Res5 calls
+        del features
+        predictions = self.box_predictor(box_features)                           # :345
+        losses = dict(self._predictor_losses(predictions, proposals))            # :347
+        if keep is not None:
+            losses = {k: v * keep for k, v in losses.items()}
         elif guard is not None and guard.raised():
+            # RES5_TRAIN_GUARD "sync": the wait is for the event behind the two Res5 calls only -- the predictor's and the
+            # losses' launches are still queued when the host returns to the caller, so the GPU does not drain.  A step that
+            # left the split arithmetic's range repeats both calls and the tail on the f32 MFMA (the first graph is dropped)
             self._warn_overflow()
-            del visual_grid_features, box_features
+            del visual_grid_features, box_features, predictions, losses
             visual_grid_features = self._with_res5_dtype("fp32", self._res5_grid, feats[0], nhwc)
             box_features = self._with_res5_dtype("fp32", self._shared_roi_transform, feats, proposal_boxes, pooled=True, nhwc=nhwc)
-        del features
-        losses = {}
-        predictions = self.box_predictor(box_features)                           # :345
+            predictions = self.box_predictor(box_features)
+            losses = dict(self._predictor_losses(predictions, proposals))
         box_features = list(box_features.split(boxes_per_image, dim=0))          # :346
-        losses.update(self._predictor_losses(predictions, proposals))            # :347
         return visual_grid_features, box_features, proposals, losses
 
     def inference_detection(self, features, proposals):

@@ -47,6 +47,18 @@ def max_over_ranks(seconds: float, device=None) -> float:
     return float(t.item())
 
 
+def all_ranks(seconds: float, device=None) -> List[float]:
+    """Every rank's value, in rank order (the bench line lists them next to the maximum so that a scaling run explains its
+    own efficiency: one slow rank vs all ranks slower)."""
+    rank, world = world_info()
+    if world == 1:
+        return [float(seconds)]
+    t = torch.zeros(world, dtype=torch.float64, device=device)
+    t[rank] = seconds
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
+
+
 def gather_per_image(local_results: List[Any], n_images: int) -> List[Any]:
     """All ranks' per-image results in global image order (every rank gets the full list).
     The counterpart of the evaluator's comm.gather of predictions."""

@@ -78,3 +78,27 @@ def test_bench_starts_its_own_ranks():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0
     assert out["config"]["parallelism"].startswith("image-sharded x2")
+
+
+def test_bench_rehearses_eight_ranks():
+    """The driver's SCALE run is the first time eight ranks exist (train_ovnet.py:100-107 launches one process per GPU): rehearse
+    the flow on ONE GPU -- `bench.py --gpus 8` starts eight ranks itself, every rank times the inference step and one LSM / STT
+    training step under DistributedDataParallel on its own images, and the line names all eight."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--dist-backend", "gloo", "--steps", "2",
+           "--warmup", "1", "--images", "1", "--proposals", "200", "--classes", "80", "--train-images", "1", "--train-samples", "32",
+           "--unfrozen-steps", "0", "--no-cpu-baseline", "--skip-s1", "--skip-f32-reference", "--skip-variants"]
+    env = _env()
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8
+    assert out["value"] > 0 and out["value"] == out["value"] and out["value"] != float("inf")
+    assert out["config"]["parallelism"].startswith("image-sharded x8")
+    assert len(out["per_rank_ms_per_step"]) == 8 and all(0 < t < 1e5 for t in out["per_rank_ms_per_step"])
+    assert abs(max(out["per_rank_ms_per_step"]) - out["ms_per_step"]) <= 1e-6 * out["ms_per_step"]
+    train = out["train"]
+    assert "8 ranks" in train["gradient_exchange"]
+    for cfg in ("lsm", "stt"):
+        assert len(train[cfg]["per_rank_ms_per_step"]) == 8 and train[cfg]["ms_per_step"] > 0

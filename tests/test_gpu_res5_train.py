@@ -490,14 +490,18 @@ def test_training_forward_backward_matches_the_stock_library_path(pkg, oracle, d
 
 @pytest.mark.parametrize("mode", ["deferred", "sync"])
 def test_training_forward_out_of_range_never_reaches_the_losses_or_the_parameters(pkg, oracle, mode, monkeypatch):
-    """A training forward whose activations leave the split arithmetic's range (|x| >= 4094).  RES5_TRAIN_GUARD "deferred"
-    (default): no host read inside the step -- the forward's outputs and the backward's Res5 gradients are zero-filled on
-    the device, the next step's labelling read reports it (one RuntimeWarning) and the module runs on the f32 MFMA from
-    then on, where the same input gives the f32 path's results.  "sync": the forward is repeated on the f32 MFMA at once."""
+    """A training forward whose activations leave the split arithmetic's range (|x| >= 4094).  RES5_TRAIN_GUARD "sync"
+    (default): the forward is repeated on the f32 MFMA inside the step -- the reference's values.  "deferred": no host read
+    inside the step -- the forward's outputs, the ROI heads' own losses and every gradient of the step's ROI-head path
+    (Res5 AND the predictor: a skipped step) are zero on the device, also when a LATER forward's labelling read has cleared
+    the guard before this forward's backward runs (gradient accumulation); the next step's labelling read reports it (one
+    RuntimeWarning) and the module runs on the f32 MFMA from then on, where the same input gives the f32 path's results."""
     import warnings
     monkeypatch.setenv("LOCOV_RES5_TRAIN_GUARD", mode)
     heads, c_in = _train_heads(pkg, oracle, "hip", "f16x2")
     assert heads.res5_train_guard == mode
+    monkeypatch.delenv("LOCOV_RES5_TRAIN_GUARD")
+    assert _train_heads(pkg, oracle, "hip", "f16x2")[0].res5_train_guard == "sync"          # the default keeps the reference's values
     ref, _ = _train_heads(pkg, oracle, "hip", "fp32")
     gen = torch.Generator().manual_seed(6)
     base = torch.randn(2, c_in, 50, 84, generator=gen).cuda()
@@ -529,10 +533,25 @@ def test_training_forward_out_of_range_never_reaches_the_losses_or_the_parameter
     assert float(grid.abs().max()) == 0.0 and all(float(b.abs().max()) == 0.0 for b in box_feats)
     assert all(bool(torch.isfinite(v).all()) for v in losses.values())
     assert bool(torch.isfinite(gfeat).all()) and float(gfeat.abs().max()) == 0.0
-    for k, g in gparams.items():
-        assert bool(torch.isfinite(g).all()), k
-        if k.startswith("res5."):
-            assert float(g.abs().max()) == 0.0, k
+    assert all(float(v) == 0.0 for v in losses.values())                 # the module's own losses are those of a skipped step
+    for k, g in gparams.items():                                         # ... and so is every gradient they send back
+        assert bool(torch.isfinite(g).all()) and float(g.abs().max()) == 0.0, k
+    # gradient accumulation: forward A (out of range), forward B (whose labelling read finds and CLEARS the guard), then A's
+    # backward -- A's own copy of the word still zeroes its gradients
+    other, _ = _train_heads(pkg, oracle, "hip", "f16x2")
+    other.zero_grad()
+    feat_a = (base * big).requires_grad_(True)
+    torch.manual_seed(2)
+    grid_a, box_a, _, losses_a = other(None, {"res4": feat_a}, props, targets)
+    with pytest.warns(RuntimeWarning, match="ZEROED on the device"):
+        torch.manual_seed(3)
+        other(None, {"res4": base.clone().requires_grad_(True)}, props, targets)
+    (sum(losses_a.values()) + grid_a.mean() + sum(b.sum() for b in box_a) * 1e-3).backward()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(feat_a.grad).all()) and float(feat_a.grad.abs().max()) == 0.0
+    for k, p in other.named_parameters():
+        if p.grad is not None:
+            assert bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) == 0.0, k
     with pytest.warns(RuntimeWarning, match="ZEROED on the device"):     # ... and reported by the next step's one host read
         got = step(heads, big, 2)
     assert heads.res5_dtype == "fp32"

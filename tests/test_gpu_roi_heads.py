@@ -487,3 +487,115 @@ def test_training_forward_contract(pkg, oracle):
     (losses["loss_box_reg"] + sum(b.sum() for b in box_feats) * 1e-3).backward()
     assert feat.grad is not None and torch.isfinite(feat.grad).all() and feat.grad.abs().sum() > 0
     assert heads.box_predictor.bbox_pred.weight.grad is not None
+
+
+def _timing_launches(lib, classes):
+    import ctypes
+    from locov_amd import _lib
+    out = {}
+    for cls in classes:
+        n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(lib.locov_gemm_timing_read(cls, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)))
+        out[cls] = n.value
+    return out
+
+
+def test_size_regime_past_32_bit_offsets(pkg, oracle, monkeypatch):
+    """no test ran above 8 000 proposals, and byte offsets pass 2^32 at 10 700 (a [49 R, 2048] fp32
+    tensor).  12 x 1000 proposals of 1333x800 images, 1203-class bank, default arithmetic (24 GB of intermediates):
+      * the 12 000-proposal call is bit-identical, row for row, to an 8 000- and a 4 000-proposal call (each below 2^32), with
+        the mean-fused last convolution ON the path (timing class 11 -- it used to be switched off silently past 10 700
+        proposals; the 256x256 kernel addresses from 64-bit tile bases).  (The fused mean adds a proposal's 49 rows in two
+        pieces cut where a 64-row chunk of the launch ends, so its LAST BITS depend on the proposal's index modulo 64:
+        a split at a multiple of 64 proposals is bit-identical, any other split -- 6 000 + 6 000 -- agrees to fp32
+        re-association, asserted at 2e-6);
+      * the un-pooled form (plain conv3 on the 4.8 GB tensor, timing class 9 three times, + the stand-alone spatial mean) is
+        bit-identical to two 6 000-proposal calls: the sharding identity of test_full_size_head_properties;
+      * its first 1 000 rows (image 0 = the inputs of test_full_size_logits_vs_oracle) are within north_star's 1e-4 of the oracle;
+      * with the 256x256 tile forbidden (LOCOV_SPLIT_BIG=0: every GEMM of the step on the 128x128 kernels, whose mean-fused
+        form DOES keep 32-bit residual offsets) the stage says so once (RuntimeWarning), runs the unfused convolution +
+        spatial mean over the 4.8 GB tensor, and agrees within the gate."""
+    import warnings
+    from locov_amd import _lib
+    from locov_amd.structures import Boxes, ShapeSpec
+    full = _full_size_oracle(oracle)
+    n_img, R = 12, 1000
+    rng = np.random.default_rng(1212)
+    feat = np.concatenate([full["feat"], rng.standard_normal((n_img - 1, 1024, 50, 84)).astype(np.float32)])
+    boxes = [full["boxes"][0]] + [oracle.synth_boxes(rng, R) for _ in range(n_img - 1)]
+    cfg = pkg.config.get_cfg()
+    cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
+    cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED = True
+    cfg.MODEL.ROI_HEADS.NAME = "EmbeddingProposalsRes5ROIHeads"
+    heads = pkg.build_roi_heads(cfg, {"res4": ShapeSpec(channels=1024, stride=16)})
+    assert heads.res5_dtype == "f16x2"
+    heads.res5.load_state_dict(full["params"])
+    h = oracle.synth_head(np.random.default_rng(768), 2048, 768, 1203)
+    bp = heads.box_predictor
+    with torch.no_grad():
+        bp.emb_pred.weight.copy_(torch.from_numpy(h["emb_w"]))
+        bp.emb_pred.bias.copy_(torch.from_numpy(h["emb_b"]))
+        bp.bbox_pred.weight.copy_(torch.from_numpy(h["bbox_w"]))
+        bp.bbox_pred.bias.copy_(torch.from_numpy(h["bbox_b"]))
+    heads = heads.cuda().eval()
+    bp.set_class_embeddings(h["cls_w"])
+    heads.num_classes = bp.num_classes
+    featd = dev(feat)
+    bx = [Boxes(torch.from_numpy(b).cuda()) for b in boxes]
+    lib = _lib.load()
+
+    def run(lo, hi):
+        with torch.no_grad():
+            bf = heads._shared_roi_transform([featd[lo:hi]], bx[lo:hi], pooled=True)
+            return bf, bp(bf)[0]
+
+    assert 49 * n_img * R * 2048 * 4 > 2 ** 32
+    lib.locov_gemm_timing_enable(1)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)                       # nothing falls back, nothing leaves the range
+            bf, scores = run(0, n_img)
+        torch.cuda.synchronize()
+        launches = _timing_launches(lib, (8, 9, 10, 11))
+    finally:
+        lib.locov_gemm_timing_enable(0)
+    assert launches[11] == 1 and launches[9] == 2 and launches[8] == 2 and launches[10] == 3, launches
+    assert tuple(scores.shape) == (n_img * R, 1204) and bool(torch.isfinite(scores).all())
+    parts = [run(0, 8), run(8, 12)]                                              # 8 000 = 125 x 64 proposals
+    assert torch.equal(torch.cat([x[0] for x in parts]), bf)
+    assert torch.equal(torch.cat([x[1] for x in parts]), scores)
+    parts = [run(0, 6), run(6, 12)]
+    assert float((torch.cat([x[0] for x in parts]) - bf).abs().max() / bf.abs().max()) <= 2e-6
+    del parts
+
+    def run_unpooled(lo, hi):
+        with torch.no_grad():
+            return heads._pooled_mean(heads._shared_roi_transform([featd[lo:hi]], bx[lo:hi]))
+
+    lib.locov_gemm_timing_enable(1)
+    try:
+        bfu = run_unpooled(0, n_img)
+        torch.cuda.synchronize()
+        launches = _timing_launches(lib, (9, 11))
+    finally:
+        lib.locov_gemm_timing_enable(0)
+    assert launches[9] == 3 and launches[11] == 0, launches
+    assert torch.equal(torch.cat([run_unpooled(0, 6), run_unpooled(6, 12)]), bfu)
+    assert float((bfu - bf).abs().max() / bf.abs().max()) <= 2e-6
+    del bfu
+    want_scores, _, _ = oracle.box_predictor_forward(full["box_features"], h["emb_w"], h["emb_b"], h["bbox_w"], h["bbox_b"], h["cls_w"])
+    ferr = np.abs(bf[:R].cpu().numpy() - full["box_features"]).max() / np.abs(full["box_features"]).max()
+    assert ferr <= 2e-5, ferr
+    assert np.abs(scores[:R].cpu().numpy() - want_scores).max() <= 1e-4
+    # the 128x128 kernels on the same 4.8 GB operands
+    monkeypatch.setenv("LOCOV_SPLIT_BIG", "0")
+    heads.res5.__dict__.pop("_warned", None)
+    with pytest.warns(RuntimeWarning, match="NOT fused"):
+        bf128, scores128 = run(0, n_img)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)                           # ... once
+        run(0, 1)
+    monkeypatch.delenv("LOCOV_SPLIT_BIG")
+    rel = float((bf128 - bf).abs().max() / bf.abs().max())
+    assert rel <= 1e-5, rel
+    assert float((scores128 - scores).abs().max()) <= 1e-4

@@ -669,7 +669,10 @@ def test_pooler_with_the_winograd_input_transform_is_bit_identical(ops):
     prev = os.environ.get("LOCOV_WINO_FUSE")
     try:
         for Nimg, H, W, C, Cw, R, N2, sr, out_split in ((2, 25, 38, 64, 64, 37, 32, 0, False), (1, 50, 67, 128, 320, 101, 64, 2, True),
-                                                       (3, 19, 23, 512, 2560, 64, 96, 0, False)):
+                                                       (3, 19, 23, 512, 2560, 64, 96, 0, False),
+                                                       # more than 8 channel slices with a RAGGED last pass of the slice -> XCD
+                                                       # mapping: 576 = 9 x 64, 1536 = 12 x 128
+                                                       (2, 13, 17, 576, 576, 29, 32, 0, False), (1, 11, 15, 1536, 1600, 23, 32, 2, True)):
             g = torch.Generator().manual_seed(Nimg * 100 + C)
             fmap = torch.randn(Nimg, H, W, Cw, generator=g).cuda()
             feat = fmap[..., :C]

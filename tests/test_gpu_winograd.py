@@ -129,3 +129,37 @@ def test_concurrent_streams_do_not_share_the_workspace(ops):
                 got.append(ops.winograd_conv3x3(x, U, relu=True))
         torch.cuda.synchronize()
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+def test_output_transform_past_32_bit_offsets(ops):
+    """wino_output_kernel<..., WIDE>: the flat-address instance the launcher picks when a ROI-major result needs byte offsets
+    past 2^32 (R * 49 * row pitch * 4).  The result of 8 600 ROIs is written into a column block of a [49 R, 2560] matrix
+    (4.3 GB: the pitch of block 0's K-concatenated operand is what makes rows this far apart) and must equal, bit for bit, the
+    same call into a compact buffer (32-bit offsets); the other columns of the wide matrix stay untouched."""
+    R, Cin, N, pitch = 8600, 32, 64, 2560
+    assert R * 49 * pitch * 4 > 2 ** 32 > R * 49 * N * 4
+    g = torch.Generator().manual_seed(86)
+    x = torch.randn(49 * R, Cin, generator=g).cuda()
+    u = ops.winograd_pack_weight((torch.randn(N, Cin, 3, 3, generator=g) * 0.05).cuda())
+    s, b = (torch.rand(N, generator=g) + 0.5).cuda(), (torch.randn(N, generator=g) * 0.1).cuda()
+    want = ops.winograd_conv3x3(x, u, scale=s, shift=b, relu=True, roi_major=True, in_roi_major=True)
+    wide = torch.full((49 * R, pitch), -7.0, device="cuda")
+    col0 = 1024
+    ops.winograd_conv3x3(x, u, scale=s, shift=b, relu=True, roi_major=True, in_roi_major=True, out=wide[:, col0:col0 + N])
+    assert torch.equal(wide[:, col0:col0 + N], want)
+    assert bool((wide[:, :col0] == -7.0).all()) and bool((wide[:, col0 + N:] == -7.0).all())
+    del wide, want
+    # ... and the split-layout result (a dense destination only): 10 800 ROIs x 2 048 output channels = 4.3 GB, against the same
+    # convolution of the two halves (32-bit offsets each)
+    R, N = 10800, 2048
+    assert R * 49 * N * 4 > 2 ** 32 > (R // 2) * 49 * N * 4
+    x = torch.randn(49 * R, Cin, generator=g).cuda()
+    us = ops.split_pack(ops.winograd_pack_weight((torch.randn(N, Cin, 3, 3, generator=g) * 0.05).cuda()))
+    s, b = (torch.rand(N, generator=g) + 0.5).cuda(), (torch.randn(N, generator=g) * 0.1).cuda()
+    kw = dict(scale=s, shift=b, relu=True, roi_major=True, in_roi_major=True, out_split_scale=16.0)
+    got = ops.winograd_conv3x3(x, us, **kw)
+    half = 49 * (R // 2)
+    for lo in (0, half):
+        want = ops.winograd_conv3x3(x[lo:lo + half], us, **kw)
+        assert torch.equal(got[lo:lo + half].view(torch.int32), want.view(torch.int32)), lo
+        del want

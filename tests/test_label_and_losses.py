@@ -218,6 +218,38 @@ def test_batched_labelling_equals_the_per_image_form(oracle):
     assert not a[1].has("gt_boxes") and not b[1].has("gt_boxes")          # the image without ground truth carries no target fields
 
 
+def _three_interval_check(oracle, device):
+    """IOU_THRESHOLDS [0.3, 0.7] / IOU_LABELS [-1, 0, 1] (the Matcher's "no match" label is IGNORE): an image without ground truth
+    inside a batch that has some still has every proposal labelled BACKGROUND ([D2-upstream] ROIHeads._sample_proposals,
+    has_gt == False), not ignored -- the batch form against the per-image form, which is the reference's code path."""
+    from locov_amd.roi_heads.roi_emb_heads import Matcher, add_ground_truth_to_proposals
+    heads = _heads(True, 10 ** 6, 1.0, device)
+    heads.proposal_matcher = Matcher([0.3, 0.7], [-1, 0, 1], allow_low_quality_matches=False)
+    rng = np.random.default_rng(17)
+    props, targets, _ = _batch(oracle, rng, device, n_img=3, r=70, n_gt=4)
+    assert len(targets[1]) == 0
+    with_gt = add_ground_truth_to_proposals(targets, props)
+    gi, labels, _, _, rows = heads._match_batch(with_gt, targets)
+    per_image = [heads._match_one_image(p, t) for p, t in zip(with_gt, targets)]
+    want = torch.cat([m[1] for m in per_image])
+    assert torch.equal(labels.cpu(), want.cpu())
+    n0 = len(with_gt[0])
+    seg = labels[n0:n0 + len(with_gt[1])]
+    assert bool((seg == 80).all())                                            # background, none ignored
+    assert int((labels == -1).sum()) > 0 and int((labels == 80).sum()) > len(seg)      # the other images use all three intervals
+    rows = rows.cpu()
+    assert int(rows[1, 0]) == 0 and int(rows[1, 1]) == len(with_gt[1])
+
+
+def test_image_without_ground_truth_is_background_under_an_ignore_matcher_cpu(oracle):
+    _three_interval_check(oracle, "cpu")
+
+
+@pytest.mark.gpu
+def test_image_without_ground_truth_is_background_under_an_ignore_matcher_gpu(oracle):
+    _three_interval_check(oracle, "cuda")
+
+
 @pytest.mark.gpu
 def test_label_kernel_equals_the_torch_ops_on_the_device(oracle, monkeypatch):
     """locov_label_proposals (one launch per batch) against the torch-op form of SampleAllROIHeads._match_batch on the same draw:

@@ -1,0 +1,58 @@
+"""developer diagnostic (round 5): where does a 12 000-proposal Res5 call differ from two 6 000-proposal calls?  Wraps the ops the
+stage calls and compares every intermediate of the big call with the concatenation of the halves' (ROI-major rows)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import locov_amd
+from locov_amd import ops
+from locov_amd.structures import Boxes, ShapeSpec
+from oracle import lsm_oracle as oracle
+oracle.build()
+
+n_img, R = 12, 1000
+rng = np.random.default_rng(1212)
+feat = torch.from_numpy(rng.standard_normal((n_img, 1024, 50, 84)).astype(np.float32)).cuda()
+boxes = [Boxes(torch.from_numpy(oracle.synth_boxes(rng, R)).cuda()) for _ in range(n_img)]
+cfg = locov_amd.config.get_cfg()
+cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
+cfg.MODEL.ROI_BOX_HEAD.EMBEDDING_BASED = True
+cfg.MODEL.ROI_HEADS.NAME = "EmbeddingProposalsRes5ROIHeads"
+heads = locov_amd.build_roi_heads(cfg, {"res4": ShapeSpec(channels=1024, stride=16)})
+heads.res5.load_state_dict(oracle.make_res5_params(2026))
+heads = heads.cuda().eval()
+
+log = []
+names = ["linear_split", "roi_align_nhwc", "roi_align_winograd_conv3x3", "winograd_conv3x3", "conv1x1_winograd_conv3x3", "linear_split_segmean"]
+orig = {n: getattr(ops, n) for n in names}
+def wrap(n):
+    def f(*a, **k):
+        out = orig[n](*a, **k)
+        log.append((n, out))
+        return out
+    return f
+for n in names:
+    setattr(ops, n, wrap(n))
+
+def run(lo, hi):
+    log.clear()
+    with torch.no_grad():
+        bf = heads._shared_roi_transform([feat[lo:hi]], boxes[lo:hi], pooled=True)
+    torch.cuda.synchronize()
+    return [(n, t) for n, t in log] + [("final", bf)]
+
+big = run(0, 12)
+big = [(n, t.clone()) for n, t in big]
+h0 = [(n, t.clone()) for n, t in run(0, 6)]
+h1 = [(n, t.clone()) for n, t in run(6, 12)]
+for i, ((n, b), (_, a0), (_, a1)) in enumerate(zip(big, h0, h1)):
+    if b.shape[0] == a0.shape[0]:            # the map GEMM: rows = pixels
+        print(i, n, tuple(b.shape), "(same rows: skipped)")
+        continue
+    cat = torch.cat([a0.view(a0.shape[0], -1), a1.view(a1.shape[0], -1)])
+    bb = b.view(b.shape[0], -1)
+    if cat.shape != bb.shape:
+        print(i, n, "shape mismatch", tuple(bb.shape), tuple(cat.shape)); continue
+    neq = (cat.view(torch.int32) != bb.view(torch.int32)).any(dim=1)
+    bad = torch.nonzero(neq).flatten()
+    print(i, n, tuple(bb.shape), "rows differing:", int(bad.numel()), "first", bad[:5].tolist(), "last", bad[-5:].tolist())
