@@ -45,6 +45,16 @@ def _rows(t: torch.Tensor, name: str) -> torch.Tensor:
     return _dev(t, name)
 
 
+def _out(out: Optional[torch.Tensor], shape, ref: torch.Tensor, name: str) -> torch.Tensor:
+    """The result tensor of an op: a fresh one, or the caller's `out` (a contiguous fp32 device tensor of that shape -- e.g. a
+    row slice of a larger matrix: the training step keeps the rows of both Res5 calls in ONE matrix per activation)."""
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=ref.device)
+    if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or out.device != ref.device or not out.is_contiguous():
+        raise ValueError(f"{name}: out must be a contiguous fp32 {tuple(shape)} tensor on {ref.device}")
+    return out
+
+
 def _stream(t: torch.Tensor) -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -248,7 +258,7 @@ def spatial_mean(x: torch.Tensor, channels_last=False) -> torch.Tensor:
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
            scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-           relu: bool = False) -> torch.Tensor:
+           relu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = epi(x . weight^T): fp32 on the f32 MFMA pipe.  x [M,K] (rows may be strided), weight [N,K]."""
     x = _rows(x, "x")
     weight = _dev(weight, "weight")
@@ -267,7 +277,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     residual = _dev(residual, "residual") if residual is not None else None
     if residual is not None and tuple(residual.shape) != (M, N):
         raise ValueError("residual must be [M,N]")
-    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    y = _out(out, (M, N), x, "linear")
     with torch.cuda.device(x.device):
         check(_lib.load().locov_gemm_nt_f32(_ptr(x), x.stride(0) if M else K, _ptr(weight), _ptr(scale), _ptr(bias), _ptr(residual),
                                             _ptr(y), N, M, N, K, _lib.EPI_RELU if relu else 0, _stream(x)),
@@ -623,7 +633,7 @@ def split_scale_for(w: torch.Tensor) -> float:
 def linear_split(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tensor] = None, *,
                  scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                  relu: bool = False, x_scale: float = 16.0, x_is_split: bool = False, out_split: bool = False,
-                 residual_is_split: bool = False) -> torch.Tensor:
+                 residual_is_split: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = epi(x . W^T), fp32 in / fp32 out, products on the f16 matrix pipe with split operands (opt-in "f16x2"
     arithmetic).  x [M,K] fp32 (rows may be strided), weight = split_pack(W [N,K]); x_scale = the power of two x is
     multiplied by before the split (|x_scale * x| must stay below 65504: |x| < 4094 at the default).
@@ -640,7 +650,7 @@ def linear_split(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tens
     residual = _dev(residual, "residual") if residual is not None else None
     if residual is not None and tuple(residual.shape) != (M, N):
         raise ValueError("residual must be [M,N]")
-    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    y = _out(out, (M, N), x, "linear_split")
     with torch.cuda.device(x.device):
         check(_lib.load().locov_gemm_nt_f32_split(_ptr(x), x.stride(0) if M else K, _ptr(wd), _ptr(scale), _ptr(bias),
                                                   _ptr(residual), _ptr(y), N, M, N, K,
@@ -823,7 +833,7 @@ def conv3x3_nhwc_ex(x: torch.Tensor, w_packed: torch.Tensor, H: int, W: int, *, 
 
 
 def winograd_conv3x3_ex(x: torch.Tensor, U: torch.Tensor, *, scale=None, shift=None, mask=None, relu: bool = False,
-                        roi_major: bool = True) -> torch.Tensor:
+                        roi_major: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """winograd_conv3x3() on the f32 MFMA with the optional output mask (rows of x, mask and the result in one order:
     ROI-major by default)."""
     x = _dev(x, "x")
@@ -837,7 +847,7 @@ def winograd_conv3x3_ex(x: torch.Tensor, U: torch.Tensor, *, scale=None, shift=N
     mask = _dev(mask, "mask") if mask is not None else None
     if mask is not None and tuple(mask.shape) != (M, N):
         raise ValueError("winograd_conv3x3_ex: mask must be [49*R, N]")
-    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    y = _out(out, (M, N), x, "winograd_conv3x3_ex")
     lib = _lib.load()
     ws = _workspace("wino", x, int(lib.locov_winograd_workspace_bytes(R, Cin, N)))
     flags = (_lib.EPI_RELU if relu else 0) | ((_lib.WINO_OUT_ROI_MAJOR | _lib.WINO_IN_ROI_MAJOR) if roi_major else 0)
@@ -936,7 +946,7 @@ def scale_slot(ref: torch.Tensor) -> torch.Tensor:
 
 def linear_split_ex(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.Tensor] = None, *, scale=None, residual=None,
                     mask=None, relu: bool = False, x_scale: float = 16.0, x_scale_dev: Optional[torch.Tensor] = None,
-                    amax_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    amax_out: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """linear_split() with the epilogue mask of linear_ex and, optionally, the operand scale of x taken from device
     memory (split_scale_from_amax / scale_slot): the data-gradient GEMMs of the training step in split arithmetic.
     amax_out: scale_slot() that receives max |y|."""
@@ -953,7 +963,7 @@ def linear_split_ex(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.T
     for t_, name in ((residual, "residual"), (mask, "mask")):
         if t_ is not None and tuple(t_.shape) != (M, N):
             raise ValueError(f"linear_split_ex: {name} must be [M,N]")
-    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    y = _out(out, (M, N), x, "linear_split_ex")
     with torch.cuda.device(x.device):
         check(_lib.load().locov_gemm_nt_f32_split_ex(_ptr(x), x.stride(0) if M else K, _ptr(wd), _ptr(scale), _ptr(bias), _ptr(residual),
                                                      _ptr(mask), _ptr(y), N, M, N, K, _lib.EPI_RELU if relu else 0, float(x_scale),
@@ -984,7 +994,7 @@ def gemm_tn_split(a: torch.Tensor, b: torch.Tensor, row_scale: Optional[torch.Te
 
 def winograd_conv3x3_split_ex(x: torch.Tensor, U: SplitWeight, *, scale=None, shift=None, mask=None, relu: bool = False,
                               roi_major: bool = True, v_scale: Optional[float] = None,
-                              amax_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                              amax_out: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """winograd_conv3x3() in split arithmetic with the output mask; v_scale None = chosen on the device from max |V| (the input
     is a gradient)."""
     x = _dev(x, "x")
@@ -998,7 +1008,7 @@ def winograd_conv3x3_split_ex(x: torch.Tensor, U: SplitWeight, *, scale=None, sh
     mask = _dev(mask, "mask") if mask is not None else None
     if mask is not None and tuple(mask.shape) != (M, N):
         raise ValueError("winograd_conv3x3_split_ex: mask must be [49*R, N]")
-    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    y = _out(out, (M, N), x, "winograd_conv3x3_split_ex")
     lib = _lib.load()
     ws = _workspace("wino", x, int(lib.locov_winograd_workspace_bytes(R, Cin, N)))
     flags = (_lib.EPI_RELU if relu else 0) | ((_lib.WINO_OUT_ROI_MAJOR | _lib.WINO_IN_ROI_MAJOR) if roi_major else 0)
@@ -1058,12 +1068,12 @@ def conv3x3_wgrad_unpack(dw_packed: torch.Tensor, row_scale: Optional[torch.Tens
     return dw
 
 
-def relu_mask(g: torch.Tensor, act: torch.Tensor, amax_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def relu_mask(g: torch.Tensor, act: torch.Tensor, amax_out: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """g where act > 0, else 0.  amax_out: scale_slot() that receives max |result|."""
     g, act = _dev(g, "g"), _dev(act, "act")
     if g.shape != act.shape or g.numel() % 4:
         raise ValueError("relu_mask: shapes must match, numel % 4 == 0")
-    out = torch.empty_like(g)
+    out = _out(out, tuple(g.shape), g, "relu_mask")
     with torch.cuda.device(g.device):
         check(_lib.load().locov_relu_mask(_ptr(g), _ptr(act), g.numel(), _ptr(out), _ptr(amax_out), _stream(g)), "locov_relu_mask")
     return out
@@ -1121,37 +1131,43 @@ def zero_if_raised(tensors, word: torch.Tensor) -> None:
             check(lib.locov_zero_if_raised(ptrs, counts, len(chunk), _ptr(word), _stream(word)), "locov_zero_if_raised")
 
 
-def spatial_mean_bwd(g: torch.Tensor, act: Optional[torch.Tensor], hw: int, amax_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def spatial_mean_bwd(g: torch.Tensor, act: Optional[torch.Tensor], hw: int, amax_out: Optional[torch.Tensor] = None,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """g [R,C] -> [R*hw, C] ROI-major rows: g[r]/hw broadcast over the positions, zeroed where act <= 0."""
     g = _dev(g, "g")
     R, C = g.shape
     act = _dev(act, "act") if act is not None else None
     if act is not None and tuple(act.shape) != (R * hw, C):
         raise ValueError("spatial_mean_bwd: act must be [R*hw, C]")
-    out = torch.empty((R * hw, C), dtype=torch.float32, device=g.device)
+    out = _out(out, (R * hw, C), g, "spatial_mean_bwd")
     with torch.cuda.device(g.device):
         check(_lib.load().locov_spatial_mean_bwd(_ptr(g), _ptr(act), R, C, hw, _ptr(out), _ptr(amax_out), _stream(g)), "locov_spatial_mean_bwd")
     return out
 
 
-def rows_stride2(src: torch.Tensor, N: int, H: int, W: int, forward: bool) -> torch.Tensor:
+def rows_stride2(src: torch.Tensor, N: int, H: int, W: int, forward: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """forward: channels-last map [N,H,W,C] -> rows of its even pixels [N*OH*OW, C]; else the adjoint (rows -> zero-filled map)."""
     src = _dev(src, "src")
     C = src.shape[-1]
     OH, OW = (H + 1) // 2, (W + 1) // 2
-    out = torch.empty((N * OH * OW, C) if forward else (N, H, W, C), dtype=torch.float32, device=src.device)
+    out = _out(out, (N * OH * OW, C) if forward else (N, H, W, C), src, "rows_stride2")
     with torch.cuda.device(src.device):
         check(_lib.load().locov_rows_stride2(_ptr(src), N, H, W, C, int(forward), _ptr(out), _stream(src)), "locov_rows_stride2")
     return out
 
 
 def roi_align_nhwc_bwd(grad_rows: torch.Tensor, feat_shape, rois: torch.Tensor, output_size: int, spatial_scale: float,
-                       sampling_ratio: int = 0, aligned: bool = True, bin_stride: int = 1, pos_major: bool = False) -> torch.Tensor:
-    """Adjoint of roi_align_nhwc: grad_rows [o*o*R, C] -> gradient of the channels-last map [N,H,W,C]."""
+                       sampling_ratio: int = 0, aligned: bool = True, bin_stride: int = 1, pos_major: bool = False,
+                       accumulate_into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Adjoint of roi_align_nhwc: grad_rows [o*o*R, C] -> gradient of the channels-last map [N,H,W,C].
+    accumulate_into: an existing [N,H,W,C] gradient the result is ADDED to (fp32 atomics, as into the zero-filled fresh one)."""
     grad_rows = _rows(grad_rows, "grad_rows")
     rois = _dev(rois, "rois")
     N, H, W, C = feat_shape
-    gf = torch.zeros((N, H, W, C), dtype=torch.float32, device=grad_rows.device)
+    if accumulate_into is None:
+        gf = torch.zeros((N, H, W, C), dtype=torch.float32, device=grad_rows.device)
+    else:
+        gf = _out(accumulate_into, (N, H, W, C), grad_rows, "roi_align_nhwc_bwd")
     with torch.cuda.device(gf.device):
         check(_lib.load().locov_roi_align_nhwc_bwd(_ptr(grad_rows), grad_rows.stride(0) if grad_rows.shape[0] else C, N, H, W, C,
                                                    _ptr(rois), rois.shape[0], output_size, output_size, float(spatial_scale),

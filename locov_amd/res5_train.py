@@ -27,13 +27,13 @@ the f32 MFMA while the forward uses split operands (developer A/B).
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import List, NamedTuple, Optional, Sequence, Tuple
 
 import torch
 
 from . import ops
 
-__all__ = ["res5_rows", "res5_grid", "roi_align_even_rows", "to_nhwc", "Res5RowsFn"]
+__all__ = ["res5_rows", "res5_grid", "roi_align_even_rows", "to_nhwc", "Res5RowsFn", "Res5Step", "Segment"]
 
 
 import os
@@ -46,86 +46,159 @@ def _wino_ok(H: int, W: int, cin: int, cout: int) -> bool:
     return H == 7 and W == 7 and cin % 32 == 0 and cout % 4 == 0
 
 
-class Res5RowsFn(torch.autograd.Function):
-    """out = Res5(x0) on ROI-major pixel rows.  x0 [R*H*W, Cin] is the stage input already sub-sampled by block 0's
-    stride (the even positions: STRIDE_IN_1X1).  Returns the rows [R*H*W, Cout], or with `pooled` their per-ROI mean [R, Cout].
-    weights: the convolution weights in module order (block 0: conv1, conv2, conv3, shortcut; then conv1..conv3 of the
-    following blocks) -- passed as inputs so that autograd routes their gradients."""
+class Segment(NamedTuple):
+    """The rows of one Res5 call inside a step's matrices: rows [row0, row0 + n * H * W) are n independent H x W grids (ROI tiles
+    or whole image grids), ROI-major."""
+    row0: int
+    n: int
+    H: int
+    W: int
 
-    @staticmethod
-    def _blocks(stage, x, H, W, split):
-        saved: List[torch.Tensor] = []
-        cols: List[torch.Tensor] = []                 # im2col patches of y1 per block (general-grid form only)
-        meta = []
-        wi = 0
-        for blk in stage:
-            has_sc = blk.shortcut is not None
+    @property
+    def rows(self) -> int:
+        return self.n * self.H * self.W
+
+    @property
+    def wino(self) -> bool:
+        return self.H == 7 and self.W == 7
+
+
+class Res5Step:
+    """The Res5 work of ONE training step.  The LSM step calls the stage twice with the same weights -- on the whole res4
+    grid (roi_emb_heads.py:323, 4 200 rows per GPU) and on the sampled proposals (:343-344, 39 200 rows) -- and every 1x1
+    convolution's data gradient and weight gradient is a GEMM over pixel rows that does not care which call a row came
+    from.  So the rows of all calls of a step live in ONE matrix per activation (a `Segment` each), the forwards run per
+    segment as soon as their input exists (the grid call is enqueued while the host still waits for the labelling; the
+    proposals' rows follow), and the backward runs ONCE over the joint rows: one launch per 1x1 data gradient and weight
+    gradient instead of one per call (the whole-grid launches are too small to fill the chip: 2.7 ms for a tenth of the
+    rows), one weight gradient per parameter instead of two that autograd has to add.  Only the 3x3 convolutions differ per
+    segment (Winograd domain for 7x7 tiles, im2col GEMM on a general grid).
+
+        step = Res5Step(stage, split, cin, device, capacity_rows)
+        x = step.input_rows(n * H * W)        # where the producer (ROIAlign, rows_stride2) writes the segment's stage input
+        step.forward(n, H, W)                 # the stage on that segment (no autograd), outputs stay in the step's matrices
+        outs = step.outputs([x_with_grad, ...], [pooled, ...])       # ONE autograd node for all segments
+    """
+
+    def __init__(self, stage, split: bool, device, capacity_rows: int):
+        self.stage, self.split, self.device = stage, bool(split), torch.device(device)
+        self.capacity = int(capacity_rows)
+        self.segments: List[Segment] = []
+        self.filled = 0
+        self._pending: Optional[int] = None
+        new = lambda c: torch.empty((self.capacity, c), dtype=torch.float32, device=self.device)
+        self.x0 = new(stage[0].conv1.in_channels)
+        # per block: y1 (conv1 + FBN + ReLU), y2 (conv2 + FBN + ReLU), out (conv3 + FBN + shortcut + ReLU) -- the post-ReLU
+        # activations the backward needs as masks and as weight-gradient operands
+        self.act = [(new(b.conv1.out_channels), new(b.conv2.out_channels), new(b.conv3.out_channels)) for b in stage]
+        self.cols = {}                                # (block, segment index) -> im2col patches of y1 (general-grid segments)
+
+    def input_rows(self, rows: int) -> torch.Tensor:
+        assert self._pending is None, "Res5Step: forward() the previous segment first"
+        if self.filled + rows > self.capacity:
+            raise ValueError(f"Res5Step: {self.filled} + {rows} rows exceed the capacity of {self.capacity}")
+        self._pending = rows
+        return self.x0[self.filled:self.filled + rows]
+
+    @torch.no_grad()
+    def forward(self, n: int, H: int, W: int) -> Segment:
+        """The stage on the segment whose input was just written into input_rows(n * H * W)."""
+        assert self._pending == n * H * W, "Res5Step.forward: input_rows(n * H * W) first"
+        seg = Segment(self.filled, n, H, W)
+        self._pending = None
+        si = len(self.segments)
+        self.segments.append(seg)
+        self.filled += seg.rows
+        if seg.rows == 0:
+            return seg
+        stage, split = self.stage, self.split
+        sl = slice(seg.row0, seg.row0 + seg.rows)
+        x = self.x0[sl]
+        for bi, blk in enumerate(stage):
+            Y1, Y2, OUT = (t[sl] for t in self.act[bi])
             w1, s1, b1 = stage._packed(blk.conv1)
             w3, s3, b3 = stage._packed(blk.conv3)
             c2 = blk.conv2
-            y1 = stage._linear(split, x, w1, b1, scale=s1, relu=True)
-            wino = _wino_ok(H, W, c2.in_channels, c2.out_channels)
-            if wino:
+            stage._linear(split, x, w1, b1, scale=s1, relu=True, out=Y1)
+            if seg.wino and _wino_ok(H, W, c2.in_channels, c2.out_channels):
                 u2, s2, b2 = stage._packed(c2, winograd=True)
-                y2 = ops.winograd_conv3x3(y1, stage._split(u2) if split else u2, scale=s2, shift=b2, relu=True,
-                                          roi_major=True, in_roi_major=True)
+                ops.winograd_conv3x3(Y1, stage._split(u2) if split else u2, scale=s2, shift=b2, relu=True,
+                                     roi_major=True, in_roi_major=True, out=Y2)
             else:
                 # general grid (the whole-grid call): 3x3 as a GEMM over im2col patches -- K = 9 Cin columns in the order of
                 # the packed weight -- so that it runs in the stage's arithmetic; the patches are kept for the weight gradient
                 w2, s2, b2 = stage._packed(c2)
-                col = ops.im2col3x3(y1, H, W)
-                y2 = stage._linear(split, col, w2, b2, scale=s2, relu=True)
-            if has_sc:
+                col = self.cols[(bi, si)] = ops.im2col3x3(Y1, H, W)
+                stage._linear(split, col, w2, b2, scale=s2, relu=True, out=Y2)
+            if blk.shortcut is not None:
                 ws, ss, bs = stage._packed(blk.shortcut)
                 sc = stage._linear(split, x, ws, bs, scale=ss)
             else:
                 sc = x
-            out = stage._linear(split, y2, w3, b3, scale=s3, residual=sc, relu=True)
-            saved += [x, y1, y2, out]
-            if not wino:
-                cols.append(col)
-            meta.append((has_sc, wino, wi))
-            wi += 4 if has_sc else 3
-            x = out
-        return saved + cols, meta, x
+            stage._linear(split, Y2, w3, b3, scale=s3, residual=sc, relu=True, out=OUT)
+            x = OUT
+        return seg
+
+    def seg_wino(self, seg: Segment, c2) -> bool:
+        return seg.wino and _wino_ok(seg.H, seg.W, c2.in_channels, c2.out_channels)
+
+    def outputs(self, inputs: Sequence[torch.Tensor], pooled: Sequence[bool]) -> List[torch.Tensor]:
+        """The segments' stage outputs as differentiable tensors ([rows, Cout] pixel rows, or with pooled[i] the per-tile mean
+        [n, Cout]) of `inputs` (the tensors the producers wrote into input_rows, carrying the graph) and the stage's weights."""
+        assert len(inputs) == len(pooled) == len(self.segments) and self._pending is None
+        outs = Res5RowsFn.apply(self, tuple(bool(p) for p in pooled), len(inputs), *inputs, *_stage_weights(self.stage))
+        return list(outs) if isinstance(outs, tuple) else [outs]
+
+
+class Res5RowsFn(torch.autograd.Function):
+    """The autograd node of a Res5Step: forward hands out what the step already computed; backward is the joint pass
+
+        with g the gradient of a block's output already masked by (output > 0), over the rows of ALL segments:
+          dW3 = s3 * g^T y2                      TN GEMM over the pixel rows (gemm_tn.hip)
+          g2  = (g . s3 W3) * [y2 > 0]           NT GEMM, mask fused into the epilogue
+          dW2 = s2 * wgrad3x3(y1, g2)            per segment: Winograd domain (121 TN GEMMs) or im2col + TN GEMM
+          g1  = conv3x3(g2, flip(s2 W2)) * [y1 > 0]         per segment
+          dW1 = s1 * g1^T x ;  dWs = ss * g^T x
+          gx  = (g1 . s1 W1 + g [. ss Ws]) * [x > 0]      = the masked gradient of the previous block's output
+
+    Inputs: (step, pooled flags, n_segments, x0 of every segment ..., the convolution weights in module order -- block 0:
+    conv1, conv2, conv3, shortcut; then conv1..conv3 of the following blocks -- passed as inputs so that autograd routes their
+    gradients).  saved_tensors: per block (x, y1, y2, out) over the joint rows (tests read the active sets from them)."""
 
     @staticmethod
-    def forward(ctx, x0, stage, R, H, W, pooled, split, guard, *weights):
-        """guard: None, or (on_overflow,) -- check the split arithmetic's range-guard word after the forward and repeat it on
-        the f32 MFMA when an activation left fp16's range (calls on_overflow() first).  Inside a caller's own
-        `ops.range_guard` block the launches raise THAT guard and nothing is read here: the caller checks once for all the
-        calls it made (EmbeddingProposalsRes5ROIHeads.forward: one read for the whole-grid and the ROI call together)."""
-        x = ops._dev(x0.detach(), "x0")
-        own = None
-        if split and guard is not None and ops.active_guard(x.device) is None:
-            own = stage.range_guard("fwd", x.device)
-            own.reset()
-        with ops.range_guard(own):
-            saved, meta, out = Res5RowsFn._blocks(stage, x, H, W, split)
-        if own is not None and own.raised():
-            if guard[0] is not None:
-                guard[0]()
-            del saved, out
-            saved, meta, out = Res5RowsFn._blocks(stage, x, H, W, False)
-        ctx.stage, ctx.meta, ctx.geom, ctx.pooled = stage, meta, (R, H, W), pooled
-        ctx.split = bool(split) and not _BWD_F32
+    def forward(ctx, step, pooled, nseg, *args):
+        stage = step.stage
+        x_in = args[:nseg]
+        rows = step.filled
+        ctx.step, ctx.pooled, ctx.nseg = step, pooled, nseg
+        ctx.split = step.split and not _BWD_F32
         # a DEFERRED guard held by the caller (the ROI heads' training forward): nothing reads it before the backward runs, so
         # the backward must not turn the inf / NaN activations of an out-of-range forward into gradients -- it zero-fills them
         # on the device when that word is set (the caller does the same with this forward's outputs)
         # (its per-forward copy `step_word`, which the caller fills at the end of ITS forward: a later forward's labelling read
         # may clear the guard's own word before this backward runs)
-        active = ops.active_guard(x.device) if split else None
+        active = ops.active_guard(step.device) if step.split else None
         ctx.skip_words = [getattr(active, "step_word", active.word)] if active is not None and getattr(active, "deferred", False) else []
-        ctx.nw = len(weights)
+        ctx.nw = len(args) - nseg
+        saved = []
+        x = step.x0[:rows]
+        for (y1, y2, out) in step.act:
+            saved += [x, y1[:rows], y2[:rows], out[:rows]]
+            x = out[:rows]
         ctx.save_for_backward(*saved)
-        if pooled:
-            return ops.spatial_mean(out.view(R, H, W, out.shape[1]), channels_last=1)
-        return out
+        outs = []
+        last = step.act[-1][2]
+        for seg, pool, xi in zip(step.segments, pooled, x_in):
+            o = last[seg.row0:seg.row0 + seg.rows]
+            if pool:
+                o = ops.spatial_mean(o.view(seg.n, seg.H, seg.W, o.shape[1]), channels_last=1) if seg.rows else o.new_zeros((0, o.shape[1]))
+            outs.append(o)
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, *grad_outs):
         if not ctx.split:
-            grads = Res5RowsFn._backward(ctx, grad_out, False)
+            grads = Res5RowsFn._backward(ctx, grad_outs, False)
             for w in ctx.skip_words:
                 ops.zero_if_raised(grads, w)
             return grads
@@ -140,31 +213,46 @@ class Res5RowsFn(torch.autograd.Function):
         # the optimizer or the all-reduce whether or not another step follows.  The ROI heads look at the word together with
         # the ONE host read of the next step's labelling (SampleAllROIHeads.label_and_sample_proposals), warn, and drop the
         # remembered scales; `stage.backward_guard_raised()` reads it on demand (e.g. next to a trainer's loss logging).
-        guard = ctx.stage.range_guard("bwd", grad_out.device)
+        guard = ctx.step.stage.range_guard("bwd", ctx.step.device)
         with ops.range_guard(guard):
-            grads = Res5RowsFn._backward(ctx, grad_out, True)
-        ops.zero_if_raised(grads, guard.word)          # (every gradient here is a freshly written contiguous tensor or a view of one)
+            grads = Res5RowsFn._backward(ctx, grad_outs, True)
+        ops.zero_if_raised(grads, guard.word)          # (every gradient here is a freshly written contiguous tensor or a row slice of one)
         for w in ctx.skip_words:
             ops.zero_if_raised(grads, w)
         return grads
 
     @staticmethod
-    def _backward(ctx, grad_out, sp):
-        stage, (R, H, W) = ctx.stage, ctx.geom
+    def _backward(ctx, grad_outs, sp):
+        step = ctx.step
+        stage, segs, nseg = step.stage, step.segments, ctx.nseg
+        rows = step.filled
         saved = ctx.saved_tensors
-        need_x = ctx.needs_input_grad[0]
-        need_w = ctx.needs_input_grad[8:]
+        need_x = any(ctx.needs_input_grad[3:3 + nseg])
+        need_w = ctx.needs_input_grad[3 + nseg:]
         gw: List[Optional[torch.Tensor]] = [None] * ctx.nw
-        grad_out = ops._dev(grad_out, "grad_out")
-        out_last = saved[4 * len(stage) - 1]
+        nb = len(stage)
+        out_last = saved[4 * nb - 1]
+        new = lambda c: torch.empty((rows, c), dtype=torch.float32, device=step.device)
         # Operand scales of the gradients (split arithmetic): every kernel that WRITES a gradient folds max |.| into a zeroed
         # 16-byte slot (ops.scale_slot) on its way out, and the GEMMs that read the gradient derive its power-of-two scale from
         # the slot -- no separate pass over the tensor, no host read.
         slot = (lambda ref: ops.scale_slot(ref)) if sp else (lambda ref: None)
-        # gradient of the last block's output, masked by its ReLU
-        # (the two element-wise kernels at the head of the chain keep the separate reduction: their waves all finish together,
+        # gradient of the last block's output, masked by its ReLU, every segment into its rows of ONE matrix
+        # (the element-wise kernels at the head of the chain keep the separate reduction: their waves all finish together,
         # so every one of them would issue its atomic -- measured +110 us on the grid's relu_mask against a 10 us reduction)
-        g = ops.spatial_mean_bwd(grad_out, out_last, H * W) if ctx.pooled else ops.relu_mask(grad_out, out_last)
+        g = new(out_last.shape[1])
+        for seg, pool, go in zip(segs, ctx.pooled, grad_outs):
+            if seg.rows == 0:
+                continue
+            sl = slice(seg.row0, seg.row0 + seg.rows)
+            go = ops._dev(go, "grad_out")
+            if pool:
+                ops.spatial_mean_bwd(go, out_last[sl], seg.H * seg.W, out=g[sl])
+            else:
+                ops.relu_mask(go, out_last[sl], out=g[sl])
+        if rows == 0:
+            return (None, None, None) + tuple(None for _ in range(nseg)) + tuple(
+                torch.zeros_like(w) if need else None for w, need in zip(_stage_weights(stage), need_w))
         sg = ops.split_scale_from_amax(g) if sp else None
 
         def keyed(t, conv, tag):                       # remembered operand scale of a per-step weight packing (Res5Stage._split)
@@ -182,44 +270,61 @@ class Res5RowsFn(torch.autograd.Function):
             y_ = ops.linear_ex(g_, wt, **kw)
             return y_, (ops.split_scale_from_amax(y_) if sp and amax_out is not None else None)
 
-        for bi in range(len(stage) - 1, -1, -1):
+        wi_of, wi = [], 0
+        for blk in stage:
+            wi_of.append(wi)
+            wi += 4 if blk.shortcut is not None else 3
+        for bi in range(nb - 1, -1, -1):
             blk = stage[bi]
-            has_sc, wino, wi = ctx.meta[bi]
+            has_sc, wi = blk.shortcut is not None, wi_of[bi]
             x, y1, y2, _ = saved[4 * bi: 4 * bi + 4]
-            col = None if wino else saved[4 * len(stage) + bi]
             w1, s1, _ = stage._packed(blk.conv1)
             w3, s3, _ = stage._packed(blk.conv3)
             c2 = blk.conv2
-            # conv3: dW3 = s3 * g^T y2 ; g2 = (g . s3 W3) [y2 > 0]
+            # conv3: dW3 = s3 * g^T y2 ; g2 = (g . s3 W3) [y2 > 0]         -- all segments, one launch each
             if need_w[wi + 2]:
                 gw[wi + 2] = wgrad_1x1(g, sg, y2, s3).view_as(blk.conv3.weight)
             g2, sg2 = dgrad_1x1(g, sg, stage._derived(blk.conv3, "wt", lambda: ops.weight_transpose_scale(w3, s3)), blk.conv3,
                                 amax_out=slot(g), mask=y2)
-            # conv2 (3x3): dW2 = s2 * wgrad(y1, g2) ; g1 = conv3x3(g2, flip(s2 W2)) [y1 > 0]
+            # conv2 (3x3), per segment: dW2 = s2 * wgrad(y1, g2) ; g1 = conv3x3(g2, flip(s2 W2)) [y1 > 0]
             _, s2, _ = stage._packed(c2)
             w2 = c2.weight.detach()
-            if need_w[wi + 1]:
-                if wino and c2.out_channels % 4 == 0 and not _NO_WINO_BWD:
-                    gw[wi + 1] = ops.winograd_wgrad(y1, g2, s2, roi_major=True, split=sp)
-                else:
-                    colw = col if col is not None else ops.im2col3x3(y1, H, W)
-                    if sp:
-                        gw[wi + 1] = ops.conv3x3_wgrad_unpack(ops.gemm_tn_split(g2, colw, None, sg2, 16.0), s2)
-                    else:
-                        gw[wi + 1] = ops.conv3x3_wgrad_unpack(ops.gemm_tn(g2, colw), s2)
             wflip = stage._derived(c2, "flip", lambda: ops.conv3x3_weight_flip(w2, s2))     # [Cin, Cout, 3, 3]
+            g1 = new(y1.shape[1])
             sg1 = slot(g2)
-            if _wino_ok(H, W, c2.out_channels, c2.in_channels) and not _NO_WINO_BWD:
-                uflip = stage._derived(c2, "uflip", lambda: ops.winograd_pack_weight(wflip))
-                if sp:
-                    g1 = ops.winograd_conv3x3_split_ex(g2, stage._split(keyed(uflip, c2, "uflip")), mask=y1, roi_major=True, amax_out=sg1)
+            # (on the f32 MFMA nothing fills sg1; in split arithmetic every segment's kernel folds its max into the ONE slot)
+            dw2 = None
+            for si, seg in enumerate(segs):
+                if seg.rows == 0:
+                    continue
+                sl = slice(seg.row0, seg.row0 + seg.rows)
+                wino = step.seg_wino(seg, c2)
+                if need_w[wi + 1]:
+                    if wino and c2.out_channels % 4 == 0 and not _NO_WINO_BWD:
+                        part = ops.winograd_wgrad(y1[sl], g2[sl], s2, roi_major=True, split=sp)
+                    else:
+                        colw = step.cols.get((bi, si))
+                        if colw is None:
+                            colw = ops.im2col3x3(y1[sl], seg.H, seg.W)
+                        if sp:
+                            part = ops.conv3x3_wgrad_unpack(ops.gemm_tn_split(g2[sl], colw, None, sg2, 16.0), s2)
+                        else:
+                            part = ops.conv3x3_wgrad_unpack(ops.gemm_tn(g2[sl], colw), s2)
+                    dw2 = part if dw2 is None else dw2.add_(part)
+                if _wino_ok(seg.H, seg.W, c2.out_channels, c2.in_channels) and not _NO_WINO_BWD:
+                    uflip = stage._derived(c2, "uflip", lambda: ops.winograd_pack_weight(wflip))
+                    if sp:
+                        ops.winograd_conv3x3_split_ex(g2[sl], stage._split(keyed(uflip, c2, "uflip")), mask=y1[sl], roi_major=True,
+                                                      amax_out=sg1, out=g1[sl])
+                    else:
+                        ops.winograd_conv3x3_ex(g2[sl], uflip, mask=y1[sl], roi_major=True, out=g1[sl])
                 else:
-                    g1 = ops.winograd_conv3x3_ex(g2, uflip, mask=y1, roi_major=True)
-            else:
-                # data gradient on the general grid: the same im2col GEMM with the flipped filter (im2col only copies and
-                # zero-pads: the patches have g2's range)
-                g1, sg1 = dgrad_1x1(ops.im2col3x3(g2, H, W), sg2, stage._derived(c2, "flip9", lambda: ops.pack_conv3x3_weight(wflip)), c2,
-                                    amax_out=sg1, mask=y1)
+                    # data gradient on the general grid: the same im2col GEMM with the flipped filter (im2col only copies and
+                    # zero-pads: the patches have g2's range)
+                    dgrad_1x1(ops.im2col3x3(g2[sl], seg.H, seg.W), sg2,
+                              stage._derived(c2, "flip9", lambda: ops.pack_conv3x3_weight(wflip)), c2, amax_out=sg1, mask=y1[sl], out=g1[sl])
+            if need_w[wi + 1]:
+                gw[wi + 1] = dw2
             del g2
             # conv1 (+ shortcut): dW1 = s1 * g1^T x ; gx = (g1 . s1 W1 + shortcut path) [x > 0]
             if need_w[wi]:
@@ -232,7 +337,7 @@ class Res5RowsFn(torch.autograd.Function):
             if first and not need_x:
                 g = None
                 break
-            # the input of block 0 is the pooler output (no ReLU in front of it); every other block's input is the
+            # the input of block 0 is the stage input (no ReLU in front of it); every other block's input is the
             # post-ReLU output of its predecessor, whose mask turns gx into that block's masked output gradient
             mask = None if first else x
             # (the slot of gx is only needed when a block below reads it: not for the stage input's gradient)
@@ -245,7 +350,12 @@ class Res5RowsFn(torch.autograd.Function):
                                     residual=gx, mask=mask)
             del g1
             g, sg = gx, sgx
-        return (g, None, None, None, None, None, None, None, *gw)
+        gxs = [None] * nseg
+        if g is not None:
+            for i, seg in enumerate(segs):
+                if ctx.needs_input_grad[3 + i]:
+                    gxs[i] = g[seg.row0:seg.row0 + seg.rows]
+        return (None, None, None, *gxs, *gw)
 
 
 def _stage_weights(stage) -> Tuple[torch.Tensor, ...]:
@@ -257,12 +367,40 @@ def _stage_weights(stage) -> Tuple[torch.Tensor, ...]:
     return tuple(ws)
 
 
+def _guarded(stage, split, guard, device, build):
+    """build(split) -> a finished Res5Step.  With `guard` ((on_overflow,)) and no caller-held range guard: check the split
+    arithmetic's range-guard word behind the forward and rebuild the step on the f32 MFMA when an activation left fp16's
+    range (calls on_overflow() first).  Inside a caller's own `ops.range_guard` block the launches raise THAT guard and
+    nothing is read here: the caller checks once for all the calls it made."""
+    own = None
+    if split and guard is not None and ops.active_guard(device) is None:
+        own = stage.range_guard("fwd", device)
+        own.reset()
+    with ops.range_guard(own):
+        step = build(split)
+    if own is not None and own.raised():
+        if guard[0] is not None:
+            guard[0]()
+        del step
+        step = build(False)
+    return step
+
+
 def res5_rows(stage, x0: torch.Tensor, R: int, H: int, W: int, pooled: bool = False, split: bool = True,
               overflow_check: bool = True, on_overflow=None) -> torch.Tensor:
-    """Differentiable Res5 on ROI-major pixel rows (see Res5RowsFn)."""
+    """Differentiable Res5 on ROI-major pixel rows: out = Res5(x0), x0 [R*H*W, Cin] the stage input already sub-sampled by
+    block 0's stride (the even positions: STRIDE_IN_1X1) -> the rows [R*H*W, Cout], or with `pooled` their per-ROI mean
+    [R, Cout].  A one-segment Res5Step."""
     assert stage.supports_rows_path(), "the rows path needs FrozenBN, STRIDE_IN_1X1 and ungrouped convolutions"
-    guard = (on_overflow,) if overflow_check else None
-    return Res5RowsFn.apply(x0, stage, R, H, W, pooled, split, guard, *_stage_weights(stage))
+    xd = ops._dev(x0.detach(), "x0")
+
+    def build(sp):
+        step = Res5Step(stage, sp, xd.device, R * H * W)
+        step.input_rows(R * H * W).copy_(xd)
+        step.forward(R, H, W)
+        return step
+    step = _guarded(stage, split, (on_overflow,) if overflow_check else None, xd.device, build)
+    return step.outputs([x0], [pooled])[0]
 
 
 class _ToNHWC(torch.autograd.Function):
@@ -291,11 +429,14 @@ def to_nhwc(x: torch.Tensor) -> torch.Tensor:
 
 
 class _RoiAlignEvenRows(torch.autograd.Function):
-    """Even-grid ROIAlign of a channels-last map -> ROI-major rows [oh*ow*R, C] (oh = P/2), differentiable in the map."""
+    """Even-grid ROIAlign of a channels-last map -> ROI-major rows [oh*ow*R, C] (oh = P/2), differentiable in the map.
+    step: a Res5Step whose next segment's input rows the result is written into (no copy)."""
 
     @staticmethod
-    def forward(ctx, nhwc, rois, P, scale, sampling_ratio, aligned):
-        out = ops.roi_align_nhwc(nhwc.detach(), rois, P, scale, sampling_ratio, aligned, bin_stride=2, pos_major=False)
+    def forward(ctx, nhwc, rois, P, scale, sampling_ratio, aligned, step=None):
+        o = (P + 1) // 2
+        dst = step.input_rows(o * o * rois.shape[0]) if step is not None else None
+        out = ops.roi_align_nhwc(nhwc.detach(), rois, P, scale, sampling_ratio, aligned, bin_stride=2, pos_major=False, out=dst)
         ctx.save_for_backward(rois)
         ctx.args = (tuple(nhwc.shape), P, scale, sampling_ratio, aligned)
         return out.view(-1, nhwc.shape[3])
@@ -305,24 +446,57 @@ class _RoiAlignEvenRows(torch.autograd.Function):
         (rois,) = ctx.saved_tensors
         shape, P, scale, sampling_ratio, aligned = ctx.args
         return ops.roi_align_nhwc_bwd(g, shape, rois, P, scale, sampling_ratio, aligned, bin_stride=2, pos_major=False), \
-            None, None, None, None, None
+            None, None, None, None, None, None
 
 
-def roi_align_even_rows(nhwc, rois, P, scale, sampling_ratio, aligned) -> torch.Tensor:
-    return _RoiAlignEvenRows.apply(nhwc, rois, int(P), float(scale), int(sampling_ratio), bool(aligned))
+def roi_align_even_rows(nhwc, rois, P, scale, sampling_ratio, aligned, step=None) -> torch.Tensor:
+    return _RoiAlignEvenRows.apply(nhwc, rois, int(P), float(scale), int(sampling_ratio), bool(aligned), step)
 
 
 class _Stride2Rows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, nhwc):
+    def forward(ctx, nhwc, step=None):
         N, H, W, _ = nhwc.shape
         ctx.dims = (N, H, W)
-        return ops.rows_stride2(nhwc.detach(), N, H, W, True)
+        dst = step.input_rows(N * ((H + 1) // 2) * ((W + 1) // 2)) if step is not None else None
+        return ops.rows_stride2(nhwc.detach(), N, H, W, True, out=dst)
 
     @staticmethod
     def backward(ctx, g):
         N, H, W = ctx.dims
-        return ops.rows_stride2(g, N, H, W, False)
+        return ops.rows_stride2(g, N, H, W, False), None
+
+
+def grid_rows(nhwc: torch.Tensor, step=None) -> torch.Tensor:
+    """The even pixels of a channels-last map as pixel rows [N * ceil(H/2) * ceil(W/2), C] (block 0's stride-2 1x1 convolutions
+    read nothing else), differentiable; with `step` written into that Res5Step's next input rows."""
+    return _Stride2Rows.apply(nhwc, step)
+
+
+def grid_segment(step: "Res5Step", nhwc: torch.Tensor) -> torch.Tensor:
+    """Enqueue the whole-grid call of roi_emb_heads.py:323 as the next segment of `step`; returns its input rows (graph)."""
+    N, H, W, _ = nhwc.shape
+    rows = grid_rows(nhwc, step)
+    step.forward(N, (H + 1) // 2, (W + 1) // 2)
+    return rows
+
+
+def roi_segment(step: "Res5Step", nhwc: torch.Tensor, rois: torch.Tensor, P: int, scale: float, sampling_ratio: int, aligned: bool) -> torch.Tensor:
+    """Enqueue the proposals' call of roi_emb_heads.py:343 (even-grid ROIAlign + the stage) as the next segment of `step`."""
+    x0 = roi_align_even_rows(nhwc, rois, P, scale, sampling_ratio, aligned, step)
+    o = (int(P) + 1) // 2
+    step.forward(rois.shape[0], o, o)
+    return x0
+
+
+def grid_capacity(nhwc: torch.Tensor) -> int:
+    N, H, W, _ = nhwc.shape
+    return N * ((H + 1) // 2) * ((W + 1) // 2)
+
+
+def to_nchw(rows: torch.Tensor, N: int, OH: int, OW: int) -> torch.Tensor:
+    """Pixel rows [N*OH*OW, C] -> logical NCHW [N, C, OH, OW], differentiable."""
+    return _ToNCHW.apply(rows.view(N, OH, OW, rows.shape[1]))
 
 
 def res5_grid(stage, nhwc: torch.Tensor, split: bool = True, overflow_check: bool = True, on_overflow=None) -> torch.Tensor:
@@ -330,8 +504,29 @@ def res5_grid(stage, nhwc: torch.Tensor, split: bool = True, overflow_check: boo
     [N, Cout, ceil(H/2), ceil(W/2)], differentiable in the map and the convolution weights.  Block 0's stride-2 1x1
     convolutions read the even pixels; the 3x3 convolutions run as implicit GEMMs over the (H/2 x W/2) grid."""
     N, H, W, _ = nhwc.shape
-    assert stage[0].stride == 2 and stage[0].stride_in_1x1
+    assert stage.supports_rows_path() and stage[0].stride == 2 and stage[0].stride_in_1x1
     OH, OW = (H + 1) // 2, (W + 1) // 2
-    rows = _Stride2Rows.apply(nhwc)
-    y = res5_rows(stage, rows, N, OH, OW, pooled=False, split=split, overflow_check=overflow_check, on_overflow=on_overflow)
-    return _ToNCHW.apply(y.view(N, OH, OW, y.shape[1]))
+    made = {}
+
+    def build(sp):
+        step = Res5Step(stage, sp, nhwc.device, N * OH * OW)
+        made["rows"] = grid_segment(step, nhwc)
+        return step
+    step = _guarded(stage, split, (on_overflow,) if overflow_check else None, nhwc.device, build)
+    return to_nchw(step.outputs([made["rows"]], [False])[0], N, OH, OW)
+
+
+def res5_rois(stage, nhwc: torch.Tensor, rois: torch.Tensor, P: int, scale: float, sampling_ratio: int, aligned: bool,
+              pooled: bool = False, split: bool = True, overflow_check: bool = True, on_overflow=None) -> torch.Tensor:
+    """roi_emb_heads.py:243-245 under autograd: even-grid ROIAlign of the channels-last map + the stage on the proposals' 7x7
+    tiles -> rows [o*o*R, Cout] (o = P/2), or with `pooled` their per-proposal mean [R, Cout]."""
+    assert stage.supports_rows_path() and stage[0].stride == 2 and stage[0].stride_in_1x1
+    o = (int(P) + 1) // 2
+    made = {}
+
+    def build(sp):
+        step = Res5Step(stage, sp, nhwc.device, o * o * rois.shape[0])
+        made["x0"] = roi_segment(step, nhwc, rois, P, scale, sampling_ratio, aligned)
+        return step
+    step = _guarded(stage, split, (on_overflow,) if overflow_check else None, nhwc.device, build)
+    return step.outputs([made["x0"]], [pooled])[0]

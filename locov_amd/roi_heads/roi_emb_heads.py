@@ -457,6 +457,7 @@ class SampleAllROIHeads(ROIHeads):
         storage = get_event_storage()
         storage.put_scalar("roi_head/num_fg_samples", float(np.mean(tot - bg)))
         storage.put_scalar("roi_head/num_bg_samples", float(np.mean(bg)))
+        st["done"] = sampled                              # (a forward that is repeated on the f32 MFMA keeps its draw)
         return sampled
 
 
@@ -612,10 +613,10 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
             P = self.pooler.output_size[0]
             if nhwc is None:
                 nhwc = res5_train.to_nhwc(features[0])
-            x0 = res5_train.roi_align_even_rows(nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned)
             R, o = rois.shape[0], P // 2
-            y = res5_train.res5_rows(self.res5, x0, R, o, o, pooled=pooled, split=self.res5_dtype == "f16x2",
-                                     overflow_check=self.res5_overflow_check, on_overflow=self._warn_overflow)
+            y = res5_train.res5_rois(self.res5, nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned,
+                                     pooled=pooled, split=self.res5_dtype == "f16x2", overflow_check=self.res5_overflow_check,
+                                     on_overflow=self._warn_overflow)
             return y if pooled else y.view(R, o, o, y.shape[1]).permute(0, 3, 1, 2)
         if not self._fused_path_ok(features):
             self._warn_stock_fallback("_shared_roi_transform", features)
@@ -874,26 +875,25 @@ class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
         pending = self._label_begin(proposals, targets)
         del targets
         feats = [features[f] for f in self.in_features]
+        joint = self._train_path_ok(feats) and self._needs_graph(feats)
         nhwc = None
-        if self._train_path_ok(feats) and self._needs_graph(feats):
+        if joint:
             from .. import res5_train
             nhwc = res5_train.to_nhwc(feats[0])          # one channels-last copy (and one gradient transpose) for both calls
-        # ONE range guard for both Res5 calls of the step (the whole grid and the sampled proposals).  Training ("deferred"):
-        # acted on on the device, read with the next step's labelling.  "sync": one read behind both calls; a step that left the
-        # split arithmetic's range repeats both on the f32 MFMA (the graph of the first attempt is simply dropped)
+        # ONE range guard for both Res5 calls of the step (the whole grid and the sampled proposals).  "sync": one look at the
+        # word, at the end of this forward; a step that left the split arithmetic's range repeats both calls on the f32 MFMA
+        # (the graph of the first attempt is simply dropped).  "deferred": acted on on the device, read with the next step's labelling
         tguard = self._train_guard(feats)
         guard = None if tguard is not None else self._deferred_guard(feats)
-        dtype_was = self.res5_dtype
         with ops.range_guard(tguard if tguard is not None else guard):
-            visual_grid_features = self._res5_grid(feats[0], nhwc)               # :323
-            proposals = self._label_finish(pending)                              # :318 (the step's one host wait)
-            if self.res5_dtype != dtype_was:
-                # that read found the PREVIOUS step's deferred guard set: RES5_DTYPE is "fp32" from here on, and the grid call
-                # enqueued above (still in split arithmetic, on data that may again be out of range) is redone
-                visual_grid_features = self._res5_grid(feats[0], nhwc)
-            proposal_boxes = [x.proposal_boxes for x in proposals]
-            boxes_per_image = [len(x) for x in proposals]
-            box_features = self._shared_roi_transform(feats, proposal_boxes, pooled=True, nhwc=nhwc)   # :343-344
+            if joint:
+                visual_grid_features, box_features, proposals = self._res5_both(feats[0], nhwc, pending)
+            else:
+                visual_grid_features = self._res5_grid(feats[0], nhwc)               # :323
+                proposals = self._label_finish(pending)                              # :318 (the step's one host wait)
+                box_features = self._shared_roi_transform(feats, [x.proposal_boxes for x in proposals], pooled=True, nhwc=nhwc)   # :343-344
+        proposal_boxes = [x.proposal_boxes for x in proposals]
+        boxes_per_image = [len(x) for x in proposals]
         keep = None
         if tguard is not None:
             keep = self._close_train_guard(tguard, [visual_grid_features, box_features])
@@ -910,12 +910,42 @@ class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
             # left the split arithmetic's range repeats both calls and the tail on the f32 MFMA (the first graph is dropped)
             self._warn_overflow()
             del visual_grid_features, box_features, predictions, losses
-            visual_grid_features = self._with_res5_dtype("fp32", self._res5_grid, feats[0], nhwc)
-            box_features = self._with_res5_dtype("fp32", self._shared_roi_transform, feats, proposal_boxes, pooled=True, nhwc=nhwc)
+            if joint:
+                visual_grid_features, box_features, _ = self._with_res5_dtype("fp32", self._res5_both, feats[0], nhwc, pending)
+            else:
+                visual_grid_features = self._with_res5_dtype("fp32", self._res5_grid, feats[0], nhwc)
+                box_features = self._with_res5_dtype("fp32", self._shared_roi_transform, feats, proposal_boxes, pooled=True, nhwc=nhwc)
             predictions = self.box_predictor(box_features)
             losses = dict(self._predictor_losses(predictions, proposals))
         box_features = list(box_features.split(boxes_per_image, dim=0))          # :346
         return visual_grid_features, box_features, proposals, losses
+
+    def _res5_both(self, feature: torch.Tensor, nhwc: torch.Tensor, pending):
+        """roi_emb_heads.py:318-344 on the hand-written training path: self.res5(features) on the whole grid (:323) and
+        res5(pooler(...)).mean() on the sampled proposals (:343-344) as the two segments of ONE res5_train.Res5Step -- the grid
+        call is enqueued first, behind the labelling's kernels, and only then does the host wait for the labelling's few
+        integers (:318; with the grid call still queued the GPU does not drain while the host samples and launches the
+        proposals' path); the backward of both is one joint pass over their 4 200 + 39 200 rows.
+        Returns (visual_grid_features [N, C5, H/2, W/2], pooled box_features [R, C5], sampled proposals)."""
+        from .. import res5_train
+        while True:
+            dtype = self.res5_dtype
+            N, H, W, _ = nhwc.shape
+            P = self.pooler.output_size[0]
+            o = (P + 1) // 2
+            step = res5_train.Res5Step(self.res5, dtype == "f16x2", nhwc.device,
+                                       res5_train.grid_capacity(nhwc) + o * o * N * self.batch_size_per_image)
+            rows = res5_train.grid_segment(step, nhwc)
+            proposals = self._label_finish(pending)                              # :318 (the step's one host wait)
+            if self.res5_dtype == dtype:
+                break
+            # that read found the PREVIOUS step's deferred guard set: RES5_DTYPE is "fp32" from here on, and the grid call
+            # enqueued above (still in split arithmetic, on data that may again be out of range) is redone
+            del step, rows
+        rois = convert_boxes_to_pooler_format([x.proposal_boxes for x in proposals])
+        x0 = res5_train.roi_segment(step, nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned)
+        grid, box_features = step.outputs([rows, x0], [False, True])
+        return res5_train.to_nchw(grid, N, (H + 1) // 2, (W + 1) // 2), box_features, proposals
 
     def inference_detection(self, features, proposals):
         """roi_emb_heads.py:351-360."""

@@ -201,7 +201,7 @@ def _stage(pkg, oracle, in_ch, mid, out_ch, seed):
     return res5.cuda().train(), params
 
 
-def _float64_stage(oracle, params, x, masks=None):
+def _float64_stage(oracle, params, x, masks=None, p=None):
     """The oracle's bottleneck chain (oracle.bottleneck = [D2-upstream] BottleneckBlock.forward) with autograd on, in
     float64.  masks = None: oracle.bottleneck itself.  masks = [(y1 > 0, y2 > 0, out > 0)] per block, NCHW bool: the same
     chain with every ReLU replaced by the given 0/1 pattern.
@@ -213,7 +213,8 @@ def _float64_stage(oracle, params, x, masks=None):
     implementations differ from float64, and from each other, by that much.  The gradient gate is therefore evaluated on the
     function the device actually computed: float64 arithmetic, the device's active set.  The forward (and hence the active
     set, up to such ties) is gated separately against the plain oracle."""
-    p = {k: v.double().requires_grad_(".norm." not in k) for k, v in params.items()}
+    if p is None:                                         # (p: the float64 parameters of an earlier call -- gradients then accumulate)
+        p = {k: v.double().requires_grad_(".norm." not in k) for k, v in params.items()}
     y = x
     for i, stride in enumerate((2, 1, 1)):
         pre = f"{i}."
@@ -407,6 +408,86 @@ def test_res5_grid_gradients_vs_float64(pkg, oracle, dims, N, H, W, split):
     assert max(errs.values()) < 1e-4, errs
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["f32mfma", "f16x2"])
+def test_joint_step_equals_the_two_calls_and_float64(pkg, oracle, split):
+    """res5_train.Res5Step: the whole-grid call (roi_emb_heads.py:323) and the proposals' call (:343-344) of one LSM step as the
+    two segments of ONE autograd node -- every 1x1 data / weight gradient is one launch over the joint rows.  Outputs are
+    bit-identical to the two separate calls (the forward IS per segment); every gradient (the map through both paths, every
+    convolution weight as the sum of both calls' contributions) agrees with the two-call form and with a float64 evaluation on
+    the device's own active sets, with very different gradient magnitudes on the two segments (the joint pass shares one
+    operand scale per gradient matrix)."""
+    from locov_amd import res5_train, ops
+    in_ch, mid, out_ch = 128, 64, 256
+    res5, params = _stage(pkg, oracle, in_ch, mid, out_ch, seed=77)
+    gen = torch.Generator().manual_seed(41)
+    N, H, W, R = 2, 26, 43, 19
+    feat = torch.randn(N, in_ch, H, W, generator=gen)
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    wh = torch.rand(R, 2, generator=gen) * torch.tensor([W * 16.0, H * 16.0]) * 0.5 + 24.0
+    xy = torch.rand(R, 2, generator=gen) * torch.tensor([W * 8.0, H * 8.0])
+    rois = torch.cat([torch.randint(0, N, (R, 1), generator=gen).float(), xy, xy + wh], dim=1).cuda()
+    Gg = torch.randn(N, out_ch, OH, OW, generator=gen).cuda() * 1e-3            # a grounding-loss-sized gradient on the grid ...
+    Gr = torch.randn(R, out_ch, generator=gen).cuda() * 3.0                      # ... against a 3 000x larger one on the proposals
+    sd = dict(res5.named_parameters())
+    keys = _weight_keys(params)
+
+    def two_calls():
+        res5.zero_grad()
+        f = feat.cuda().requires_grad_(True)
+        nhwc = res5_train.to_nhwc(f)
+        grid = res5_train.res5_grid(res5, nhwc, split=split)
+        box = res5_train.res5_rois(res5, nhwc, rois, 14, 1.0 / 16, 0, True, pooled=True, split=split)
+        ((grid * Gg).sum() + (box * Gr).sum()).backward()
+        return grid.detach(), box.detach(), f.grad.clone(), {k: sd[k].grad.clone() for k in keys}
+
+    def joint():
+        res5.zero_grad()
+        f = feat.cuda().requires_grad_(True)
+        nhwc = res5_train.to_nhwc(f)
+        step = res5_train.Res5Step(res5, split, f.device, N * OH * OW + 49 * R + 100)      # (spare capacity: fewer proposals than planned)
+        rows = res5_train.grid_segment(step, nhwc)
+        x0 = res5_train.roi_segment(step, nhwc, rois, 14, 1.0 / 16, 0, True)
+        grid_rows, box = step.outputs([rows, x0], [False, True])
+        grid = res5_train.to_nchw(grid_rows, N, OH, OW)
+        # the joint node's own active sets (grid rows first, then the proposals' 7x7 tiles), read before the backward frees them
+        stack, fn = [grid.grad_fn], None
+        while stack:
+            n = stack.pop()
+            if n is None:
+                continue
+            if "Res5RowsFn" in type(n).__name__:
+                fn = n
+                break
+            stack += [f_ for f_, _ in n.next_functions]
+        saved = fn.saved_tensors
+        ng = N * OH * OW
+        assert saved[0].shape[0] == ng + 49 * R                                  # the rows in use, not the capacity
+        gm = [tuple((saved[4 * b + j][:ng].view(N, OH, OW, -1).permute(0, 3, 1, 2) > 0).cpu() for j in (1, 2, 3)) for b in range(3)]
+        rm = [tuple((saved[4 * b + j][ng:].view(R, 7, 7, -1).permute(0, 3, 1, 2) > 0).cpu() for j in (1, 2, 3)) for b in range(3)]
+        ((grid * Gg).sum() + (box * Gr).sum()).backward()
+        return grid.detach(), box.detach(), f.grad.clone(), {k: sd[k].grad.clone() for k in keys}, gm, rm
+
+    g2, b2, fx2, w2 = two_calls()
+    gj, bj, fxj, wj, gmasks, rmasks = joint()
+    assert torch.equal(gj, g2) and torch.equal(bj, b2)
+    assert rel_err(fxj, fx2) < 1e-5
+    for k in keys:
+        assert rel_err(wj[k], w2[k]) < 1e-5, k
+    # float64 on those active sets
+    fd = feat.double().requires_grad_(True)
+    yg, pd = _float64_stage(oracle, params, fd, gmasks)
+    # the proposals' stage input in float64: the device's even-grid ROIAlign is linear in the map -- differentiate it through
+    # the fp32 op's own adjoint by treating it as a fixed linear map: x14 = A f  (A applied by the device op on a float64-valued copy)
+    x0d = ops.roi_align_nhwc(ops.nchw_to_nhwc(feat.cuda()), rois, 14, 1.0 / 16, 0, True, bin_stride=2).view(R, 7, 7, in_ch)
+    x14 = torch.zeros(R, in_ch, 14, 14, dtype=torch.float64)
+    x14[:, :, ::2, ::2] = x0d.permute(0, 3, 1, 2).double().cpu()
+    x14.requires_grad_(True)
+    yr, _ = _float64_stage(oracle, params, x14, rmasks, p=pd)
+    ((yg * Gg.double().cpu()).sum() + (yr.mean(dim=[2, 3]) * Gr.double().cpu()).sum()).backward()
+    for k in keys:
+        assert rel_err(wj[k], pd[k].grad) < 1e-4, k
+
+
 # ------------------------------------------------------------------------------------------------ the heads
 def _train_heads(pkg, oracle, backend, dtype, small=True):
     from locov_amd.structures import ShapeSpec
@@ -538,6 +619,7 @@ def test_training_forward_out_of_range_never_reaches_the_losses_or_the_parameter
         assert bool(torch.isfinite(g).all()) and float(g.abs().max()) == 0.0, k
     # gradient accumulation: forward A (out of range), forward B (whose labelling read finds and CLEARS the guard), then A's
     # backward -- A's own copy of the word still zeroes its gradients
+    monkeypatch.setenv("LOCOV_RES5_TRAIN_GUARD", "deferred")
     other, _ = _train_heads(pkg, oracle, "hip", "f16x2")
     other.zero_grad()
     feat_a = (base * big).requires_grad_(True)
