@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LOCOV_ABI_VERSION 5
+#define LOCOV_ABI_VERSION 6
 
 #define LOCOV_OK 0
 #define LOCOV_ERR_INVALID_ARG (-1)
@@ -595,6 +595,14 @@ int locov_gemm_tn_f32(const float *a, int64_t lda, int64_t stride_a, const float
  *                                 gradient's scale is chosen on the device, the transformed activation is scaled by 0.25). */
 int locov_split_scale_from_amax(const float *x, int64_t n, float target_log2, float *scale_out,
                                 locov_stream_t stream);
+/* An upper bound of max |.| of a tensor that is about to be derived from SMALL ones, without a pass over the large tensor:
+ * folds  max_i (muls[i] * max |xs[i]|)  (count <= LOCOV_AMAX_BOUND_MAX device tensors of ns[i] elements, ns[i] % 4 == 0; host
+ * arrays) into word 2 of `slot`, a ZEROED 16-byte operand-scale slot as for amax_out.  The training step's head of the
+ * backward chain: the masked broadcast of the pooled gradient (locov_spatial_mean_bwd: g = grad / 49 where the activation is
+ * positive) and the masked whole-grid gradient (locov_relu_mask) are bounded by their small inputs (roi_emb_heads.py:344,:323). */
+#define LOCOV_AMAX_BOUND_MAX 4
+int locov_amax_bound(const float *const *xs, const int64_t *ns, const float *muls, int count, float *slot,
+                     locov_stream_t stream);
 int locov_split_scale_from_amax_zeroed(const float *x, int64_t n, float target_log2, float *scale_out,
                                        locov_stream_t stream);
 int locov_gemm_nt_f32_split_ex(const float *x, int64_t lda, const void *W_split, const float *scale,
@@ -611,7 +619,10 @@ int locov_gemm_tn_f32_split(const float *a, int64_t lda, int64_t stride_a, const
  * scale of the transformed input chosen on the device (the input is a gradient: the data gradient of a 3x3 convolution).
  * y_split_scale > 0: y is written in the split layout of locov_split_f16x2_pack scaled by y_split_scale (N % 32 == 0, ldy == N,
  * no mask) -- the pre-split A operand (LOCOV_GEMM_A_SPLIT) of the 1x1 convolution that follows; out-of-range values raise
- * *overflow here.  (With a fixed v_scale the transformed input is handed to the batched GEMM in that layout as well.) */
+ * *overflow here.  (With a fixed v_scale the transformed input is handed to the batched GEMM in that layout as well.)
+ * y_split_scale < 0 (no mask): y stays fp32 and is RANGE-CHECKED for the split GEMM that will read it at operand scale
+ * -y_split_scale (|scale * y| >= 65504 raises *overflow here, one launch before that GEMM's own check: a caller that waits for
+ * the guard word -- roi_emb_heads.py:343-347 under autograd -- can record its event in front of the stage's last launches). */
 int locov_winograd_conv3x3_f32_split_ex(const float *x, int64_t R, int Cin, const void *U_split, float u_scale,
                                         float v_scale, int v_scale_auto, const float *scale, const float *shift,
                                         const float *mask, float *y, int64_t ldy, int N, unsigned flags,
@@ -658,6 +669,31 @@ int64_t locov_winograd_wgrad_workspace_bytes(int64_t R, int Cin, int N);
 int locov_winograd_wgrad_f32(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags,
                              const float *row_scale, float *dw, void *workspace, int64_t workspace_bytes,
                              locov_stream_t stream);
+
+/* Every split-operand form of the Res5 convolution weights a training step needs, in ONE launch (csrc/weight_prep.hip).
+ * The LSM configuration trains the Res5 convolutions (configs/coco_lsm.yaml:8), so each step re-derives, per 1x1 convolution,
+ * W [N,K] (forward, roi_emb_heads.py:323,343) and (s W)^T [K,N] (data gradient); per 3x3 convolution the Winograd-domain
+ * filter of the proposals' 7x7 tiles, the im2col filter of the whole-grid call, and both forms of the flipped filter
+ * flip(s w) -- each in the (hi, lo) f16 split layout of locov_split_f16x2_pack, scaled by `scale` (a power of two).  One job =
+ * one operand; results are bit-identical to locov_weight_transpose_scale / locov_conv3x3_weight_flip /
+ * locov_winograd_pack_weight / locov_pack_conv3x3_weight followed by locov_split_f16x2_pack.  `overflow` as there. */
+#define LOCOV_WEIGHT_PREP_MAX_JOBS 32
+enum {
+    LOCOV_PREP_PLAIN = 0,       /* w [N,K]                -> [N,K]                        (K % 32 == 0)   */
+    LOCOV_PREP_TRANSPOSE = 1,   /* w [N,K], s[N]          -> [K,N] = (s w)^T              (N % 32 == 0)   */
+    LOCOV_PREP_IM2COL = 2,      /* w [N,Cin,3,3]          -> [N, 9 Cin], column = tap * Cin + c   (Cin % 32 == 0) */
+    LOCOV_PREP_IM2COL_FLIP = 3, /* w [N,Cin,3,3], s[N]    -> [Cin, 9 N] of flip(s w)      (N % 32 == 0)   */
+    LOCOV_PREP_WINO = 4,        /* w [N,Cin,3,3]          -> U [121, N, Cin]              (Cin % 32 == 0) */
+    LOCOV_PREP_WINO_FLIP = 5    /* w [N,Cin,3,3], s[N]    -> U [121, Cin, N] of flip(s w) (N % 32 == 0)   */
+};
+typedef struct locov_weight_prep_job {
+    const float *w;             /* the convolution weight as stored (device) */
+    const float *row_scale;     /* FrozenBN scale s[n] (device) or NULL */
+    void *out;                  /* destination, same byte size as the fp32 operand would have (device) */
+    float scale;                /* power-of-two operand scale */
+    int kind, N, K;             /* K = Cin for the 3x3 kinds */
+} locov_weight_prep_job;
+int locov_res5_weight_prep(const locov_weight_prep_job *jobs, int n_jobs, unsigned *overflow, locov_stream_t stream);
 
 int locov_weight_transpose_scale(const float *w, int N, int K, const float *row_scale, float *out,
                                  locov_stream_t stream);

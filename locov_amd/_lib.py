@@ -26,9 +26,19 @@ EPI_RES_SPLIT = 0x4000
 MAX_LEVELS = 8
 ZERO_LIST_MAX = 24
 LABEL_MAX_IMAGES, LABEL_MAX_THRESHOLDS = 64, 6
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _p = c_void_p  # device pointer
+
+WEIGHT_PREP_MAX_JOBS = 32
+AMAX_BOUND_MAX = 4
+PREP_PLAIN, PREP_TRANSPOSE, PREP_IM2COL, PREP_IM2COL_FLIP, PREP_WINO, PREP_WINO_FLIP = range(6)
+
+
+class WeightPrepJob(ctypes.Structure):
+    """locov_weight_prep_job of include/locov_hip.h"""
+    _fields_ = [("w", c_void_p), ("row_scale", c_void_p), ("out", c_void_p), ("scale", c_float), ("kind", c_int), ("N", c_int), ("K", c_int)]
+
 
 # name -> (restype, argtypes); mirrors include/locov_hip.h declaration by declaration
 SIGNATURES = {
@@ -107,6 +117,7 @@ SIGNATURES = {
     "locov_gemm_tn_f32": (c_int, [_p, c_int64, c_int64, _p, c_int64, c_int64, _p, c_int64, c_int64, c_int64, c_int, c_int, c_int,
                                   _p, _p, c_int64, _p]),
     "locov_split_scale_from_amax": (c_int, [_p, c_int64, c_float, _p, _p]),
+    "locov_amax_bound": (c_int, [POINTER(c_void_p), POINTER(c_int64), POINTER(c_float), c_int, _p, _p]),
     "locov_split_scale_from_amax_zeroed": (c_int, [_p, c_int64, c_float, _p, _p]),
     "locov_gemm_nt_f32_split_ex": (c_int, [_p, c_int64, _p, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint, c_float, _p,
                                            c_float, _p, _p, _p]),
@@ -125,6 +136,7 @@ SIGNATURES = {
                                                          _p, _p, _p, c_int64, c_int, c_uint, c_float, _p, c_int64, _p, _p]),
     "locov_winograd_wgrad_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
     "locov_winograd_wgrad_f32": (c_int, [_p, _p, c_int64, c_int, c_int, c_uint, _p, _p, _p, c_int64, _p]),
+    "locov_res5_weight_prep": (c_int, [POINTER(WeightPrepJob), c_int, _p, _p]),
     "locov_weight_transpose_scale": (c_int, [_p, c_int, c_int, _p, _p, _p]),
     "locov_conv3x3_weight_flip": (c_int, [_p, c_int, c_int, _p, _p, _p]),
     "locov_im2col3x3_nhwc": (c_int, [_p, c_int64, c_int, c_int, c_int, _p, _p]),

@@ -679,6 +679,38 @@ __global__ __launch_bounds__(256) void split_amax_kernel(const float *__restrict
     }
 }
 
+// max_i (mul_i * max |x_i|) of up to LOCOV_AMAX_BOUND_MAX small tensors folded into word 2 of a zeroed operand-scale slot
+struct AmaxBoundList {
+    const float *x[LOCOV_AMAX_BOUND_MAX];
+    int64_t n4[LOCOV_AMAX_BOUND_MAX];
+    float mul[LOCOV_AMAX_BOUND_MAX];
+    unsigned first_block[LOCOV_AMAX_BOUND_MAX + 1];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void amax_bound_kernel(AmaxBoundList L, float *__restrict__ slot)
+{
+    int ti = 0;
+    while (ti + 1 < L.count && blockIdx.x >= L.first_block[ti + 1]) ti++;
+    const unsigned blocks = L.first_block[ti + 1] - L.first_block[ti];
+    const f32x4 *x = reinterpret_cast<const f32x4 *>(L.x[ti]);
+    float m = 0.f;
+    for (int64_t i = (int64_t)(blockIdx.x - L.first_block[ti]) * 256 + threadIdx.x; i < L.n4[ti]; i += (int64_t)blocks * 256) {
+        const f32x4 v = x[i];
+        m = fmaxf(fmaxf(m, fabsf(v[0])), fabsf(v[1]));
+        m = fmaxf(fmaxf(m, fabsf(v[2])), fabsf(v[3]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {                    // ONE atomic per workgroup
+        m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])) * L.mul[ti];
+        if (m > 0.f) atomicMax(reinterpret_cast<unsigned *>(slot) + 2, __float_as_uint(m));      // non-negative floats order like their bits
+    }
+}
+
 int launch_gemm_split(const float *A, int64_t lda, const void *Wsplit, float *C, int64_t ldc, int64_t M, int N, int K,
                       const Epilogue &epi, float a_scale, float w_scale, hipStream_t s, const char *what, const Batch &bt,
                       unsigned *overflow, const float *a_scale_dev)
@@ -847,6 +879,33 @@ int locov_split_scale_from_amax(const float *x, int64_t n, float target_log2, fl
 int locov_split_scale_from_amax_zeroed(const float *x, int64_t n, float target_log2, float *scale_out, locov_stream_t stream)
 {
     return split_scale_from_amax(x, n, target_log2, scale_out, true, stream);
+}
+
+int locov_amax_bound(const float *const *xs, const int64_t *ns, const float *muls, int count, float *slot, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(count >= 0 && count <= LOCOV_AMAX_BOUND_MAX, "locov_amax_bound: 0..%d tensors per call", LOCOV_AMAX_BOUND_MAX);
+    if (count == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(xs && ns && muls && slot, "locov_amax_bound: null pointer");
+    AmaxBoundList L{};
+    unsigned next = 0;
+    int used = 0;
+    for (int i = 0; i < count; i++) {
+        LOCOV_REQUIRE(ns[i] >= 0 && ns[i] % 4 == 0 && (ns[i] == 0 || (xs[i] && (uintptr_t)xs[i] % 16 == 0)) && muls[i] >= 0.f,
+                      "locov_amax_bound: tensor %d: numel %% 4, 16-byte pointer, non-negative multiplier", i);
+        if (ns[i] == 0) continue;
+        const int64_t n4 = ns[i] / 4, want = ceil_div(n4, 256 * 8);
+        L.x[used] = xs[i];
+        L.n4[used] = n4;
+        L.mul[used] = muls[i];
+        L.first_block[used] = next;
+        next += (unsigned)(want < 1 ? 1 : want < 512 ? want : 512);
+        used++;
+    }
+    if (used == 0) return LOCOV_OK;
+    L.first_block[used] = next;
+    L.count = used;
+    hipLaunchKernelGGL(amax_bound_kernel, dim3(next), dim3(256), 0, as_stream(stream), L, slot);
+    return check_launch("locov_amax_bound");
 }
 
 int locov_gemm_nt_f32_split_ex(const float *x, int64_t lda, const void *W_split, const float *scale, const float *shift,

@@ -18,6 +18,7 @@
 // The transforms keep two channels per lane (8-byte accesses, 512 contiguous bytes per wave and
 // row) so that a 7x7 patch (49 x 2 registers) or the 7x7 accumulators fit without spilling.
 #include "winograd_transform.h"
+#include "winograd_filter.h"
 
 #include <cstdlib>
 
@@ -54,10 +55,10 @@ __global__ __launch_bounds__(256) void wino_pack_weight_kernel(const float *__re
     for (int fy = 0; fy < NF; fy++) {
         double t[3];
 #pragma unroll
-        for (int b = 0; b < 3; b++) t[b] = G[fy][0] * g[0][b] + G[fy][1] * g[1][b] + G[fy][2] * g[2][b];
+        for (int b = 0; b < 3; b++) t[b] = wino::filter_dot3(fy, g[0][b], g[1][b], g[2][b]);
 #pragma unroll
         for (int fx = 0; fx < NF; fx++)
-            U[(int64_t)(fy * NF + fx) * NC + i] = (float)(G[fx][0] * t[0] + G[fx][1] * t[1] + G[fx][2] * t[2]);
+            U[(int64_t)(fy * NF + fx) * NC + i] = (float)wino::filter_dot3(fx, t[0], t[1], t[2]);
     }
 }
 
@@ -113,7 +114,11 @@ __global__ __launch_bounds__(256, LOCOV_WINO_IN_MINW) void wino_input_kernel(con
 // wave per SIMD on a kernel that lives on memory-level parallelism; now 254 and two (8 000 ROIs, 512 channels: 540 -> 485 us).  The
 // compiler still issues all 121 loads before the first add -- scheduling fences between the rows of planes and a lower register budget
 // (LOCOV_WINO_OUT_MINW) only turn the loaded values into scratch traffic -- which at two waves per SIMD is what keeps HBM busy.
-template <bool SPLIT = false, bool WIDE = false>
+// MASKED (the data gradient of a 3x3 convolution: the ReLU backward of the saved activation in the epilogue): the 49 mask values
+// of the lane's (ROI, channel pair) are requested TOGETHER once the accumulators are final -- the transform's operands are dead by
+// then, so the registers are there.  Left inside the store loop every position's load sat between two stores the compiler may not
+// move it across (49 dependent round trips per lane: 142 us per launch against the forward's 57 us at 800 ROIs).
+template <bool SPLIT = false, bool WIDE = false, bool MASKED = false>
 __global__ __launch_bounds__(256, LOCOV_WINO_OUT_MINW) void wino_output_kernel(const float *__restrict__ Mv, int64_t ld_pos, int64_t ld_roi, int64_t Rc, int N,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, int relu,
@@ -176,6 +181,16 @@ __global__ __launch_bounds__(256, LOCOV_WINO_OUT_MINW) void wino_output_kernel(c
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(mask ? mask : y), 0, 0xffffffff, 0x00020000);
     const unsigned row_off = (unsigned)(r * ld_roi * ldy * 4), pos_bytes = (unsigned)(ld_pos * ldy * 4);
     const unsigned y_off = row_off + (SPLIT ? (unsigned)split_pair_offset(n) : (unsigned)n * 4u);
+    f32x2 mk[MASKED ? 7 : 1][MASKED ? 7 : 1];
+    if constexpr (MASKED) {
+#pragma unroll
+        for (int yy = 0; yy < 7; yy++)
+#pragma unroll
+            for (int xx = 0; xx < 7; xx++)
+                mk[yy][xx] = WIDE ? *reinterpret_cast<const f32x2 *>(msk + (int64_t)(yy * 7 + xx) * ld_pos * ldy)
+                                  : __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rk, row_off + (unsigned)n * 4u,
+                                                                                                   (unsigned)(yy * 7 + xx) * pos_bytes, 0));
+    }
 #pragma unroll
     for (int yy = 0; yy < 7; yy++) {
 #pragma unroll
@@ -185,12 +200,9 @@ __global__ __launch_bounds__(256, LOCOV_WINO_OUT_MINW) void wino_output_kernel(c
                 v[0] = fmaxf(v[0], 0.f);
                 v[1] = fmaxf(v[1], 0.f);
             }
-            if (!SPLIT && msk) {                                   // (a split-layout output takes no mask: locov_winograd_conv3x3_f32_split_ex)
-                const f32x2 mk = WIDE ? *reinterpret_cast<const f32x2 *>(msk + (int64_t)(yy * 7 + xx) * ld_pos * ldy)
-                                      : __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rk, row_off + (unsigned)n * 4u,
-                                                                                                       (unsigned)(yy * 7 + xx) * pos_bytes, 0));
-                v[0] = mk[0] > 0.f ? v[0] : 0.f;
-                v[1] = mk[1] > 0.f ? v[1] : 0.f;
+            if constexpr (MASKED) {                                // (a split-layout output takes no mask: locov_winograd_conv3x3_f32_split_ex)
+                v[0] = mk[yy][xx][0] > 0.f ? v[0] : 0.f;
+                v[1] = mk[yy][xx][1] > 0.f ? v[1] : 0.f;
             }
             amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
             if constexpr (SPLIT) {
@@ -208,7 +220,9 @@ __global__ __launch_bounds__(256, LOCOV_WINO_OUT_MINW) void wino_output_kernel(c
         }
     }
     }
-    if (SPLIT && overflow != nullptr && amax * y_scale >= 65504.f) atomicOr(overflow, 1u);
+    // (SPLIT: what was just written no longer holds the fp32 value.  fp32 output with `overflow`: the caller asks for the range check
+    //  of the split GEMM that will read y at operand scale y_scale -- the guard word is then final one launch earlier)
+    if (overflow != nullptr && amax * y_scale >= 65504.f) atomicOr(overflow, 1u);
     if (!SPLIT && amax_out != nullptr) amax_fold(amax_out, amax);
 }
 
@@ -527,13 +541,21 @@ static int winograd_conv3x3(const float *x, int64_t R, int Cin, const float *U, 
         const int relu_i = (flags & LOCOV_EPI_RELU) ? 1 : 0;
         const dim3 og((unsigned)ceil_div(tout, 256));
 #define LOCOV_WINO_OUT(SP, WD, ...) hipLaunchKernelGGL((wino_output_kernel<SP, WD>), og, dim3(256), 0, s, Mv, lp, lr, rc, N, scale, shift, relu_i, yo, ldy, __VA_ARGS__)
+#define LOCOV_WINO_OUT_MASKED(WD, ...) hipLaunchKernelGGL((wino_output_kernel<false, WD, true>), og, dim3(256), 0, s, Mv, lp, lr, rc, N, scale, shift, relu_i, yo, ldy, __VA_ARGS__)
         if (y_split_scale > 0.f) {
             if (wide) LOCOV_WINO_OUT(true, true, static_cast<const float *>(nullptr), y_split_scale, overflow, static_cast<float *>(nullptr));
             else LOCOV_WINO_OUT(true, false, static_cast<const float *>(nullptr), y_split_scale, overflow, static_cast<float *>(nullptr));
+        } else if (mo != nullptr) {
+            if (wide) LOCOV_WINO_OUT_MASKED(true, mo, 1.f, static_cast<unsigned *>(nullptr), amax_out);
+            else LOCOV_WINO_OUT_MASKED(false, mo, 1.f, static_cast<unsigned *>(nullptr), amax_out);
         } else {
-            if (wide) LOCOV_WINO_OUT(false, true, mo, 1.f, static_cast<unsigned *>(nullptr), amax_out);
-            else LOCOV_WINO_OUT(false, false, mo, 1.f, static_cast<unsigned *>(nullptr), amax_out);
+            // y_split_scale < 0: fp32 output, range-checked at operand scale -y_split_scale
+            unsigned *const chk = y_split_scale < 0.f ? overflow : nullptr;
+            const float chk_scale = y_split_scale < 0.f ? -y_split_scale : 1.f;
+            if (wide) LOCOV_WINO_OUT(false, true, mo, chk_scale, chk, amax_out);
+            else LOCOV_WINO_OUT(false, false, mo, chk_scale, chk, amax_out);
         }
+#undef LOCOV_WINO_OUT_MASKED
 #undef LOCOV_WINO_OUT
         rcode = check_launch("locov_winograd_conv3x3_f32 (output transform)");
         if (rcode) return rcode;

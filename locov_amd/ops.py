@@ -338,7 +338,8 @@ def winograd_pack_weight(w: torch.Tensor) -> torch.Tensor:
 
 def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool = False,
                      out: Optional[torch.Tensor] = None, v_scale: float = 0.25, roi_major: bool = False,
-                     in_roi_major: bool = False, out_split_scale: Optional[float] = None) -> torch.Tensor:
+                     in_roi_major: bool = False, out_split_scale: Optional[float] = None,
+                     range_check_scale: Optional[float] = None) -> torch.Tensor:
     """3x3 / pad 1 / stride 1 convolution of 7x7 position-major tiles in the Winograd domain.
     x [49*R, Cin] (row = pos*R + r), U [121, N, Cin] (winograd_pack_weight) -> [49*R, N].
     out: optional [49*R, N] destination whose rows may be a column block of a wider matrix.
@@ -349,7 +350,9 @@ def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool =
     in_roi_major: x is given in that order.
     out_split_scale (split U only): write the output in the split layout of split_pack scaled by that power of two -- the
     pre-split A operand (`x_is_split`) of the split GEMM that consumes it, which then stages it by LDS DMA with no conversion.
-    The returned tensor is float32-TYPED storage of that layout (same shape and size), not fp32 values."""
+    The returned tensor is float32-TYPED storage of that layout (same shape and size), not fp32 values.
+    range_check_scale (split U, fp32 output): raise the range guard here when |range_check_scale * y| >= 65504 -- the check the
+    split GEMM reading y at that operand scale would make, one launch earlier."""
     x = _dev(x, "x")
     split = U if isinstance(U, SplitWeight) else None
     U = _dev(split.data if split is not None else U, "U")
@@ -383,7 +386,8 @@ def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool =
                 raise ValueError("winograd_conv3x3: a split-layout output needs N % 32 == 0 and a dense destination")
             check(lib.locov_winograd_conv3x3_f32_split_ex(_ptr(x), R, Cin, _ptr(U), split.scale, float(v_scale), 0, _ptr(scale),
                                                           _ptr(shift), None, _ptr(y), ldy, N, wflags,
-                                                          float(out_split_scale or 0.0), _ptr(ws), ws.numel(),
+                                                          float(out_split_scale or (-range_check_scale if range_check_scale else 0.0)),
+                                                          _ptr(ws), ws.numel(),
                                                           _ptr(_overflow_word(x)), None, _stream(x)),
                   "locov_winograd_conv3x3_f32_split_ex")
         else:
@@ -914,6 +918,23 @@ def split_scale_from_amax(x: torch.Tensor, target_log2: float = 13.0) -> torch.T
     return out
 
 
+def amax_bound(tensors, muls) -> torch.Tensor:
+    """A zeroed operand-scale slot (scale_slot) whose max word holds max_i (muls[i] * max |tensors[i]|): the range of a LARGE
+    tensor about to be derived from these small ones (a broadcast / masked copy), without a pass over it.  No host read."""
+    ts = [(_dev(t, "tensor"), float(m)) for t, m in zip(tensors, muls) if t is not None and t.numel() > 0]
+    if not ts:
+        raise ValueError("amax_bound: no tensor")
+    if len(ts) > _lib.AMAX_BOUND_MAX or any(t.numel() % 4 for t, _ in ts):
+        raise ValueError(f"amax_bound: at most {_lib.AMAX_BOUND_MAX} tensors, numel % 4 == 0")
+    slot = _scale_slot(ts[0][0], lazy=True)
+    ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t, _ in ts])
+    ns = (ctypes.c_int64 * len(ts))(*[t.numel() for t, _ in ts])
+    ms = (ctypes.c_float * len(ts))(*[m for _, m in ts])
+    with torch.cuda.device(slot.device):
+        check(_lib.load().locov_amax_bound(ptrs, ns, ms, len(ts), _ptr(slot), _stream(slot)), "locov_amax_bound")
+    return slot
+
+
 _SCALE_SLOTS = {}
 
 
@@ -1019,6 +1040,36 @@ def winograd_conv3x3_split_ex(x: torch.Tensor, U: SplitWeight, *, scale=None, sh
     return y
 
 
+PREP_KINDS = {"plain": _lib.PREP_PLAIN, "t": _lib.PREP_TRANSPOSE, "col": _lib.PREP_IM2COL, "flip9": _lib.PREP_IM2COL_FLIP,
+              "wino": _lib.PREP_WINO, "uflip": _lib.PREP_WINO_FLIP}
+
+
+def prep_shape(kind: str, w: torch.Tensor) -> Tuple[int, ...]:
+    """Shape of the operand locov_res5_weight_prep derives from the convolution weight w for `kind`."""
+    N, C = w.shape[0], w.shape[1]
+    return {"plain": (N, C), "t": (C, N), "col": (N, 9 * C), "flip9": (C, 9 * N), "wino": (121, N, C), "uflip": (121, C, N)}[kind]
+
+
+def res5_weight_prep(jobs) -> None:
+    """jobs: [(kind, weight [N,K] | [N,Cin,3,3], FrozenBN row scale | None, out, split scale)] -- every split-layout operand of a
+    training step in ONE launch (locov_res5_weight_prep); `out` are float32-typed tensors of prep_shape(kind, weight)."""
+    if not jobs:
+        return
+    lib = _lib.load()
+    ref = jobs[0][1]
+    for i in range(0, len(jobs), _lib.WEIGHT_PREP_MAX_JOBS):
+        chunk = jobs[i:i + _lib.WEIGHT_PREP_MAX_JOBS]
+        arr = (_lib.WeightPrepJob * len(chunk))()
+        for a, (kind, w, rs, out, scale) in zip(arr, chunk):
+            w = _dev(w, "weight")
+            if tuple(out.shape) != prep_shape(kind, w) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != w.device:
+                raise ValueError(f"res5_weight_prep: out of a {kind!r} job must be a contiguous fp32 {prep_shape(kind, w)} tensor")
+            a.w, a.row_scale, a.out = w.data_ptr(), (_dev(rs, "row_scale").data_ptr() if rs is not None else None), out.data_ptr()
+            a.scale, a.kind, a.N, a.K = float(scale), PREP_KINDS[kind], int(w.shape[0]), int(w.shape[1])
+        with torch.cuda.device(ref.device):
+            check(lib.locov_res5_weight_prep(arr, len(chunk), _ptr(_overflow_word(ref)), _stream(ref)), "locov_res5_weight_prep")
+
+
 def weight_transpose_scale(w: torch.Tensor, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """w [N,K] -> [K,N] with out[k,n] = row_scale[n] * w[n,k]."""
     w = _dev(w, "w")
@@ -1080,6 +1131,7 @@ def relu_mask(g: torch.Tensor, act: torch.Tensor, amax_out: Optional[torch.Tenso
 
 
 LABEL_MAX_IMAGES, LABEL_MAX_THRESHOLDS = _lib.LABEL_MAX_IMAGES, _lib.LABEL_MAX_THRESHOLDS
+AMAX_BOUND_MAX = _lib.AMAX_BOUND_MAX
 
 
 def label_proposals(boxes: torch.Tensor, n_props, gt_boxes: torch.Tensor, gt_classes: torch.Tensor, n_gt, thresholds, labels_of,

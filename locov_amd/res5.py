@@ -31,6 +31,7 @@ import os
 # tests/test_gpu_roi_heads.py::test_full_size_head_properties).  LOCOV_RES5_OUT_SPLIT=0 turns it off.
 _OUT_SPLIT = os.environ.get("LOCOV_RES5_OUT_SPLIT", "1") != "0"
 _FUSE12 = os.environ.get("LOCOV_RES5_FUSE12", "1") != "0"      # developer A/B: conv1 + conv2 through ops.conv1x1_winograd_conv3x3
+_ONE_LAUNCH_PREP = os.environ.get("LOCOV_RES5_PREP", "1") != "0"    # developer A/B: a training step's operands from one launch (TrainOperands)
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -214,6 +215,31 @@ class Res5Stage(nn.Sequential):
             return hit[1]
         val = fn()
         self._cache[slot] = (key, val)
+        return val
+
+    def _fold(self, conv: Conv2d):
+        """(scale, shift) of conv's FrozenBN (cached until the statistics change; no launch after the first call)."""
+        from . import ops
+        n = conv.norm
+        fkey = (n.weight._version, n.bias._version, n.running_mean._version, n.running_var._version, n.weight.data_ptr())
+        fhit = self._cache.get(("fold", id(n)))
+        if fhit is not None and fhit[0] == fkey:
+            return fhit[1]
+        val = ops.frozen_bn_fold(n.weight, n.bias, n.running_mean, n.running_var, n.eps)
+        self._cache[("fold", id(n))] = (fkey, val)
+        return val
+
+    def train_operands(self, split: bool, grid: bool = True, rois: bool = True) -> "TrainOperands":
+        """The GEMM operands of one training step (forward and backward of every convolution), valid for the current weight
+        versions: built once per step, by the first Res5 call that asks (see TrainOperands)."""
+        key = (bool(split), bool(grid), bool(rois)) + tuple(
+            (c.weight.data_ptr(), c.weight._version, c.norm.weight._version, c.norm.running_var._version)
+            for blk in self for c in (blk.conv1, blk.conv2, blk.conv3, blk.shortcut) if c is not None)
+        hit = self.__dict__.get("_train_ops")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        val = TrainOperands(self, split, grid, rois)
+        self.__dict__["_train_ops"] = (key, val)
         return val
 
     def _packed_block0_tail(self):
@@ -523,6 +549,92 @@ class Res5Stage(nn.Sequential):
             return ops.spatial_mean(x.view(H, W, R, x.shape[1]), channels_last=2) if pos_major else \
                 ops.spatial_mean(x.view(R, H, W, x.shape[1]), channels_last=1)
         return x
+
+
+class TrainOperands:
+    """Every weight-derived GEMM operand of ONE training step of the stage.
+
+        get(conv, tag) -> ops.SplitWeight (split arithmetic, eligible shape) | fp32 tensor
+        tags:  "plain"  W [N,K]                         forward of a 1x1 convolution
+               "t"      (s W)^T [K,N]                   its data gradient
+               "wino"   U = (G (x) G) w [121,N,Cin]     forward of a 3x3 convolution on 7x7 tiles
+               "col"    [N, 9 Cin]                      ... on a general grid (im2col GEMM)
+               "uflip"  (G (x) G) flip(s w) [121,Cin,N] data gradient on 7x7 tiles
+               "flip9"  [Cin, 9 N] of flip(s w)         ... on a general grid
+
+    In split arithmetic, once every operand's power-of-two scale is remembered (Res5Stage._scales: chosen from max |.| on the
+    host, re-used for 64 steps with 8x headroom; the pack kernel raises the range guard if one stops covering its data), ALL of
+    them come out of ONE launch (ops.res5_weight_prep) into buffers the stage keeps -- enqueued by the step's first Res5 call,
+    i.e. in front of the labelling wait.  Otherwise (first step, a refresh step, the f32 MFMA, odd shapes) each operand is
+    built on demand by the multi-launch chain it replaces (_packed / _derived / _split), which also chooses the scales."""
+
+    REFRESH = 64
+
+    def __init__(self, stage: "Res5Stage", split: bool, grid: bool, rois: bool):
+        from . import ops
+        self.stage, self.split = stage, bool(split)
+        self.ready = {}
+        if not self.split:
+            return
+        wanted = []
+        for blk in stage:
+            for conv in (blk.conv1, blk.conv3, blk.shortcut):
+                if conv is not None:
+                    wanted += [(conv, "plain"), (conv, "t")]
+            c2 = blk.conv2
+            if rois:
+                wanted += [(c2, "wino"), (c2, "uflip")]
+            if grid:
+                wanted += [(c2, "col"), (c2, "flip9")]
+        recs = [stage._scales.get(self.scale_key(conv, tag)) for conv, tag in wanted]
+        ok = _ONE_LAUNCH_PREP and all(r is not None and r[1] < self.REFRESH for r in recs) and all(
+            conv.weight.is_cuda and conv.weight.dtype == torch.float32 and conv.weight.is_contiguous()
+            and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and conv.groups == 1 for conv, _ in wanted)
+        if not ok:
+            return
+        bufs = stage.__dict__.setdefault("_prep_bufs", {})
+        jobs = []
+        for (conv, tag), rec in zip(wanted, recs):
+            w = conv.weight.detach()
+            shape = ops.prep_shape(tag, w)
+            bk = (id(conv), tag)
+            buf = bufs.get(bk)
+            if buf is None or tuple(buf.shape) != shape or buf.device != w.device:
+                buf = bufs[bk] = torch.empty(shape, dtype=torch.float32, device=w.device)
+            rs = stage._fold(conv)[0] if tag in ("t", "uflip", "flip9") else None
+            jobs.append((tag, w, rs, buf, rec[0]))
+            stage._scales[self.scale_key(conv, tag)] = (rec[0], rec[1] + 1)
+            self.ready[bk] = ops.SplitWeight(buf, rec[0])
+        ops.res5_weight_prep(jobs)
+
+    @staticmethod
+    def scale_key(conv, tag):
+        """The key Res5Stage._split remembers this operand's scale under (set by _packed / the backward's `keyed`)."""
+        return (id(conv), {"plain": False, "col": False, "wino": True}.get(tag, tag))
+
+    def get(self, conv, tag: str):
+        hit = self.ready.get((id(conv), tag))
+        if hit is not None:
+            return hit
+        from . import ops
+        st = self.stage
+        if tag in ("plain", "col", "wino"):
+            t = st._packed(conv, winograd=tag == "wino")[0]
+        else:
+            s = st._fold(conv)[0]
+            if tag == "t":
+                w = st._packed(conv)[0]
+                t = st._derived(conv, "wt", lambda: ops.weight_transpose_scale(w, s))
+            else:
+                wflip = st._derived(conv, "flip", lambda: ops.conv3x3_weight_flip(conv.weight.detach(), s))     # [Cin, Cout, 3, 3]
+                if tag == "uflip":
+                    t = st._derived(conv, "uflip", lambda: ops.winograd_pack_weight(wflip))
+                else:
+                    t = st._derived(conv, "flip9", lambda: ops.pack_conv3x3_weight(wflip))
+            t._locov_key = (id(conv), tag)                  # remembered operand scale of a per-step packing (Res5Stage._split)
+        if self.split and t.shape[-1] % 32 == 0 and t.shape[-2] % 4 == 0:
+            return st._split(t)
+        return t
 
 
 def build_res5_block(cfg):

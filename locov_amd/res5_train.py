@@ -80,8 +80,10 @@ class Res5Step:
         outs = step.outputs([x_with_grad, ...], [pooled, ...])       # ONE autograd node for all segments
     """
 
-    def __init__(self, stage, split: bool, device, capacity_rows: int):
+    def __init__(self, stage, split: bool, device, capacity_rows: int, grid: bool = True, rois: bool = True):
         self.stage, self.split, self.device = stage, bool(split), torch.device(device)
+        # every weight-derived operand of the step's forward AND backward (one launch in split arithmetic: Res5Stage.train_operands)
+        self.operands = stage.train_operands(self.split, grid=grid, rois=rois)
         self.capacity = int(capacity_rows)
         self.segments: List[Segment] = []
         self.filled = 0
@@ -101,8 +103,11 @@ class Res5Step:
         return self.x0[self.filled:self.filled + rows]
 
     @torch.no_grad()
-    def forward(self, n: int, H: int, W: int) -> Segment:
-        """The stage on the segment whose input was just written into input_rows(n * H * W)."""
+    def forward(self, n: int, H: int, W: int, on_range_final=None) -> Segment:
+        """The stage on the segment whose input was just written into input_rows(n * H * W).
+        on_range_final: called (split arithmetic, 7x7 tiles) in front of the LAST convolution's launch, at which point every
+        value a split GEMM of this segment will read has been range-checked (the last block's conv2 checks its own output) --
+        a caller that waits for the range guard records its event there instead of behind the stage."""
         assert self._pending == n * H * W, "Res5Step.forward: input_rows(n * H * W) first"
         seg = Segment(self.filled, n, H, W)
         self._pending = None
@@ -111,31 +116,37 @@ class Res5Step:
         self.filled += seg.rows
         if seg.rows == 0:
             return seg
-        stage, split = self.stage, self.split
+        stage, T = self.stage, self.operands
         sl = slice(seg.row0, seg.row0 + seg.rows)
         x = self.x0[sl]
         for bi, blk in enumerate(stage):
             Y1, Y2, OUT = (t[sl] for t in self.act[bi])
-            w1, s1, b1 = stage._packed(blk.conv1)
-            w3, s3, b3 = stage._packed(blk.conv3)
+            s1, b1 = stage._fold(blk.conv1)
+            s2, b2 = stage._fold(blk.conv2)
+            s3, b3 = stage._fold(blk.conv3)
             c2 = blk.conv2
-            stage._linear(split, x, w1, b1, scale=s1, relu=True, out=Y1)
+            _linear(x, T.get(blk.conv1, "plain"), b1, scale=s1, relu=True, out=Y1)
+            early = False
             if seg.wino and _wino_ok(H, W, c2.in_channels, c2.out_channels):
-                u2, s2, b2 = stage._packed(c2, winograd=True)
-                ops.winograd_conv3x3(Y1, stage._split(u2) if split else u2, scale=s2, shift=b2, relu=True,
-                                     roi_major=True, in_roi_major=True, out=Y2)
+                u2 = T.get(c2, "wino")
+                early = (on_range_final is not None and bi == len(stage) - 1 and blk.shortcut is None
+                         and isinstance(u2, ops.SplitWeight) and isinstance(T.get(blk.conv3, "plain"), ops.SplitWeight))
+                ops.winograd_conv3x3(Y1, u2, scale=s2, shift=b2, relu=True, roi_major=True, in_roi_major=True, out=Y2,
+                                     range_check_scale=16.0 if early else None)
+                if early:
+                    on_range_final()
+                    on_range_final = None
             else:
                 # general grid (the whole-grid call): 3x3 as a GEMM over im2col patches -- K = 9 Cin columns in the order of
                 # the packed weight -- so that it runs in the stage's arithmetic; the patches are kept for the weight gradient
-                w2, s2, b2 = stage._packed(c2)
                 col = self.cols[(bi, si)] = ops.im2col3x3(Y1, H, W)
-                stage._linear(split, col, w2, b2, scale=s2, relu=True, out=Y2)
+                _linear(col, T.get(c2, "col"), b2, scale=s2, relu=True, out=Y2)
             if blk.shortcut is not None:
-                ws, ss, bs = stage._packed(blk.shortcut)
-                sc = stage._linear(split, x, ws, bs, scale=ss)
+                ss, bs = stage._fold(blk.shortcut)
+                sc = _linear(x, T.get(blk.shortcut, "plain"), bs, scale=ss)
             else:
                 sc = x
-            stage._linear(split, Y2, w3, b3, scale=s3, residual=sc, relu=True, out=OUT)
+            _linear(Y2, T.get(blk.conv3, "plain"), b3, scale=s3, residual=sc, relu=True, out=OUT)
             x = OUT
         return seg
 
@@ -148,6 +159,13 @@ class Res5Step:
         assert len(inputs) == len(pooled) == len(self.segments) and self._pending is None
         outs = Res5RowsFn.apply(self, tuple(bool(p) for p in pooled), len(inputs), *inputs, *_stage_weights(self.stage))
         return list(outs) if isinstance(outs, tuple) else [outs]
+
+
+def _linear(x, W, bias=None, **kw):
+    """One 1x1 convolution / im2col GEMM: split-operand f16 MFMA for an ops.SplitWeight, the f32 MFMA for a plain tensor."""
+    if isinstance(W, ops.SplitWeight):
+        return ops.linear_split(x, W, bias, **kw)
+    return ops.linear(x, W, bias, **kw)
 
 
 class Res5RowsFn(torch.autograd.Function):
@@ -241,6 +259,7 @@ class Res5RowsFn(torch.autograd.Function):
         # (the element-wise kernels at the head of the chain keep the separate reduction: their waves all finish together,
         # so every one of them would issue its atomic -- measured +110 us on the grid's relu_mask against a 10 us reduction)
         g = new(out_last.shape[1])
+        bound_of, bound_mul = [], []
         for seg, pool, go in zip(segs, ctx.pooled, grad_outs):
             if seg.rows == 0:
                 continue
@@ -250,23 +269,32 @@ class Res5RowsFn(torch.autograd.Function):
                 ops.spatial_mean_bwd(go, out_last[sl], seg.H * seg.W, out=g[sl])
             else:
                 ops.relu_mask(go, out_last[sl], out=g[sl])
+            bound_of.append(go)
+            bound_mul.append(1.0 / (seg.H * seg.W) if pool else 1.0)
         if rows == 0:
             return (None, None, None) + tuple(None for _ in range(nseg)) + tuple(
                 torch.zeros_like(w) if need else None for w, need in zip(_stage_weights(stage), need_w))
-        sg = ops.split_scale_from_amax(g) if sp else None
+        # the operand scale of g: its range is bounded by the SMALL tensors it was just derived from (a broadcast of the pooled
+        # gradient / 49, a masked copy of the grid's) -- one launch over those instead of a pass over g's 43 400 x 2 048 values
+        if not sp:
+            sg = None
+        elif len(bound_of) <= ops.AMAX_BOUND_MAX and all(t.numel() % 4 == 0 for t in bound_of):
+            sg = ops.amax_bound(bound_of, bound_mul)
+        else:
+            sg = ops.split_scale_from_amax(g)
 
-        def keyed(t, conv, tag):                       # remembered operand scale of a per-step weight packing (Res5Stage._split)
-            t._locov_key = (id(conv), tag)
-            return t
+        # (LOCOV_RES5_BWD_F32: a split forward with the backward on the f32 MFMA takes the fp32 operand set)
+        T = step.operands if step.operands.split == bool(sp) else stage.train_operands(bool(sp))
 
         def wgrad_1x1(g_, sg_, x_, s_):                # dW = s * g^T x
             if sp and g_.shape[1] % 4 == 0 and x_.shape[1] % 4 == 0 and g_.shape[0] > 0:
                 return ops.gemm_tn_split(g_, x_, s_, sg_, 16.0)
             return ops.gemm_tn(g_, x_, s_)
 
-        def dgrad_1x1(g_, sg_, wt, conv, amax_out=None, **kw):        # (g . wt^T [+ residual]) [mask]; amax_out: slot of the result
-            if sp and wt.shape[1] % 32 == 0 and wt.shape[0] % 4 == 0:
-                return ops.linear_split_ex(g_, stage._split(keyed(wt, conv, "t")), x_scale_dev=sg_, amax_out=amax_out, **kw), amax_out
+        def dgrad_1x1(g_, sg_, conv, tag="t", amax_out=None, **kw):   # (g . wt^T [+ residual]) [mask]; amax_out: slot of the result
+            wt = T.get(conv, tag)
+            if isinstance(wt, ops.SplitWeight):
+                return ops.linear_split_ex(g_, wt, x_scale_dev=sg_, amax_out=amax_out, **kw), amax_out
             y_ = ops.linear_ex(g_, wt, **kw)
             return y_, (ops.split_scale_from_amax(y_) if sp and amax_out is not None else None)
 
@@ -278,18 +306,13 @@ class Res5RowsFn(torch.autograd.Function):
             blk = stage[bi]
             has_sc, wi = blk.shortcut is not None, wi_of[bi]
             x, y1, y2, _ = saved[4 * bi: 4 * bi + 4]
-            w1, s1, _ = stage._packed(blk.conv1)
-            w3, s3, _ = stage._packed(blk.conv3)
+            s1, s2, s3 = stage._fold(blk.conv1)[0], stage._fold(blk.conv2)[0], stage._fold(blk.conv3)[0]
             c2 = blk.conv2
             # conv3: dW3 = s3 * g^T y2 ; g2 = (g . s3 W3) [y2 > 0]         -- all segments, one launch each
             if need_w[wi + 2]:
                 gw[wi + 2] = wgrad_1x1(g, sg, y2, s3).view_as(blk.conv3.weight)
-            g2, sg2 = dgrad_1x1(g, sg, stage._derived(blk.conv3, "wt", lambda: ops.weight_transpose_scale(w3, s3)), blk.conv3,
-                                amax_out=slot(g), mask=y2)
+            g2, sg2 = dgrad_1x1(g, sg, blk.conv3, amax_out=slot(g), mask=y2)
             # conv2 (3x3), per segment: dW2 = s2 * wgrad(y1, g2) ; g1 = conv3x3(g2, flip(s2 W2)) [y1 > 0]
-            _, s2, _ = stage._packed(c2)
-            w2 = c2.weight.detach()
-            wflip = stage._derived(c2, "flip", lambda: ops.conv3x3_weight_flip(w2, s2))     # [Cin, Cout, 3, 3]
             g1 = new(y1.shape[1])
             sg1 = slot(g2)
             # (on the f32 MFMA nothing fills sg1; in split arithmetic every segment's kernel folds its max into the ONE slot)
@@ -312,17 +335,15 @@ class Res5RowsFn(torch.autograd.Function):
                             part = ops.conv3x3_wgrad_unpack(ops.gemm_tn(g2[sl], colw), s2)
                     dw2 = part if dw2 is None else dw2.add_(part)
                 if _wino_ok(seg.H, seg.W, c2.out_channels, c2.in_channels) and not _NO_WINO_BWD:
-                    uflip = stage._derived(c2, "uflip", lambda: ops.winograd_pack_weight(wflip))
-                    if sp:
-                        ops.winograd_conv3x3_split_ex(g2[sl], stage._split(keyed(uflip, c2, "uflip")), mask=y1[sl], roi_major=True,
-                                                      amax_out=sg1, out=g1[sl])
+                    uflip = T.get(c2, "uflip")
+                    if isinstance(uflip, ops.SplitWeight):
+                        ops.winograd_conv3x3_split_ex(g2[sl], uflip, mask=y1[sl], roi_major=True, amax_out=sg1, out=g1[sl])
                     else:
                         ops.winograd_conv3x3_ex(g2[sl], uflip, mask=y1[sl], roi_major=True, out=g1[sl])
                 else:
                     # data gradient on the general grid: the same im2col GEMM with the flipped filter (im2col only copies and
                     # zero-pads: the patches have g2's range)
-                    dgrad_1x1(ops.im2col3x3(g2[sl], seg.H, seg.W), sg2,
-                              stage._derived(c2, "flip9", lambda: ops.pack_conv3x3_weight(wflip)), c2, amax_out=sg1, mask=y1[sl], out=g1[sl])
+                    dgrad_1x1(ops.im2col3x3(g2[sl], seg.H, seg.W), sg2, c2, "flip9", amax_out=sg1, mask=y1[sl], out=g1[sl])
             if need_w[wi + 1]:
                 gw[wi + 1] = dw2
             del g2
@@ -330,7 +351,7 @@ class Res5RowsFn(torch.autograd.Function):
             if need_w[wi]:
                 gw[wi] = wgrad_1x1(g1, sg1, x, s1).view_as(blk.conv1.weight)
             if has_sc:
-                ws, ss, _ = stage._packed(blk.shortcut)
+                ss = stage._fold(blk.shortcut)[0]
                 if need_w[wi + 3]:
                     gw[wi + 3] = wgrad_1x1(g, sg, x, ss).view_as(blk.shortcut.weight)
             first = bi == 0
@@ -341,13 +362,10 @@ class Res5RowsFn(torch.autograd.Function):
             # post-ReLU output of its predecessor, whose mask turns gx into that block's masked output gradient
             mask = None if first else x
             # (the slot of gx is only needed when a block below reads it: not for the stage input's gradient)
-            gx, sgx = dgrad_1x1(g1, sg1, stage._derived(blk.conv1, "wt", lambda: ops.weight_transpose_scale(w1, s1)), blk.conv1,
-                                amax_out=None if (first or has_sc) else slot(g1),
+            gx, sgx = dgrad_1x1(g1, sg1, blk.conv1, amax_out=None if (first or has_sc) else slot(g1),
                                 residual=None if has_sc else g, mask=None if has_sc else mask)
             if has_sc:
-                gx, sgx = dgrad_1x1(g, sg, stage._derived(blk.shortcut, "wt", lambda: ops.weight_transpose_scale(ws, ss)), blk.shortcut,
-                                    amax_out=None if first else slot(g),
-                                    residual=gx, mask=mask)
+                gx, sgx = dgrad_1x1(g, sg, blk.shortcut, amax_out=None if first else slot(g), residual=gx, mask=mask)
             del g1
             g, sg = gx, sgx
         gxs = [None] * nseg
@@ -379,6 +397,10 @@ def _guarded(stage, split, guard, device, build):
     with ops.range_guard(own):
         step = build(split)
     if own is not None and own.raised():
+        # (what left the range may be a remembered operand scale that stopped covering its weight -- the step's operands are
+        # packed under this guard: the scales are chosen afresh at the next packing)
+        stage._scales.clear()
+        stage._cache.clear()
         if guard[0] is not None:
             guard[0]()
         del step
@@ -395,7 +417,7 @@ def res5_rows(stage, x0: torch.Tensor, R: int, H: int, W: int, pooled: bool = Fa
     xd = ops._dev(x0.detach(), "x0")
 
     def build(sp):
-        step = Res5Step(stage, sp, xd.device, R * H * W)
+        step = Res5Step(stage, sp, xd.device, R * H * W, grid=not (H == 7 and W == 7), rois=H == 7 and W == 7)
         step.input_rows(R * H * W).copy_(xd)
         step.forward(R, H, W)
         return step
@@ -481,11 +503,12 @@ def grid_segment(step: "Res5Step", nhwc: torch.Tensor) -> torch.Tensor:
     return rows
 
 
-def roi_segment(step: "Res5Step", nhwc: torch.Tensor, rois: torch.Tensor, P: int, scale: float, sampling_ratio: int, aligned: bool) -> torch.Tensor:
+def roi_segment(step: "Res5Step", nhwc: torch.Tensor, rois: torch.Tensor, P: int, scale: float, sampling_ratio: int, aligned: bool,
+                on_range_final=None) -> torch.Tensor:
     """Enqueue the proposals' call of roi_emb_heads.py:343 (even-grid ROIAlign + the stage) as the next segment of `step`."""
     x0 = roi_align_even_rows(nhwc, rois, P, scale, sampling_ratio, aligned, step)
     o = (int(P) + 1) // 2
-    step.forward(rois.shape[0], o, o)
+    step.forward(rois.shape[0], o, o, on_range_final=on_range_final)
     return x0
 
 
@@ -509,7 +532,7 @@ def res5_grid(stage, nhwc: torch.Tensor, split: bool = True, overflow_check: boo
     made = {}
 
     def build(sp):
-        step = Res5Step(stage, sp, nhwc.device, N * OH * OW)
+        step = Res5Step(stage, sp, nhwc.device, N * OH * OW, rois=False)
         made["rows"] = grid_segment(step, nhwc)
         return step
     step = _guarded(stage, split, (on_overflow,) if overflow_check else None, nhwc.device, build)
@@ -525,7 +548,7 @@ def res5_rois(stage, nhwc: torch.Tensor, rois: torch.Tensor, P: int, scale: floa
     made = {}
 
     def build(sp):
-        step = Res5Step(stage, sp, nhwc.device, o * o * rois.shape[0])
+        step = Res5Step(stage, sp, nhwc.device, o * o * rois.shape[0], grid=False, rois=o == 7)
         made["x0"] = roi_segment(step, nhwc, rois, P, scale, sampling_ratio, aligned)
         return step
     step = _guarded(stage, split, (on_overflow,) if overflow_check else None, nhwc.device, build)

@@ -897,7 +897,7 @@ class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
         keep = None
         if tguard is not None:
             keep = self._close_train_guard(tguard, [visual_grid_features, box_features])
-        elif guard is not None:
+        elif guard is not None and guard.event is None:
             guard.snapshot()                                 # 4 bytes to pinned memory + an event, behind both Res5 calls
         del features
         predictions = self.box_predictor(box_features)                           # :345
@@ -943,7 +943,12 @@ class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
             # enqueued above (still in split arithmetic, on data that may again be out of range) is redone
             del step, rows
         rois = convert_boxes_to_pooler_format([x.proposal_boxes for x in proposals])
-        x0 = res5_train.roi_segment(step, nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned)
+        # (a guard the caller will WAIT for -- RES5_TRAIN_GUARD "sync" -- is snapshot in front of the stage's last convolution, the
+        # first point at which nothing can raise it any more: ~0.3 ms of queued GPU work more for the host to come back to)
+        held = ops.active_guard(nhwc.device)
+        early = held.snapshot if held is not None and not getattr(held, "deferred", False) else None
+        x0 = res5_train.roi_segment(step, nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned,
+                                    on_range_final=early)
         grid, box_features = step.outputs([rows, x0], [False, True])
         return res5_train.to_nchw(grid, N, (H + 1) // 2, (W + 1) // 2), box_features, proposals
 

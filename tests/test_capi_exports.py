@@ -32,7 +32,7 @@ def test_every_symbol_is_exported(lib):
     for name in _declared():
         assert hasattr(lib, name), name
     from locov_amd import _lib
-    assert lib.locov_abi_version() == _lib.ABI_VERSION == 5        # 2: range-guard word on the split entry points; 3: amax_out slots; 4: locov_zero_if_raised, exact fused workspaces, timing_read_ex; 5: locov_box_reg_loss, locov_grounding_ce_fwd / _bwd
+    assert lib.locov_abi_version() == _lib.ABI_VERSION == 6        # 2: range-guard word on the split entry points; 3: amax_out slots; 4: locov_zero_if_raised, exact fused workspaces, timing_read_ex; 5: locov_box_reg_loss, locov_grounding_ce_fwd / _bwd; 6: locov_res5_weight_prep, locov_gemm_segmean_supported
 
 
 def test_argument_errors_are_reported_without_a_gpu(lib):

@@ -316,13 +316,17 @@ def test_res5_rows_gradients_vs_float64(pkg, oracle, dims, R, split):
     assert max(errs.values()) < 1e-4, errs
 
 
-def test_a_stale_backward_weight_scale_never_reaches_the_parameters(pkg, oracle):
+@pytest.mark.parametrize("one_launch", [False, True], ids=["packed_in_the_backward", "one_launch_prep"])
+def test_a_stale_backward_weight_scale_never_reaches_the_parameters(pkg, oracle, one_launch, monkeypatch):
     """the split-arithmetic backward re-uses remembered power-of-two weight scales; when one stops covering its
-    (grown) weight the pack kernel raises the stage's "bwd" range-guard word and the GEMMs behind it produce inf / NaN.  Nothing
-    reads the word inside autograd -- so the pass itself must keep those values from an optimizer: every gradient it produced
-    is zero-filled on the device (locov_zero_if_raised), the word stays set for the next host read, and the step after that
-    (scales chosen afresh) is correct again."""
-    from locov_amd import res5_train
+    (grown) weight the pack kernel raises a range-guard word and the GEMMs behind it would produce inf / NaN.
+    Operands packed inside the backward (the steps that choose scales; LOCOV_RES5_PREP=0): the stage's "bwd" word -- nothing
+    reads it inside autograd, so the pass itself keeps those values from an optimizer: every gradient it produced is zero-filled
+    on the device (locov_zero_if_raised), the word stays set for the next host read, and the step after that (scales chosen
+    afresh) is correct again.  Operands from the step's ONE preparation launch (every other step): that launch runs under the
+    FORWARD's guard, whose reader repeats the step on the f32 MFMA -- correct gradients at once -- and drops the scales."""
+    from locov_amd import res5 as res5_mod, res5_train
+    monkeypatch.setattr(res5_mod, "_ONE_LAUNCH_PREP", one_launch)
     R, (in_ch, mid, out_ch) = 21, (128, 64, 256)
     res5, params = _stage(pkg, oracle, in_ch, mid, out_ch, seed=5)
     gen = torch.Generator().manual_seed(23)
@@ -351,6 +355,14 @@ def test_a_stale_backward_weight_scale_never_reaches_the_parameters(pkg, oracle)
             poisoned += 1
     assert poisoned >= 9
     gx, gw = step()
+    if one_launch:
+        # the f32 MFMA's results: two fp32 evaluations of one step (a ReLU tie may flip between them, see _float64_stage)
+        rel_l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+        assert rel_l2(gx, gx_ref) < 5e-3 and all(rel_l2(gw[k], gw_ref[k]) < 5e-3 for k in keys)
+        assert not res5.backward_guard_raised(x0.device) and not res5._scales
+        gx2, gw2 = step()
+        assert torch.equal(gx2, gx_ref) and all(torch.equal(gw2[k], gw_ref[k]) for k in keys)
+        return
     for name, g in [("x0", gx)] + list(gw.items()):
         assert bool(torch.isfinite(g).all()), name
         assert float(g.abs().max()) == 0.0, f"{name}: the skipped pass must leave zeros, not partial gradients"
@@ -486,6 +498,79 @@ def test_joint_step_equals_the_two_calls_and_float64(pkg, oracle, split):
     ((yg * Gg.double().cpu()).sum() + (yr.mean(dim=[2, 3]) * Gr.double().cpu()).sum()).backward()
     for k in keys:
         assert rel_err(wj[k], pd[k].grad) < 1e-4, k
+
+
+def test_one_launch_weight_prep_is_bit_identical(pkg):
+    """locov_res5_weight_prep: every split-layout operand of a training step from ONE launch, against the multi-launch chain it
+    replaces (transpose / flip / Winograd filter transform / im2col packing, then split_pack) -- the same bits, for Res5's shapes
+    and a small one, with and without the FrozenBN row scale."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(12)
+    for (N, C) in ((64, 128), (512, 2048), (2048, 512), (96, 32)):
+        w = (torch.randn(N, C, generator=g) * 0.05).cuda()
+        s = (torch.rand(N, generator=g) + 0.5).cuda()
+        plain, t = torch.empty(N, C, device="cuda"), torch.empty(C, N, device="cuda")
+        ops.res5_weight_prep([("plain", w, None, plain, 4096.0), ("t", w, s, t, 2048.0)])
+        assert torch.equal(plain.view(torch.int32), ops.split_pack(w, 4096.0).data.view(torch.int32))
+        assert torch.equal(t.view(torch.int32), ops.split_pack(ops.weight_transpose_scale(w, s), 2048.0).data.view(torch.int32))
+    for (N, C) in ((64, 64), (512, 512), (32, 96)):
+        w = (torch.randn(N, C, 3, 3, generator=g) * 0.05).cuda()
+        s = (torch.rand(N, generator=g) + 0.5).cuda()
+        outs = {k: torch.empty(ops.prep_shape(k, w), device="cuda") for k in ("wino", "col", "uflip", "flip9")}
+        ops.res5_weight_prep([("wino", w, None, outs["wino"], 1024.0), ("col", w, None, outs["col"], 4096.0),
+                              ("uflip", w, s, outs["uflip"], 512.0), ("flip9", w, s, outs["flip9"], 2048.0)])
+        wflip = ops.conv3x3_weight_flip(w, s)
+        want = {"wino": ops.split_pack(ops.winograd_pack_weight(w), 1024.0), "col": ops.split_pack(ops.pack_conv3x3_weight(w), 4096.0),
+                "uflip": ops.split_pack(ops.winograd_pack_weight(wflip), 512.0), "flip9": ops.split_pack(ops.pack_conv3x3_weight(wflip), 2048.0)}
+        for k in outs:
+            assert torch.equal(outs[k].view(torch.int32), want[k].data.view(torch.int32)), (N, C, k)
+    # the range guard: a scale that no longer covers the weight
+    ops.split_overflow_reset("cuda")
+    w = torch.full((32, 32), 3.0, device="cuda")
+    ops.res5_weight_prep([("plain", w, None, torch.empty(32, 32, device="cuda"), 2.0 ** 20)])
+    assert ops.split_overflow_raised("cuda")
+    ops.split_overflow_reset("cuda")
+
+
+def test_training_steps_with_prepared_operands_equal_the_first_step(pkg, oracle):
+    """The first training step of a stage chooses the operand scales (multi-launch chain, host reads); the following ones build
+    every operand in one launch (Res5Stage.train_operands).  Same weights, same input -> the same outputs and gradients, bit
+    for bit, and the one-launch path is really taken."""
+    from locov_amd import res5_train
+    R, (in_ch, mid, out_ch) = 21, (128, 64, 256)
+    res5, params = _stage(pkg, oracle, in_ch, mid, out_ch, seed=8)
+    gen = torch.Generator().manual_seed(29)
+    N, H, W = 2, 26, 43
+    feat = torch.randn(N, in_ch, H, W, generator=gen).cuda()
+    wh = torch.rand(R, 2, generator=gen) * 300 + 30
+    xy = torch.rand(R, 2, generator=gen) * 300
+    rois = torch.cat([torch.randint(0, N, (R, 1), generator=gen).float(), xy, xy + wh], dim=1).cuda()
+    named = dict(res5.named_parameters())
+    keys = _weight_keys(params)
+
+    def step():
+        res5.zero_grad()
+        f = feat.clone().requires_grad_(True)
+        nhwc = res5_train.to_nhwc(f)
+        st = res5_train.Res5Step(res5, True, f.device, N * 13 * 22 + 49 * R)
+        rows = res5_train.grid_segment(st, nhwc)
+        x0 = res5_train.roi_segment(st, nhwc, rois, 14, 1.0 / 16, 0, True)
+        grid, box = st.outputs([rows, x0], [False, True])
+        (grid.square().mean() + box.sum()).backward()
+        torch.cuda.synchronize()
+        return len(st.operands.ready), grid.detach().clone(), box.detach().clone(), f.grad.clone(), {k: named[k].grad.clone() for k in keys}
+
+    first = step()
+    assert first[0] == 0                                         # cold: scales chosen on the way
+    with torch.no_grad():
+        for k in keys:
+            named[k].add_(0.0)                                   # an "optimizer step": every weight's version moves
+    second = step()
+    assert second[0] == 2 * 7 + 4 * 3                            # warm: 26 operands from one launch
+    assert torch.equal(first[1], second[1]) and torch.equal(first[2], second[2])
+    assert rel_err(second[3], first[3]) < 1e-6                   # (the map's gradient: ROIAlign's backward adds with fp32 atomics)
+    for k in keys:
+        assert torch.equal(first[4][k], second[4][k]), k
 
 
 # ------------------------------------------------------------------------------------------------ the heads

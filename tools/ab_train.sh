@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
   for mode in deferred sync; do
     for cfg in lsm stt; do
-      echo -n "$mode $cfg: "; LOCOV_RES5_TRAIN_GUARD=$mode python3 tools/train_step_only.py --steps 12 --warmup 6 --train-config $cfg 2>/dev/null | tail -1
+      echo -n "$mode $cfg: "; LOCOV_RES5_TRAIN_GUARD=$mode python3 tools/train_step_only.py --steps 60 --warmup 8 --train-config $cfg 2>/dev/null | tail -1
     done
   done
 done
