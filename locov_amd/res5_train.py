@@ -38,6 +38,18 @@ __all__ = ["res5_rows", "res5_grid", "roi_align_even_rows", "to_nhwc", "Res5Rows
 
 import os
 
+_BWD_STREAMS = bool(int(os.environ.get("LOCOV_RES5_BWD_STREAMS", "1")))    # the grid segment's 3x3 gradients on a side stream (0: one stream)
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = (torch.device(device), torch.cuda.current_stream(device).cuda_stream)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 _NO_WINO_BWD = bool(int(os.environ.get("LOCOV_RES5_BWD_DIRECT", "0")))      # developer A/B: 3x3 gradients in the direct form
 _BWD_F32 = bool(int(os.environ.get("LOCOV_RES5_BWD_F32", "0")))              # developer A/B: backward GEMMs on the f32 MFMA
 
@@ -316,35 +328,55 @@ class Res5RowsFn(torch.autograd.Function):
             g1 = new(y1.shape[1])
             sg1 = slot(g2)
             # (on the f32 MFMA nothing fills sg1; in split arithmetic every segment's kernel folds its max into the ONE slot)
-            dw2 = None
-            for si, seg in enumerate(segs):
-                if seg.rows == 0:
-                    continue
+            # The segments' 3x3 gradients are independent of each other: with two of them (whole grid + proposals) the general-grid
+            # segment's chain -- im2col GEMMs of 4 200 rows that fill half the chip -- runs on a SIDE stream next to the proposals'
+            # Winograd-domain chain (between two joins with the main stream per block)
+            live = [(si, seg) for si, seg in enumerate(segs) if seg.rows > 0]
+            side = _side_stream(step.device) if _BWD_STREAMS and len(live) == 2 and sum(step.seg_wino(sg_, c2) for _, sg_ in live) == 1 else None
+            main = torch.cuda.current_stream(step.device)
+            parts = []
+            for si, seg in live:
                 sl = slice(seg.row0, seg.row0 + seg.rows)
                 wino = step.seg_wino(seg, c2)
-                if need_w[wi + 1]:
+                on_side = side is not None and not wino
+                if on_side:
+                    side.wait_stream(main)
+                    for t_ in (g1, g2, y1):
+                        t_.record_stream(side)
+                with torch.cuda.stream(side if on_side else main):
+                  part = None
+                  if need_w[wi + 1]:
                     if wino and c2.out_channels % 4 == 0 and not _NO_WINO_BWD:
                         part = ops.winograd_wgrad(y1[sl], g2[sl], s2, roi_major=True, split=sp)
                     else:
                         colw = step.cols.get((bi, si))
                         if colw is None:
                             colw = ops.im2col3x3(y1[sl], seg.H, seg.W)
+                        elif on_side:
+                            colw.record_stream(side)
                         if sp:
                             part = ops.conv3x3_wgrad_unpack(ops.gemm_tn_split(g2[sl], colw, None, sg2, 16.0), s2)
                         else:
                             part = ops.conv3x3_wgrad_unpack(ops.gemm_tn(g2[sl], colw), s2)
-                    dw2 = part if dw2 is None else dw2.add_(part)
-                if _wino_ok(seg.H, seg.W, c2.out_channels, c2.in_channels) and not _NO_WINO_BWD:
+                    if on_side:
+                        part.record_stream(main)
+                    parts.append(part)
+                  if _wino_ok(seg.H, seg.W, c2.out_channels, c2.in_channels) and not _NO_WINO_BWD:
                     uflip = T.get(c2, "uflip")
                     if isinstance(uflip, ops.SplitWeight):
                         ops.winograd_conv3x3_split_ex(g2[sl], uflip, mask=y1[sl], roi_major=True, amax_out=sg1, out=g1[sl])
                     else:
                         ops.winograd_conv3x3_ex(g2[sl], uflip, mask=y1[sl], roi_major=True, out=g1[sl])
-                else:
+                  else:
                     # data gradient on the general grid: the same im2col GEMM with the flipped filter (im2col only copies and
                     # zero-pads: the patches have g2's range)
                     dgrad_1x1(ops.im2col3x3(g2[sl], seg.H, seg.W), sg2, c2, "flip9", amax_out=sg1, mask=y1[sl], out=g1[sl])
+            if side is not None:
+                main.wait_stream(side)
             if need_w[wi + 1]:
+                dw2 = parts[0]
+                for part in parts[1:]:
+                    dw2 = dw2.add_(part)
                 gw[wi + 1] = dw2
             del g2
             # conv1 (+ shortcut): dW1 = s1 * g1^T x ; gx = (g1 . s1 W1 + shortcut path) [x > 0]
