@@ -51,7 +51,14 @@ __device__ __forceinline__ void store4_policy(float *p, const float4 &v)
     else if (AUX == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
     else *reinterpret_cast<float4 *>(p) = v;
 }
-__device__ __forceinline__ void store4_out(float *p, const float4 &v) { store4_policy<LOCOV_POOL_STORE_AUX>(p, v); }
+#ifndef LOCOV_POOL_NO_STORE
+#define LOCOV_POOL_NO_STORE 0                              // developer timing (tools/ab_pool_nostore.sh): 1 = the gather alone (wrong results)
+#endif
+__device__ __forceinline__ void store4_out(float *p, const float4 &v)
+{
+    if (LOCOV_POOL_NO_STORE && v.x != 1234.56789f) return;       // (a value nothing takes: the loads stay, the store goes)
+    store4_policy<LOCOV_POOL_STORE_AUX>(p, v);
+}
 __device__ __forceinline__ void store4(__bf16 *p, const float4 &v)
 {
     bf16x4 o;
