@@ -798,6 +798,12 @@ int launch_gemm_nt(const T *A, int64_t lda, const T *B, int64_t ldb, TOut *C, in
         return launch_cfg<T, TOut, 128, 128, 2, 4, 4>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, bt, s, what);
     if (forced_cfg() == 2)   // deep tile: BK = 64 (f32) / 128 (bf16), 136 KiB LDS, one workgroup per CU
         return launch_cfg<T, TOut, 128, 128, 2, 2, 1, 16>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, bt, s, what);
+    // a plain GEMM whose 128 x 128 tiles would leave most of the 256 CUs idle (the predictor's FCs of a training step: 800 sampled
+    // proposals x 768 / 1204 columns = 42-70 tiles, each walking K = 2048 alone): 64 x 64 tiles, four times the workgroups.  Every
+    // output element accumulates the same products in the same order in both configurations (same BK steps, same MFMA), so the
+    // choice does not change a bit of the result (tests/test_gpu_kernels.py).
+    if (forced_cfg() != 0 && cg.H == 0 && (bt.count <= 1) && ceil_div(M, 128) * ceil_div(N, 128) < 128 && M > 64)
+        return launch_cfg<T, TOut, 64, 64, 2, 2, 4>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, bt, s, what);
     return launch_cfg<T, TOut, 128, 128, 2, 2, 2>(A, lda, B, ldb, C, ldc, M, N, K, epi, cg, bt, s, what);
 }
 

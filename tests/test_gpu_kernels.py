@@ -202,6 +202,23 @@ def test_linear_fp32(ops, oracle, M, N, K):
     np.testing.assert_allclose(got, oracle.linear(x, w, None), atol=1e-4, rtol=1e-5)
 
 
+def test_linear_fp32_tile_choice_does_not_change_a_bit(ops):
+    """launch_gemm_nt picks 64 x 64 tiles for a GEMM whose 128 x 128 tiles would leave most CUs idle (the predictor's FCs on 800
+    sampled proposals) and 128 x 128 ones otherwise: a row's result must not depend on how many rows share its launch (image
+    sharding), so both configurations have to produce the same bits -- rows of a 6 000-row call against the same rows as 800-,
+    200- and 65-row calls, with bias, scale, residual and ReLU in the epilogue."""
+    g = torch.Generator().manual_seed(64)
+    for N, K in ((768, 2048), (1204, 768), (132, 96)):
+        x = torch.randn(6000, K, generator=g).cuda()
+        w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+        b, sc = torch.randn(N, generator=g).cuda(), (torch.rand(N, generator=g) + 0.5).cuda()
+        res = torch.randn(6000, N, generator=g).cuda()
+        full = ops.linear(x, w, b, scale=sc, residual=res, relu=True)
+        for m in (800, 200, 65):
+            part = ops.linear(x[:m], w, b, scale=sc, residual=res[:m], relu=True)
+            assert torch.equal(part, full[:m]), (N, K, m)
+
+
 def test_linear_epilogue(ops, oracle):
     rng = np.random.default_rng(5)
     M, N, K = 300, 96, 64
