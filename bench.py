@@ -76,7 +76,7 @@ def parse(argv=None):
                         "3 img x 512 sampled)")
     p.add_argument("--train-backends", default="hip,miopen", help="--mode train: which Res5 backends to time (profile runs: hip)")
     p.add_argument("--unfrozen-steps", type=int, default=-1,
-                   help="training steps timed WITHOUT gc.freeze() for train.*.ms_per_step_unfrozen_heap (-1: max(5 x steps/2, 50); 0: skip)")
+                   help="training steps timed WITHOUT gc.freeze() for train.*.ms_per_step_unfrozen_heap (-1: max(3 x steps, 50); 0: skip)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--skip-f32-reference", action="store_true",
                    help="do not also time the f32-MFMA form of the Res5 GEMMs (profile runs)")
@@ -329,7 +329,7 @@ class TrainWorkload:
         return n_sampled
 
 
-TRAFFIC_FILE = "r04_pmc_traffic.json"
+TRAFFIC_FILE = "r05_pmc_traffic.json"
 
 
 def recorded_traffic(args, kernel_key: str):
@@ -467,34 +467,45 @@ def main():
 
     wall = {}
     per_rank = {}                               # key -> every rank's ms per step of that bracket (rank order)
+    step_stats = {}                             # key -> median / min / max of the single steps of that bracket on this rank (ms)
 
     def timed(fn, steps, warmup, on_start=None, key=None, freeze=True, **kw):
         """K steps between barrier + synchronize on both sides; the time is hipEventElapsedTime between two events recorded
         on the launch stream inside that bracket, max over ranks; the host wall clock of the same bracket is
-        kept beside it (wall[key]).  The interpreter's full garbage-collection pass is taken HERE, after the warm-up and before the
-        bracket, and the objects alive at that point are frozen (gc.freeze): with a quarter of a million tracked objects a
+        kept beside it (wall[key]).  The interpreter's full garbage-collection pass is taken HERE, in front of the warm-up steps and
+        the bracket, and the objects alive at that point are frozen (gc.freeze): with a quarter of a million tracked objects a
         generation-2 pass takes ~90 ms, and one landing at a random step inside a 10-step training window moved
         `train.lsm.ms_per_step` between 14.5 and 24 ms from run to run (tools/ab_fused_losses.py).  Collections of the younger
         generations keep running inside the bracket, and the heap is un-frozen behind it (a frozen object is never collected:
         freezing per phase would pin every earlier workload's tensors).  freeze=False: nothing of that -- the interpreter's
         collector runs as it does under an unchanged train_ovnet.py (`train.*.ms_per_step_unfrozen_heap`)."""
         import gc
-        for _ in range(warmup):
-            fn()
+        # (the full pass first, the warm-up steps behind it: a full pass over an un-frozen heap keeps the host busy for ~0.1 s, long
+        # enough for the idle GPU to drop its clocks -- a short bracket right behind it, e.g. the ten 2.5 ms ROIAlign calls of
+        # S1_roi_align_roofline, then ran 10 % slower than the same kernel measures in steady state)
         if freeze:
             gc.collect()
             gc.freeze()
+        for _ in range(warmup):
+            fn()
         barrier()
         if on_start is not None:
             on_start()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps)] if key is not None else []
         t0 = time.perf_counter()
         e0.record()
-        for _ in range(steps):
+        for i in range(steps):
             fn(**kw)
+            if marks:
+                marks[i].record()                   # (one event per step: the distribution of the single steps, beside the bracket's mean)
         e1.record()
         barrier()
         dt_wall = time.perf_counter() - t0
+        if marks:
+            ends = [e0] + marks
+            single = sorted(ends[i].elapsed_time(ends[i + 1]) for i in range(steps))
+            step_stats[key] = {"median": single[len(single) // 2], "min": single[0], "max": single[-1]}
         if freeze:
             gc.unfreeze()
         dt = e0.elapsed_time(e1) * 1e-3
@@ -566,13 +577,14 @@ def main():
     def time_train(config, backend):
         tw = TrainWorkload(args, device, backend, world, data_seed=1992 + rank, config=config)
         n_sampled = tw.step()
-        steps = max(args.steps // 2, 3)
-        dtt = timed(tw.step, steps, max(args.warmup, 5), key="train_" + config)      # (the first steps still grow the allocator's pools and pick the operand scales)
+        steps = max(args.steps, 3)
+        dtt = timed(tw.step, steps, max(args.warmup, 8), key="train_" + config)      # (the first steps still grow the allocator's pools and pick the operand scales)
         # the same step with the interpreter's collector left alone (no collect / freeze in front of the bracket): what a trainer
         # that does not freeze its heap gets.  A full collection of torch's ~250 k tracked objects takes ~90 ms and comes every few
         # dozen steps, so this figure is taken over enough steps to hold its share of them
-        steps_u = max(5 * steps, 50) if args.unfrozen_steps < 0 else args.unfrozen_steps
+        steps_u = max(3 * steps, 50) if args.unfrozen_steps < 0 else args.unfrozen_steps
         out = {"sampled_proposals_per_s": n_sampled * world * steps / dtt, "ms_per_step": dtt / steps * 1e3,
+               "single_steps_ms": step_stats["train_" + config],
                "per_rank_ms_per_step": per_rank["train_" + config], "sampled_proposals_per_step_per_gpu": n_sampled}
         if steps_u > 0:
             import gc
@@ -728,11 +740,11 @@ def main():
             "unit": "proposals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt2 / args.steps * 1e3,
-            "per_rank_ms_per_step": per_rank["s2"],
+            "per_rank_ms_per_step": per_rank["s2"], "single_steps_ms": step_stats["s2"],
             "timing": {"how": "hipEventElapsedTime between two events on the launch stream around the K timed steps, inside the "
                               "barrier + synchronize bracket, max over ranks (per_rank_ms_per_step lists every rank's); the interpreter's full "
-                              "garbage-collection pass is taken between warm-up and bracket (gc.collect + gc.freeze, un-frozen "
-                              "behind it), not at a random step inside it; train.*.ms_per_step_unfrozen_heap is the same step "
+                              "garbage-collection pass is taken in front of the warm-up steps (gc.collect + gc.freeze, un-frozen "
+                              "behind the bracket), not at a random step inside it; train.*.ms_per_step_unfrozen_heap is the same step "
                               "with the collector left alone",
                        "wall_ms_per_step": wall["s2"] / args.steps * 1e3},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

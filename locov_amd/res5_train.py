@@ -99,7 +99,7 @@ class Res5Step:
         self.capacity = int(capacity_rows)
         self.segments: List[Segment] = []
         self.filled = 0
-        self._pending: Optional[int] = None
+        self._pending: List[int] = []
         new = lambda c: torch.empty((self.capacity, c), dtype=torch.float32, device=self.device)
         self.x0 = new(stage[0].conv1.in_channels)
         # per block: y1 (conv1 + FBN + ReLU), y2 (conv2 + FBN + ReLU), out (conv3 + FBN + shortcut + ReLU) -- the post-ReLU
@@ -108,11 +108,12 @@ class Res5Step:
         self.cols = {}                                # (block, segment index) -> im2col patches of y1 (general-grid segments)
 
     def input_rows(self, rows: int) -> torch.Tensor:
-        assert self._pending is None, "Res5Step: forward() the previous segment first"
-        if self.filled + rows > self.capacity:
-            raise ValueError(f"Res5Step: {self.filled} + {rows} rows exceed the capacity of {self.capacity}")
-        self._pending = rows
-        return self.x0[self.filled:self.filled + rows]
+        """Where the producer of the NEXT segment's stage input writes it (several segments may be reserved before one forward)."""
+        row0 = self.filled + sum(self._pending)
+        if row0 + rows > self.capacity:
+            raise ValueError(f"Res5Step: {row0} + {rows} rows exceed the capacity of {self.capacity}")
+        self._pending.append(rows)
+        return self.x0[row0:row0 + rows]
 
     @torch.no_grad()
     def forward(self, n: int, H: int, W: int, on_range_final=None) -> Segment:
@@ -120,47 +121,70 @@ class Res5Step:
         on_range_final: called (split arithmetic, 7x7 tiles) in front of the LAST convolution's launch, at which point every
         value a split GEMM of this segment will read has been range-checked (the last block's conv2 checks its own output) --
         a caller that waits for the range guard records its event there instead of behind the stage."""
-        assert self._pending == n * H * W, "Res5Step.forward: input_rows(n * H * W) first"
-        seg = Segment(self.filled, n, H, W)
-        self._pending = None
-        si = len(self.segments)
-        self.segments.append(seg)
-        self.filled += seg.rows
-        if seg.rows == 0:
-            return seg
+        return self.forward_segments([(n, H, W)], on_range_final)[0]
+
+    @torch.no_grad()
+    def forward_segments(self, geoms: Sequence[Tuple[int, int, int]], on_range_final=None) -> List[Segment]:
+        """The stage on ALL the segments whose inputs are waiting in input_rows (geoms: their (n, H, W) in reservation order) in
+        ONE pass: the 1x1 convolutions run over the joint rows (one launch each instead of one per segment -- the whole-grid
+        call's 4 200 rows alone fill half the chip), the 3x3 convolutions per segment.  The last block's last convolution stays
+        per segment, the general-grid segments first, so that on_range_final (see forward) can still be called in front of the
+        7x7 segment's."""
+        assert [g[0] * g[1] * g[2] for g in geoms] == self._pending, "Res5Step.forward: input_rows() of every segment first"
+        new = []
+        for (n, H, W) in geoms:
+            seg = Segment(self.filled, n, H, W)
+            new.append((len(self.segments), seg))
+            self.segments.append(seg)
+            self.filled += seg.rows
+        self._pending = []
+        live = [(si, seg) for si, seg in new if seg.rows > 0]
+        if not live:
+            return [seg for _, seg in new]
         stage, T = self.stage, self.operands
-        sl = slice(seg.row0, seg.row0 + seg.rows)
-        x = self.x0[sl]
+        lo, hi = live[0][1].row0, live[-1][1].row0 + live[-1][1].rows
+        joint = slice(lo, hi)
+        x = self.x0[joint]
+        nb = len(stage)
         for bi, blk in enumerate(stage):
-            Y1, Y2, OUT = (t[sl] for t in self.act[bi])
+            Y1, Y2, OUT = self.act[bi]
             s1, b1 = stage._fold(blk.conv1)
             s2, b2 = stage._fold(blk.conv2)
             s3, b3 = stage._fold(blk.conv3)
             c2 = blk.conv2
-            _linear(x, T.get(blk.conv1, "plain"), b1, scale=s1, relu=True, out=Y1)
-            early = False
-            if seg.wino and _wino_ok(H, W, c2.in_channels, c2.out_channels):
-                u2 = T.get(c2, "wino")
-                early = (on_range_final is not None and bi == len(stage) - 1 and blk.shortcut is None
-                         and isinstance(u2, ops.SplitWeight) and isinstance(T.get(blk.conv3, "plain"), ops.SplitWeight))
-                ops.winograd_conv3x3(Y1, u2, scale=s2, shift=b2, relu=True, roi_major=True, in_roi_major=True, out=Y2,
-                                     range_check_scale=16.0 if early else None)
-                if early:
-                    on_range_final()
-                    on_range_final = None
-            else:
-                # general grid (the whole-grid call): 3x3 as a GEMM over im2col patches -- K = 9 Cin columns in the order of
-                # the packed weight -- so that it runs in the stage's arithmetic; the patches are kept for the weight gradient
-                col = self.cols[(bi, si)] = ops.im2col3x3(Y1, H, W)
-                _linear(col, T.get(c2, "col"), b2, scale=s2, relu=True, out=Y2)
+            _linear(x, T.get(blk.conv1, "plain"), b1, scale=s1, relu=True, out=Y1[joint])
             if blk.shortcut is not None:
                 ss, bs = stage._fold(blk.shortcut)
                 sc = _linear(x, T.get(blk.shortcut, "plain"), bs, scale=ss)
             else:
                 sc = x
-            _linear(Y2, T.get(blk.conv3, "plain"), b3, scale=s3, residual=sc, relu=True, out=OUT)
-            x = OUT
-        return seg
+            last = bi == nb - 1
+            w3 = T.get(blk.conv3, "plain")
+            # (last block: 7x7 segments behind the general-grid ones, each followed by ITS last convolution)
+            order = sorted(live, key=lambda it: self.seg_wino(it[1], c2)) if last else live
+            for si, seg in order:
+                sl = slice(seg.row0, seg.row0 + seg.rows)
+                early = False
+                if self.seg_wino(seg, c2):
+                    u2 = T.get(c2, "wino")
+                    early = (on_range_final is not None and last and blk.shortcut is None
+                             and isinstance(u2, ops.SplitWeight) and isinstance(w3, ops.SplitWeight))
+                    ops.winograd_conv3x3(Y1[sl], u2, scale=s2, shift=b2, relu=True, roi_major=True, in_roi_major=True, out=Y2[sl],
+                                         range_check_scale=16.0 if early else None)
+                    if early:
+                        on_range_final()
+                        on_range_final = None
+                else:
+                    # general grid (the whole-grid call): 3x3 as a GEMM over im2col patches -- K = 9 Cin columns in the order of
+                    # the packed weight -- so that it runs in the stage's arithmetic; the patches are kept for the weight gradient
+                    col = self.cols[(bi, si)] = ops.im2col3x3(Y1[sl], seg.H, seg.W)
+                    _linear(col, T.get(c2, "col"), b2, scale=s2, relu=True, out=Y2[sl])
+                if last and len(live) > 1:
+                    _linear(Y2[sl], w3, b3, scale=s3, residual=sc[sl.start - lo:sl.stop - lo], relu=True, out=OUT[sl])
+            if not (last and len(live) > 1):
+                _linear(Y2[joint], w3, b3, scale=s3, residual=sc, relu=True, out=OUT[joint])
+            x = OUT[joint]
+        return [seg for _, seg in new]
 
     def seg_wino(self, seg: Segment, c2) -> bool:
         return seg.wino and _wino_ok(seg.H, seg.W, c2.in_channels, c2.out_channels)
@@ -168,7 +192,7 @@ class Res5Step:
     def outputs(self, inputs: Sequence[torch.Tensor], pooled: Sequence[bool]) -> List[torch.Tensor]:
         """The segments' stage outputs as differentiable tensors ([rows, Cout] pixel rows, or with pooled[i] the per-tile mean
         [n, Cout]) of `inputs` (the tensors the producers wrote into input_rows, carrying the graph) and the stage's weights."""
-        assert len(inputs) == len(pooled) == len(self.segments) and self._pending is None
+        assert len(inputs) == len(pooled) == len(self.segments) and not self._pending
         outs = Res5RowsFn.apply(self, tuple(bool(p) for p in pooled), len(inputs), *inputs, *_stage_weights(self.stage))
         return list(outs) if isinstance(outs, tuple) else [outs]
 
@@ -542,6 +566,19 @@ def roi_segment(step: "Res5Step", nhwc: torch.Tensor, rois: torch.Tensor, P: int
     o = (int(P) + 1) // 2
     step.forward(rois.shape[0], o, o, on_range_final=on_range_final)
     return x0
+
+
+def grid_and_roi_segments(step: "Res5Step", nhwc: torch.Tensor, rois: torch.Tensor, P: int, scale: float, sampling_ratio: int, aligned: bool,
+                          on_range_final=None):
+    """Both calls of roi_emb_heads.py:323 and :343 as the two segments of `step`, forwarded TOGETHER (their 1x1 convolutions
+    share launches): possible when the sampled proposals are known without a host wait.  Returns (grid input rows, proposals'
+    input rows) carrying the graph."""
+    N, H, W, _ = nhwc.shape
+    rows = grid_rows(nhwc, step)
+    x0 = roi_align_even_rows(nhwc, rois, P, scale, sampling_ratio, aligned, step)
+    o = (int(P) + 1) // 2
+    step.forward_segments([(N, (H + 1) // 2, (W + 1) // 2), (rois.shape[0], o, o)], on_range_final=on_range_final)
+    return rows, x0
 
 
 def grid_capacity(nhwc: torch.Tensor) -> int:

@@ -26,6 +26,8 @@ from ..structures import Boxes, Instances, ShapeSpec, pairwise_iou
 from .box_emb_head import build_box_predictor
 
 ROI_HEADS_REGISTRY = Registry("ROI_HEADS")
+_SPECULATE = os.environ.get("LOCOV_LABEL_SPECULATE", "1") != "0"      # developer A/B: 0 = the training forwards wait for the labelling
+_JOINT_FORWARD = os.environ.get("LOCOV_RES5_JOINT_FWD", "1") != "0"    # developer A/B: 0 = the two Res5 calls are forwarded one after the other
 
 __all__ = ["ROI_HEADS_REGISTRY", "build_roi_heads", "Matcher", "subsample_labels", "add_ground_truth_to_proposals",
            "ROIHeads", "SampleAllROIHeads", "EmbeddingRes5ROIHeads", "EmbeddingProposalsRes5ROIHeads"]
@@ -392,16 +394,17 @@ class SampleAllROIHeads(ROIHeads):
         else:
             host = flat
         return {"proposals": proposals, "targets": targets, "gt_index": gt_index, "labels": labels, "pos_order": pos_order,
-                "neg_order": neg_order, "rows_shape": tuple(rows.shape), "host": host, "event": event, "guards": guards}
+                "neg_order": neg_order, "rows": rows, "rows_shape": tuple(rows.shape), "host": host, "event": event, "guards": guards}
 
     @torch.no_grad()
-    def _label_finish(self, st) -> List[Instances]:
-        if "done" in st:
-            return st["done"]
-        proposals, targets = st["proposals"], st["targets"]
-        gt_index, labels, pos_order, neg_order = st["gt_index"], st["labels"], st["pos_order"], st["neg_order"]
+    def _label_host(self, st):
+        """The host half of the labelling's ONE read: wait for the event behind the labelling kernels, act on the deferred
+        range-guard words that travelled with it, raise the reference's two asserts, and return the per-image population sizes
+        [(foreground candidates, background candidates)].  Idempotent per labelling."""
+        if "avail" in st:
+            return st["avail"]
         if st["event"] is not None:
-            st["event"].synchronize()                       # the step's one host wait: for the labelling kernels only
+            st["event"].synchronize()                       # the step's host wait for the labelling kernels
         n_rows = st["rows_shape"][0] * st["rows_shape"][1]
         flat = st["host"].clone() if st["event"] is not None else st["host"].cpu()
         rows_h, guard_h = flat[:n_rows].view(st["rows_shape"]), flat[n_rows:]
@@ -410,21 +413,26 @@ class SampleAllROIHeads(ROIHeads):
             self._deferred_guards_tripped(tripped)
         assert not bool(rows_h[:, 2].any()), "Matcher: the match quality matrix has negative entries"
         assert not bool(rows_h[:, 3].any()), "Input boxes to Box2BoxTransform are not valid!"
-        avail = rows_h[:, :2].tolist()
-        # subsample_labels' counts per image, then ONE gather per field for the batch (the sampled rows of image i are a slice of
-        # the two image-major orders: its foreground draws sit at the head of its segment of pos_order, likewise neg_order)
-        n_r = [len(p) for p in proposals]
-        n_g = [len(t) for t in targets]
-        off_r = np.concatenate([[0], np.cumsum(n_r)]).tolist()
-        off_g = np.concatenate([[0], np.cumsum(n_g)]).tolist()
-        pieces, sizes, bg_counts = [], [], []
-        for i, (n_pos_avail, n_neg_avail) in enumerate(avail):
+        st["avail"] = rows_h[:, :2].tolist()
+        return st["avail"]
+
+    def _sample_counts(self, avail):
+        """subsample_labels' counts per image: [(num_pos, num_neg)]."""
+        out = []
+        for n_pos_avail, n_neg_avail in avail:
             num_pos = min(int(n_pos_avail), int(self.batch_size_per_image * self.positive_fraction))
-            num_neg = min(int(n_neg_avail), self.batch_size_per_image - num_pos)
-            pieces += [pos_order[off_r[i]:off_r[i] + num_pos], neg_order[off_r[i]:off_r[i] + num_neg]]
-            sizes.append(num_pos + num_neg)
-            bg_counts.append(num_neg)
-        picked = torch.cat(pieces, dim=0)                                       # rows of the concatenated proposals
+            out.append((num_pos, min(int(n_neg_avail), self.batch_size_per_image - num_pos)))
+        return out
+
+    @torch.no_grad()
+    def _label_build(self, st, picked: torch.Tensor, sizes: List[int]) -> List[Instances]:
+        """The sampled Instances of a batch from `picked` (rows of the concatenated candidates, image-major) and the per-image
+        sample counts: ONE gather per field for the batch (the sampled rows of image i are a slice of the two image-major orders:
+        its foreground draws sit at the head of its segment of pos_order, likewise neg_order)."""
+        proposals, targets = st["proposals"], st["targets"]
+        gt_index, labels = st["gt_index"], st["labels"]
+        n_g = [len(t) for t in targets]
+        off_g = np.concatenate([[0], np.cumsum(n_g)]).tolist()
         picked_labels = labels[picked]
         classes = torch.split(picked_labels, sizes)
         fg_flags = torch.split((picked_labels != self.num_classes).to(picked_labels.dtype), sizes)     # (one launch pair for the batch)
@@ -452,13 +460,71 @@ class SampleAllROIHeads(ROIHeads):
                         sampled[i].set(name, targets[i].get(name)[src])
         for out, flag in zip(sampled, fg_flags):
             out.set("fg_proposal", flag)
-        bg = np.asarray(bg_counts, dtype=np.float64)
-        tot = np.asarray(sizes, dtype=np.float64)
+        return sampled
+
+    def _label_log(self, counts) -> None:
+        bg = np.asarray([n for _, n in counts], dtype=np.float64)
+        fg = np.asarray([p for p, _ in counts], dtype=np.float64)
         storage = get_event_storage()
-        storage.put_scalar("roi_head/num_fg_samples", float(np.mean(tot - bg)))
+        storage.put_scalar("roi_head/num_fg_samples", float(np.mean(fg)))
         storage.put_scalar("roi_head/num_bg_samples", float(np.mean(bg)))
+
+    @torch.no_grad()
+    def _label_finish(self, st) -> List[Instances]:
+        if "done" in st:
+            return st["done"]
+        counts = self._sample_counts(self._label_host(st))
+        pos_order, neg_order = st["pos_order"], st["neg_order"]
+        off_r = np.concatenate([[0], np.cumsum([len(p) for p in st["proposals"]])]).tolist()
+        pieces = []
+        for i, (num_pos, num_neg) in enumerate(counts):
+            pieces += [pos_order[off_r[i]:off_r[i] + num_pos], neg_order[off_r[i]:off_r[i] + num_neg]]
+        picked = torch.cat(pieces, dim=0)                                       # rows of the concatenated proposals
+        sampled = self._label_build(st, picked, [p + n for p, n in counts])
+        self._label_log(counts)
         st["done"] = sampled                              # (a forward that is repeated on the f32 MFMA keeps its draw)
         return sampled
+
+    @torch.no_grad()
+    def _label_speculate(self, st) -> Optional[List[Instances]]:
+        """The sampled Instances WITHOUT the host read, on the assumption that every image fills its budget of
+        batch_size_per_image samples (it does whenever it has batch_size_per_image - num_pos background candidates: 1 000
+        proposals against a budget of 200 / 512): the per-image counts then only decide where the foreground draws end inside
+        each image's rows, which a device select can do.  The caller enqueues everything that depends on the sample (ROIAlign,
+        Res5, predictor, losses) and validates afterwards (_label_validate) at a point where it waits for the GPU anyway; a
+        batch that does not fill its budget is redone from _label_finish.  None when the assumption cannot hold or nothing
+        would be gained (host tensors, a foreign matcher, fewer candidates than the budget)."""
+        if "done" in st or st.get("event") is None or not _SPECULATE:
+            return None
+        B = int(self.batch_size_per_image)
+        n_r = [len(p) for p in st["proposals"]]
+        if B <= 0 or min(n_r) < B:
+            return None
+        rows, pos_order, neg_order = st["rows"], st["pos_order"], st["neg_order"]
+        dev = rows.device
+        # (the per-image row offsets and the slot numbers only depend on the batch's shape: built once -- a host-to-device copy of
+        # pageable memory per step would wait for everything the stream still holds)
+        key = (tuple(n_r), B, dev)
+        cached = self.__dict__.get("_spec_index")
+        if cached is None or cached[0] != key:
+            off = torch.tensor(np.concatenate([[0], np.cumsum(n_r)[:-1]]), dtype=torch.int64).to(dev)[:, None]   # [n_img, 1]
+            cached = self.__dict__["_spec_index"] = (key, off, torch.arange(B, dtype=torch.int64, device=dev)[None, :])
+        _, off, j = cached
+        num_pos = rows[:, 0].clamp(max=int(B * self.positive_fraction))[:, None]                                    # [n_img, 1]
+        last = pos_order.numel() - 1
+        picked = torch.where(j < num_pos, pos_order[(off + j).clamp(max=last)], neg_order[(off + (j - num_pos).clamp(min=0)).clamp(max=last)])
+        st["speculated"] = True
+        return self._label_build(st, picked.reshape(-1), [B] * len(n_r))
+
+    @torch.no_grad()
+    def _label_validate(self, st) -> bool:
+        """The host read behind a speculated sample: the reference's asserts, the deferred guard words, the logged counts -- and
+        whether every image did fill its budget (else the caller repeats the step from _label_finish)."""
+        counts = self._sample_counts(self._label_host(st))
+        ok = all(p + n == int(self.batch_size_per_image) for p, n in counts)
+        if ok:
+            self._label_log(counts)
+        return ok
 
 
 @ROI_HEADS_REGISTRY.register()
@@ -776,34 +842,47 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
     def forward(self, images, features, proposals, targets=None):
         """roi_emb_heads.py:247-282."""
         del images
-        if self.training:
-            assert targets
-            proposals = self.label_and_sample_proposals(proposals, targets)
-        del targets
         if not self.training:
+            del targets
             return self._detect(features, proposals)
-        proposal_boxes = [x.proposal_boxes for x in proposals]
+        assert targets
+        # (:250 labels first.  Here the labelling's kernels are enqueued and nothing waits for them: the sample is formed on the
+        # device on the assumption that every image fills its budget (_label_speculate), ROIAlign, Res5, the predictor and the
+        # losses are enqueued behind it, and the step's ONE host wait -- the labelling's integers and the range-guard word --
+        # comes at the end of this forward; a batch that did not fill its budget is repeated from the true counts)
+        pending = self._label_begin(proposals, targets)
+        del targets
         feats = [features[f] for f in self.in_features]
-        tguard = self._train_guard(feats)
-        guard = None if tguard is not None else self._deferred_guard(feats)
-        with ops.range_guard(tguard if tguard is not None else guard):
-            box_features = self._shared_roi_transform(feats, proposal_boxes, pooled=True)
-        keep = None
-        if tguard is not None:
-            keep = self._close_train_guard(tguard, [box_features])
-        elif guard is not None:
-            guard.snapshot()                                 # 4 bytes to pinned memory + an event, behind the Res5 launches
-        predictions = self.box_predictor(box_features)       # (:261-262: the mean is all the predictor sees)
-        losses = self._predictor_losses(predictions, proposals)
-        if keep is not None:
-            losses = {k: v * keep for k, v in losses.items()}
-        elif guard is not None and guard.raised():           # RES5_TRAIN_GUARD "sync": waits for the event only -- the predictor's
-            self._warn_overflow()                            # and the losses' launches stay queued behind it
-            del box_features, predictions, losses
-            box_features = self._with_res5_dtype("fp32", self._shared_roi_transform, feats, proposal_boxes, pooled=True)
-            predictions = self.box_predictor(box_features)
-            losses = self._predictor_losses(predictions, proposals)
         del features
+
+        def attempt(sampled):
+            props = sampled if sampled is not None else self._label_finish(pending)
+            proposal_boxes = [x.proposal_boxes for x in props]
+            tguard = self._train_guard(feats)
+            guard = None if tguard is not None else self._deferred_guard(feats)
+            with ops.range_guard(tguard if tguard is not None else guard):
+                box_features = self._shared_roi_transform(feats, proposal_boxes, pooled=True)
+            keep = None
+            if tguard is not None:
+                keep = self._close_train_guard(tguard, [box_features])
+            elif guard is not None and guard.event is None:
+                guard.snapshot()                             # 4 bytes to pinned memory + an event, behind the Res5 launches
+            predictions = self.box_predictor(box_features)   # (:261-262: the mean is all the predictor sees)
+            losses = self._predictor_losses(predictions, props)
+            if keep is not None:
+                losses = {k: v * keep for k, v in losses.items()}
+            return props, losses, guard
+
+        dtype_was = self.res5_dtype
+        sampled = self._label_speculate(pending)
+        proposals, losses, guard = attempt(sampled)
+        if sampled is not None and not (self._label_validate(pending) and self.res5_dtype == dtype_was):
+            del losses
+            proposals, losses, guard = attempt(None)
+        if guard is not None and guard.raised():             # RES5_TRAIN_GUARD "sync": waits for the event only -- the predictor's
+            self._warn_overflow()                            # and the losses' launches stay queued behind it
+            del losses
+            proposals, losses, _ = self._with_res5_dtype("fp32", attempt, proposals)
         return [], losses
 
     def _predictor_losses(self, predictions, proposals):
@@ -869,9 +948,12 @@ class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
         del images
         if targets is None:                              # keyed on targets, not self.training (:316)
             return self.inference_detection(features, proposals)
-        # (:318 labels first, :323 then runs Res5 on the whole grid: the two are independent, so the labelling's kernels are
-        # enqueued, the grid call is enqueued BEHIND them, and only then does the host wait for the labelling's few integers --
-        # with the grid call's work still queued the GPU does not drain while the host samples and launches the ROI path)
+        # :318 labels first, :323 then runs Res5 on the whole grid, :343 on the sampled proposals.  Here the labelling's kernels are
+        # enqueued and NOTHING waits for them: the sample is formed on the device on the assumption that every image fills its
+        # budget (_label_speculate), the grid call, ROIAlign, the proposals' call, the predictor and the losses are enqueued
+        # behind it, and the ONE host wait of the step comes at the end of this forward -- the labelling's few integers (asserts,
+        # counts, whether the budget was filled) and the range-guard word together.  A batch that did not fill its budget, or a
+        # forward that left the split arithmetic's range, is repeated (from the true counts / on the f32 MFMA).
         pending = self._label_begin(proposals, targets)
         del targets
         feats = [features[f] for f in self.in_features]
@@ -880,63 +962,77 @@ class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
         if joint:
             from .. import res5_train
             nhwc = res5_train.to_nhwc(feats[0])          # one channels-last copy (and one gradient transpose) for both calls
-        # ONE range guard for both Res5 calls of the step (the whole grid and the sampled proposals).  "sync": one look at the
-        # word, at the end of this forward; a step that left the split arithmetic's range repeats both calls on the f32 MFMA
-        # (the graph of the first attempt is simply dropped).  "deferred": acted on on the device, read with the next step's labelling
-        tguard = self._train_guard(feats)
-        guard = None if tguard is not None else self._deferred_guard(feats)
-        with ops.range_guard(tguard if tguard is not None else guard):
-            if joint:
-                visual_grid_features, box_features, proposals = self._res5_both(feats[0], nhwc, pending)
-            else:
-                visual_grid_features = self._res5_grid(feats[0], nhwc)               # :323
-                proposals = self._label_finish(pending)                              # :318 (the step's one host wait)
-                box_features = self._shared_roi_transform(feats, [x.proposal_boxes for x in proposals], pooled=True, nhwc=nhwc)   # :343-344
-        proposal_boxes = [x.proposal_boxes for x in proposals]
-        boxes_per_image = [len(x) for x in proposals]
-        keep = None
-        if tguard is not None:
-            keep = self._close_train_guard(tguard, [visual_grid_features, box_features])
-        elif guard is not None and guard.event is None:
-            guard.snapshot()                                 # 4 bytes to pinned memory + an event, behind both Res5 calls
         del features
-        predictions = self.box_predictor(box_features)                           # :345
-        losses = dict(self._predictor_losses(predictions, proposals))            # :347
-        if keep is not None:
-            losses = {k: v * keep for k, v in losses.items()}
-        elif guard is not None and guard.raised():
-            # RES5_TRAIN_GUARD "sync": the wait is for the event behind the two Res5 calls only -- the predictor's and the
-            # losses' launches are still queued when the host returns to the caller, so the GPU does not drain.  A step that
-            # left the split arithmetic's range repeats both calls and the tail on the f32 MFMA (the first graph is dropped)
+
+        def attempt(sampled):
+            """One forward of the step; sampled: the speculated sample, or None = wait for the labelling (behind the grid call)."""
+            # ONE range guard for both Res5 calls (the whole grid and the sampled proposals).  "sync": one look at the word, at the
+            # end; "deferred": acted on on the device, read with the next step's labelling
+            tguard = self._train_guard(feats)
+            guard = None if tguard is not None else self._deferred_guard(feats)
+            with ops.range_guard(tguard if tguard is not None else guard):
+                if joint:
+                    grid, box, props = self._res5_both(feats[0], nhwc, pending, sampled)
+                else:
+                    grid = self._res5_grid(feats[0], nhwc)                           # :323
+                    props = sampled if sampled is not None else self._label_finish(pending)      # :318
+                    box = self._shared_roi_transform(feats, [x.proposal_boxes for x in props], pooled=True, nhwc=nhwc)   # :343-344
+            keep = None
+            if tguard is not None:
+                keep = self._close_train_guard(tguard, [grid, box])
+            elif guard is not None and guard.event is None:
+                guard.snapshot()                             # 4 bytes to pinned memory + an event, behind both Res5 calls
+            predictions = self.box_predictor(box)                                    # :345
+            losses = dict(self._predictor_losses(predictions, props))                # :347
+            if keep is not None:
+                losses = {k: v * keep for k, v in losses.items()}
+            return grid, box, props, losses, guard
+
+        dtype_was = self.res5_dtype
+        sampled = self._label_speculate(pending)
+        visual_grid_features, box_features, proposals, losses, guard = attempt(sampled)
+        if sampled is not None and not (self._label_validate(pending) and self.res5_dtype == dtype_was):
+            # the budget was not filled (the true counts are known now), or the read found the PREVIOUS step's deferred guard set
+            # (RES5_DTYPE is "fp32" from here on): the forward enqueued above is dropped and repeated
+            del visual_grid_features, box_features, proposals, losses
+            visual_grid_features, box_features, proposals, losses, guard = attempt(None)
+        if guard is not None and guard.raised():
+            # RES5_TRAIN_GUARD "sync": the wait is for the event in front of the stage's last convolution -- the launches behind
+            # it (that convolution, the predictor, the losses) are still queued when the host returns to the caller, so the GPU
+            # does not drain.  A step that left the split arithmetic's range is repeated on the f32 MFMA (the first graph is dropped)
             self._warn_overflow()
-            del visual_grid_features, box_features, predictions, losses
-            if joint:
-                visual_grid_features, box_features, _ = self._with_res5_dtype("fp32", self._res5_both, feats[0], nhwc, pending)
-            else:
-                visual_grid_features = self._with_res5_dtype("fp32", self._res5_grid, feats[0], nhwc)
-                box_features = self._with_res5_dtype("fp32", self._shared_roi_transform, feats, proposal_boxes, pooled=True, nhwc=nhwc)
-            predictions = self.box_predictor(box_features)
-            losses = dict(self._predictor_losses(predictions, proposals))
-        box_features = list(box_features.split(boxes_per_image, dim=0))          # :346
+            del visual_grid_features, box_features, losses
+            visual_grid_features, box_features, proposals, losses, _ = self._with_res5_dtype("fp32", attempt, proposals)
+        box_features = list(box_features.split([len(x) for x in proposals], dim=0))      # :346
         return visual_grid_features, box_features, proposals, losses
 
-    def _res5_both(self, feature: torch.Tensor, nhwc: torch.Tensor, pending):
+    def _res5_both(self, feature: torch.Tensor, nhwc: torch.Tensor, pending, sampled=None):
         """roi_emb_heads.py:318-344 on the hand-written training path: self.res5(features) on the whole grid (:323) and
-        res5(pooler(...)).mean() on the sampled proposals (:343-344) as the two segments of ONE res5_train.Res5Step -- the grid
-        call is enqueued first, behind the labelling's kernels, and only then does the host wait for the labelling's few
-        integers (:318; with the grid call still queued the GPU does not drain while the host samples and launches the
-        proposals' path); the backward of both is one joint pass over their 4 200 + 39 200 rows.
+        res5(pooler(...)).mean() on the sampled proposals (:343-344) as the two segments of ONE res5_train.Res5Step; the
+        backward of both is one joint pass over their 4 200 + 39 200 rows.  Without a speculated sample the grid call is enqueued
+        first and the host then waits for the labelling's few integers (:318) with that call still queued.
         Returns (visual_grid_features [N, C5, H/2, W/2], pooled box_features [R, C5], sampled proposals)."""
         from .. import res5_train
+        N, H, W, _ = nhwc.shape
+        P = self.pooler.output_size[0]
+        o = (P + 1) // 2
+        held = ops.active_guard(nhwc.device)
+        early = held.snapshot if held is not None and not getattr(held, "deferred", False) else None
+        if sampled is not None and _JOINT_FORWARD:
+            # the sample is known without a host wait: both calls are forwarded together (their 1x1 convolutions share launches)
+            step = res5_train.Res5Step(self.res5, self.res5_dtype == "f16x2", nhwc.device,
+                                       res5_train.grid_capacity(nhwc) + o * o * N * self.batch_size_per_image)
+            rois = convert_boxes_to_pooler_format([x.proposal_boxes for x in sampled])
+            rows, x0 = res5_train.grid_and_roi_segments(step, nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio,
+                                                        self.pooler.aligned, on_range_final=early)
+            grid, box_features = step.outputs([rows, x0], [False, True])
+            return res5_train.to_nchw(grid, N, (H + 1) // 2, (W + 1) // 2), box_features, sampled
         while True:
             dtype = self.res5_dtype
-            N, H, W, _ = nhwc.shape
-            P = self.pooler.output_size[0]
-            o = (P + 1) // 2
             step = res5_train.Res5Step(self.res5, dtype == "f16x2", nhwc.device,
                                        res5_train.grid_capacity(nhwc) + o * o * N * self.batch_size_per_image)
             rows = res5_train.grid_segment(step, nhwc)
-            proposals = self._label_finish(pending)                              # :318 (the step's one host wait)
+            proposals = sampled if sampled is not None else self._label_finish(pending)      # :318
             if self.res5_dtype == dtype:
                 break
             # that read found the PREVIOUS step's deferred guard set: RES5_DTYPE is "fp32" from here on, and the grid call
@@ -945,8 +1041,6 @@ class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
         rois = convert_boxes_to_pooler_format([x.proposal_boxes for x in proposals])
         # (a guard the caller will WAIT for -- RES5_TRAIN_GUARD "sync" -- is snapshot in front of the stage's last convolution, the
         # first point at which nothing can raise it any more: ~0.3 ms of queued GPU work more for the host to come back to)
-        held = ops.active_guard(nhwc.device)
-        early = held.snapshot if held is not None and not getattr(held, "deferred", False) else None
         x0 = res5_train.roi_segment(step, nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio, self.pooler.aligned,
                                     on_range_final=early)
         grid, box_features = step.outputs([rows, x0], [False, True])

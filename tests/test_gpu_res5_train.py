@@ -420,8 +420,9 @@ def test_res5_grid_gradients_vs_float64(pkg, oracle, dims, N, H, W, split):
     assert max(errs.values()) < 1e-4, errs
 
 
+@pytest.mark.parametrize("together", [False, True], ids=["forwards_per_segment", "forwards_together"])
 @pytest.mark.parametrize("split", [False, True], ids=["f32mfma", "f16x2"])
-def test_joint_step_equals_the_two_calls_and_float64(pkg, oracle, split):
+def test_joint_step_equals_the_two_calls_and_float64(pkg, oracle, split, together):
     """res5_train.Res5Step: the whole-grid call (roi_emb_heads.py:323) and the proposals' call (:343-344) of one LSM step as the
     two segments of ONE autograd node -- every 1x1 data / weight gradient is one launch over the joint rows.  Outputs are
     bit-identical to the two separate calls (the forward IS per segment); every gradient (the map through both paths, every
@@ -457,8 +458,11 @@ def test_joint_step_equals_the_two_calls_and_float64(pkg, oracle, split):
         f = feat.cuda().requires_grad_(True)
         nhwc = res5_train.to_nhwc(f)
         step = res5_train.Res5Step(res5, split, f.device, N * OH * OW + 49 * R + 100)      # (spare capacity: fewer proposals than planned)
-        rows = res5_train.grid_segment(step, nhwc)
-        x0 = res5_train.roi_segment(step, nhwc, rois, 14, 1.0 / 16, 0, True)
+        if together:          # (the sample is known without a host wait: the 1x1 convolutions of both calls share launches)
+            rows, x0 = res5_train.grid_and_roi_segments(step, nhwc, rois, 14, 1.0 / 16, 0, True)
+        else:
+            rows = res5_train.grid_segment(step, nhwc)
+            x0 = res5_train.roi_segment(step, nhwc, rois, 14, 1.0 / 16, 0, True)
         grid_rows, box = step.outputs([rows, x0], [False, True])
         grid = res5_train.to_nchw(grid_rows, N, OH, OW)
         # the joint node's own active sets (grid rows first, then the proposals' 7x7 tiles), read before the backward frees them

@@ -251,6 +251,47 @@ def test_image_without_ground_truth_is_background_under_an_ignore_matcher_gpu(or
 
 
 @pytest.mark.gpu
+def test_speculated_sample_equals_the_host_driven_one(oracle):
+    """The training forwards form the sample on the device WITHOUT the host read, assuming every image fills its budget
+    (_label_speculate), and validate afterwards (_label_validate).  On the same draw the speculated Instances equal the
+    host-driven ones field for field; a batch that cannot fill its budget (too few background candidates) fails the validation,
+    and the forward then returns the reference's counts."""
+    from locov_amd.roi_heads.roi_emb_heads import get_event_storage
+    heads = _heads(True, 64, 0.25, "cuda")
+    rng = np.random.default_rng(33)
+    props, targets, _ = _batch(oracle, rng, "cuda", n_img=3, r=150, n_gt=6)
+    torch.manual_seed(4)
+    st_a = heads._label_begin(props, targets)
+    torch.manual_seed(4)
+    st_b = heads._label_begin(props, targets)
+    spec = heads._label_speculate(st_a)
+    assert spec is not None and heads._label_validate(st_a)
+    want = heads._label_finish(st_b)
+    assert len(spec) == len(want) == 3
+    for a, b in zip(spec, want):
+        assert len(a) == len(b) == 64 and set(a.get_fields()) == set(b.get_fields())
+        for k in b.get_fields():
+            va, vb = a.get(k), b.get(k)
+            assert torch.equal(va.tensor if hasattr(va, "tensor") else va, vb.tensor if hasattr(vb, "tensor") else vb), k
+    assert get_event_storage().scalars["roi_head/num_fg_samples"] > 0
+    # too few background candidates: every proposal sits on a ground-truth box, 25 % of a budget of 64 may be foreground
+    for p, t in zip(props, targets):
+        if len(t):
+            g = t.gt_boxes.tensor
+            p.proposal_boxes = Boxes(g[torch.arange(len(p)) % len(g)] + torch.rand(len(p), 4, device="cuda") * 2 - 1)
+    st_c = heads._label_begin(props, targets)
+    spec = heads._label_speculate(st_c)
+    assert spec is not None and not heads._label_validate(st_c)
+    true = heads._label_finish(st_c)
+    assert [len(x) for x in true] != [64, 64, 64] and all(len(x) <= 64 for x in true)
+    feat = torch.randn(3, 128, 50, 84, device="cuda", requires_grad=True)
+    _, box_feats, sampled, losses = heads(None, {"res4": feat}, props, targets)
+    assert [len(x) for x in sampled] == [b.shape[0] for b in box_feats] and all(len(x) <= 64 for x in sampled)
+    assert [len(x) for x in sampled][1] == 64                       # (the image without ground truth: background only, budget filled)
+    assert all(bool(torch.isfinite(v)) for v in losses.values())
+
+
+@pytest.mark.gpu
 def test_label_kernel_equals_the_torch_ops_on_the_device(oracle, monkeypatch):
     """locov_label_proposals (one launch per batch) against the torch-op form of SampleAllROIHeads._match_batch on the same draw:
     matched ground truth, labels, both sampling orders and the per-image rows -- equal element for element, incl. an image without
