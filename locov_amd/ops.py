@@ -918,15 +918,17 @@ def split_scale_from_amax(x: torch.Tensor, target_log2: float = 13.0) -> torch.T
     return out
 
 
-def amax_bound(tensors, muls) -> torch.Tensor:
+def amax_bound(tensors, muls, slot: Optional[torch.Tensor] = None) -> torch.Tensor:
     """A zeroed operand-scale slot (scale_slot) whose max word holds max_i (muls[i] * max |tensors[i]|): the range of a LARGE
-    tensor about to be derived from these small ones (a broadcast / masked copy), without a pass over it.  No host read."""
+    tensor about to be derived from these small ones (a broadcast / masked copy), without a pass over it.  No host read.
+    slot: fold into this existing (lazy) slot instead of a fresh one."""
     ts = [(_dev(t, "tensor"), float(m)) for t, m in zip(tensors, muls) if t is not None and t.numel() > 0]
     if not ts:
         raise ValueError("amax_bound: no tensor")
     if len(ts) > _lib.AMAX_BOUND_MAX or any(t.numel() % 4 for t, _ in ts):
         raise ValueError(f"amax_bound: at most {_lib.AMAX_BOUND_MAX} tensors, numel % 4 == 0")
-    slot = _scale_slot(ts[0][0], lazy=True)
+    if slot is None:
+        slot = _scale_slot(ts[0][0], lazy=True)
     ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t, _ in ts])
     ns = (ctypes.c_int64 * len(ts))(*[t.numel() for t, _ in ts])
     ms = (ctypes.c_float * len(ts))(*[m for _, m in ts])

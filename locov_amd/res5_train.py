@@ -391,10 +391,14 @@ class Res5RowsFn(torch.autograd.Function):
                         ops.winograd_conv3x3_split_ex(g2[sl], uflip, mask=y1[sl], roi_major=True, amax_out=sg1, out=g1[sl])
                     else:
                         ops.winograd_conv3x3_ex(g2[sl], uflip, mask=y1[sl], roi_major=True, out=g1[sl])
+                        if sp and g1[sl].numel() % 4 == 0:
+                            ops.amax_bound([g1[sl]], [1.0], slot=sg1)
                   else:
                     # data gradient on the general grid: the same im2col GEMM with the flipped filter (im2col only copies and
                     # zero-pads: the patches have g2's range)
-                    dgrad_1x1(ops.im2col3x3(g2[sl], seg.H, seg.W), sg2, c2, "flip9", amax_out=sg1, mask=y1[sl], out=g1[sl])
+                    _, got = dgrad_1x1(ops.im2col3x3(g2[sl], seg.H, seg.W), sg2, c2, "flip9", amax_out=sg1, mask=y1[sl], out=g1[sl])
+                    if sp and got is not sg1 and g1[sl].numel() % 4 == 0:
+                        ops.amax_bound([g1[sl]], [1.0], slot=sg1)      # (an operand the split GEMM cannot take: its f32 result's range by a pass)
             if side is not None:
                 main.wait_stream(side)
             if need_w[wi + 1]:
