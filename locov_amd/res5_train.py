@@ -27,16 +27,14 @@ the f32 MFMA while the forward uses split operands (developer A/B).
 """
 from __future__ import annotations
 
+import os
 from typing import List, NamedTuple, Optional, Sequence, Tuple
 
 import torch
 
 from . import ops
 
-__all__ = ["res5_rows", "res5_grid", "roi_align_even_rows", "to_nhwc", "Res5RowsFn", "Res5Step", "Segment"]
-
-
-import os
+__all__ = ["res5_rows", "res5_grid", "res5_rois", "roi_align_even_rows", "to_nhwc", "Res5RowsFn", "Res5Step", "Segment"]
 
 _BWD_STREAMS = bool(int(os.environ.get("LOCOV_RES5_BWD_STREAMS", "1")))    # the grid segment's 3x3 gradients on a side stream (0: one stream)
 _SIDE_STREAMS = {}
@@ -79,16 +77,18 @@ class Res5Step:
     """The Res5 work of ONE training step.  The LSM step calls the stage twice with the same weights -- on the whole res4
     grid (roi_emb_heads.py:323, 4 200 rows per GPU) and on the sampled proposals (:343-344, 39 200 rows) -- and every 1x1
     convolution's data gradient and weight gradient is a GEMM over pixel rows that does not care which call a row came
-    from.  So the rows of all calls of a step live in ONE matrix per activation (a `Segment` each), the forwards run per
-    segment as soon as their input exists (the grid call is enqueued while the host still waits for the labelling; the
-    proposals' rows follow), and the backward runs ONCE over the joint rows: one launch per 1x1 data gradient and weight
+    from.  So the rows of all calls of a step live in ONE matrix per activation (a `Segment` each); the forwards run per
+    segment as soon as their input exists, or -- when every input is there before anything has to wait for the host
+    (the ROI heads form the sample on the device) -- together, with the 1x1 convolutions sharing launches
+    (forward_segments); and the backward runs ONCE over the joint rows: one launch per 1x1 data gradient and weight
     gradient instead of one per call (the whole-grid launches are too small to fill the chip: 2.7 ms for a tenth of the
     rows), one weight gradient per parameter instead of two that autograd has to add.  Only the 3x3 convolutions differ per
     segment (Winograd domain for 7x7 tiles, im2col GEMM on a general grid).
 
-        step = Res5Step(stage, split, cin, device, capacity_rows)
+        step = Res5Step(stage, split, device, capacity_rows)
         x = step.input_rows(n * H * W)        # where the producer (ROIAlign, rows_stride2) writes the segment's stage input
         step.forward(n, H, W)                 # the stage on that segment (no autograd), outputs stay in the step's matrices
+        ...                                   # (or: input_rows() of several segments, then forward_segments([(n, H, W), ...]))
         outs = step.outputs([x_with_grad, ...], [pooled, ...])       # ONE autograd node for all segments
     """
 
