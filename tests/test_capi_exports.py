@@ -50,6 +50,32 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
     assert lib.locov_roi_align_fwd(None, 1, 4, 8, 8, None, 0, 7, 7, 0.0625, 0, 1, None, None) == 0
 
 
+def test_round5_entry_points_validate_their_arguments(lib):
+    """locov_res5_weight_prep / locov_amax_bound / locov_gemm_segmean_supported: argument errors before any HIP call."""
+    import ctypes
+    from locov_amd import _lib
+    assert lib.locov_res5_weight_prep(None, 0, None, None) == 0                       # no jobs: a no-op
+    assert lib.locov_res5_weight_prep(None, 3, None, None) == -1 and b"null job list" in lib.locov_last_error()
+    jobs = (_lib.WeightPrepJob * 1)()
+    assert lib.locov_res5_weight_prep(jobs, _lib.WEIGHT_PREP_MAX_JOBS + 1, None, None) == -1
+    jobs[0].w, jobs[0].out, jobs[0].scale, jobs[0].kind, jobs[0].N, jobs[0].K = 256, 512, 1.0, _lib.PREP_PLAIN, 64, 48
+    assert lib.locov_res5_weight_prep(jobs, 1, None, None) == -1 and b"K % 32" in lib.locov_last_error()
+    jobs[0].K, jobs[0].kind = 64, 17
+    assert lib.locov_res5_weight_prep(jobs, 1, None, None) == -1 and b"unknown kind" in lib.locov_last_error()
+    jobs[0].kind, jobs[0].out = _lib.PREP_TRANSPOSE, 513
+    assert lib.locov_res5_weight_prep(jobs, 1, None, None) == -1 and b"misaligned" in lib.locov_last_error()
+    assert lib.locov_amax_bound(None, None, None, 0, None, None) == 0
+    assert lib.locov_amax_bound(None, None, None, _lib.AMAX_BOUND_MAX + 1, None, None) == -1
+    ptrs, ns, ms = (ctypes.c_void_p * 1)(256), (ctypes.c_int64 * 1)(6), (ctypes.c_float * 1)(1.0)
+    assert lib.locov_amax_bound(ptrs, ns, ms, 1, ctypes.c_void_p(512), None) == -1 and b"numel % 4" in lib.locov_last_error()
+    # the mean-fused convolution: the 256x256 form takes any M (pre-split x, ROI-major residual, >= 1 024 tiles), the 128x128 form M * N * 4 < 2^32
+    big = _lib.GEMM_A_SPLIT | _lib.SEGMEAN_RES_ROI_MAJOR | _lib.EPI_RELU
+    assert lib.locov_gemm_segmean_supported(512, 49 * 12000, 2048, 512, 49, big) == 1
+    assert lib.locov_gemm_segmean_supported(512, 49 * 12000, 2048, 512, 49, _lib.EPI_RELU) == 0         # fp32 x: the 128x128 form, 4.8 GB
+    assert lib.locov_gemm_segmean_supported(512, 49 * 1000, 2048, 512, 49, _lib.EPI_RELU) == 1
+    assert lib.locov_gemm_segmean_supported(512, 49 * 1000, 2048, 512, 40, big) == 0                   # seg < 43
+
+
 def test_cpu_tensors_are_rejected_loudly():
     import torch
     from locov_amd import ops

@@ -577,6 +577,62 @@ def test_training_steps_with_prepared_operands_equal_the_first_step(pkg, oracle)
         assert torch.equal(first[4][k], second[4][k]), k
 
 
+def test_amax_bound_and_the_scale_it_implies(pkg):
+    """ops.amax_bound: max_i (mul_i * max |x_i|) of small tensors in a lazy operand-scale slot -- the scale a split GEMM derives from
+    it puts the bounded tensor's max in [2^12, 2^13); folding into an existing slot keeps the larger value."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(5)
+    a = (torch.randn(800, 2048, generator=g) * 3e-3).cuda()
+    b = (torch.randn(4200, 2048, generator=g) * 1e-5).cuda()
+    slot = ops.amax_bound([a, b], [1.0 / 49, 1.0])
+    torch.cuda.synchronize()
+    want = max(float(a.abs().max()) / 49, float(b.abs().max()))
+    got = float(slot.view(torch.int32)[2:3].view(torch.float32))
+    assert abs(got - want) <= 1e-6 * want and float(slot[0]) == 0.0            # a LAZY slot: consumers derive the scale
+    x = torch.randn(256, 64, generator=g).cuda()
+    x = x / x.abs().max() * want                                               # a tensor whose max is the bound
+    w = ops.split_pack((torch.randn(32, 64, generator=g) * 0.1).cuda())
+    ops.split_overflow_reset("cuda")
+    y = ops.linear_split_ex(x, w, x_scale_dev=slot)
+    assert not ops.split_overflow_raised("cuda")
+    assert rel_err(y, x.double() @ ops.split_unpack(w.data, w.scale).double().t()) < 3e-6
+    ops.amax_bound([a], [1e-3], slot=slot)                                     # a smaller contribution: unchanged
+    torch.cuda.synchronize()
+    assert float(slot.view(torch.int32)[2:3].view(torch.float32)) == got
+    ops.amax_bound([a], [10.0], slot=slot)                                     # a larger one: raised
+    torch.cuda.synchronize()
+    assert float(slot.view(torch.int32)[2:3].view(torch.float32)) > got
+    with pytest.raises(ValueError):
+        ops.amax_bound([torch.zeros(6, device="cuda")], [1.0])
+
+
+def test_res5_step_edge_cases(pkg, oracle):
+    """Res5Step: an empty segment (an image batch without sampled proposals) between two live ones, spare capacity, the capacity
+    check, and three segments forwarded together -- outputs equal the single-segment calls, gradients flow to every input."""
+    from locov_amd import res5_train
+    in_ch, mid, out_ch = 128, 64, 256
+    res5, params = _stage(pkg, oracle, in_ch, mid, out_ch, seed=19)
+    gen = torch.Generator().manual_seed(3)
+    xa = torch.randn(5 * 49, in_ch, generator=gen).cuda().requires_grad_(True)            # 5 proposals
+    xg = torch.randn(1 * 9 * 11, in_ch, generator=gen).cuda().requires_grad_(True)        # one 9 x 11 grid
+    xe = torch.zeros(0, in_ch, device="cuda", requires_grad=True)
+    want_a = res5_train.res5_rows(res5, xa.detach().clone().requires_grad_(True), 5, 7, 7, pooled=True, split=True)
+    want_g = res5_train.res5_rows(res5, xg.detach().clone().requires_grad_(True), 1, 9, 11, pooled=False, split=True)
+    step = res5_train.Res5Step(res5, True, xa.device, 5 * 49 + 99 + 500)
+    for x in (xa, xe, xg):
+        step.input_rows(x.shape[0]).copy_(x.detach())
+    with pytest.raises(ValueError, match="exceed the capacity"):
+        step.input_rows(10 ** 6)
+    segs = step.forward_segments([(5, 7, 7), (0, 7, 7), (1, 9, 11)])
+    assert [s.rows for s in segs] == [245, 0, 99] and step.filled == 344
+    out_a, out_e, out_g = step.outputs([xa, xe, xg], [True, True, False])
+    assert tuple(out_e.shape) == (0, out_ch) and torch.equal(out_a, want_a) and torch.equal(out_g, want_g)
+    (out_a.sum() + out_g.square().mean() + out_e.sum()).backward()
+    assert xa.grad is not None and float(xa.grad.abs().max()) > 0 and float(xg.grad.abs().max()) > 0
+    assert xe.grad is None or xe.grad.numel() == 0
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for k, p in res5.named_parameters() if k.endswith(".weight") and ".norm." not in k)
+
+
 # ------------------------------------------------------------------------------------------------ the heads
 def _train_heads(pkg, oracle, backend, dtype, small=True):
     from locov_amd.structures import ShapeSpec

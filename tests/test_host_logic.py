@@ -314,6 +314,8 @@ def _worker(rank, world, port, n_images, out_dir):
     assert [r[0] for r in allres] == images and [r[1] for r in allres] == [100 + i for i in images]
     t = max_over_ranks(1.0 + rank)                      # slowest rank defines the job time
     assert t == float(world)
+    from locov_amd.sharding import all_ranks
+    assert all_ranks(10.0 + rank) == [10.0 + r for r in range(world)]      # the bench line's per_rank_ms_per_step, rank order
     total = torch.tensor([sum(r[1] for r in local)], dtype=torch.float64)
     dist.all_reduce(total)                              # whole-job proposal count = sum over ranks
     assert total.item() == sum(100 + i for i in images)

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_train
 rm -rf $OUT && mkdir -p $OUT
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 tools/train_step_only.py --steps 6 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 tools/train_step_only.py --steps 6 --warmup 2 $TRAIN_ARGS > $OUT/bench.json 2> $OUT/bench.err
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/stats/**/*kernel_stats.csv", recursive=True)[0]
