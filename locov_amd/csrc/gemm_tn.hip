@@ -207,11 +207,13 @@ int launch_gemm_tn(const float *A, int64_t lda, int64_t sa, const float *B, int6
         return set_error(LOCOV_ERR_INVALID_ARG, "%s: row pitch too large for 32-bit chunk offsets", what);
     const int64_t wgs = ceil_div(N, TBM) * ceil_div(K, TBN) * splits * batch;
     if (wgs > 0x7fffffffLL) return set_error(LOCOV_ERR_INVALID_ARG, "%s: problem too large", what);
+    // (one chunk, dense unscaled output: the partial tiles are the result, see gemm_tn_split.hip)
+    const bool direct = splits == 1 && row_scale == nullptr && ldo == K && (batch == 1 || so == (int64_t)N * K);
     const int trec = timing_begin(s, 6, 2.0 * (double)M * N * K * batch);        // class 6: TN (wgrad) GEMM
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)wgs), dim3(TNT), 0, s, A, lda, B, ldb, ws, M, N, K, splits, m_chunk, sa, sb);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)wgs), dim3(TNT), 0, s, A, lda, B, ldb, direct ? out : ws, M, N, K, splits, m_chunk, sa, sb);
     timing_end(trec, s);
     int rc = check_launch(what);
-    if (rc) return rc;
+    if (rc || direct) return rc;
     return launch_tn_reduce(ws, N, K, splits, batch, row_scale, out, ldo, so, s, what);
 }
 

@@ -233,12 +233,15 @@ int launch_gemm_tn_split(const float *A, int64_t lda, int64_t sa, const float *B
         return set_error(LOCOV_ERR_INVALID_ARG, "%s: row pitch too large for 32-bit chunk offsets", what);
     const int64_t wgs = ceil_div(N, SBM) * ceil_div(K, SBN) * splits * batch;
     if (wgs > 0x7fffffffLL) return set_error(LOCOV_ERR_INVALID_ARG, "%s: problem too large", what);
+    // ONE chunk and a dense, unscaled output (the 121 transform-domain problems of the Winograd weight gradient: 1 936 tiles, M = the
+    // proposals): the "partial" tiles ARE the result -- written straight to `out`, no reduction pass (it was a 127 MB copy per launch)
+    const bool direct = splits == 1 && row_scale == nullptr && ldo == K && (batch == 1 || so == (int64_t)N * K);
     const int trec = timing_begin(s, 7, 2.0 * (double)M * N * K * batch);        // class 7: split-operand TN GEMM
-    hipLaunchKernelGGL(gemm_tn_split_kernel, dim3((unsigned)wgs), dim3(SNT), 0, s, A, lda, B, ldb, ws, M, N, K, splits, m_chunk, sa, sb,
+    hipLaunchKernelGGL(gemm_tn_split_kernel, dim3((unsigned)wgs), dim3(SNT), 0, s, A, lda, B, ldb, direct ? out : ws, M, N, K, splits, m_chunk, sa, sb,
                        a_scale_dev, b_scale, overflow);
     timing_end(trec, s);
     int rc = check_launch(what);
-    if (rc) return rc;
+    if (rc || direct) return rc;
     return launch_tn_reduce(ws, N, K, splits, batch, row_scale, out, ldo, so, s, what);
 }
 
