@@ -107,8 +107,11 @@ __global__ __launch_bounds__(kNhwcThreads, WINO == 64 ? 6 : WINO ? 4 : 1) void r
     const TIn *__restrict__ feat, int N, int H, int W, int C, const float *__restrict__ rois, int PH, int PW,
     float scale, int sampling_ratio, int aligned, int bin_stride, int OH, int OW, int pos_major,
     TOut *__restrict__ out, int64_t out_ld, int64_t feat_ld, const float *__restrict__ ch_scale,
-    const float *__restrict__ ch_shift, int relu, int nslices, int64_t R, float v_scale = 1.f, unsigned *overflow = nullptr)
+    const float *__restrict__ ch_shift, int relu, int nslices, int64_t R, float v_scale = 1.f, unsigned *overflow = nullptr,
+    int bwd_win_floats = 0)
 {
+    // BWD: dynamic LDS of bwd_win_floats floats -- the gradient window of a SMALL proposal (see the BWD branch below)
+    extern __shared__ float bwd_win[];
     constexpr int kWinoPitch = WINO + 4;
     __shared__ float wino_tile_s[WINO ? 49 * kWinoPitch : 1];
     float *const wino_tile = wino_tile_s;
@@ -229,8 +232,90 @@ __global__ __launch_bounds__(kNhwcThreads, WINO == 64 ? 6 : WINO ? 4 : 1) void r
     // (out_ld = elements between consecutive pixel rows, >= C: the rows may be a column block of a wider matrix)
     const int64_t bin_stride_out = pos_major ? R * out_ld : out_ld;
     TOut *obase = pos_major ? out + r * out_ld : out + (r * OH * (int64_t)OW) * out_ld;
-    // (bin, channel quad) of this thread: advanced incrementally, no integer division in the loop
     const int nbins = OH * OW;
+    if constexpr (BWD) {
+        // SMALL proposals (the 49 bins of a proposal below ~70 px land on at most 40 distinct map pixels, 4 pixels each): the bins'
+        // contributions are first added up per pixel in an LDS window over the proposal's pixel rectangle (ds_add_f32), then every
+        // touched (pixel, channel) costs ONE memory-side atomic instead of five to fifty on the same line.  The scatter of the LARGE
+        // proposals, which bounds the launch, gets the atomic units the small ones no longer occupy: LSM step's launch 0.77 -> 0.60 ms,
+        // STT's 1.44 -> 1.08 ms (the launcher's comment has the window-size sweep).
+        __shared__ int rect[4];                            // {y0 (byte offset), x0 (byte offset), rows, columns}
+        if (threadIdx.x == 0) {
+            int ya = 0x7fffffff, yb = -1, xa = 0x7fffffff, xb = -1;
+            if (separable && valid_b) {
+                for (int i = 0; i < OH; i++)
+                    if (ypix[i][1] > 0) {
+                        ya = min(ya, ypix[i][0]);
+                        yb = max(yb, ypix[i][0] + (ypix[i][1] - 1) * (int)ystride);
+                    }
+                for (int i = 0; i < OW; i++)
+                    if (xpix[i][1] > 0) {
+                        xa = min(xa, xpix[i][0]);
+                        xb = max(xb, xpix[i][0] + (xpix[i][1] - 1) * (int)xstride);
+                    }
+            }
+            const bool any = yb >= 0 && xb >= 0;
+            rect[0] = ya;
+            rect[1] = xa;
+            rect[2] = any ? (yb - ya) / (int)ystride + 1 : 0;
+            rect[3] = any ? (xb - xa) / (int)xstride + 1 : 0;
+        }
+        __syncthreads();
+        const int wh = rect[2], ww = rect[3];
+        if (wh > 0 && (int64_t)wh * ww * c4n <= bwd_win_floats) {
+            const int y0 = rect[0], x0 = rect[1];
+            const int nwin = wh * ww * c4n;
+            for (int i = threadIdx.x; i < nwin; i += kNhwcThreads) bwd_win[i] = 0.f;
+            __syncthreads();
+            // thread = (bin, channel), bins advanced incrementally (c4n channels per bin)
+            int bin = 0, oh = 0, ow = 0, cq = threadIdx.x;
+            while (true) {
+                while (cq >= c4n) {
+                    cq -= c4n;
+                    bin++;
+                    if (++ow == OW) {
+                        ow = 0;
+                        oh++;
+                    }
+                }
+                if (bin >= nbins) break;
+                const TOut *optr = obase + (int64_t)bin * bin_stride_out + ((q_lo << 2) + cq);
+                const float g = (float)optr[0] * inv_count;
+                const int nyp = ypix[oh][1], nxp = xpix[ow][1];
+                const float *yw = ypw + oh * (kSepGrid + 1), *xw = xpw + ow * (kSepGrid + 1);
+                const int py0 = (ypix[oh][0] - y0) / (int)ystride, px0 = (xpix[ow][0] - x0) / (int)xstride;
+                for (int ky = 0; ky < nyp; ky++)
+                    for (int kx = 0; kx < nxp; kx++) {
+                        const float w = yw[ky] * xw[kx];
+                        if (w != 0.f)      // (the native LDS float add, ds_add_f32: the generic atomicAdd compiles to a compare-and-swap loop)
+                            __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)&bwd_win[((py0 + ky) * ww + px0 + kx) * c4n + cq],
+                                                      w * g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
+                    }
+                cq += kNhwcThreads;
+            }
+            __syncthreads();
+            char *gimg = reinterpret_cast<char *>(const_cast<TIn *>(img));
+            // flush: consecutive threads = consecutive channels of one pixel (256-byte atomic instructions per wave)
+            int pix = 0, c = threadIdx.x;
+            while (true) {
+                while (c >= c4n) {
+                    c -= c4n;
+                    pix++;
+                }
+                if (pix >= wh * ww) break;
+                const float v = bwd_win[pix * c4n + c];
+                if (v != 0.f) {
+                    const int py = pix / ww, px = pix - py * ww;
+                    unsafeAtomicAdd(reinterpret_cast<float *>(gimg + (unsigned)y0 + (unsigned)py * ystride + (unsigned)x0 + (unsigned)px * xstride +
+                                                              (unsigned)((q_lo << 2) + c) * (unsigned)sizeof(TIn)),
+                                    v);
+                }
+                c += kNhwcThreads;
+            }
+            return;
+        }
+    }
+    // (bin, channel quad) of this thread: advanced incrementally, no integer division in the loop
     int bin = 0, oh = 0, ow = 0, cq = threadIdx.x;
     auto normalise = [&]() {
         while (cq >= c4n) {
@@ -1039,13 +1124,28 @@ int locov_roi_align_nhwc_bwd(const float *grad_rows, int64_t grad_ld, int N, int
     LOCOV_REQUIRE(R <= 0x7fffffffLL, "locov_roi_align_nhwc_bwd: R too large");
     LOCOV_REQUIRE(((uintptr_t)grad_rows | (uintptr_t)grad_feat) % 16 == 0, "locov_roi_align_nhwc_bwd: misaligned pointer");
     const int OH = (pooled_h + bin_stride - 1) / bin_stride, OW = (pooled_w + bin_stride - 1) / bin_stride;
-    const int nslices = nhwc_slices(C);
+    // (slices of at most 128 channels where C allows: the 20 KB gradient window then holds the 40 pixels of a proposal below ~70 px)
+    int nslices = nhwc_slices(C);
+    while (nslices < 8 && C / (2 * nslices) >= 128 && (C >> 2) % (2 * nslices) == 0) nslices *= 2;
     LOCOV_REQUIRE(R * nslices <= 0x7fffffffLL, "locov_roi_align_nhwc_bwd: R too large");
     dim3 grid((unsigned)(R * nslices));
-    hipLaunchKernelGGL((roi_align_nhwc_kernel<float, float, true>), grid, dim3(kNhwcThreads), 0, as_stream(stream),
+    // Window size: measured on the LSM step's launch (800 proposals, 4 images, 1024 channels) / the STT step's (1536 proposals, 3 images),
+    // tools/ab_pool_bwd_sizes.py: none 0.771 / 1.437 ms, 16 KB 0.615 / 1.111, 20 KB 0.603 / 1.084, 24 KB 0.608 / 1.101, 32 KB 0.667 / 1.234,
+    // 64 KB 0.835 -- a larger window takes more proposals but fewer workgroups per CU, and the window path needs the occupancy its two
+    // barriers cost.  (Proposals of one small size class ALONE run slower through the window, 0.55 -> 0.71 ms: what it buys is room at the
+    // memory-side atomic units for the large proposals' scatter, which bounds the launch.)
+    // developer A/B: LOCOV_POOL_BWD_WINDOW=<bytes>, 0 -> every proposal scatters straight to memory
+    const char *we = getenv("LOCOV_POOL_BWD_WINDOW");          // (read per launch: tests flip it)
+    const int win_bytes = we ? atoi(we) : 20480;
+    static const bool attr_ok = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&roi_align_nhwc_kernel<float, float, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess;
+    }();
+    const int wb = attr_ok && win_bytes > 0 ? (win_bytes < 65536 ? win_bytes : 65536) : 0;
+    hipLaunchKernelGGL((roi_align_nhwc_kernel<float, float, true>), grid, dim3(kNhwcThreads), (size_t)wb, as_stream(stream),
                        (const float *)grad_feat, N, H, W, C, rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, bin_stride,
                        OH, OW, pos_major, const_cast<float *>(grad_rows), grad_ld, (int64_t)C, (const float *)nullptr,
-                       (const float *)nullptr, 0, nslices, R);
+                       (const float *)nullptr, 0, nslices, R, 1.f, static_cast<unsigned *>(nullptr), wb / 4);
     return check_launch("locov_roi_align_nhwc_bwd");
 }
 

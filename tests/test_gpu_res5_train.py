@@ -137,6 +137,37 @@ def test_roi_align_even_backward_is_the_adjoint(pkg, oracle):
             assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1.0)
 
 
+def test_roi_align_even_backward_window_equals_the_direct_scatter(pkg, oracle, monkeypatch):
+    """The backward of the even-grid ROIAlign adds a SMALL proposal's bins up per pixel in an LDS window before it touches memory
+    (one atomic per touched pixel and channel instead of one per bin and pixel); larger proposals scatter directly.  At the LSM
+    step's shape (800 proposals over 4 images, 1024 channels, the bench's size mix incl. boxes that leave the image and empty ones)
+    both forms give the same map gradient up to the order of the fp32 additions, and a float64 evaluation of the adjoint agrees."""
+    ops = pkg.ops
+    rng = np.random.default_rng(18)
+    N, C, H, W, per = 4, 1024, 50, 84, 200
+    boxes = [oracle.synth_boxes(rng, per) for _ in range(N)]
+    boxes[0][0] = [-40.0, -30.0, 20.0, 25.0]
+    boxes[1][1] = [5.0, 5.0, 5.0, 5.0]
+    boxes[2][:40] = np.concatenate([rng.uniform(0, 1200, (40, 2)), rng.uniform(0, 1200, (40, 2))], 1).astype(np.float32)
+    boxes[2][:40, 2:] = boxes[2][:40, :2] + rng.uniform(8, 60, (40, 2)).astype(np.float32)      # many tiny proposals
+    rois = dev(oracle.boxes_to_pooler_format(boxes))
+    G = torch.randn(49 * N * per, C, generator=torch.Generator().manual_seed(2)).cuda()
+    out = {}
+    for win in ("0", "20480", "65536"):
+        monkeypatch.setenv("LOCOV_POOL_BWD_WINDOW", win)
+        out[win] = ops.roi_align_nhwc_bwd(G, (N, H, W, C), rois, 14, 1 / 16, 0, True, bin_stride=2)
+    monkeypatch.delenv("LOCOV_POOL_BWD_WINDOW")
+    scale = float(out["0"].abs().max())
+    assert scale > 0
+    for win in ("20480", "65536"):
+        assert float((out[win] - out["0"]).abs().max()) <= 2e-6 * scale, win
+    # the adjoint identity in float64 on a channel slice: <ROIAlign_even(F), G> == <F, ROIAlign_even^T(G)>
+    F = torch.randn(N, H, W, C, generator=torch.Generator().manual_seed(3)).cuda()
+    y = ops.roi_align_nhwc(F, rois, 14, 1 / 16, 0, True, bin_stride=2).view(-1, C)
+    lhs, rhs = float((y.double() * G.double()).sum()), float((F.double() * out["20480"].double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * float(y.double().norm() * G.double().norm())
+
+
 @pytest.mark.parametrize("R,Cin,N", [(5, 32, 48), (70, 64, 64), (300, 128, 96)])
 def test_winograd_gradients_vs_float64(pkg, R, Cin, N):
     """3x3 convolution of 7x7 tiles: weight gradient (Winograd-domain TN GEMMs) and masked data gradient (Winograd
