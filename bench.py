@@ -87,6 +87,9 @@ def parse(argv=None):
     # developer/test knobs: rehearse the multi-process flow on a box with fewer GPUs than ranks
     p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl")
     p.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (single-GPU test boxes; implies --dist-backend gloo)")
+    p.add_argument("--force-dist", action="store_true",
+                   help="initialise the process group and wrap the training step in DistributedDataParallel even with ONE rank: the RCCL "
+                        "rehearsal a 1-GPU box allows (communicator, DDP's bucketed all-reduce hooks, the timing collectives)")
     args = p.parse_args(argv)
     if args.share_gpu and args.dist_backend == "nccl":
         # RCCL cannot place two ranks on one device (the attempt hangs for minutes before it fails): single-GPU test boxes use gloo
@@ -95,13 +98,17 @@ def parse(argv=None):
     return args
 
 
-def launch_ranks(args) -> int:
-    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `torch.distributed.run` (nothing in this
-    process has touched the GPU yet, and it never will), relay rank 0's JSON line and the child's exit code."""
+def free_port() -> int:
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+        return s.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `torch.distributed.run` (nothing in this
+    process has touched the GPU yet, and it never will), relay rank 0's JSON line and the child's exit code."""
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
@@ -247,7 +254,7 @@ class TrainWorkload:
 
             self.module = STTStep()
             self.run = self.module
-            if world > 1:
+            if world > 1 or args.force_dist:
                 from torch.nn.parallel import DistributedDataParallel as DDP
                 self.run = DDP(self.module, device_ids=None if args.share_gpu else [device.index], broadcast_buffers=False)
             params = [p for p in self.module.parameters() if p.requires_grad]
@@ -282,7 +289,7 @@ class TrainWorkload:
 
         self.module = LSMStep()
         self.run = self.module
-        if world > 1:       # the gradient exchange of the path: DDP's bucketed all-reduce (RCCL over xGMI), overlapped with backward
+        if world > 1 or args.force_dist:       # the gradient exchange of the path: DDP's bucketed all-reduce (RCCL over xGMI), overlapped with backward
             from torch.nn.parallel import DistributedDataParallel as DDP
             self.run = DDP(self.module, device_ids=None if args.share_gpu else [device.index], broadcast_buffers=False)
         params = [p for p in self.module.parameters() if p.requires_grad]
@@ -444,7 +451,13 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     rccl_ranks = 1
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
+        if world == 1:                        # --force-dist without a launcher: a one-rank rendezvous on the loopback
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":       # RCCL over xGMI
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -461,7 +474,7 @@ def main():
     wl = Workload(args, device)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -609,7 +622,7 @@ def main():
                              what=f"3 img/GPU x {args.proposals} proposals -> 512 sampled/img, 48-class bank, emb_pred frozen; "
                                   "EmbeddingRes5ROIHeads.forward(targets) + backward + SGD step"),
                  "backend": "hip", "res5_dtype": args.res5_dtype,
-                 "gradient_exchange": (f"DistributedDataParallel over {world} ranks ({args.dist_backend})" if world > 1 else "none (1 rank)")}
+                 "gradient_exchange": (f"DistributedDataParallel over {world} ranks ({args.dist_backend})" if dist_on else "none (1 rank)")}
     if args.mode == "train":
         train = {}
         for backend in args.train_backends.split(","):
@@ -765,6 +778,7 @@ def main():
                        "res5_dtype": args.res5_dtype,
                        "parallelism": f"image-sharded x{world}, no data-path collective"},
             "rccl_ranks": rccl_ranks,
+            "process_group": f"{args.dist_backend} x{world}" if dist_on else None,
             "scopes": {"S2_full_head_proposals_per_s": props_per_step * args.steps / dt2,
                        "S1_handwritten_kernels_proposals_per_s": None if args.skip_s1 else props_per_step * args.steps / dt1,
                        "S1_ms_per_step": None if args.skip_s1 else dt1 / args.steps * 1e3, "S1_roi_align_roofline": s1_roi, **variants},
@@ -779,7 +793,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -587,11 +587,23 @@ class TrainOperands:
             if grid:
                 wanted += [(c2, "col"), (c2, "flip9")]
         recs = [stage._scales.get(self.scale_key(conv, tag)) for conv, tag in wanted]
-        ok = _ONE_LAUNCH_PREP and all(r is not None and r[1] < self.REFRESH for r in recs) and all(
+        fresh = [r is not None and r[1] < self.REFRESH for r in recs]
+        ok = _ONE_LAUNCH_PREP and any(fresh) and all(
             conv.weight.is_cuda and conv.weight.dtype == torch.float32 and conv.weight.is_contiguous()
             and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and conv.groups == 1 for conv, _ in wanted)
         if not ok:
             return
+        if not all(fresh):
+            # SOME scales are remembered: the others belong to operands the previous steps never asked for (block 0's data
+            # gradient when the stage input needs none: a frozen backbone) -- on the on-demand chain they would stay unknown for
+            # good and keep every step off the one launch.  They are built here by that chain (one host read each, once per
+            # REFRESH steps).
+            for (conv, tag), f in zip(wanted, fresh):
+                if not f:
+                    self.get(conv, tag)
+            recs = [stage._scales.get(self.scale_key(conv, tag)) for conv, tag in wanted]
+            if not all(r is not None and r[1] < self.REFRESH for r in recs):
+                return
         bufs = stage.__dict__.setdefault("_prep_bufs", {})
         jobs = []
         for (conv, tag), rec in zip(wanted, recs):

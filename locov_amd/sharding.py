@@ -40,7 +40,7 @@ def world_info() -> Tuple[int, int]:
 def max_over_ranks(seconds: float, device=None) -> float:
     """Wall time of the slowest rank (the bench contract times the whole job by it)."""
     rank, world = world_info()
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(seconds)
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -51,7 +51,7 @@ def all_ranks(seconds: float, device=None) -> List[float]:
     """Every rank's value, in rank order (the bench line lists them next to the maximum so that a scaling run explains its
     own efficiency: one slow rank vs all ranks slower)."""
     rank, world = world_info()
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):      # (an initialised one-rank group still runs the collective: bench.py --force-dist)
         return [float(seconds)]
     t = torch.zeros(world, dtype=torch.float64, device=device)
     t[rank] = seconds

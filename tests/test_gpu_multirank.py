@@ -102,3 +102,45 @@ def test_bench_rehearses_eight_ranks():
     assert "8 ranks" in train["gradient_exchange"]
     for cfg in ("lsm", "stt"):
         assert len(train[cfg]["per_rank_ms_per_step"]) == 8 and train[cfg]["ms_per_step"] > 0
+
+
+def test_rccl_one_rank_rehearsal():
+    """RCCL itself on this code (the two-rank tests above share one GPU and therefore run gloo): `bench.py --force-dist` creates the
+    RCCL communicator with ONE rank, wraps both training steps in DistributedDataParallel -- its bucketed all-reduce hooks fire
+    inside the joint Res5 backward with its side stream, on the RCCL stream -- and takes the timing collectives on device tensors."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--steps", "2",
+           "--warmup", "1", "--images", "1", "--proposals", "200", "--classes", "80", "--train-images", "1", "--train-samples", "32",
+           "--unfrozen-steps", "0", "--no-cpu-baseline", "--skip-s1", "--skip-f32-reference", "--skip-variants"]
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["process_group"] == "nccl x1" and out["value"] > 0
+    assert "DistributedDataParallel over 1 ranks (nccl)" in out["train"]["gradient_exchange"]
+    for cfg in ("lsm", "stt"):
+        assert out["train"][cfg]["ms_per_step"] > 0
+
+
+def test_rccl_one_rank_ddp_gradients_equal_the_plain_step(tmp_path):
+    """The gradients DistributedDataParallel leaves behind an RCCL all-reduce over one rank are the plain step's."""
+    worker = os.path.join(ROOT, "tests", "ddp_worker.py")
+    env = _env()
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", LOCOV_DDP_WORKER_BACKEND="nccl")
+    r = subprocess.run([sys.executable, worker, str(tmp_path)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    sys.path.insert(0, ROOT)
+    import bench
+    from tests import ddp_worker
+    args = bench.parse(ddp_worker.ARGS)
+    tw = bench.TrainWorkload(args, torch.device("cuda", 0), "hip", world=1, data_seed=100)
+    torch.manual_seed(500)
+    loss, n = tw.forward_backward()
+    assert n == got["n_sampled"] and abs(float(loss) - got["loss"]) <= 1e-5 * max(1.0, abs(float(loss)))
+    single = {k: p.grad.detach().cpu() for k, p in tw.module.named_parameters() if p.grad is not None}
+    assert set(single) == set(got["grads"])
+    for k in single:
+        scale = float(single[k].abs().max().clamp_min(1e-30))
+        assert float((single[k] - got["grads"][k]).abs().max()) / scale <= 1e-5, k

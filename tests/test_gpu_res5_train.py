@@ -745,6 +745,41 @@ def test_training_forward_backward_matches_the_stock_library_path(pkg, oracle, d
     assert worst[0] < 5e-3, worst
 
 
+def test_one_launch_operands_with_a_frozen_backbone(pkg, oracle):
+    """A res4 map that needs no gradient (frozen backbone): block 0's data-gradient operands are never asked for, so the on-demand
+    chain never learns their scales -- the one-launch preparation must still take over from the second step (it learns the
+    missing scales itself), and the steps' losses and Res5 weight gradients equal those of the on-demand chain bit for bit."""
+    from locov_amd import res5 as res5_mod
+    runs = {}
+    for one_launch in (False, True):
+        was, res5_mod._ONE_LAUNCH_PREP = res5_mod._ONE_LAUNCH_PREP, one_launch
+        try:
+            heads, c_in = _train_heads(pkg, oracle, "hip", "f16x2")
+            opt = torch.optim.SGD([p for p in heads.parameters() if p.requires_grad], lr=1e-3)
+            feat = torch.randn(2, c_in, 50, 84, generator=torch.Generator().manual_seed(5)).cuda()        # requires no gradient
+            props, targets = _train_batch(pkg, oracle, 2, 60, 5, seed=31)
+            seen, ready = [], []
+            for it in range(3):
+                opt.zero_grad(set_to_none=True)
+                torch.manual_seed(77 + it)
+                grid, box_feats, sampled, losses = heads(None, {"res4": feat}, props, targets)
+                ready.append(len(heads.res5.__dict__["_train_ops"][1].ready))
+                loss = losses["loss_box_reg"] + losses["loss_cls"] + 1e-3 * grid.square().mean() + 1e-2 * torch.cat(box_feats).square().mean()
+                loss.backward()
+                seen.append((float(loss.detach()), {k: p.grad.clone() for k, p in heads.named_parameters()
+                                                    if p.grad is not None and k.startswith("res5.")}))
+                opt.step()
+            torch.cuda.synchronize()
+        finally:
+            res5_mod._ONE_LAUNCH_PREP = was
+        runs[one_launch] = (seen, ready)
+    assert runs[False][1] == [0, 0, 0] and runs[True][1] == [0, 26, 26]
+    for (la, ga), (lb, gb) in zip(runs[False][0], runs[True][0]):
+        assert la == lb and set(ga) == set(gb) and len(ga) >= 10
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
+
+
 @pytest.mark.parametrize("mode", ["deferred", "sync"])
 def test_training_forward_out_of_range_never_reaches_the_losses_or_the_parameters(pkg, oracle, mode, monkeypatch):
     """A training forward whose activations leave the split arithmetic's range (|x| >= 4094).  RES5_TRAIN_GUARD "sync"
