@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LOCOV_ABI_VERSION 6
+#define LOCOV_ABI_VERSION 7
 
 #define LOCOV_OK 0
 #define LOCOV_ERR_INVALID_ARG (-1)
@@ -415,6 +415,27 @@ int locov_label_proposals(const float *boxes, const int *prop_offsets, const flo
                           const int *gt_offsets, int n_images, const float *thr_lo, const float *thr_hi, const int *thr_label,
                           int n_thresholds, int64_t num_classes, const double *rnd, int64_t *gt_index, int64_t *labels,
                           double *key_pos, double *key_neg, int64_t *rows, locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a-11  the sampler behind that labelling, for a batch in which every image fills its budget: the rest of
+ * SampleAllROIHeads.label_and_sample_proposals (ovr/modeling/roi_heads/roi_emb_heads.py:79-106: [D2-upstream]
+ * ROIHeads._sample_proposals -> subsample_labels, then `proposals_per_image[sampled_idxs]`, gt_classes, the matched target's
+ * fields, fg_proposal) in ONE launch, without a host read.  Image i takes num_pos = min(rows[i][0], max_pos) foreground proposals
+ * in ascending key_pos, then budget - num_pos background proposals in ascending key_neg (the heads of the image's segments of
+ * the two global argsorts the torch form takes), into slots [i * budget, (i + 1) * budget) of every output:
+ *   picked (row of the concatenated proposals), out_boxes [.,4], out_classes (= labels[picked]), out_gt_boxes [.,4] (the matched
+ *   ground-truth box; zeros for an image without ground truth), out_fg (class != num_classes), rois [.,5] = (image, box) -- the
+ *   pooler's input format, convert_boxes_to_pooler_format of the sampled boxes -- and, when `field` is given, field_out =
+ *   field[picked] (one more fp32 per-proposal field: objectness_logits).
+ * All inputs are locov_label_proposals' outputs / inputs of the same batch, on the same stream.  A batch in which an image has
+ * fewer candidates than its budget gets in-range but meaningless rows there: the caller learns it from `rows` (its one host read)
+ * and samples that batch the host-driven way.  1..4096 proposals per image, ties between equal keys broken by row number.
+ * ------------------------------------------------------------------------------------- */
+int locov_sample_proposals(const double *key_pos, const double *key_neg, const int64_t *labels, const int64_t *gt_index,
+                           const int64_t *rows, const float *boxes, const float *gt_boxes, const float *field,
+                           const int *prop_offsets, const int *gt_offsets, int n_images, int budget, int max_pos,
+                           int64_t num_classes, int64_t *picked, float *out_boxes, int64_t *out_classes, float *out_gt_boxes,
+                           int64_t *out_fg, float *rois, float *field_out, locov_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * a-11  the box-regression loss of the training heads in ONE launch.  Replaces the torch-op chain of [D2-upstream]

@@ -25,8 +25,8 @@ EPI_OUT_SPLIT = 0x2000
 EPI_RES_SPLIT = 0x4000
 MAX_LEVELS = 8
 ZERO_LIST_MAX = 24
-LABEL_MAX_IMAGES, LABEL_MAX_THRESHOLDS = 64, 6
-ABI_VERSION = 6
+LABEL_MAX_IMAGES, LABEL_MAX_THRESHOLDS, SAMPLE_MAX_PROPOSALS = 64, 6, 4096
+ABI_VERSION = 7
 
 _p = c_void_p  # device pointer
 
@@ -83,6 +83,8 @@ SIGNATURES = {
     "locov_frozen_bn_fold": (c_int, [_p, _p, _p, _p, c_float, c_int, _p, _p, _p]),
     "locov_label_proposals": (c_int, [_p, POINTER(c_int), _p, _p, POINTER(c_int), c_int, POINTER(c_float), POINTER(c_float),
                                       POINTER(c_int), c_int, c_int64, _p, _p, _p, _p, _p, _p, _p]),
+    "locov_sample_proposals": (c_int, [_p, _p, _p, _p, _p, _p, _p, _p, POINTER(c_int), POINTER(c_int), c_int, c_int, c_int, c_int64,
+                                       _p, _p, _p, _p, _p, _p, _p, _p]),
     "locov_box_reg_loss": (c_int, [_p, _p, _p, c_int64, _p, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float, _p, _p, _p]),
     "locov_grounding_ce_fwd": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, _p, _p]),
     "locov_grounding_ce_bwd": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, _p, _p, _p, _p, _p, _p, _p]),

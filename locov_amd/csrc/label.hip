@@ -81,7 +81,123 @@ __global__ __launch_bounds__(256) void label_proposals_kernel(const float4 *__re
     if (degenerate) atomicAdd(row + 3, 1ull);
 }
 
+// The sampler behind the labelling, for a batch whose every image fills its budget (the training forwards' speculation,
+// roi_emb_heads.py:25-118 -> [D2-upstream] ROIHeads._sample_proposals / subsample_labels): image i takes its
+// num_pos = min(foreground candidates, max_pos) foreground proposals of smallest key_pos, then budget - num_pos background proposals
+// of smallest key_neg, in key order -- the first entries of the image's segment of argsort(key_pos) / argsort(key_neg), which is
+// what the torch form reads off two global sorts -- and gathers every field of the sampled Instances in the same launch.
+// grid (image, 2): workgroup (i, 0) sorts image i by key_pos and fills the foreground slots, (i, 1) by key_neg and fills the rest.
+// The sort is a bitonic network over the image's keys in LDS (at most kSampleMax proposals per image), ties broken by row number.
+constexpr int kSampleMax = 4096, kSampleThreads = 1024;
+
+struct SampleGeom {
+    int n_img;
+    int roff[LOCOV_LABEL_MAX_IMAGES + 1];
+    int goff[LOCOV_LABEL_MAX_IMAGES + 1];
+    int budget, max_pos;
+};
+
+__global__ __launch_bounds__(kSampleThreads) void sample_proposals_kernel(
+    const double *__restrict__ key_pos, const double *__restrict__ key_neg, const int64_t *__restrict__ labels,
+    const int64_t *__restrict__ gt_index, const unsigned long long *__restrict__ rows, const float4 *__restrict__ boxes,
+    const float4 *__restrict__ gt, const float *__restrict__ field, SampleGeom g, int64_t num_classes, int64_t *__restrict__ picked,
+    float4 *__restrict__ out_boxes, int64_t *__restrict__ out_classes, float4 *__restrict__ out_gt, int64_t *__restrict__ out_fg,
+    float *__restrict__ rois, float *__restrict__ field_out)
+{
+    __shared__ double k[kSampleMax];
+    __shared__ unsigned short idx[kSampleMax];
+    const int img = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+    const int r0 = g.roff[img], n = g.roff[img + 1] - r0;
+    if (n <= 0) return;
+    int P = 1;
+    while (P < n) P <<= 1;
+    const double *key = (part == 0 ? key_pos : key_neg) + r0;
+    for (int i = tid; i < P; i += kSampleThreads) {
+        k[i] = i < n ? key[i] : __builtin_inf();
+        idx[i] = (unsigned short)i;
+    }
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (P >> 1); t += kSampleThreads) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool ascending = (lo & size) == 0;
+                const double a = k[lo], b = k[hi];
+                const unsigned short ia = idx[lo], ib = idx[hi];
+                const bool a_after_b = a > b || (a == b && ia > ib);
+                if (a_after_b == ascending) {
+                    k[lo] = b;
+                    k[hi] = a;
+                    idx[lo] = ib;
+                    idx[hi] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    const unsigned long long avail = rows[4 * img];
+    const int num_pos = avail < (unsigned long long)g.max_pos ? (int)avail : g.max_pos;
+    const int j_lo = part == 0 ? 0 : num_pos, j_hi = part == 0 ? num_pos : g.budget;
+    const bool has_gt = g.goff[img + 1] > g.goff[img];
+    for (int j = j_lo + tid; j < j_hi && j < g.budget; j += kSampleThreads) {
+        // (an image that does not fill its budget reads past its population: the caller throws such a batch's sample away; the
+        //  index only has to stay inside the image)
+        const int rank = j - j_lo;
+        const int row = r0 + (int)idx[rank < n ? rank : n - 1];
+        const int64_t slot = (int64_t)img * g.budget + j;
+        const float4 b = boxes[row];
+        const int64_t cls = labels[row];
+        picked[slot] = row;
+        out_boxes[slot] = b;
+        out_classes[slot] = cls;
+        out_fg[slot] = cls != num_classes ? 1 : 0;
+        out_gt[slot] = has_gt ? gt[gt_index[row]] : float4{0.f, 0.f, 0.f, 0.f};
+        float *r = rois + 5 * slot;
+        r[0] = (float)img;
+        r[1] = b.x;
+        r[2] = b.y;
+        r[3] = b.z;
+        r[4] = b.w;
+        if (field_out != nullptr) field_out[slot] = field[row];
+    }
+}
+
 }  // namespace locov
+
+extern "C" int locov_sample_proposals(const double *key_pos, const double *key_neg, const int64_t *labels, const int64_t *gt_index,
+                                      const int64_t *rows, const float *boxes, const float *gt_boxes, const float *field,
+                                      const int *prop_offsets, const int *gt_offsets, int n_images, int budget, int max_pos,
+                                      int64_t num_classes, int64_t *picked, float *out_boxes, int64_t *out_classes, float *out_gt_boxes,
+                                      int64_t *out_fg, float *rois, float *field_out, locov_stream_t stream)
+{
+    using namespace locov;
+    LOCOV_REQUIRE(n_images >= 0 && n_images <= LOCOV_LABEL_MAX_IMAGES, "locov_sample_proposals: 0..%d images per call", LOCOV_LABEL_MAX_IMAGES);
+    LOCOV_REQUIRE(budget >= 0 && max_pos >= 0 && max_pos <= budget, "locov_sample_proposals: 0 <= max_pos <= budget");
+    if (n_images == 0 || budget == 0) return LOCOV_OK;
+    LOCOV_REQUIRE(prop_offsets && gt_offsets, "locov_sample_proposals: null host array");
+    SampleGeom g{};
+    g.n_img = n_images;
+    g.budget = budget;
+    g.max_pos = max_pos;
+    for (int i = 0; i <= n_images; i++) {
+        g.roff[i] = prop_offsets[i];
+        g.goff[i] = gt_offsets[i];
+        LOCOV_REQUIRE(g.roff[i] >= 0 && g.goff[i] >= 0 && (i == 0 || (g.roff[i] >= g.roff[i - 1] && g.goff[i] >= g.goff[i - 1])),
+                      "locov_sample_proposals: offsets must be non-decreasing");
+        LOCOV_REQUIRE(i == 0 || (g.roff[i] - g.roff[i - 1] >= 1 && g.roff[i] - g.roff[i - 1] <= kSampleMax),
+                      "locov_sample_proposals: 1..%d proposals per image (got %d)", kSampleMax, i ? g.roff[i] - g.roff[i - 1] : 0);
+    }
+    LOCOV_REQUIRE(g.roff[0] == 0 && g.goff[0] == 0, "locov_sample_proposals: offsets start at 0");
+    LOCOV_REQUIRE(key_pos && key_neg && labels && gt_index && rows && boxes && picked && out_boxes && out_classes && out_gt_boxes && out_fg &&
+                      rois && (g.goff[n_images] == 0 || gt_boxes) && ((field == nullptr) == (field_out == nullptr)),
+                  "locov_sample_proposals: null pointer");
+    LOCOV_REQUIRE(((uintptr_t)boxes | (uintptr_t)gt_boxes | (uintptr_t)out_boxes | (uintptr_t)out_gt_boxes) % 16 == 0,
+                  "locov_sample_proposals: boxes must be 16-byte aligned");
+    hipLaunchKernelGGL(sample_proposals_kernel, dim3((unsigned)n_images, 2), dim3(kSampleThreads), 0, as_stream(stream), key_pos, key_neg, labels,
+                       gt_index, reinterpret_cast<const unsigned long long *>(rows), reinterpret_cast<const float4 *>(boxes),
+                       reinterpret_cast<const float4 *>(gt_boxes), field, g, num_classes, picked, reinterpret_cast<float4 *>(out_boxes),
+                       out_classes, reinterpret_cast<float4 *>(out_gt_boxes), out_fg, rois, field_out);
+    return check_launch("locov_sample_proposals");
+}
 
 extern "C" int locov_label_proposals(const float *boxes, const int *prop_offsets, const float *gt_boxes, const int64_t *gt_classes,
                                      const int *gt_offsets, int n_images, const float *thr_lo, const float *thr_hi, const int *thr_label,

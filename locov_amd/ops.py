@@ -1167,6 +1167,43 @@ def label_proposals(boxes: torch.Tensor, n_props, gt_boxes: torch.Tensor, gt_cla
     return gt_index, labels, keys[0], keys[1], rows
 
 
+SAMPLE_MAX_PROPOSALS = _lib.SAMPLE_MAX_PROPOSALS
+
+
+def sample_proposals(key_pos: torch.Tensor, key_neg: torch.Tensor, labels: torch.Tensor, gt_index: torch.Tensor, rows: torch.Tensor,
+                     boxes: torch.Tensor, gt_boxes: Optional[torch.Tensor], n_props, n_gt, budget: int, max_pos: int, num_classes: int,
+                     field: Optional[torch.Tensor] = None):
+    """The sampler behind label_proposals for a batch whose every image fills its budget, every field of the sampled Instances
+    from one launch and no host read (locov_sample_proposals; roi_emb_heads.py:79-106).  Inputs: label_proposals' outputs and inputs
+    of the same batch; field: one more fp32 per-proposal field (objectness_logits).  Returns (picked, boxes [B*budget, 4], classes,
+    matched gt boxes [B*budget, 4], fg flags, rois [B*budget, 5], field[picked] | None), image-major."""
+    boxes = _dev(boxes, "boxes")
+    B, total = len(n_props), int(sum(n_props))
+    if B > _lib.LABEL_MAX_IMAGES or boxes.shape[0] != total or not n_props or max(n_props) > SAMPLE_MAX_PROPOSALS or min(n_props) < 1:
+        raise ValueError("sample_proposals: 1..64 images of 1..4096 proposals each, counts that add up")
+    dev = boxes.device
+    key_pos, key_neg = _dev(key_pos, "key_pos", torch.float64), _dev(key_neg, "key_neg", torch.float64)
+    labels, gt_index, rows = _dev(labels, "labels", torch.int64), _dev(gt_index, "gt_index", torch.int64), _dev(rows, "rows", torch.int64)
+    gt_boxes = _dev(gt_boxes, "gt_boxes") if sum(n_gt) else None
+    field = _dev(field, "field") if field is not None else None
+    n = B * int(budget)
+    picked = torch.empty(n, dtype=torch.int64, device=dev)
+    out_boxes = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    classes = torch.empty(n, dtype=torch.int64, device=dev)
+    out_gt = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    fg = torch.empty(n, dtype=torch.int64, device=dev)
+    rois = torch.empty((n, 5), dtype=torch.float32, device=dev)
+    field_out = torch.empty(n, dtype=torch.float32, device=dev) if field is not None else None
+    roff = (ctypes.c_int * (B + 1))(*([0] + list(itertools.accumulate(int(v) for v in n_props))))
+    goff = (ctypes.c_int * (B + 1))(*([0] + list(itertools.accumulate(int(v) for v in n_gt))))
+    with torch.cuda.device(dev):
+        check(_lib.load().locov_sample_proposals(_ptr(key_pos), _ptr(key_neg), _ptr(labels), _ptr(gt_index), _ptr(rows), _ptr(boxes),
+                                                 _ptr(gt_boxes), _ptr(field), roff, goff, B, int(budget), int(max_pos), int(num_classes),
+                                                 _ptr(picked), _ptr(out_boxes), _ptr(classes), _ptr(out_gt), _ptr(fg), _ptr(rois),
+                                                 _ptr(field_out), _stream(boxes)), "locov_sample_proposals")
+    return picked, out_boxes, classes, out_gt, fg, rois, field_out
+
+
 def zero_if_raised(tensors, word: torch.Tensor) -> None:
     """Zero-fill every tensor of `tensors` (contiguous fp32 device tensors, None entries skipped) ON THE DEVICE when the
     range-guard word `word` is set; a no-op launch otherwise.  No host read (locov_zero_if_raised)."""

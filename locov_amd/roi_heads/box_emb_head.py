@@ -25,7 +25,7 @@ from torch.nn import functional as F
 
 from .. import ops
 from ..registry import configurable
-from ..structures import Boxes, Instances, ShapeSpec, boxes_class_of
+from ..structures import Boxes, Instances, ShapeSpec, boxes_class_of, cat_rows
 
 __all__ = ["Box2BoxTransform", "FastRCNNOutputLayers", "EmbeddingFastRCNNOutputLayers", "build_box_predictor",
            "fast_rcnn_inference", "batched_nms"]
@@ -348,13 +348,13 @@ class FastRCNNOutputLayers(nn.Module):
         """boxes_validated: the proposals come from SampleAllROIHeads.label_and_sample_proposals, which has already
         checked (and raised for) degenerate foreground boxes -- get_deltas' host-side assert is then skipped."""
         scores, proposal_deltas = predictions
-        gt_classes = (torch.cat([p.gt_classes for p in proposals], dim=0) if len(proposals)
+        # (cat_rows: the sampled Instances of a step are per-image views of batch-wide tensors -- their concatenation is a view)
+        gt_classes = (cat_rows([p.gt_classes for p in proposals]) if len(proposals)
                       else torch.empty(0, dtype=torch.int64, device=scores.device))
         if len(proposals):
-            proposal_boxes = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+            proposal_boxes = cat_rows([p.proposal_boxes.tensor for p in proposals])
             assert not proposal_boxes.requires_grad, "Proposals should not require gradients!"
-            gt_boxes = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals],
-                                 dim=0)
+            gt_boxes = cat_rows([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals])
         else:
             proposal_boxes = gt_boxes = torch.empty((0, 4), device=proposal_deltas.device)
         if gt_classes.numel() == 0:
@@ -364,7 +364,8 @@ class FastRCNNOutputLayers(nn.Module):
         losses = {"loss_cls": loss_cls,
                   "loss_box_reg": self.box_reg_loss(proposal_boxes, gt_boxes, proposal_deltas, gt_classes,
                                                     boxes_validated=boxes_validated)}
-        return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+        # (a weight of exactly 1 changes no bit: no launch for it, forward or backward)
+        return {k: v if self.loss_weight.get(k, 1.0) == 1.0 else v * self.loss_weight[k] for k, v in losses.items()}
 
     def box_reg_loss(self, proposal_boxes, gt_boxes, pred_deltas, gt_classes, boxes_validated: bool = False):
         """[D2-upstream] smooth-L1 over the foreground rows, normalised by ALL rows.  The foreground rows are selected by a

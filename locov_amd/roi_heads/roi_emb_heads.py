@@ -27,6 +27,7 @@ from .box_emb_head import build_box_predictor
 
 ROI_HEADS_REGISTRY = Registry("ROI_HEADS")
 _SPECULATE = os.environ.get("LOCOV_LABEL_SPECULATE", "1") != "0"      # developer A/B: 0 = the training forwards wait for the labelling
+_SAMPLE_KERNEL = os.environ.get("LOCOV_LABEL_SAMPLE_KERNEL", "1") != "0"  # developer A/B: 0 = the speculated sample from torch ops (two sorts, ~35 launches)
 _JOINT_FORWARD = os.environ.get("LOCOV_RES5_JOINT_FWD", "1") != "0"    # developer A/B: 0 = the two Res5 calls are forwarded one after the other
 
 __all__ = ["ROI_HEADS_REGISTRY", "build_roi_heads", "Matcher", "subsample_labels", "add_ground_truth_to_proposals",
@@ -369,32 +370,117 @@ class SampleAllROIHeads(ROIHeads):
         way to pinned memory behind an event -- and NOTHING waits.  A caller with independent device work (the whole-grid Res5
         call of EmbeddingProposalsRes5ROIHeads.forward) enqueues it between _label_begin and _label_finish: the host then waits
         for the labelling kernels only, with that work still queued behind them, instead of draining the GPU once per step."""
-        if self.proposal_append_gt:
-            proposals = add_ground_truth_to_proposals(targets, proposals)
-        if not proposals:
-            return {"done": []}
-        if type(self.proposal_matcher) is not Matcher:
-            return {"done": self._label_and_sample_per_image(proposals, targets)}
-        gt_index, labels, pos_order, neg_order, rows = self._match_batch(proposals, targets)        # no host value needed
+        lean = self._label_lean_inputs(proposals, targets)
+        if lean is not None:
+            # the training step's batch (device fp32 boxes, the stock Matcher, every image at least its budget of candidates):
+            # one concatenation per field, the labelling kernel, and -- _label_speculate -- the sampling kernel; the per-image
+            # Instances with the ground truth appended and the two sorts of the host-driven form are only built if it is needed
+            gt_index, labels, key_pos, key_neg, rows = ops.label_proposals(lean["box"], lean["n_r"], lean["gtb"], lean["gtc"], lean["n_g"],
+                                                                           self.proposal_matcher.thresholds, self.proposal_matcher.labels,
+                                                                           self.num_classes, lean["rnd"])
+            raw, pos_order, neg_order = proposals, None, None
+            proposals = None
+        else:
+            raw, key_pos, key_neg = None, None, None
+            if self.proposal_append_gt:
+                proposals = add_ground_truth_to_proposals(targets, proposals)
+            if not proposals:
+                return {"done": []}
+            if type(self.proposal_matcher) is not Matcher:
+                return {"done": self._label_and_sample_per_image(proposals, targets)}
+            gt_index, labels, pos_order, neg_order, rows = self._match_batch(proposals, targets)        # no host value needed
         # ONE host read for the whole batch: population sizes, the reference's two validity asserts, and -- it costs nothing
         # here -- the deferred range-guard words of the previous step (Res5's backward, the training forward)
         guards = self._deferred_guards(rows.device)
         flat = rows.reshape(-1)
-        if guards:
-            flat = torch.cat([flat, torch.stack([g.word.reshape(()) for _, g in guards]).to(rows.dtype)])
-        event = None
+        event, host_g = None, None
         if flat.is_cuda:
+            # (one small copy per tensor straight into pinned memory: no concatenation / dtype-conversion launches in front of it)
             host = self.__dict__.get("_label_pinned")
             if host is None or host.numel() < flat.numel() or host.dtype != flat.dtype:
                 host = self.__dict__["_label_pinned"] = torch.empty(max(flat.numel(), 256), dtype=flat.dtype).pin_memory()
             host = host[:flat.numel()]
             host.copy_(flat, non_blocking=True)
+            if guards:
+                host_g = self.__dict__.get("_label_pinned_guards")
+                if host_g is None or host_g.numel() < len(guards) or host_g.dtype != guards[0][1].word.dtype:
+                    host_g = self.__dict__["_label_pinned_guards"] = torch.empty(max(len(guards), 8), dtype=guards[0][1].word.dtype).pin_memory()
+                for i, (_, g) in enumerate(guards):
+                    host_g[i:i + 1].copy_(g.word.reshape(1), non_blocking=True)
             event = torch.cuda.Event()
             event.record(torch.cuda.current_stream(flat.device))
         else:
             host = flat
-        return {"proposals": proposals, "targets": targets, "gt_index": gt_index, "labels": labels, "pos_order": pos_order,
-                "neg_order": neg_order, "rows": rows, "rows_shape": tuple(rows.shape), "host": host, "event": event, "guards": guards}
+            if guards:
+                host_g = torch.stack([g.word.reshape(()) for _, g in guards]).cpu()
+        st = {"targets": targets, "gt_index": gt_index, "labels": labels, "rows": rows, "rows_shape": tuple(rows.shape), "host": host,
+              "host_guards": host_g, "event": event, "guards": guards}
+        if lean is not None:
+            st.update(lean=lean, raw_proposals=raw, keys=(key_pos, key_neg))
+        else:
+            st.update(proposals=proposals, pos_order=pos_order, neg_order=neg_order)
+        return st
+
+    def _label_lean_inputs(self, proposals: List[Instances], targets: List[Instances]):
+        """The concatenated inputs of the one-launch labelling + one-launch sampling, or None when the batch is not of the
+        training step's plain kind: proposals carrying proposal_boxes (+ objectness_logits), targets carrying gt_boxes + gt_classes,
+        fp32 device boxes, the stock Matcher without low-quality matches, and per image (ground truth appended) between the
+        budget and ops.SAMPLE_MAX_PROPOSALS candidates."""
+        if not (_SPECULATE and _SAMPLE_KERNEL) or not proposals or len(proposals) != len(targets) or len(proposals) > ops.LABEL_MAX_IMAGES:
+            return None
+        matcher = self.proposal_matcher
+        if type(matcher) is not Matcher or matcher.allow_low_quality_matches or len(matcher.labels) > ops.LABEL_MAX_THRESHOLDS:
+            return None
+        with_logits = proposals[0].has("objectness_logits")
+        fields = {"proposal_boxes", "objectness_logits"} if with_logits else {"proposal_boxes"}
+        B = int(self.batch_size_per_image)
+        append = bool(self.proposal_append_gt)
+        pieces, logit_pieces, gtbs, gtcs, n_r, n_g = [], [], [], [], [], []
+        for p, t in zip(proposals, targets):
+            if set(p.get_fields()) != fields or set(t.get_fields()) != {"gt_boxes", "gt_classes"} or type(t) is not type(p):
+                return None
+            pb, gb, gc = p.proposal_boxes.tensor, t.gt_boxes.tensor, t.gt_classes
+            if not (pb.is_cuda and pb.dtype == torch.float32 and gb.dtype == torch.float32 and gb.device == pb.device
+                    and gc.dtype == torch.int64 and gc.device == pb.device and type(t.gt_boxes) is type(p.proposal_boxes)):
+                return None
+            n = len(p) + (len(t) if append else 0)
+            if not (max(B, 1) <= n <= ops.SAMPLE_MAX_PROPOSALS) or B <= 0:
+                return None
+            pieces.append(pb)
+            if with_logits:
+                lg = p.objectness_logits
+                if not (lg.dtype == torch.float32 and lg.dim() == 1 and lg.device == pb.device):
+                    return None
+                logit_pieces.append(lg)
+            if append and len(t):
+                pieces.append(gb)
+                if with_logits:
+                    logit_pieces.append(self._gt_logits(len(t), pb.device))
+            if len(t):
+                gtbs.append(gb)
+                gtcs.append(gc)
+            n_r.append(n)
+            n_g.append(len(t))
+        dev = pieces[0].device
+        box = torch.cat(pieces, dim=0)
+        return {"box": box, "n_r": n_r, "n_g": n_g, "gtb": torch.cat(gtbs, dim=0) if gtbs else None,
+                "gtc": torch.cat(gtcs, dim=0) if gtcs else None, "logits": torch.cat(logit_pieces, dim=0) if with_logits else None,
+                "rnd": torch.rand((2, box.shape[0]), device=dev, dtype=torch.float64)}
+
+    def _gt_logits(self, n: int, device) -> torch.Tensor:
+        """n objectness logits of appended ground-truth boxes (add_ground_truth_to_proposals' constant), a view of a cached tensor."""
+        hit = self.__dict__.get("_gt_logit_const")
+        if hit is None or hit.numel() < n or hit.device != device:
+            hit = self.__dict__["_gt_logit_const"] = torch.full((max(n, 64),), math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10))), device=device)
+        return hit[:n]
+
+    def _label_materialize(self, st) -> None:
+        """What the host-driven sampling needs and the lean labelling skipped: the per-image candidates with the ground truth
+        appended, and the two global sampling orders."""
+        if "proposals" not in st:
+            raw = st["raw_proposals"]
+            st["proposals"] = add_ground_truth_to_proposals(st["targets"], raw) if self.proposal_append_gt else raw
+            st["pos_order"], st["neg_order"] = torch.argsort(st["keys"][0]), torch.argsort(st["keys"][1])
 
     @torch.no_grad()
     def _label_host(self, st):
@@ -407,8 +493,9 @@ class SampleAllROIHeads(ROIHeads):
             st["event"].synchronize()                       # the step's host wait for the labelling kernels
         n_rows = st["rows_shape"][0] * st["rows_shape"][1]
         flat = st["host"].clone() if st["event"] is not None else st["host"].cpu()
-        rows_h, guard_h = flat[:n_rows].view(st["rows_shape"]), flat[n_rows:]
-        tripped = {kind for (kind, _), v in zip(st["guards"], guard_h.tolist()) if v}
+        rows_h = flat[:n_rows].view(st["rows_shape"])
+        guard_h = st["host_guards"][:len(st["guards"])].tolist() if st["guards"] else []
+        tripped = {kind for (kind, _), v in zip(st["guards"], guard_h) if v}
         if tripped:
             self._deferred_guards_tripped(tripped)
         assert not bool(rows_h[:, 2].any()), "Matcher: the match quality matrix has negative entries"
@@ -474,6 +561,7 @@ class SampleAllROIHeads(ROIHeads):
         if "done" in st:
             return st["done"]
         counts = self._sample_counts(self._label_host(st))
+        self._label_materialize(st)
         pos_order, neg_order = st["pos_order"], st["neg_order"]
         off_r = np.concatenate([[0], np.cumsum([len(p) for p in st["proposals"]])]).tolist()
         pieces = []
@@ -497,6 +585,28 @@ class SampleAllROIHeads(ROIHeads):
         if "done" in st or st.get("event") is None or not _SPECULATE:
             return None
         B = int(self.batch_size_per_image)
+        lean = st.get("lean")
+        if lean is not None:
+            # labels, keys and counts are on the device: ONE launch sorts every image's candidates by the two keys, takes the budget
+            # and gathers every field of the sampled Instances (and the pooler's rois)
+            picked, boxes, classes, gt_boxes, fg, rois, logits = ops.sample_proposals(
+                st["keys"][0], st["keys"][1], st["labels"], st["gt_index"], st["rows"], lean["box"], lean["gtb"], lean["n_r"], lean["n_g"],
+                B, int(B * self.positive_fraction), self.num_classes, field=lean["logits"])
+            sampled = []
+            for i, (p, t) in enumerate(zip(st["raw_proposals"], st["targets"])):
+                sl = slice(i * B, (i + 1) * B)
+                out = type(p)(p.image_size)
+                out.set("proposal_boxes", type(p.proposal_boxes)(boxes[sl]))
+                if logits is not None:
+                    out.set("objectness_logits", logits[sl])
+                out.gt_classes = classes[sl]
+                if lean["n_g"][i] > 0:
+                    out.set("gt_boxes", type(t.gt_boxes)(gt_boxes[sl]))
+                out.set("fg_proposal", fg[sl])
+                sampled.append(out)
+            st.update(speculated=True, picked=picked, rois=rois, rois_of=sampled)
+            return sampled
+        self._label_materialize(st)
         n_r = [len(p) for p in st["proposals"]]
         if B <= 0 or min(n_r) < B:
             return None
@@ -515,6 +625,13 @@ class SampleAllROIHeads(ROIHeads):
         picked = torch.where(j < num_pos, pos_order[(off + j).clamp(max=last)], neg_order[(off + (j - num_pos).clamp(min=0)).clamp(max=last)])
         st["speculated"] = True
         return self._label_build(st, picked.reshape(-1), [B] * len(n_r))
+
+    @staticmethod
+    def _sampled_rois(st, sampled: List[Instances]) -> torch.Tensor:
+        """The pooler's [R, 5] input of a sampled batch: the sampling kernel's own output when `sampled` is what it produced."""
+        if st.get("rois_of") is sampled:
+            return st["rois"]
+        return convert_boxes_to_pooler_format([x.proposal_boxes for x in sampled])
 
     @torch.no_grad()
     def _label_validate(self, st) -> bool:
@@ -662,7 +779,7 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
                                     on_overflow=self._warn_overflow)
 
     def _shared_roi_transform(self, features: List[torch.Tensor], boxes: List[Boxes], pooled: bool = False,
-                              nhwc: Optional[torch.Tensor] = None):
+                              nhwc: Optional[torch.Tensor] = None, rois: Optional[torch.Tensor] = None):
         """roi_emb_heads.py:243-245: res5(pooler(features, boxes)) -> [R, C5, P/2, P/2]; with `pooled` the spatial
         mean of that tensor, [R, C5] (:262,:344,:356), which on the hand-written path in split arithmetic comes fused
         out of Res5's last 1x1 convolution.
@@ -675,7 +792,8 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
             # weight gradients -> mean); `nhwc` lets the caller share the channels-last copy with the whole-grid call
             from .. import res5_train
             assert len(boxes) == features[0].shape[0]
-            rois = convert_boxes_to_pooler_format(boxes)
+            if rois is None:                                 # (else: the pooler-format rows of `boxes`, already on the device)
+                rois = convert_boxes_to_pooler_format(boxes)
             P = self.pooler.output_size[0]
             if nhwc is None:
                 nhwc = res5_train.to_nhwc(features[0])
@@ -861,7 +979,8 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
             tguard = self._train_guard(feats)
             guard = None if tguard is not None else self._deferred_guard(feats)
             with ops.range_guard(tguard if tguard is not None else guard):
-                box_features = self._shared_roi_transform(feats, proposal_boxes, pooled=True)
+                box_features = self._shared_roi_transform(feats, proposal_boxes, pooled=True,
+                                                          rois=pending["rois"] if pending.get("rois_of") is props else None)
             keep = None
             if tguard is not None:
                 keep = self._close_train_guard(tguard, [box_features])
@@ -1022,7 +1141,7 @@ class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
             # the sample is known without a host wait: both calls are forwarded together (their 1x1 convolutions share launches)
             step = res5_train.Res5Step(self.res5, self.res5_dtype == "f16x2", nhwc.device,
                                        res5_train.grid_capacity(nhwc) + o * o * N * self.batch_size_per_image)
-            rois = convert_boxes_to_pooler_format([x.proposal_boxes for x in sampled])
+            rois = self._sampled_rois(pending, sampled)
             rows, x0 = res5_train.grid_and_roi_segments(step, nhwc, rois, P, self.pooler.scales[0], self.pooler.sampling_ratio,
                                                         self.pooler.aligned, on_range_final=early)
             grid, box_features = step.outputs([rows, x0], [False, True])

@@ -217,6 +217,26 @@ class ImageList:
         return self.tensor.device
 
 
+def cat_rows(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
+    """torch.cat(tensors, dim=0) -- as a VIEW, without a launch, when the pieces are contiguous, consecutive row ranges of one
+    storage (the per-image views of a batch-wide gather: what the sampled Instances of a training step hold)."""
+    tensors = list(tensors)
+    if len(tensors) == 1:
+        return tensors[0]
+    if tensors and tensors[0].dim() >= 1:
+        t0 = tensors[0]
+        store, ptr, total = t0.untyped_storage().data_ptr(), t0.data_ptr(), 0
+        for t in tensors:
+            if (t.requires_grad or t.dtype != t0.dtype or t.shape[1:] != t0.shape[1:] or not t.is_contiguous() or t.data_ptr() != ptr
+                    or t.untyped_storage().data_ptr() != store):
+                break
+            ptr += t.numel() * t.element_size()
+            total += t.shape[0]
+        else:
+            return t0.as_strided((total,) + tuple(t0.shape[1:]), t0.stride())
+    return torch.cat(tensors, dim=0)
+
+
 def boxes_class_of(proposals: Sequence[Any]):
     """(Instances class, Boxes class) of the caller's objects: results are built with the SAME classes the caller handed in,
     so that under Detectron2 the meta-architecture gets detectron2.structures back (detector_postprocess calls

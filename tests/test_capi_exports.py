@@ -32,7 +32,7 @@ def test_every_symbol_is_exported(lib):
     for name in _declared():
         assert hasattr(lib, name), name
     from locov_amd import _lib
-    assert lib.locov_abi_version() == _lib.ABI_VERSION == 6        # 2: range-guard word on the split entry points; 3: amax_out slots; 4: locov_zero_if_raised, exact fused workspaces, timing_read_ex; 5: locov_box_reg_loss, locov_grounding_ce_fwd / _bwd; 6: locov_res5_weight_prep, locov_gemm_segmean_supported
+    assert lib.locov_abi_version() == _lib.ABI_VERSION == 7        # 2: range-guard word on the split entry points; 3: amax_out slots; 4: locov_zero_if_raised, exact fused workspaces, timing_read_ex; 5: locov_box_reg_loss, locov_grounding_ce_fwd / _bwd; 6: locov_res5_weight_prep, locov_gemm_segmean_supported; 7: locov_sample_proposals
 
 
 def test_argument_errors_are_reported_without_a_gpu(lib):
@@ -74,6 +74,22 @@ def test_round5_entry_points_validate_their_arguments(lib):
     assert lib.locov_gemm_segmean_supported(512, 49 * 12000, 2048, 512, 49, _lib.EPI_RELU) == 0         # fp32 x: the 128x128 form, 4.8 GB
     assert lib.locov_gemm_segmean_supported(512, 49 * 1000, 2048, 512, 49, _lib.EPI_RELU) == 1
     assert lib.locov_gemm_segmean_supported(512, 49 * 1000, 2048, 512, 40, big) == 0                   # seg < 43
+
+
+def test_sample_proposals_validates_its_arguments(lib):
+    """locov_sample_proposals: argument errors before any HIP call."""
+    import ctypes
+    from locov_amd import _lib
+    none = [None] * 8
+    outs = [None] * 7
+    off = (ctypes.c_int * 2)(0, 100)
+    assert lib.locov_sample_proposals(*none, off, off, 0, 16, 4, 80, *outs, None) == 0                  # no images: a no-op
+    assert lib.locov_sample_proposals(*none, off, off, 1, 0, 0, 80, *outs, None) == 0                   # no budget: a no-op
+    assert lib.locov_sample_proposals(*none, off, off, 1, 16, 17, 80, *outs, None) == -1 and b"max_pos <= budget" in lib.locov_last_error()
+    assert lib.locov_sample_proposals(*none, off, off, _lib.LABEL_MAX_IMAGES + 1, 16, 4, 80, *outs, None) == -1
+    big = (ctypes.c_int * 2)(0, _lib.SAMPLE_MAX_PROPOSALS + 1)
+    assert lib.locov_sample_proposals(*none, big, off, 1, 16, 4, 80, *outs, None) == -1 and b"proposals per image" in lib.locov_last_error()
+    assert lib.locov_sample_proposals(*none, off, off, 1, 16, 4, 80, *outs, None) == -1 and b"null pointer" in lib.locov_last_error()
 
 
 def test_cpu_tensors_are_rejected_loudly():

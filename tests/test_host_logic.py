@@ -422,3 +422,25 @@ def test_stock_library_fallback_is_announced_once_with_the_failed_condition(lsm_
     with pytest.warns(RuntimeWarning, match="stock library path"):
         with pytest.raises(Exception):
             heads._shared_roi_transform([feat], [Boxes(torch.tensor([[0.0, 0.0, 32.0, 32.0]]))])
+
+
+def test_cat_rows_is_a_view_of_adjacent_pieces_and_a_copy_otherwise():
+    """structures.cat_rows: the concatenation of per-image views of one batch-wide tensor costs no launch; anything else is torch.cat."""
+    import torch
+    from locov_amd.structures import cat_rows
+    b = torch.arange(40.).view(10, 4)
+    v = cat_rows([b[2:5], b[5:9]])
+    assert v.data_ptr() == b[2:].data_ptr() and torch.equal(v, b[2:9])
+    v = cat_rows([b[2:5], b[6:9]])                                   # a gap: a copy
+    assert torch.equal(v, torch.cat([b[2:5], b[6:9]])) and v.data_ptr() != b[2:].data_ptr()
+    parts = torch.split(torch.arange(12), [3, 4, 5])
+    v = cat_rows(list(parts))
+    assert torch.equal(v, torch.arange(12)) and v.data_ptr() == parts[0].data_ptr()
+    assert cat_rows([torch.ones(3), torch.zeros(2)]).tolist() == [1, 1, 1, 0, 0]             # two storages
+    assert torch.equal(cat_rows([b[:, :2][1:3], b[:, :2][3:4]]), b[1:4, :2])                  # non-contiguous pieces
+    assert torch.equal(cat_rows([b[0:2], b[2:2], b[2:4]]), b[0:4])                            # an empty piece in between
+    c = torch.arange(24.).view(6, 4)
+    assert torch.equal(cat_rows([b[0:2], c[2:3]]), torch.cat([b[0:2], c[2:3]]))
+    g = torch.ones(4, 2, requires_grad=True) * 1.0
+    assert cat_rows([g[0:2], g[2:4]]).requires_grad                                           # autograd tensors: torch.cat
+    assert cat_rows([b[1:3]]).data_ptr() == b[1:3].data_ptr()

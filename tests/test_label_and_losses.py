@@ -251,12 +251,16 @@ def test_image_without_ground_truth_is_background_under_an_ignore_matcher_gpu(or
 
 
 @pytest.mark.gpu
-def test_speculated_sample_equals_the_host_driven_one(oracle):
+@pytest.mark.parametrize("kernel", [True, False], ids=["sampling_kernel", "torch_ops"])
+def test_speculated_sample_equals_the_host_driven_one(oracle, kernel, monkeypatch):
     """The training forwards form the sample on the device WITHOUT the host read, assuming every image fills its budget
-    (_label_speculate), and validate afterwards (_label_validate).  On the same draw the speculated Instances equal the
-    host-driven ones field for field; a batch that cannot fill its budget (too few background candidates) fails the validation,
-    and the forward then returns the reference's counts."""
+    (_label_speculate: locov_sample_proposals, or with LOCOV_LABEL_SAMPLE_KERNEL=0 the torch-op form behind two global sorts), and
+    validate afterwards (_label_validate).  On the same draw the speculated Instances equal the host-driven ones field for field,
+    in the same field order; a batch that cannot fill its budget (too few background candidates) fails the validation, and the
+    forward then returns the reference's counts."""
+    from locov_amd.roi_heads import roi_emb_heads
     from locov_amd.roi_heads.roi_emb_heads import get_event_storage
+    monkeypatch.setattr(roi_emb_heads, "_SAMPLE_KERNEL", kernel)
     heads = _heads(True, 64, 0.25, "cuda")
     rng = np.random.default_rng(33)
     props, targets, _ = _batch(oracle, rng, "cuda", n_img=3, r=150, n_gt=6)
@@ -265,11 +269,15 @@ def test_speculated_sample_equals_the_host_driven_one(oracle):
     torch.manual_seed(4)
     st_b = heads._label_begin(props, targets)
     spec = heads._label_speculate(st_a)
+    assert ("lean" in st_a) == kernel and (st_a.get("rois") is not None) == kernel
     assert spec is not None and heads._label_validate(st_a)
     want = heads._label_finish(st_b)
     assert len(spec) == len(want) == 3
+    if kernel:          # the pooler's rows come out of the same launch
+        from locov_amd.poolers import convert_boxes_to_pooler_format
+        assert torch.equal(heads._sampled_rois(st_a, spec), convert_boxes_to_pooler_format([x.proposal_boxes for x in want]))
     for a, b in zip(spec, want):
-        assert len(a) == len(b) == 64 and set(a.get_fields()) == set(b.get_fields())
+        assert len(a) == len(b) == 64 and list(a.get_fields()) == list(b.get_fields())
         for k in b.get_fields():
             va, vb = a.get(k), b.get(k)
             assert torch.equal(va.tensor if hasattr(va, "tensor") else va, vb.tensor if hasattr(vb, "tensor") else vb), k
@@ -289,6 +297,103 @@ def test_speculated_sample_equals_the_host_driven_one(oracle):
     assert [len(x) for x in sampled] == [b.shape[0] for b in box_feats] and all(len(x) <= 64 for x in sampled)
     assert [len(x) for x in sampled][1] == 64                       # (the image without ground truth: background only, budget filled)
     assert all(bool(torch.isfinite(v)) for v in losses.values())
+
+
+@pytest.mark.gpu
+def test_sampling_kernel_equals_the_two_global_sorts():
+    """locov_sample_proposals against what it replaces -- argsort of the two image-major keys, then per image the first num_pos
+    entries of the foreground order and budget - num_pos of the background order -- on images of 16 .. 4 096 proposals (powers of
+    two, one above, one below), budgets that are / are not filled, duplicate keys (ties go to the lower row), an image without
+    ground truth; every gathered field equals the indexed tensor."""
+    from locov_amd import ops
+    gen = torch.Generator().manual_seed(12)
+    n_r = [16, 1000, 1025, 4096, 64, 333, 2047]
+    n_g = [3, 7, 0, 5, 1, 9, 2]
+    B, max_pos, K = 16, 4, 80
+    total, tg = sum(n_r), sum(n_g)
+    off_r, off_g = np.concatenate([[0], np.cumsum(n_r)]), np.concatenate([[0], np.cumsum(n_g)])
+    img = torch.repeat_interleave(torch.arange(len(n_r)), torch.tensor(n_r))
+    # labels: a few foreground classes, background K, ignored -1; the image without ground truth: all background
+    labels = torch.where(torch.rand(total, generator=gen) < 0.02, torch.randint(0, K, (total,), generator=gen), torch.full((total,), K))
+    labels[torch.rand(total, generator=gen) < 0.05] = -1
+    labels[img == 2] = K
+    labels[off_r[4]:off_r[5]] = K                                  # image 4: no foreground at all
+    labels[off_r[5]:off_r[5] + 200] = 3                            # image 5: more foreground than max_pos
+    labels[off_r[0]:off_r[0] + 14] = 5                             # image 0 (16 proposals): 2 background candidates -> budget NOT filled
+    pos, neg = (labels != -1) & (labels != K), labels == K
+    rnd = torch.rand((2, total), generator=gen, dtype=torch.float64)
+    rnd[0, off_r[1] + 10:off_r[1] + 20] = rnd[0, off_r[1] + 10]    # ties
+    rnd[1, off_r[3] + 100:off_r[3] + 140] = 0.0
+    key_pos = rnd[0] + (~pos).double() * 2.0 + img.double() * 4.0
+    key_neg = rnd[1] + (~neg).double() * 2.0 + img.double() * 4.0
+    rows = torch.zeros((len(n_r), 4), dtype=torch.int64)
+    for i in range(len(n_r)):
+        sl = slice(off_r[i], off_r[i + 1])
+        rows[i, 0], rows[i, 1] = int(pos[sl].sum()), int(neg[sl].sum())
+    gt_index = torch.zeros(total, dtype=torch.int64)
+    for i in range(len(n_r)):
+        if n_g[i]:
+            gt_index[off_r[i]:off_r[i + 1]] = torch.randint(int(off_g[i]), int(off_g[i + 1]), (n_r[i],), generator=gen)
+    boxes = torch.rand((total, 4), generator=gen) * 500
+    gtb = torch.rand((tg, 4), generator=gen) * 500
+    field = torch.randn(total, generator=gen)
+    d = lambda t: t.cuda()
+    picked, ob, oc, og, fg, rois, fo = ops.sample_proposals(d(key_pos), d(key_neg), d(labels), d(gt_index), d(rows), d(boxes), d(gtb), n_r, n_g,
+                                                            B, max_pos, K, field=d(field))
+    torch.cuda.synchronize()
+    # expectation: stable sorts (ties -> lower row), per image
+    want = []
+    for i in range(len(n_r)):
+        sl = slice(int(off_r[i]), int(off_r[i + 1]))
+        po = np.argsort(key_pos[sl].numpy(), kind="stable") + off_r[i]
+        no = np.argsort(key_neg[sl].numpy(), kind="stable") + off_r[i]
+        num_pos = min(int(rows[i, 0]), max_pos)
+        take = lambda order, k: [int(order[min(j, n_r[i] - 1)]) for j in range(k)]
+        want += take(po, num_pos) + take(no, B - num_pos)
+    want = torch.tensor(want)
+    assert torch.equal(picked.cpu(), want)
+    filled = [min(int(rows[i, 0]), max_pos) + int(rows[i, 1]) >= B for i in range(len(n_r))]
+    assert filled == [False, True, True, True, True, True, True]
+    for i in range(len(n_r)):
+        if filled[i]:           # a filled budget holds foreground, then background -- never an ignored proposal
+            c = oc[i * B:(i + 1) * B].cpu()
+            k = min(int(rows[i, 0]), max_pos)
+            assert bool(((c[:k] >= 0) & (c[:k] < K)).all()) and bool((c[k:] == K).all())
+    assert torch.equal(ob.cpu(), boxes[want]) and torch.equal(oc.cpu(), labels[want]) and torch.equal(fo.cpu(), field[want])
+    assert torch.equal(fg.cpu(), (labels[want] != K).long())
+    has_gt = torch.tensor([n_g[i] > 0 for i in range(len(n_r))]).repeat_interleave(B)
+    assert torch.equal(og.cpu()[has_gt], gtb[gt_index[want]][has_gt]) and not bool(og.cpu()[~has_gt].any())
+    assert torch.equal(rois.cpu(), torch.cat([torch.arange(len(n_r)).repeat_interleave(B).float()[:, None], boxes[want]], dim=1))
+    # without the extra field, and the argument checks of the wrapper
+    out = ops.sample_proposals(d(key_pos), d(key_neg), d(labels), d(gt_index), d(rows), d(boxes), d(gtb), n_r, n_g, B, max_pos, K)
+    assert out[-1] is None and torch.equal(out[0].cpu(), want)
+    with pytest.raises(ValueError):
+        ops.sample_proposals(d(key_pos), d(key_neg), d(labels), d(gt_index), d(rows), d(boxes), d(gtb), n_r[:-1] + [5000], n_g, B, max_pos, K)
+
+
+@pytest.mark.gpu
+def test_training_forward_with_the_sampling_kernel_equals_the_torch_op_form(oracle, monkeypatch):
+    """One training forward + backward of the LSM heads with the lean labelling + sampling kernel and with the torch-op form, same
+    seeds: the same sampled proposals, losses and Res5 weight gradients, bit for bit."""
+    from locov_amd.roi_heads import roi_emb_heads
+    outs = {}
+    for kernel in (True, False):
+        monkeypatch.setattr(roi_emb_heads, "_SAMPLE_KERNEL", kernel)
+        heads = _heads(True, 64, 0.25, "cuda")
+        rng = np.random.default_rng(33)
+        props, targets, _ = _batch(oracle, rng, "cuda", n_img=3, r=150, n_gt=6)
+        feat = torch.randn(3, 128, 50, 84, generator=torch.Generator().manual_seed(2)).cuda().requires_grad_(True)
+        torch.manual_seed(4)
+        grid, box_feats, sampled, losses = heads(None, {"res4": feat}, props, targets)
+        (sum(losses.values()) + 1e-3 * grid.square().mean() + 1e-2 * torch.cat(box_feats).square().mean()).backward()
+        outs[kernel] = ([x.proposal_boxes.tensor.clone() for x in sampled], [x.gt_classes.clone() for x in sampled],
+                        {k: float(v) for k, v in losses.items()},
+                        {k: p.grad.clone() for k, p in heads.named_parameters() if p.grad is not None and k.startswith("res5.")})
+    a, b = outs[True], outs[False]
+    assert all(torch.equal(x, y) for x, y in zip(a[0], b[0])) and all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+    assert a[2] == b[2] and set(a[3]) == set(b[3]) and len(a[3]) >= 10
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
 
 
 @pytest.mark.gpu
