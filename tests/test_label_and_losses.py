@@ -300,6 +300,39 @@ def test_speculated_sample_equals_the_host_driven_one(oracle, kernel, monkeypatc
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("append_gt,logits,n_img,r", [(True, True, 1, 64), (False, True, 4, 64), (True, False, 5, 150), (False, False, 2, 97),
+                                                      (True, True, 3, 4090), (True, True, 2, 5000)])
+def test_lean_labelling_edge_cases_equal_the_host_driven_form(oracle, append_gt, logits, n_img, r):
+    """The lean front end (one concatenation per field, labelling kernel, sampling kernel) on the shapes at its borders: a single
+    image; exactly the budget of candidates; ground truth not appended; proposals without objectness_logits; 4 096 candidates per
+    image with the appended ground truth; more than that (the general path must take over) -- always the host-driven Instances."""
+    heads = _heads(True, 64, 0.25, "cuda")
+    heads.proposal_append_gt = append_gt
+    rng = np.random.default_rng(50 + n_img + r)
+    props, targets, _ = _batch(oracle, rng, "cuda", n_img=n_img, r=r, n_gt=6)
+    if not logits:
+        for p in props:
+            p.remove("objectness_logits")
+    torch.manual_seed(9)
+    st_a = heads._label_begin(props, targets)
+    torch.manual_seed(9)
+    st_b = heads._label_begin(props, targets)
+    assert ("lean" in st_a) == (r + (6 if append_gt else 0) <= 4096)
+    spec = heads._label_speculate(st_a)
+    assert spec is not None
+    if heads._label_validate(st_a):
+        want = heads._label_finish(st_b)
+        for a, b in zip(spec, want):
+            assert len(a) == len(b) == 64 and list(a.get_fields()) == list(b.get_fields())
+            for k in b.get_fields():
+                va, vb = a.get(k), b.get(k)
+                assert torch.equal(va.tensor if hasattr(va, "tensor") else va, vb.tensor if hasattr(vb, "tensor") else vb), k
+    else:               # (exactly the budget of candidates and some of them ignored: the batch goes the host-driven way)
+        assert r == 64
+        assert all(len(x) <= 64 for x in heads._label_finish(st_a))
+
+
+@pytest.mark.gpu
 def test_sampling_kernel_equals_the_two_global_sorts():
     """locov_sample_proposals against what it replaces -- argsort of the two image-major keys, then per image the first num_pos
     entries of the foreground order and budget - num_pos of the background order -- on images of 16 .. 4 096 proposals (powers of
