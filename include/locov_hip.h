@@ -652,6 +652,20 @@ int locov_winograd_conv3x3_f32_split_ex(const float *x, int64_t R, int Cin, cons
 int locov_winograd_wgrad_f32_split(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags,
                                    const float *row_scale, float *dw, unsigned *overflow, void *workspace,
                                    int64_t workspace_bytes, locov_stream_t stream);
+/* ... with the transformed activation the FORWARD already made: v_split = the first 121 * R * Cin floats of the workspace that
+ * locov_winograd_conv3x3_f32_split[_ex] was given for the same x (split layout x 0.25, one pass: R proposals) -- a training step
+ * that keeps that workspace per bottleneck (roi_emb_heads.py:343-347 under autograd) saves the second input transform, and the TN
+ * GEMMs stage the operand as it is (locov_gemm_tn_f32_split_b).  Cin % 8 == 0.  The same bits as locov_winograd_wgrad_f32_split.
+ *   locov_gemm_tn_f32_split_b : locov_gemm_tn_f32_split whose b is ALREADY in the split layout of locov_split_f16x2_pack at scale
+ *   b_scale (K, ldb, stride_b multiples of 8): transposed on its way into LDS, not converted; the same bits. */
+int locov_winograd_wgrad_f32_split_v(const float *v_split, const float *g, int64_t R, int Cin, int N, unsigned flags,
+                                     const float *row_scale, float *dw, unsigned *overflow, void *workspace,
+                                     int64_t workspace_bytes, locov_stream_t stream);
+int locov_gemm_tn_f32_split_b(const float *a, int64_t lda, int64_t stride_a, const float *b_split, int64_t ldb,
+                              int64_t stride_b, float *out, int64_t ldo, int64_t stride_o, int64_t M, int N,
+                              int K, int batch, const float *row_scale, const float *a_scale_dev,
+                              float b_scale, unsigned *overflow, void *workspace, int64_t workspace_bytes,
+                              locov_stream_t stream);
 /* A bottleneck's first two convolutions in ONE call (roi_emb_heads.py:217-245: conv1 1x1 + FrozenBN + ReLU, then conv2 3x3 + FrozenBN
  * + ReLU?) in split arithmetic:  y = locov_winograd_conv3x3_f32_split_ex(relu(x . W1^T * scale1 + shift1), ...)  -- the same bits as
  * locov_gemm_nt_f32_split (LOCOV_GEMM_A_SPLIT | LOCOV_EPI_RELU) followed by that call, which is what it falls back to.  Where the shapes

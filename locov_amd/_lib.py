@@ -125,9 +125,12 @@ SIGNATURES = {
                                            c_float, _p, _p, _p]),
     "locov_gemm_tn_f32_split": (c_int, [_p, c_int64, c_int64, _p, c_int64, c_int64, _p, c_int64, c_int64, c_int64, c_int, c_int, c_int,
                                         _p, _p, c_float, _p, _p, c_int64, _p]),
+    "locov_gemm_tn_f32_split_b": (c_int, [_p, c_int64, c_int64, _p, c_int64, c_int64, _p, c_int64, c_int64, c_int64, c_int, c_int, c_int,
+                                        _p, _p, c_float, _p, _p, c_int64, _p]),
     "locov_winograd_conv3x3_f32_split_ex": (c_int, [_p, c_int64, c_int, _p, c_float, c_float, c_int, _p, _p, _p, _p, c_int64, c_int,
                                                     c_uint, c_float, _p, c_int64, _p, _p, _p]),
     "locov_winograd_wgrad_f32_split": (c_int, [_p, _p, c_int64, c_int, c_int, c_uint, _p, _p, _p, _p, c_int64, _p]),
+    "locov_winograd_wgrad_f32_split_v": (c_int, [_p, _p, c_int64, c_int, c_int, c_uint, _p, _p, _p, _p, c_int64, _p]),
     "locov_conv1x1_winograd_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
     "locov_conv1x1_winograd_workspace_bytes_for": (c_int64, [c_int64, c_int, c_int, c_int, c_int64]),
     "locov_roi_align_winograd_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),

@@ -114,6 +114,6 @@ int64_t gemm_tn_workspace_bytes(int64_t M, int N, int K, int batch);
 // the same in split-operand arithmetic (gemm_tn_split.hip): a = gradient, scale {s, 1/s} in device memory; b = activation, scale by value
 int launch_gemm_tn_split(const float *A, int64_t lda, int64_t sa, const float *B, int64_t ldb, int64_t sb, float *out, int64_t ldo,
                          int64_t so, int64_t M, int N, int K, int batch, const float *row_scale, const float *a_scale_dev, float b_scale,
-                         unsigned *overflow, float *ws, int64_t ws_bytes, hipStream_t s, const char *what);
+                         unsigned *overflow, float *ws, int64_t ws_bytes, hipStream_t s, const char *what, bool b_split = false);
 
 }  // namespace locov

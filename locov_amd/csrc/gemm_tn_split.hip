@@ -15,6 +15,12 @@
 // layout and XOR swizzle of gemm_split.hip's W tile, so the fragment reads (lane l: row l%16, m-group l/16) are its
 // conflict-free ones.  128x128 output tile, 4 waves x 64x64 = 4x4 blocks, two LDS stages (64 KB), two workgroups per CU;
 // M is cut into chunks as in gemm_tn.hip and the partial tiles are reduced in a fixed order by gemm_tn_reduce_kernel.
+//
+// B_SPLIT: b is ALREADY in the split layout of locov_split_f16x2_pack at scale b_scale (the Winograd-domain input V the forward's
+// transform wrote for its own GEMMs: the weight gradient of a 3x3 convolution re-uses it instead of transforming the activation a
+// second time).  The waves that stage b then load the hi and lo halves of their 8 (m) x 4 (columns) block directly (two 8-byte
+// loads per row) and only transpose -- 32 v_perm_b32 instead of 64 v_fma_mix + 32 v_max -- writing the same LDS bytes the
+// converting path would have produced from the fp32 values: the result is bit-identical.
 #include "gemm_nt.h"
 
 namespace locov {
@@ -24,6 +30,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SBM = 128, SBN = 128, SBK = 32, SNT = 256;
 constexpr int SROWB = 128;                         // bytes per LDS row (32 m: 4 groups x (8 hi + 8 lo) halves)
@@ -52,6 +59,7 @@ __device__ __forceinline__ void split2(float x0, float x1, float s, unsigned &hi
 
 }  // namespace
 
+template <bool B_SPLIT>
 __global__ __launch_bounds__(SNT, 2) void gemm_tn_split_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                                                                int64_t ldb, float *__restrict__ P, int64_t M, int N, int K,
                                                                int splits, int64_t m_chunk, int64_t sa, int64_t sb,
@@ -88,7 +96,9 @@ __global__ __launch_bounds__(SNT, 2) void gemm_tn_split_kernel(const float *__re
     col = col + 4 <= ncol ? col : ncol - 4;                            // clamped columns only feed outputs that are never stored
     const char *base = reinterpret_cast<const char *>((is_a ? A + b * sa : B + b * sb) + m_lo * (int64_t)ld);
     int64_t left = rows * (int64_t)ld * 4;                             // bytes from the running base to the chunk's end
-    const unsigned voff = (unsigned)(((int64_t)(mg * 8) * ld + col) * 4);
+    // (B_SPLIT, the b half: the 4 columns' hi halves sit at byte (col / 8) * 32 + (col % 8) * 2 of the row, their lo halves 16 bytes on)
+    const bool pre = B_SPLIT && !is_a;
+    const unsigned voff = (unsigned)((int64_t)(mg * 8) * ld * 4 + (pre ? (col >> 3) * 32 + (col & 4) * 2 : col * 4));
     const unsigned rstep = (unsigned)ld * 4u;
     const float scale = is_a ? a_scale : b_scale;
     // LDS destination of column j (row cg*4 + j of this operand's tile), chunk 2*mg (hi) / 2*mg + 1 (lo), XOR-swizzled
@@ -104,10 +114,37 @@ __global__ __launch_bounds__(SNT, 2) void gemm_tn_split_kernel(const float *__re
     auto load = [&]() {
         const unsigned nrec = left > 0 ? (unsigned)left : 0u;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, nrec, 0x00020000);
+        if (B_SPLIT && pre) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + i * rstep, 0, 0));
+            for (int i = 0; i < 8; i++) {
+                const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff + i * rstep, 0, 0));
+                const u32x2 l = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff + i * rstep + 16, 0, 0));
+                r[i] = __builtin_bit_cast(f32x4, u32x4{h[0], h[1], l[0], l[1]});
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + i * rstep, 0, 0));
+        }
         base += (int64_t)SBK * ld * 4;
         left -= (int64_t)SBK * ld * 4;
+    };
+    // B_SPLIT, the b half: r[m] = {hi halves of columns 0-1, 2-3, lo halves of columns 0-1, 2-3} of row m; column j's chunk pairs
+    // the halves of consecutive m (v_perm_b32: selector bytes 0-3 address the second source, 4-7 the first)
+    auto store_pre = [&](int stage) {
+        char *d = ldsb + stage * SSTAGEB;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            u32x4 hi, lo;
+            const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const u32x4 e = __builtin_bit_cast(u32x4, r[2 * p]), o = __builtin_bit_cast(u32x4, r[2 * p + 1]);
+                hi[p] = __builtin_amdgcn_perm(o[j >> 1], e[j >> 1], sel);
+                lo[p] = __builtin_amdgcn_perm(o[2 + (j >> 1)], e[2 + (j >> 1)], sel);
+            }
+            *reinterpret_cast<u32x4 *>(d + dst[j][0]) = hi;
+            *reinterpret_cast<u32x4 *>(d + dst[j][1]) = lo;
+        }
     };
     auto store = [&](int stage) {
         char *d = ldsb + stage * SSTAGEB;
@@ -161,7 +198,10 @@ __global__ __launch_bounds__(SNT, 2) void gemm_tn_split_kernel(const float *__re
 
     const int steps = (int)((rows + SBK - 1) / SBK);
     load();
-    store(0);
+    if (pre)
+        store_pre(0);
+    else
+        store(0);
     if (steps > 1) load();
     __syncthreads();
 #ifndef LOCOV_TNS_INTERLEAVE
@@ -171,6 +211,31 @@ __global__ __launch_bounds__(SNT, 2) void gemm_tn_split_kernel(const float *__re
     // steady state: the K-tile's 48 MFMAs and the conversion of the NEXT tile (64 v_fma_mix + 32 max, then 8 LDS writes) in ONE
     // scheduling region, interleaved 1 : 2 -- the conversion then runs on the vector ALU while the wave's own MFMAs occupy the
     // matrix pipe, instead of behind them
+    if (pre) {
+        // (B_SPLIT, the waves that stage b: the same loop in its own scheduling region -- 32 v_perm_b32 under the 48 MFMAs)
+        for (; tt + 2 < steps; tt++) {
+            const int st = tt & 1;
+            compute(st);
+            store_pre(st ^ 1);
+            if (LOCOV_TNS_INTERLEAVE) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+                for (int i = 0; i < 48; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+            }
+            load();
+            __syncthreads();
+        }
+        for (; tt < steps; tt++) {
+            const int st = tt & 1;
+            compute(st);
+            if (tt + 1 < steps) store_pre(st ^ 1);
+            __syncthreads();
+        }
+    } else {
     for (; tt + 2 < steps; tt++) {
         const int st = tt & 1;
         compute(st);
@@ -192,6 +257,7 @@ __global__ __launch_bounds__(SNT, 2) void gemm_tn_split_kernel(const float *__re
         compute(st);
         if (tt + 1 < steps) store(st ^ 1);
         __syncthreads();
+    }
     }
     if (overflow != nullptr && amax * scale >= 65504.f) atomicOr(overflow, 1u);
 
@@ -217,7 +283,7 @@ int launch_tn_reduce(const float *ws, int N, int K, int splits, int batch, const
 
 int launch_gemm_tn_split(const float *A, int64_t lda, int64_t sa, const float *B, int64_t ldb, int64_t sb, float *out, int64_t ldo,
                          int64_t so, int64_t M, int N, int K, int batch, const float *row_scale, const float *a_scale_dev, float b_scale,
-                         unsigned *overflow, float *ws, int64_t ws_bytes, hipStream_t s, const char *what)
+                         unsigned *overflow, float *ws, int64_t ws_bytes, hipStream_t s, const char *what, bool b_split)
 {
     int splits;
     int64_t m_chunk;
@@ -237,8 +303,14 @@ int launch_gemm_tn_split(const float *A, int64_t lda, int64_t sa, const float *B
     // proposals): the "partial" tiles ARE the result -- written straight to `out`, no reduction pass (it was a 127 MB copy per launch)
     const bool direct = splits == 1 && row_scale == nullptr && ldo == K && (batch == 1 || so == (int64_t)N * K);
     const int trec = timing_begin(s, 7, 2.0 * (double)M * N * K * batch);        // class 7: split-operand TN GEMM
-    hipLaunchKernelGGL(gemm_tn_split_kernel, dim3((unsigned)wgs), dim3(SNT), 0, s, A, lda, B, ldb, direct ? out : ws, M, N, K, splits, m_chunk, sa, sb,
-                       a_scale_dev, b_scale, overflow);
+    if (b_split) {
+        // (the split layout is written in groups of 8 columns; a chunk of M starts at a row, so any m_chunk is fine)
+        if (K % 8 || ldb % 8 || sb % 8) return set_error(LOCOV_ERR_UNSUPPORTED, "%s: a pre-split b needs K, ldb and its batch stride to be multiples of 8", what);
+        hipLaunchKernelGGL(gemm_tn_split_kernel<true>, dim3((unsigned)wgs), dim3(SNT), 0, s, A, lda, B, ldb, direct ? out : ws, M, N, K, splits, m_chunk, sa,
+                           sb, a_scale_dev, b_scale, overflow);
+    } else
+        hipLaunchKernelGGL(gemm_tn_split_kernel<false>, dim3((unsigned)wgs), dim3(SNT), 0, s, A, lda, B, ldb, direct ? out : ws, M, N, K, splits, m_chunk, sa,
+                           sb, a_scale_dev, b_scale, overflow);
     timing_end(trec, s);
     int rc = check_launch(what);
     if (rc || direct) return rc;
@@ -260,7 +332,19 @@ int locov_gemm_tn_f32_split(const float *a, int64_t lda, int64_t stride_a, const
     LOCOV_REQUIRE(a && b && out && workspace && a_scale_dev, "locov_gemm_tn_f32_split: null pointer");
     LOCOV_REQUIRE(lda >= N && ldb >= K && ldo >= K, "locov_gemm_tn_f32_split: lda < N, ldb < K or ldo < K");
     return launch_gemm_tn_split(a, lda, stride_a, b, ldb, stride_b, out, ldo, stride_o, M, N, K, batch, row_scale, a_scale_dev, b_scale,
-                                overflow, static_cast<float *>(workspace), workspace_bytes, as_stream(stream), "locov_gemm_tn_f32_split");
+                                overflow, static_cast<float *>(workspace), workspace_bytes, as_stream(stream), "locov_gemm_tn_f32_split", false);
+}
+
+int locov_gemm_tn_f32_split_b(const float *a, int64_t lda, int64_t stride_a, const float *b_split, int64_t ldb, int64_t stride_b, float *out,
+                              int64_t ldo, int64_t stride_o, int64_t M, int N, int K, int batch, const float *row_scale,
+                              const float *a_scale_dev, float b_scale, unsigned *overflow, void *workspace, int64_t workspace_bytes,
+                              locov_stream_t stream)
+{
+    LOCOV_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "locov_gemm_tn_f32_split_b: bad shape M=%lld N=%d K=%d batch=%d", (long long)M, N, K, batch);
+    LOCOV_REQUIRE(a && b_split && out && workspace && a_scale_dev, "locov_gemm_tn_f32_split_b: null pointer");
+    LOCOV_REQUIRE(lda >= N && ldb >= K && ldo >= K, "locov_gemm_tn_f32_split_b: lda < N, ldb < K or ldo < K");
+    return launch_gemm_tn_split(a, lda, stride_a, b_split, ldb, stride_b, out, ldo, stride_o, M, N, K, batch, row_scale, a_scale_dev, b_scale,
+                                overflow, static_cast<float *>(workspace), workspace_bytes, as_stream(stream), "locov_gemm_tn_f32_split_b", true);
 }
 
 }  // extern "C"

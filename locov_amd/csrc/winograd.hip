@@ -571,7 +571,8 @@ int64_t locov_winograd_wgrad_workspace_bytes(int64_t R, int Cin, int N)
 }
 
 static int winograd_wgrad(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags, const float *row_scale,
-                          float *dw, void *workspace, int64_t workspace_bytes, locov_stream_t stream, bool split, unsigned *overflow);
+                          float *dw, void *workspace, int64_t workspace_bytes, locov_stream_t stream, bool split, unsigned *overflow,
+                          const float *v_split = nullptr);
 
 int locov_winograd_wgrad_f32(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags, const float *row_scale,
                              float *dw, void *workspace, int64_t workspace_bytes, locov_stream_t stream)
@@ -585,8 +586,19 @@ int locov_winograd_wgrad_f32_split(const float *x, const float *g, int64_t R, in
     return winograd_wgrad(x, g, R, Cin, N, flags, row_scale, dw, workspace, workspace_bytes, stream, true, overflow);
 }
 
+int locov_winograd_wgrad_f32_split_v(const float *v_split, const float *g, int64_t R, int Cin, int N, unsigned flags, const float *row_scale,
+                                     float *dw, unsigned *overflow, void *workspace, int64_t workspace_bytes, locov_stream_t stream)
+{
+    LOCOV_REQUIRE(v_split != nullptr || R == 0, "locov_winograd_wgrad_f32_split_v: null transformed input");
+    LOCOV_REQUIRE(Cin % 8 == 0, "locov_winograd_wgrad_f32_split_v: Cin must be a multiple of 8 (got %d)", Cin);
+    return winograd_wgrad(v_split, g, R, Cin, N, flags, row_scale, dw, workspace, workspace_bytes, stream, true, overflow, v_split);
+}
+
+// v_split: the forward's transformed input (wino_input_kernel<false, true>: [121][R][Cin] in the split layout at scale 0.25) kept by the
+// caller -- x is then not transformed again and the TN GEMMs stage it as it is (gemm_tn_split.hip, B_SPLIT: the same bits)
 static int winograd_wgrad(const float *x, const float *g, int64_t R, int Cin, int N, unsigned flags, const float *row_scale,
-                          float *dw, void *workspace, int64_t workspace_bytes, locov_stream_t stream, bool split, unsigned *overflow)
+                          float *dw, void *workspace, int64_t workspace_bytes, locov_stream_t stream, bool split, unsigned *overflow,
+                          const float *v_split)
 {
     LOCOV_REQUIRE(R >= 0 && Cin > 0 && N > 0, "locov_winograd_wgrad_f32: bad shape");
     LOCOV_REQUIRE(dw, "locov_winograd_wgrad_f32: null output");
@@ -607,9 +619,13 @@ static int winograd_wgrad(const float *x, const float *g, int64_t R, int Cin, in
     float *tn_ws = dU + (int64_t)NF * NF * N * Cin;
     const bool rm = (flags & LOCOV_WINO_IN_ROI_MAJOR) != 0;
     const int64_t ld_pos = rm ? 1 : R, ld_roi = rm ? 49 : 1;
-    hipLaunchKernelGGL(wino_input_kernel<false>, dim3((unsigned)ceil_div(R * (Cin / 2), 256)), dim3(256), 0, s, x, ld_pos, ld_roi, R, Cin, V);
-    int rc = check_launch("locov_winograd_wgrad_f32 (input transform)");
-    if (rc) return rc;
+    int rc = LOCOV_OK;
+    if (v_split == nullptr) {
+        hipLaunchKernelGGL(wino_input_kernel<false>, dim3((unsigned)ceil_div(R * (Cin / 2), 256)), dim3(256), 0, s, x, ld_pos, ld_roi, R, Cin, V);
+        rc = check_launch("locov_winograd_wgrad_f32 (input transform)");
+        if (rc) return rc;
+    } else
+        LOCOV_REQUIRE((uintptr_t)v_split % 16 == 0, "locov_winograd_wgrad_f32_split_v: misaligned transformed input");
     float *dm_slot = split ? reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_bytes - 16) : nullptr;
     if (dm_slot && hipMemsetAsync(dm_slot, 0, 16, s) != hipSuccess) return set_error(LOCOV_ERR_LAUNCH, "locov_winograd_wgrad_f32_split: memset failed");
     hipLaunchKernelGGL(wino_input_kernel<true>, dim3((unsigned)ceil_div(R * (N / 2), 256)), dim3(256), 0, s, g, ld_pos, ld_roi, R, N, dM, 1.f,
@@ -622,8 +638,9 @@ static int winograd_wgrad(const float *x, const float *g, int64_t R, int Cin, in
         // operand scales: dM from its max |.| on the device (last 16 bytes of the workspace), V as in the forward (0.25)
         // operand scales: dM from the max |.| its transform folded into the slot, V as in the forward (0.25)
         float *sc = dm_slot;
-        rc = launch_gemm_tn_split(dM, (int64_t)N, R * N, V, (int64_t)Cin, R * Cin, dU, (int64_t)Cin, (int64_t)N * Cin, R, N, Cin, NF * NF,
-                                  nullptr, sc, 0.25f, overflow, tn_ws, tn_bytes, s, "locov_winograd_wgrad_f32_split (batched TN GEMM)");
+        rc = launch_gemm_tn_split(dM, (int64_t)N, R * N, v_split ? v_split : V, (int64_t)Cin, R * Cin, dU, (int64_t)Cin, (int64_t)N * Cin, R, N, Cin,
+                                  NF * NF, nullptr, sc, 0.25f, overflow, tn_ws, tn_bytes, s, "locov_winograd_wgrad_f32_split (batched TN GEMM)",
+                                  v_split != nullptr);
     } else
         rc = launch_gemm_tn(dM, (int64_t)N, R * N, V, (int64_t)Cin, R * Cin, dU, (int64_t)Cin, (int64_t)N * Cin, R, N, Cin, NF * NF, nullptr,
                             tn_ws, tn_bytes, s, "locov_winograd_wgrad_f32 (batched TN GEMM)");

@@ -339,7 +339,7 @@ def winograd_pack_weight(w: torch.Tensor) -> torch.Tensor:
 def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool = False,
                      out: Optional[torch.Tensor] = None, v_scale: float = 0.25, roi_major: bool = False,
                      in_roi_major: bool = False, out_split_scale: Optional[float] = None,
-                     range_check_scale: Optional[float] = None) -> torch.Tensor:
+                     range_check_scale: Optional[float] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """3x3 / pad 1 / stride 1 convolution of 7x7 position-major tiles in the Winograd domain.
     x [49*R, Cin] (row = pos*R + r), U [121, N, Cin] (winograd_pack_weight) -> [49*R, N].
     out: optional [49*R, N] destination whose rows may be a column block of a wider matrix.
@@ -352,7 +352,10 @@ def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool =
     pre-split A operand (`x_is_split`) of the split GEMM that consumes it, which then stages it by LDS DMA with no conversion.
     The returned tensor is float32-TYPED storage of that layout (same shape and size), not fp32 values.
     range_check_scale (split U, fp32 output): raise the range guard here when |range_check_scale * y| >= 65504 -- the check the
-    split GEMM reading y at that operand scale would make, one launch earlier."""
+    split GEMM reading y at that operand scale would make, one launch earlier.
+    workspace: a caller-owned uint8 device buffer of at least winograd_workspace_bytes(R, Cin, N) bytes instead of the cached one; with
+    a split U it starts with the transformed input [121, R, Cin] in the split layout x v_scale, which winograd_wgrad(v_split=...)
+    takes as it is (a training step keeps one per bottleneck)."""
     x = _dev(x, "x")
     split = U if isinstance(U, SplitWeight) else None
     U = _dev(split.data if split is not None else U, "U")
@@ -372,12 +375,18 @@ def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool =
     ldy = y.stride(0) if M else N
     lib = _lib.load()
     need = int(lib.locov_winograd_workspace_bytes(R, Cin, N))
-    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
-    ws = _WINO_WS.get(key)
-    if ws is None or ws.numel() < need:
-        ws = None
-        _WINO_WS.pop(key, None)
-        ws = _WINO_WS[key] = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+    if workspace is not None:
+        ws = workspace
+        if not (ws.is_cuda and ws.device == x.device and ws.dtype == torch.uint8 and ws.is_contiguous() and ws.numel() >= need
+                and ws.data_ptr() % 16 == 0):
+            raise ValueError(f"winograd_conv3x3: workspace must be a contiguous uint8 device buffer of >= {need} bytes")
+    else:
+        key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+        ws = _WINO_WS.get(key)
+        if ws is None or ws.numel() < need:
+            ws = None
+            _WINO_WS.pop(key, None)
+            ws = _WINO_WS[key] = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
     wflags = ((_lib.EPI_RELU if relu else 0) | (_lib.WINO_OUT_ROI_MAJOR if roi_major else 0)
               | (_lib.WINO_IN_ROI_MAJOR if in_roi_major else 0))
     with torch.cuda.device(x.device):
@@ -397,6 +406,11 @@ def winograd_conv3x3(x: torch.Tensor, U, *, scale=None, shift=None, relu: bool =
                                                  wflags, _ptr(ws), ws.numel(), _stream(x)),
                   "locov_winograd_conv3x3_f32")
     return y
+
+
+def winograd_workspace_bytes(R: int, Cin: int, N: int) -> int:
+    """Bytes of the workspace winograd_conv3x3 needs for R tiles (locov_winograd_workspace_bytes)."""
+    return int(_lib.load().locov_winograd_workspace_bytes(int(R), int(Cin), int(N)))
 
 
 def conv1x1_winograd_conv3x3(x: torch.Tensor, w1: SplitWeight, b1: Optional[torch.Tensor], U: SplitWeight, *,
@@ -880,21 +894,30 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, row_scale: Optional[torch.Tensor] 
 
 
 def winograd_wgrad(x: torch.Tensor, g: torch.Tensor, row_scale: Optional[torch.Tensor] = None,
-                   roi_major: bool = True, split: bool = False) -> torch.Tensor:
+                   roi_major: bool = True, split: bool = False, v_split: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dw [N,Cin,3,3] = row_scale[n] * d/dw of conv3x3(x) . g over R 7x7 tiles, in the Winograd domain.
-    x [49*R, Cin], g [49*R, N], both in the same row order.  split: the 121 TN GEMMs in split-operand arithmetic."""
+    x [49*R, Cin], g [49*R, N], both in the same row order.  split: the 121 TN GEMMs in split-operand arithmetic.
+    v_split (split only): the workspace winograd_conv3x3(x, SplitWeight, workspace=...) was given in the forward -- it starts with
+    the transformed x in the split layout, which is then not computed again (same bits)."""
     x, g = _dev(x, "x"), _dev(g, "g")
     M, Cin = x.shape
     N = g.shape[1]
     if g.shape[0] != M or M % 49 or Cin % 4 or N % 4:
         raise ValueError("winograd_wgrad: inconsistent shapes")
     R = M // 49
+    if v_split is not None and not (split and R > 0 and Cin % 8 == 0 and v_split.is_cuda and v_split.device == x.device
+                                    and v_split.numel() * v_split.element_size() >= 121 * R * Cin * 4 and v_split.data_ptr() % 16 == 0):
+        raise ValueError("winograd_wgrad: v_split needs the split arithmetic, Cin % 8 == 0 and the forward's workspace of the same x")
     row_scale = _dev(row_scale, "row_scale") if row_scale is not None else None
     dw = torch.empty((N, Cin, 3, 3), dtype=torch.float32, device=x.device)
     lib = _lib.load()
     ws = _workspace("wino_wgrad", x, int(lib.locov_winograd_wgrad_workspace_bytes(R, Cin, N)))
     with torch.cuda.device(x.device):
-        if split and R > 0:
+        if v_split is not None:
+            check(lib.locov_winograd_wgrad_f32_split_v(_ptr(v_split), _ptr(g), R, Cin, N, _lib.WINO_IN_ROI_MAJOR if roi_major else 0,
+                                                       _ptr(row_scale), _ptr(dw), _ptr(_overflow_word(x)), _ptr(ws), ws.numel(),
+                                                       _stream(x)), "locov_winograd_wgrad_f32_split_v")
+        elif split and R > 0:
             check(lib.locov_winograd_wgrad_f32_split(_ptr(x), _ptr(g), R, Cin, N, _lib.WINO_IN_ROI_MAJOR if roi_major else 0,
                                                      _ptr(row_scale), _ptr(dw), _ptr(_overflow_word(x)), _ptr(ws), ws.numel(),
                                                      _stream(x)), "locov_winograd_wgrad_f32_split")
@@ -996,22 +1019,24 @@ def linear_split_ex(x: torch.Tensor, weight: SplitWeight, bias: Optional[torch.T
 
 
 def gemm_tn_split(a: torch.Tensor, b: torch.Tensor, row_scale: Optional[torch.Tensor], a_scale_dev: torch.Tensor,
-                  b_scale: float = 16.0) -> torch.Tensor:
+                  b_scale: float = 16.0, b_is_split: bool = False) -> torch.Tensor:
     """gemm_tn() in split-operand arithmetic: a (gradient) scaled by a_scale_dev[0] (split_scale_from_amax), b (activation)
-    by b_scale."""
+    by b_scale.  b_is_split: b is float32-typed storage of the split layout at that scale (split_pack / out_split), K % 8 == 0:
+    transposed on its way into LDS instead of converted -- the same bits."""
     a, b = _rows(a, "a"), _rows(b, "b")
     M, N = a.shape
     K = b.shape[1]
-    if b.shape[0] != M or N % 4 or K % 4 or M == 0:
-        raise ValueError(f"gemm_tn_split: a {tuple(a.shape)} b {tuple(b.shape)} (N, K multiples of 4, M > 0)")
+    if b.shape[0] != M or N % 4 or K % 4 or M == 0 or (b_is_split and (K % 8 or b.stride(0) % 8)):
+        raise ValueError(f"gemm_tn_split: a {tuple(a.shape)} b {tuple(b.shape)} (N, K multiples of 4 -- 8 for a pre-split b --, M > 0)")
     row_scale = _dev(row_scale, "row_scale") if row_scale is not None else None
     out = torch.empty((N, K), dtype=torch.float32, device=a.device)
     lib = _lib.load()
     ws = _workspace("tn", a, int(lib.locov_gemm_tn_workspace_bytes(M, N, K, 1)))
     with torch.cuda.device(a.device):
-        check(lib.locov_gemm_tn_f32_split(_ptr(a), a.stride(0), 0, _ptr(b), b.stride(0), 0, _ptr(out), K, 0, M, N, K, 1, _ptr(row_scale),
-                                          _ptr(a_scale_dev), float(b_scale), _ptr(_overflow_word(a)), _ptr(ws), ws.numel(), _stream(a)),
-              "locov_gemm_tn_f32_split")
+        fn = lib.locov_gemm_tn_f32_split_b if b_is_split else lib.locov_gemm_tn_f32_split
+        check(fn(_ptr(a), a.stride(0), 0, _ptr(b), b.stride(0), 0, _ptr(out), K, 0, M, N, K, 1, _ptr(row_scale),
+                 _ptr(a_scale_dev), float(b_scale), _ptr(_overflow_word(a)), _ptr(ws), ws.numel(), _stream(a)),
+              "locov_gemm_tn_f32_split_b" if b_is_split else "locov_gemm_tn_f32_split")
     return out
 
 

@@ -48,6 +48,7 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return st
 
 
+_KEEP_V = bool(int(os.environ.get("LOCOV_RES5_KEEP_V", "1")))               # the forward's Winograd-domain input kept for the weight gradient (0: transformed again)
 _NO_WINO_BWD = bool(int(os.environ.get("LOCOV_RES5_BWD_DIRECT", "0")))      # developer A/B: 3x3 gradients in the direct form
 _BWD_F32 = bool(int(os.environ.get("LOCOV_RES5_BWD_F32", "0")))              # developer A/B: backward GEMMs on the f32 MFMA
 
@@ -106,6 +107,9 @@ class Res5Step:
         # activations the backward needs as masks and as weight-gradient operands
         self.act = [(new(b.conv1.out_channels), new(b.conv2.out_channels), new(b.conv3.out_channels)) for b in stage]
         self.cols = {}                                # (block, segment index) -> im2col patches of y1 (general-grid segments)
+        # (block, segment index) -> the workspace of that 3x3 convolution's Winograd-domain forward (split arithmetic): it starts
+        # with the transformed y1 in the split layout, which the weight gradient's TN GEMMs take as it is
+        self.wino_ws = {}
 
     def input_rows(self, rows: int) -> torch.Tensor:
         """Where the producer of the NEXT segment's stage input writes it (several segments may be reserved before one forward)."""
@@ -169,8 +173,12 @@ class Res5Step:
                     u2 = T.get(c2, "wino")
                     early = (on_range_final is not None and last and blk.shortcut is None
                              and isinstance(u2, ops.SplitWeight) and isinstance(w3, ops.SplitWeight))
+                    keep = None
+                    if _KEEP_V and isinstance(u2, ops.SplitWeight) and c2.in_channels % 8 == 0 and seg.n > 0:
+                        keep = self.wino_ws[(bi, si)] = torch.empty(
+                            ops.winograd_workspace_bytes(seg.n, c2.in_channels, c2.out_channels), dtype=torch.uint8, device=self.device)
                     ops.winograd_conv3x3(Y1[sl], u2, scale=s2, shift=b2, relu=True, roi_major=True, in_roi_major=True, out=Y2[sl],
-                                         range_check_scale=16.0 if early else None)
+                                         range_check_scale=16.0 if early else None, workspace=keep)
                     if early:
                         on_range_final()
                         on_range_final = None
@@ -371,7 +379,7 @@ class Res5RowsFn(torch.autograd.Function):
                   part = None
                   if need_w[wi + 1]:
                     if wino and c2.out_channels % 4 == 0 and not _NO_WINO_BWD:
-                        part = ops.winograd_wgrad(y1[sl], g2[sl], s2, roi_major=True, split=sp)
+                        part = ops.winograd_wgrad(y1[sl], g2[sl], s2, roi_major=True, split=sp, v_split=step.wino_ws.get((bi, si)) if sp else None)
                     else:
                         colw = step.cols.get((bi, si))
                         if colw is None:

@@ -32,7 +32,7 @@ def test_every_symbol_is_exported(lib):
     for name in _declared():
         assert hasattr(lib, name), name
     from locov_amd import _lib
-    assert lib.locov_abi_version() == _lib.ABI_VERSION == 7        # 2: range-guard word on the split entry points; 3: amax_out slots; 4: locov_zero_if_raised, exact fused workspaces, timing_read_ex; 5: locov_box_reg_loss, locov_grounding_ce_fwd / _bwd; 6: locov_res5_weight_prep, locov_gemm_segmean_supported; 7: locov_sample_proposals
+    assert lib.locov_abi_version() == _lib.ABI_VERSION == 7        # 2: range-guard word on the split entry points; 3: amax_out slots; 4: locov_zero_if_raised, exact fused workspaces, timing_read_ex; 5: locov_box_reg_loss, locov_grounding_ce_fwd / _bwd; 6: locov_res5_weight_prep, locov_gemm_segmean_supported; 7: locov_sample_proposals, locov_gemm_tn_f32_split_b, locov_winograd_wgrad_f32_split_v
 
 
 def test_argument_errors_are_reported_without_a_gpu(lib):
@@ -90,6 +90,22 @@ def test_sample_proposals_validates_its_arguments(lib):
     big = (ctypes.c_int * 2)(0, _lib.SAMPLE_MAX_PROPOSALS + 1)
     assert lib.locov_sample_proposals(*none, big, off, 1, 16, 4, 80, *outs, None) == -1 and b"proposals per image" in lib.locov_last_error()
     assert lib.locov_sample_proposals(*none, off, off, 1, 16, 4, 80, *outs, None) == -1 and b"null pointer" in lib.locov_last_error()
+
+
+def test_presplit_weight_gradient_entry_points_validate_their_arguments(lib):
+    """locov_gemm_tn_f32_split_b / locov_winograd_wgrad_f32_split_v: argument errors before any HIP call."""
+    import ctypes
+    p = ctypes.c_void_p
+    assert lib.locov_gemm_tn_f32_split_b(None, 64, 0, None, 64, 0, None, 64, 0, 100, 64, 64, 1, None, None, 16.0, None, None, 0, None) == -1
+    assert b"null pointer" in lib.locov_last_error()
+    assert lib.locov_gemm_tn_f32_split_b(p(256), 64, 0, p(512), 32, 0, p(1024), 64, 0, 100, 64, 64, 1, None, p(2048), 16.0, None, p(4096), 1 << 30, None) == -1
+    assert b"ldb < K" in lib.locov_last_error()
+    assert lib.locov_gemm_tn_f32_split_b(p(256), 64, 0, p(512), 68, 0, p(1024), 64, 0, 100, 64, 60, 1, None, p(2048), 16.0, None, p(4096), 1 << 30, None) < 0
+    assert b"multiples of 8" in lib.locov_last_error()
+    assert lib.locov_winograd_wgrad_f32_split_v(None, p(256), 10, 64, 64, 0, None, p(512), None, p(1024), 1 << 30, None) == -1
+    assert b"null transformed input" in lib.locov_last_error()
+    assert lib.locov_winograd_wgrad_f32_split_v(p(256), p(512), 10, 36, 64, 0, None, p(1024), None, p(2048), 1 << 30, None) == -1
+    assert b"multiple of 8" in lib.locov_last_error()
 
 
 def test_cpu_tensors_are_rejected_loudly():

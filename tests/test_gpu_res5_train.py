@@ -909,6 +909,83 @@ def test_gemm_tn_split_vs_float64(pkg, M, N, K):
     ops.split_overflow_reset(a.device)
 
 
+@pytest.mark.parametrize("M,N,K,scale", [(1000, 128, 128, 16.0), (777, 64, 96, 0.25), (4097, 256, 160, 16.0), (39200, 512, 256, 0.25), (31, 4, 2048, 16.0)])
+def test_gemm_tn_split_with_a_presplit_operand_is_the_same_bits(pkg, M, N, K, scale):
+    """locov_gemm_tn_f32_split_b: the activation operand handed over in the split layout (what a producer's epilogue or the forward's
+    Winograd input transform wrote) is transposed on its way into LDS instead of converted -- the result equals the converting
+    launch's bit for bit, for ragged M chunks, N / K below and above a tile, and both operand scales."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(M + K)
+    a = (torch.randn(M, N, generator=g) * 1e-5).cuda()
+    b = (torch.randn(M, K, generator=g) * (3.0 if scale == 16.0 else 90.0)).cuda()
+    s = (torch.rand(N, generator=g) + 0.5).cuda()
+    sc = ops.split_scale_from_amax(a)
+    want = ops.gemm_tn_split(a, b, s, sc, scale)
+    bs = ops.split_pack(b, scale)
+    assert bs.scale == scale and bs.data.shape == b.shape
+    ops.split_overflow_reset(a.device)
+    got = ops.gemm_tn_split(a, bs.data, s, sc, scale, b_is_split=True)
+    assert not ops.split_overflow_raised(a.device)
+    assert torch.equal(got, want)
+    assert torch.equal(ops.gemm_tn_split(a, bs.data, None, sc, scale, b_is_split=True), ops.gemm_tn_split(a, b, None, sc, scale))
+    with pytest.raises(ValueError):
+        ops.gemm_tn_split(a, b[:, :4].contiguous(), None, sc, scale, b_is_split=True)          # K % 8
+
+
+@pytest.mark.parametrize("R,Cin,N", [(70, 64, 64), (300, 128, 96), (800, 512, 512)])
+def test_winograd_weight_gradient_from_the_forwards_transformed_input(pkg, R, Cin, N):
+    """The 3x3 convolution's weight gradient with the Winograd-domain input the FORWARD wrote (the head of its workspace, split
+    layout x 0.25) instead of a second input transform: the same bits."""
+    ops = pkg.ops
+    gen = torch.Generator().manual_seed(R + 5)
+    x = torch.relu(torch.randn(R * 49, Cin, generator=gen)).cuda() * 2.0
+    w = (torch.randn(N, Cin, 3, 3, generator=gen) * 0.05).cuda()
+    gy = (torch.randn(R * 49, N, generator=gen) * 2e-5).cuda()
+    s = (torch.rand(N, generator=gen) + 0.5).cuda()
+    U = ops.split_pack(ops.winograd_pack_weight(w))
+    ws = torch.empty(ops.winograd_workspace_bytes(R, Cin, N), dtype=torch.uint8, device="cuda")
+    y_kept = ops.winograd_conv3x3(x, U, relu=True, roi_major=True, in_roi_major=True, workspace=ws)
+    y = ops.winograd_conv3x3(x, U, relu=True, roi_major=True, in_roi_major=True)
+    assert torch.equal(y_kept, y)
+    want = ops.winograd_wgrad(x, gy, s, roi_major=True, split=True)
+    got = ops.winograd_wgrad(x, gy, s, roi_major=True, split=True, v_split=ws)
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        ops.winograd_wgrad(x, gy, s, roi_major=True, split=False, v_split=ws)
+    with pytest.raises(ValueError):
+        ops.winograd_conv3x3(x, U, roi_major=True, in_roi_major=True, workspace=ws[:1000])
+
+
+def test_training_step_with_the_kept_transformed_input_is_the_same_bits(pkg, oracle, monkeypatch):
+    """One joint LSM-shaped Res5 step (whole grid + proposals) with the forward's Winograd-domain inputs kept for the weight gradients
+    (default) and with the second transform (LOCOV_RES5_KEEP_V=0): every output and gradient equal bit for bit, and the kept path is taken."""
+    from locov_amd import res5_train
+    R, (in_ch, mid, out_ch) = 21, (128, 64, 256)
+    outs = {}
+    for keep in (True, False):
+        monkeypatch.setattr(res5_train, "_KEEP_V", keep)
+        res5, params = _stage(pkg, oracle, in_ch, mid, out_ch, seed=8)
+        gen = torch.Generator().manual_seed(29)
+        N, H, W = 2, 26, 43
+        feat = torch.randn(N, in_ch, H, W, generator=gen).cuda().requires_grad_(True)
+        wh = torch.rand(R, 2, generator=gen) * 300 + 30
+        xy = torch.rand(R, 2, generator=gen) * 300
+        rois = torch.cat([torch.randint(0, N, (R, 1), generator=gen).float(), xy, xy + wh], dim=1).cuda()
+        nhwc = res5_train.to_nhwc(feat)
+        st = res5_train.Res5Step(res5, True, feat.device, N * 13 * 22 + 49 * R)
+        rows = res5_train.grid_segment(st, nhwc)
+        x0 = res5_train.roi_segment(st, nhwc, rois, 14, 1.0 / 16, 0, True)
+        assert len(st.wino_ws) == (3 if keep else 0)
+        grid, box = st.outputs([rows, x0], [False, True])
+        (grid.square().mean() + box.sum()).backward()
+        torch.cuda.synchronize()
+        named = dict(res5.named_parameters())
+        outs[keep] = (grid.detach().clone(), box.detach().clone(), {k: named[k].grad.clone() for k in _weight_keys(params)})
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    for k in outs[True][2]:
+        assert torch.equal(outs[True][2][k], outs[False][2][k]), k
+
+
 def test_linear_split_ex_mask_and_device_scale(pkg):
     ops = pkg.ops
     g = torch.Generator().manual_seed(9)
