@@ -32,6 +32,7 @@ import os
 _OUT_SPLIT = os.environ.get("LOCOV_RES5_OUT_SPLIT", "1") != "0"
 _FUSE12 = os.environ.get("LOCOV_RES5_FUSE12", "1") != "0"      # developer A/B: conv1 + conv2 through ops.conv1x1_winograd_conv3x3
 _ONE_LAUNCH_PREP = os.environ.get("LOCOV_RES5_PREP", "1") != "0"    # developer A/B: a training step's operands from one launch (TrainOperands)
+_ASYNC_REFRESH = os.environ.get("LOCOV_RES5_SCALE_REFRESH", "async") != "sync"   # developer A/B: "sync" = every 64th step re-chooses the scales on the host-read chain
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -562,13 +563,19 @@ class TrainOperands:
                "uflip"  (G (x) G) flip(s w) [121,Cin,N] data gradient on 7x7 tiles
                "flip9"  [Cin, 9 N] of flip(s w)         ... on a general grid
 
-    In split arithmetic, once every operand's power-of-two scale is remembered (Res5Stage._scales: chosen from max |.| on the
-    host, re-used for 64 steps with 8x headroom; the pack kernel raises the range guard if one stops covering its data), ALL of
-    them come out of ONE launch (ops.res5_weight_prep) into buffers the stage keeps -- enqueued by the step's first Res5 call,
-    i.e. in front of the labelling wait.  Otherwise (first step, a refresh step, the f32 MFMA, odd shapes) each operand is
-    built on demand by the multi-launch chain it replaces (_packed / _derived / _split), which also chooses the scales."""
+    In split arithmetic, once every operand's power-of-two scale is remembered (Res5Stage._scales: first chosen from max |.| on
+    the host, 8x headroom; the pack kernel raises the range guard if one stops covering its data), ALL of them come out of ONE
+    launch (ops.res5_weight_prep) into buffers the stage keeps -- enqueued by the step's first Res5 call.  Otherwise (first step,
+    the f32 MFMA, odd shapes) each operand is built on demand by the multi-launch chain it replaces (_packed / _derived /
+    _split), which also chooses the scales.
+    Every REFRESH steps the scales are chosen again WITHOUT a host wait: max |w| of every weight and max |s| of every FrozenBN
+    scale go to pinned memory behind an event (two launches), a later step that finds the event complete derives each operand's
+    scale from the BOUND  max |operand| <= max |s| * max |w| (* WINO_GAIN in the Winograd domain)  and the steps in between keep
+    the old scales, which the headroom still covers.  (The chain's refresh read the exact max of each operand on the host: 26
+    waits and ~80 launches, a 5 ms step every 64 -- LOCOV_RES5_SCALE_REFRESH=sync keeps that form.)"""
 
     REFRESH = 64
+    WINO_GAIN = 2.25          # max_f (sum_a |G[f][a]|)^2 of csrc/winograd_tables.h: |((G (x) G) w)[f]| <= 2.25 max |w|
 
     def __init__(self, stage: "Res5Stage", split: bool, grid: bool, rois: bool):
         from . import ops
@@ -586,8 +593,11 @@ class TrainOperands:
                 wanted += [(c2, "wino"), (c2, "uflip")]
             if grid:
                 wanted += [(c2, "col"), (c2, "flip9")]
+        if _ASYNC_REFRESH:
+            self._adopt_refresh()
         recs = [stage._scales.get(self.scale_key(conv, tag)) for conv, tag in wanted]
-        fresh = [r is not None and r[1] < self.REFRESH for r in recs]
+        # (async refresh: a remembered scale stays usable past REFRESH -- the new one is on its way; sync: it sends the step to the chain)
+        fresh = [r is not None and (_ASYNC_REFRESH or r[1] < self.REFRESH) for r in recs]
         ok = _ONE_LAUNCH_PREP and any(fresh) and all(
             conv.weight.is_cuda and conv.weight.dtype == torch.float32 and conv.weight.is_contiguous()
             and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and conv.groups == 1 for conv, _ in wanted)
@@ -602,8 +612,10 @@ class TrainOperands:
                 if not f:
                     self.get(conv, tag)
             recs = [stage._scales.get(self.scale_key(conv, tag)) for conv, tag in wanted]
-            if not all(r is not None and r[1] < self.REFRESH for r in recs):
+            if not all(r is not None and (_ASYNC_REFRESH or r[1] < self.REFRESH) for r in recs):
                 return
+        if _ASYNC_REFRESH and any(r[1] >= self.REFRESH for r in recs):
+            self._start_refresh(wanted)
         bufs = stage.__dict__.setdefault("_prep_bufs", {})
         jobs = []
         for (conv, tag), rec in zip(wanted, recs):
@@ -618,6 +630,45 @@ class TrainOperands:
             stage._scales[self.scale_key(conv, tag)] = (rec[0], rec[1] + 1)
             self.ready[bk] = ops.SplitWeight(buf, rec[0])
         ops.res5_weight_prep(jobs)
+
+    def _start_refresh(self, wanted) -> None:
+        """Enqueue max |w| / max |s| of every convolution of `wanted` towards pinned memory (no wait); one refresh in flight."""
+        stage = self.stage
+        if stage.__dict__.get("_scale_refresh") is not None:
+            return
+        convs = list({id(c): c for c, _ in wanted}.values())
+        ts = [c.weight.detach() for c in convs] + [stage._fold(c)[0] for c in convs]
+        try:
+            norms = torch._foreach_norm(ts, float("inf"))
+        except (RuntimeError, TypeError):                    # (a torch without the foreach form of the max norm)
+            norms = [t.abs().max() for t in ts]
+        dev = torch.stack([n.reshape(()).to(torch.float32) for n in norms])
+        host = torch.empty(dev.numel(), dtype=torch.float32).pin_memory()
+        host.copy_(dev, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(dev.device))
+        stage.__dict__["_scale_refresh"] = (event, host, [id(c) for c in convs], list(wanted))
+
+    def _adopt_refresh(self) -> None:
+        """A refresh whose numbers have arrived: every operand's scale from the bound on its max |.| (counts start again)."""
+        import math
+        stage = self.stage
+        pending = stage.__dict__.get("_scale_refresh")
+        if pending is None or not pending[0].query():
+            return
+        stage.__dict__["_scale_refresh"] = None
+        _, host, ids, wanted = pending
+        vals = host.tolist()
+        n = len(ids)
+        amax_w, amax_s = dict(zip(ids, vals[:n])), dict(zip(ids, vals[n:]))
+        for conv, tag in wanted:
+            key = self.scale_key(conv, tag)
+            if key not in stage._scales:                     # (dropped in between -- a guard tripped: the chain chooses afresh)
+                continue
+            bound = amax_w[id(conv)] * (amax_s[id(conv)] if tag in ("t", "uflip", "flip9") else 1.0) * (
+                self.WINO_GAIN if tag in ("wino", "uflip") else 1.0)
+            scale = 2.0 ** (12 - math.floor(math.log2(bound))) if bound > 0 and math.isfinite(bound) else 1.0
+            stage._scales[key] = (min(max(scale, 2.0 ** -100), 2.0 ** 100), 0)
 
     @staticmethod
     def scale_key(conv, tag):

@@ -745,6 +745,49 @@ def test_training_forward_backward_matches_the_stock_library_path(pkg, oracle, d
     assert worst[0] < 5e-3, worst
 
 
+def test_operand_scales_are_refreshed_without_a_host_wait(pkg, oracle, monkeypatch):
+    """Every REFRESH steps the remembered operand scales are chosen again from max |w| / max |s| sent to pinned memory behind an event
+    (TrainOperands._start_refresh / _adopt_refresh): the one-launch preparation is never left (the synchronous form sends every
+    REFRESH-th step to the host-read chain), the new scales cover their operands with the chain's headroom or one power of two
+    less, and the training run stays what it is with scales that are never refreshed."""
+    from locov_amd import res5 as res5_mod
+    ops = pkg.ops
+    w = torch.randn(64, 32, 3, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    assert float(ops.winograd_pack_weight(w).abs().max()) <= res5_mod.TrainOperands.WINO_GAIN * float(w.abs().max())
+    runs = {}
+    for refresh in (2, 10 ** 9):
+        monkeypatch.setattr(res5_mod.TrainOperands, "REFRESH", refresh)
+        heads, c_in = _train_heads(pkg, oracle, "hip", "f16x2")
+        opt = torch.optim.SGD([p for p in heads.parameters() if p.requires_grad], lr=1e-3)
+        feat = torch.randn(2, c_in, 50, 84, generator=torch.Generator().manual_seed(5)).cuda().requires_grad_(True)
+        props, targets = _train_batch(pkg, oracle, 2, 60, 5, seed=31)
+        losses, ready, adopted = [], [], 0
+        for it in range(8):
+            opt.zero_grad(set_to_none=True)
+            torch.manual_seed(77 + it)
+            before = dict(heads.res5._scales)
+            grid, box_feats, sampled, ls = heads(None, {"res4": feat}, props, targets)
+            ready.append(len(heads.res5.__dict__["_train_ops"][1].ready))
+            adopted += any(v[1] < before.get(k, (0, -1))[1] for k, v in heads.res5._scales.items())
+            loss = ls["loss_box_reg"] + ls["loss_cls"] + 1e-3 * grid.square().mean() + 1e-2 * torch.cat(box_feats).square().mean()
+            loss.backward()
+            losses.append(float(loss.detach()))
+            opt.step()
+            torch.cuda.synchronize()                     # (the refresh's event is complete by the next step)
+        runs[refresh] = (losses, ready, adopted)
+        # every remembered scale covers its operand: |scale * operand| < 2^13 (the chain's target), and not by more than 2^3 below it
+        stage = heads.res5
+        for blk in stage:
+            for conv in (blk.conv1, blk.conv3):
+                rec = stage._scales[(id(conv), False)]
+                top = rec[0] * float(conv.weight.abs().max())
+                assert 2.0 ** 9 <= top < 2.0 ** 13, top
+    assert runs[2][1] == [0] + [26] * 7 and runs[10 ** 9][1] == [0] + [26] * 7
+    assert runs[2][2] >= 2 and runs[10 ** 9][2] == 0                     # scales re-chosen several times / never
+    for a, b in zip(runs[2][0], runs[10 ** 9][0]):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (a, b)
+
+
 def test_one_launch_operands_with_a_frozen_backbone(pkg, oracle):
     """A res4 map that needs no gradient (frozen backbone): block 0's data-gradient operands are never asked for, so the on-demand
     chain never learns their scales -- the one-launch preparation must still take over from the second step (it learns the
