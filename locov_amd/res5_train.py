@@ -267,7 +267,7 @@ class Res5RowsFn(torch.autograd.Function):
         # Split arithmetic.  What can leave fp16's range here is not data: the activations passed the forward's guard (the
         # weight-gradient GEMMs and the Winograd transforms see the same tensors at the same scales) and every gradient's
         # operand scale is chosen on the device from its own max |g|.  Only a REMEMBERED weight scale (Res5Stage._split: chosen
-        # afresh every 64 packings, 8x headroom) that stopped covering a weight could trip the guard -- the pack kernel
+        # again every 64 steps, 8x headroom) that stopped covering a weight could trip the guard -- the pack kernel
         # raises it.  That is recorded in the stage's "bwd" guard and nothing is read inside autograd (a host read here would
         # stall DDP's overlapped all-reduce).  Instead the pass ends with a GradScaler-style skip decided ON THE DEVICE: when the
         # word is set every gradient this pass produced (stage input and all convolution weights) is zero-filled
