@@ -643,7 +643,10 @@ class TrainOperands:
         except (RuntimeError, TypeError):                    # (a torch without the foreach form of the max norm)
             norms = [t.abs().max() for t in ts]
         dev = torch.stack([n.reshape(()).to(torch.float32) for n in norms])
-        host = torch.empty(dev.numel(), dtype=torch.float32).pin_memory()
+        host = stage.__dict__.get("_scale_refresh_host")     # (one refresh in flight, adopted before the next starts: one buffer)
+        if host is None or host.numel() < dev.numel():
+            host = stage.__dict__["_scale_refresh_host"] = torch.empty(max(dev.numel(), 64), dtype=torch.float32).pin_memory()
+        host = host[:dev.numel()]
         host.copy_(dev, non_blocking=True)
         event = torch.cuda.Event()
         event.record(torch.cuda.current_stream(dev.device))
