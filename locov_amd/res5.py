@@ -569,7 +569,7 @@ class TrainOperands:
     the f32 MFMA, odd shapes) each operand is built on demand by the multi-launch chain it replaces (_packed / _derived /
     _split), which also chooses the scales.
     Every REFRESH steps the scales are chosen again WITHOUT a host wait: max |w| of every weight and max |s| of every FrozenBN
-    scale go to pinned memory behind an event (two launches), a later step that finds the event complete derives each operand's
+    scale go to pinned memory behind an event (two launches), the step two later derives each operand's
     scale from the BOUND  max |operand| <= max |s| * max |w| (* WINO_GAIN in the Winograd domain)  and the steps in between keep
     the old scales, which the headroom still covers.  (The chain's refresh read the exact max of each operand on the host: 26
     waits and ~80 launches, a 5 ms step every 64 -- LOCOV_RES5_SCALE_REFRESH=sync keeps that form.)"""
@@ -650,17 +650,21 @@ class TrainOperands:
         host.copy_(dev, non_blocking=True)
         event = torch.cuda.Event()
         event.record(torch.cuda.current_stream(dev.device))
-        stage.__dict__["_scale_refresh"] = (event, host, [id(c) for c in convs], list(wanted))
+        stage.__dict__["_scale_refresh"] = (event, host, [id(c) for c in convs], list(wanted), stage.__dict__.get("_prep_steps", 0))
 
     def _adopt_refresh(self) -> None:
-        """A refresh whose numbers have arrived: every operand's scale from the bound on its max |.| (counts start again)."""
+        """Two steps after a refresh was enqueued: every operand's scale from the bound on its max |.| (counts start again)."""
         import math
         stage = self.stage
+        steps = stage.__dict__["_prep_steps"] = stage.__dict__.get("_prep_steps", 0) + 1
         pending = stage.__dict__.get("_scale_refresh")
-        if pending is None or not pending[0].query():
+        # adopted a FIXED two steps after it was enqueued (its event completed a step ago -- every step waits for the GPU once --
+        # so the wait below is free): the schedule of scales does not depend on timing
+        if pending is None or steps - pending[4] < 2:
             return
+        pending[0].synchronize()
         stage.__dict__["_scale_refresh"] = None
-        _, host, ids, wanted = pending
+        _, host, ids, wanted, _ = pending
         vals = host.tolist()
         n = len(ids)
         amax_w, amax_s = dict(zip(ids, vals[:n])), dict(zip(ids, vals[n:]))
