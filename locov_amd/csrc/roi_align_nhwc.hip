@@ -990,6 +990,175 @@ int64_t roi_align_tiles_plan_bytes(int64_t R);
 int launch_roi_align_tiles(const float *feat_nhwc, int N, int H, int W, int C, const float *rois, int64_t R, int PH, int PW,
                            float scale, int sampling_ratio, int aligned, void *plan_ws, float *out, hipStream_t s);
 
+// ---- the even-grid pooler's backward by OWNERSHIP: one workgroup = one 8 x 8 pixel tile of one image x one 128-channel slice ---------
+//
+// roi_align_nhwc_kernel<BWD> gives every (proposal, slice) a workgroup and adds each bin's contributions to the map with fp32
+// memory-side atomics: 0.9-1.5 T atomic lanes per second, four times the scattered rate of the units (docs/experiments.md R5.23), and
+// still 0.64 / 1.15 ms of the LSM / STT step for 0.16 / 0.3 GB of gradient rows.  Here the map is cut into tiles and a workgroup
+// COLLECTS: it lists (in proposal order) the proposals of its image whose footprint reaches its tile, and for each of them builds the
+// separable per-pixel weights of the seven bin rows / columns on ITS eight pixel rows / columns (the sums of the samples' bilinear
+// weights, as in the forward's separable form), reads the gradient rows of the bins that reach the tile (its 128 channels: 512
+// contiguous bytes per bin) and adds  sum_oh w_y[oh][py] (sum_ow w_x[ow][px] g[oh][ow])  to REGISTER accumulators: a thread owns one
+// channel and the 8 x 4 pixels of its column parity (two small dense products per proposal, at most 420 FMAs, instead of sparse updates).
+// The tile is written (added to what the map gradient already holds) once: no atomics, and a sum whose order is the proposals'
+// order -- the result is reproducible bit for bit.
+constexpr int kBT = 8, kBwdCh = 128, kBwdList = 2048;
+
+__global__ __launch_bounds__(256, 3) void roi_align_even_bwd_tiles_kernel(const float *__restrict__ grad_rows, int64_t grad_ld,
+                                                                      const float *__restrict__ rois, int R, int N, int H, int W, int C, int PH,
+                                                                      int PW, float scale, int sampling_ratio, int aligned, int bin_stride,
+                                                                      float *__restrict__ grad_feat, int nslices, int tiles_x, int tiles_y)
+{
+    constexpr int OB = 7;
+    __shared__ float wy[2][OB][kBT];
+    __shared__ float4 wx[2][2][OB];                               // [buffer][column parity][bin column] = the four columns of that parity
+    __shared__ unsigned long long mask[2][2];
+    __shared__ unsigned short list[kBwdList];
+    __shared__ int wave_cnt[4], list_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int t = blockIdx.x;
+    const int slice = t % nslices;                                // (= the XCD under round-robin dispatch: an XCD reads ONE channel slice)
+    t /= nslices;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, img = t / tiles_y;
+    const int ty0 = ty * kBT, tx0 = tx * kBT, c0 = slice * kBwdCh;
+    const float off = aligned ? 0.5f : 0.0f;
+    // this thread's accumulators: channel c, the 8 pixel rows x the 4 pixel columns of its parity
+    float acc_r[kBT][kBT / 2];
+#pragma unroll
+    for (int py = 0; py < kBT; py++)
+#pragma unroll
+        for (int q = 0; q < kBT / 2; q++) acc_r[py][q] = 0.f;
+
+    struct Geo { float start_w, start_h, bin_w, bin_h; int gw, gh; };
+    auto geometry = [&](const float *roi) {
+        Geo g;
+        g.start_w = __fsub_rn(__fmul_rn(roi[1], scale), off);
+        g.start_h = __fsub_rn(__fmul_rn(roi[2], scale), off);
+        const float end_w = __fsub_rn(__fmul_rn(roi[3], scale), off), end_h = __fsub_rn(__fmul_rn(roi[4], scale), off);
+        float rw = __fsub_rn(end_w, g.start_w), rh = __fsub_rn(end_h, g.start_h);
+        if (!aligned) {
+            rw = fmaxf(rw, 1.f);
+            rh = fmaxf(rh, 1.f);
+        }
+        g.bin_h = __fdiv_rn(rh, (float)PH);
+        g.bin_w = __fdiv_rn(rw, (float)PW);
+        g.gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(g.bin_h);
+        g.gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(g.bin_w);
+        return g;
+    };
+    const int c = tid & (kBwdCh - 1), half = tid >> 7;
+
+    for (int base = 0; base < R; base += kBwdList) {
+        // ---- the proposals of this image whose footprint (conservatively: the box in map pixels, two pixels wider) reaches the tile,
+        //      in proposal order (ballots + prefix counts: the order of the sums below must not depend on timing)
+        if (tid == 0) list_n = 0;
+        __syncthreads();
+        const int stop = min(R, base + kBwdList);
+        for (int r0 = base; r0 < stop; r0 += 256) {
+            const int r = r0 + tid;
+            bool ok = false;
+            if (r < stop) {
+                const float *roi = rois + (int64_t)r * 5;
+                if ((int)roi[0] == img) {
+                    const Geo g = geometry(roi);
+                    const float y_lo = g.start_h - 2.f, y_hi = g.start_h + g.bin_h * (float)PH + 2.f;
+                    const float x_lo = g.start_w - 2.f, x_hi = g.start_w + g.bin_w * (float)PW + 2.f;
+                    // (NaN coordinates fail every comparison: such a proposal contributes nothing here, as its samples are invalid there)
+                    ok = y_hi >= (float)ty0 && y_lo <= (float)(ty0 + kBT) && x_hi >= (float)tx0 && x_lo <= (float)(tx0 + kBT) && g.gh > 0 && g.gw > 0;
+                }
+            }
+            const unsigned long long b = __ballot(ok);
+            if (lane == 0) wave_cnt[wave] = __popcll(b);
+            __syncthreads();
+            int pos = list_n;
+            for (int w = 0; w < wave; w++) pos += wave_cnt[w];
+            if (ok) list[pos + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)(r - base);
+            __syncthreads();
+            if (tid == 0) list_n += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            __syncthreads();
+        }
+        const int n_list = list_n;
+        // Tables of proposal li + 1 are built (wave 0: rows, wave 1: columns) while proposal li's gradient rows are in flight, into
+        // the other of two buffers: ONE barrier per proposal.  mask[buf][0 / 1]: bit 8 o + p set when bin row / column o has a weight
+        // on tile row / column p (a ballot of the building wave).
+        auto build = [&](int li, int buf) {
+            if (wave > 1 || lane >= OB * kBT) return;
+            const int r = base + (int)list[li];
+            const Geo g = geometry(rois + (int64_t)r * 5);
+            const bool is_y = wave == 0;
+            const int o = lane / kBT, p = lane % kBT;
+            const int P = (is_y ? ty0 : tx0) + p, n = is_y ? g.gh : g.gw, size = is_y ? H : W;
+            const float start = is_y ? g.start_h : g.start_w, bin = is_y ? g.bin_h : g.bin_w;
+            float w = 0.f;
+            for (int i = 0; i < n; i++) {
+                const AxisSampleN sm = axis_sample_n(start, bin, o * bin_stride, i, n, size);
+                w += (sm.lo == P ? sm.wh : 0.f) + (sm.hi == P ? sm.wl : 0.f);
+            }
+            if (is_y)
+                wy[buf][o][p] = w;
+            else
+                reinterpret_cast<float *>(&wx[buf][p & 1][o])[p >> 1] = w;
+            const unsigned long long m = __ballot(w != 0.f);
+            if (lane == 0) mask[buf][is_y ? 0 : 1] = m;
+        };
+        if (n_list > 0) build(0, 0);
+        __syncthreads();
+        for (int li = 0; li < n_list; li++) {
+            const int buf = li & 1;
+            const int r = base + (int)list[li];
+            const Geo g = geometry(rois + (int64_t)r * 5);
+            const unsigned long long my = mask[buf][0], mx = mask[buf][1];
+            // ---- the gradient rows of the bins that reach the tile: all requested before any is used (and before the next tables)
+            const int prod = g.gh * g.gw;
+            const float inv_count = 1.f / (float)(prod > 1 ? prod : 1);
+            const float *grow = grad_rows + (int64_t)r * (OB * OB) * grad_ld + c0 + c;
+            float gv[OB * OB];
+#pragma unroll
+            for (int oh = 0; oh < OB; oh++)
+#pragma unroll
+                for (int ow = 0; ow < OB; ow++)
+                    gv[oh * OB + ow] = ((my >> (8 * oh)) & 0xffull) != 0 && ((mx >> (8 * ow)) & 0xffull) != 0 ? grow[(int64_t)(oh * OB + ow) * grad_ld] : 0.f;
+            if (li + 1 < n_list) build(li + 1, buf ^ 1);
+            // ---- in registers:  acc[py][px] += sum_oh wy[oh][py] * (sum_ow wx[ow][px] * g[oh][ow])   for this thread's 8 x 4 pixels
+#pragma unroll
+            for (int oh = 0; oh < OB; oh++) {
+                if (((my >> (8 * oh)) & 0xffull) == 0) continue;     // (wave-uniform: a bin row without a weight on this tile)
+                float tq[kBT / 2] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ow = 0; ow < OB; ow++) {
+                    const float4 w4 = wx[buf][half][ow];              // this thread's four columns (its parity) of the column weights
+                    const float gq = gv[oh * OB + ow];
+                    tq[0] = fmaf(w4.x, gq, tq[0]);
+                    tq[1] = fmaf(w4.y, gq, tq[1]);
+                    tq[2] = fmaf(w4.z, gq, tq[2]);
+                    tq[3] = fmaf(w4.w, gq, tq[3]);
+                }
+#pragma unroll
+                for (int q = 0; q < kBT / 2; q++) tq[q] *= inv_count;
+#pragma unroll
+                for (int py = 0; py < kBT; py++) {
+                    const float w = wy[buf][oh][py];
+#pragma unroll
+                    for (int q = 0; q < kBT / 2; q++) acc_r[py][q] = fmaf(w, tq[q], acc_r[py][q]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // ---- the tile, added to what the map gradient holds (a wave writes 256 contiguous bytes per pixel)
+#pragma unroll
+    for (int py = 0; py < kBT; py++)
+#pragma unroll
+        for (int q = 0; q < kBT / 2; q++) {
+            const int y = ty0 + py, x = tx0 + 2 * q + half;
+            const float v = acc_r[py][q];
+            if (y < H && x < W && v != 0.f) grad_feat[(((int64_t)img * H + y) * W + x) * C + c0 + c] += v;
+        }
+}
+
 static int nhwc_slices(int C)
 {
     static const int forced = [] { const char *e = getenv("LOCOV_ROIALIGN_SLICES"); return e ? atoi(e) : 0; }();
@@ -1124,6 +1293,18 @@ int locov_roi_align_nhwc_bwd(const float *grad_rows, int64_t grad_ld, int N, int
     LOCOV_REQUIRE(R <= 0x7fffffffLL, "locov_roi_align_nhwc_bwd: R too large");
     LOCOV_REQUIRE(((uintptr_t)grad_rows | (uintptr_t)grad_feat) % 16 == 0, "locov_roi_align_nhwc_bwd: misaligned pointer");
     const int OH = (pooled_h + bin_stride - 1) / bin_stride, OW = (pooled_w + bin_stride - 1) / bin_stride;
+    // the ownership form (7 x 7 bins, ROI-major rows, 128-channel slices): developer A/B LOCOV_POOL_BWD_TILES=0 -> the scatter below
+    {
+        const char *te = getenv("LOCOV_POOL_BWD_TILES");      // (read per launch: tests flip it)
+        if ((!te || atoi(te) != 0) && OH == 7 && OW == 7 && !pos_major && C % kBwdCh == 0) {
+            const int tiles_x = (W + kBT - 1) / kBT, tiles_y = (H + kBT - 1) / kBT, ns = C / kBwdCh;
+            const int64_t wgs = (int64_t)N * tiles_x * tiles_y * ns;
+            LOCOV_REQUIRE(wgs <= 0x7fffffffLL, "locov_roi_align_nhwc_bwd: map too large");
+            hipLaunchKernelGGL(roi_align_even_bwd_tiles_kernel, dim3((unsigned)wgs), dim3(256), 0, as_stream(stream), grad_rows, grad_ld, rois, (int)R,
+                               N, H, W, C, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, bin_stride, grad_feat, ns, tiles_x, tiles_y);
+            return check_launch("locov_roi_align_nhwc_bwd (tiles)");
+        }
+    }
     // (slices of at most 128 channels where C allows: the 20 KB gradient window then holds the 40 pixels of a proposal below ~70 px)
     int nslices = nhwc_slices(C);
     while (nslices < 8 && C / (2 * nslices) >= 128 && (C >> 2) % (2 * nslices) == 0) nslices *= 2;

@@ -153,10 +153,12 @@ def test_roi_align_even_backward_window_equals_the_direct_scatter(pkg, oracle, m
     rois = dev(oracle.boxes_to_pooler_format(boxes))
     G = torch.randn(49 * N * per, C, generator=torch.Generator().manual_seed(2)).cuda()
     out = {}
+    monkeypatch.setenv("LOCOV_POOL_BWD_TILES", "0")          # (the scatter forms; the ownership form has its own test below)
     for win in ("0", "20480", "65536"):
         monkeypatch.setenv("LOCOV_POOL_BWD_WINDOW", win)
         out[win] = ops.roi_align_nhwc_bwd(G, (N, H, W, C), rois, 14, 1 / 16, 0, True, bin_stride=2)
     monkeypatch.delenv("LOCOV_POOL_BWD_WINDOW")
+    monkeypatch.delenv("LOCOV_POOL_BWD_TILES")
     scale = float(out["0"].abs().max())
     assert scale > 0
     for win in ("20480", "65536"):
@@ -166,6 +168,53 @@ def test_roi_align_even_backward_window_equals_the_direct_scatter(pkg, oracle, m
     y = ops.roi_align_nhwc(F, rois, 14, 1 / 16, 0, True, bin_stride=2).view(-1, C)
     lhs, rhs = float((y.double() * G.double()).sum()), float((F.double() * out["20480"].double()).sum())
     assert abs(lhs - rhs) <= 1e-5 * float(y.double().norm() * G.double().norm())
+
+
+@pytest.mark.parametrize("N,C,H,W,per", [(4, 1024, 50, 84, 200), (3, 1024, 50, 84, 512), (2, 128, 13, 9, 40), (1, 256, 64, 64, 2500)])
+def test_roi_align_even_backward_by_tile_ownership(pkg, oracle, N, C, H, W, per, monkeypatch):
+    """The ownership form of the even-grid ROIAlign backward (a workgroup per 8 x 8 map tile and 128-channel slice collects the
+    proposals that reach its tile; no atomics) against the scatter form at the LSM / STT steps' shapes, a map smaller than two tiles
+    and more proposals than one list pass holds: the same gradient up to the order of the fp32 additions, the oracle's
+    roi_align_backward on a channel slice, accumulation into an existing gradient -- and the same bits on every run."""
+    ops = pkg.ops
+    rng = np.random.default_rng(18 + per)
+    boxes = [oracle.synth_boxes(rng, per) for _ in range(N)]
+    for b in boxes:
+        b[:, [0, 2]] *= (W * 16) / 1333.0
+        b[:, [1, 3]] *= (H * 16) / 800.0
+    boxes[0][0] = [-40.0, -30.0, 20.0, 25.0]                                     # partly outside the map
+    boxes[-1][1] = [5.0, 5.0, 5.0, 5.0]                                          # empty box
+    boxes[0][2] = [0.0, 0.0, W * 16.0 + 50.0, H * 16.0 + 50.0]                   # larger than the map
+    boxes[-1][3:23] = np.concatenate([rng.uniform(0, W * 12, (20, 2)), np.zeros((20, 2))], 1).astype(np.float32)
+    boxes[-1][3:23, 2:] = boxes[-1][3:23, :2] + rng.uniform(8, 60, (20, 2)).astype(np.float32)     # tiny proposals
+    rois_np = oracle.boxes_to_pooler_format(boxes)
+    rois = dev(rois_np)
+    G = torch.randn(49 * N * per, C, generator=torch.Generator().manual_seed(2)).cuda()
+    monkeypatch.setenv("LOCOV_POOL_BWD_TILES", "0")
+    want = ops.roi_align_nhwc_bwd(G, (N, H, W, C), rois, 14, 1 / 16, 0, True, bin_stride=2)
+    monkeypatch.delenv("LOCOV_POOL_BWD_TILES")
+    got = ops.roi_align_nhwc_bwd(G, (N, H, W, C), rois, 14, 1 / 16, 0, True, bin_stride=2)
+    scale = float(want.abs().max())
+    assert scale > 0 and float((got - want).abs().max()) <= 3e-6 * scale
+    assert torch.equal(got, ops.roi_align_nhwc_bwd(G, (N, H, W, C), rois, 14, 1 / 16, 0, True, bin_stride=2))      # reproducible
+    # the oracle's torchvision-style backward fed the gradient at the even bins, on the first 8 channels
+    R = N * per
+    if R <= 1600:
+        g14 = np.zeros((R, 8, 14, 14), np.float32)
+        g14[:, :, ::2, ::2] = G[:, :8].view(R, 7, 7, 8).permute(0, 3, 1, 2).cpu().numpy()
+        ref = oracle.roi_align_backward(g14, (N, 8, H, W), rois_np, 1 / 16, 0, True)
+        assert np.abs(got[..., :8].permute(0, 3, 1, 2).cpu().numpy() - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1.0)
+    # accumulation into an existing gradient, a proposal whose image index is out of range (ignored), no proposals at all
+    seed = torch.randn(N, H, W, C, generator=torch.Generator().manual_seed(4)).cuda()
+    acc = ops.roi_align_nhwc_bwd(G, (N, H, W, C), rois, 14, 1 / 16, 0, True, bin_stride=2, accumulate_into=seed.clone())
+    assert float((acc - (seed + got)).abs().max()) <= 1e-6 * max(scale, 1.0)
+    bad = rois.clone()
+    bad[:5, 0] = N + 3
+    g_bad = ops.roi_align_nhwc_bwd(G, (N, H, W, C), bad, 14, 1 / 16, 0, True, bin_stride=2)
+    G0 = G.clone()
+    G0.view(R, 49, C)[:5] = 0
+    assert float((g_bad - ops.roi_align_nhwc_bwd(G0, (N, H, W, C), rois, 14, 1 / 16, 0, True, bin_stride=2)).abs().max()) <= 3e-6 * scale
+    assert not bool(ops.roi_align_nhwc_bwd(G[:0], (N, H, W, C), rois[:0], 14, 1 / 16, 0, True, bin_stride=2).any())
 
 
 @pytest.mark.parametrize("R,Cin,N", [(5, 32, 48), (70, 64, 64), (300, 128, 96)])
