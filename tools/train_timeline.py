@@ -5,7 +5,8 @@ usage: python tools/train_timeline.py [trace.csv] > profiles/<tag>_train_timelin
 import csv, glob, re, sys
 f = sys.argv[1] if len(sys.argv) > 1 else glob.glob("gpurun_out/prof_train/stats/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "roi_align_nhwc_kernel<float, float, true" in r["Kernel_Name"]]      # one ROIAlign backward per step
+marks = [i for i, r in enumerate(rows) if "roi_align_even_bwd_tiles_kernel" in r["Kernel_Name"]
+         or "roi_align_nhwc_kernel<float, float, true" in r["Kernel_Name"]]                                   # one ROIAlign backward per step
 seg = rows[marks[-2] + 1: marks[-1] + 1]
 
 
