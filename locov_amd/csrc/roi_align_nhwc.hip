@@ -995,9 +995,9 @@ int launch_roi_align_tiles(const float *feat_nhwc, int N, int H, int W, int C, c
 // roi_align_nhwc_kernel<BWD> gives every (proposal, slice) a workgroup and adds each bin's contributions to the map with fp32
 // memory-side atomics: 0.9-1.5 T atomic lanes per second, four times the scattered rate of the units (docs/experiments.md R5.23), and
 // still 0.64 / 1.15 ms of the LSM / STT step for 0.16 / 0.3 GB of gradient rows.  Here the map is cut into tiles and a workgroup
-// COLLECTS: it lists (in proposal order) the proposals of its image whose footprint reaches its tile, and for each of them builds the
-// separable per-pixel weights of the seven bin rows / columns on ITS eight pixel rows / columns (the sums of the samples' bilinear
-// weights, as in the forward's separable form), reads the gradient rows of the bins that reach the tile (its 128 channels: 512
+// COLLECTS: it lists (in proposal order) the proposals of its image whose footprint reaches its tile, and for each of them every wave
+// builds the separable per-pixel weights of the seven bin rows / columns on ITS eight pixel rows / four pixel columns (the sums of the
+// samples' bilinear weights, as in the forward's separable form; no barrier between the waves inside the list), reads the gradient rows of the bins that reach the tile (its 128 channels: 512
 // contiguous bytes per bin) and adds  sum_oh w_y[oh][py] (sum_ow w_x[ow][px] g[oh][ow])  to REGISTER accumulators: a thread owns one
 // channel and the 8 x 4 pixels of its column parity (two small dense products per proposal, at most 420 FMAs, instead of sparse updates).
 // The tile is written (added to what the map gradient already holds) once: no atomics, and a sum whose order is the proposals'
@@ -1010,9 +1010,8 @@ __global__ __launch_bounds__(256, 3) void roi_align_even_bwd_tiles_kernel(const 
                                                                       float *__restrict__ grad_feat, int nslices, int tiles_x, int tiles_y)
 {
     constexpr int OB = 7;
-    __shared__ float wy[2][OB][kBT];
-    __shared__ float4 wx[2][2][OB];                               // [buffer][column parity][bin column] = the four columns of that parity
-    __shared__ unsigned long long mask[2][2];
+    __shared__ float wy[4][OB][kBT];                              // per WAVE: weights of the bin rows on the tile's pixel rows
+    __shared__ float4 wx[4][OB];                                  // per wave: weights of the bin columns on the four tile columns of its parity
     __shared__ unsigned short list[kBwdList];
     __shared__ int wave_cnt[4], list_n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1080,37 +1079,40 @@ __global__ __launch_bounds__(256, 3) void roi_align_even_bwd_tiles_kernel(const 
             __syncthreads();
         }
         const int n_list = list_n;
-        // Tables of proposal li + 1 are built (wave 0: rows, wave 1: columns) while proposal li's gradient rows are in flight, into
-        // the other of two buffers: ONE barrier per proposal.  mask[buf][0 / 1]: bit 8 o + p set when bin row / column o has a weight
-        // on tile row / column p (a ballot of the building wave).
-        auto build = [&](int li, int buf) {
-            if (wave > 1 || lane >= OB * kBT) return;
-            const int r = base + (int)list[li];
-            const Geo g = geometry(rois + (int64_t)r * 5);
-            const bool is_y = wave == 0;
-            const int o = lane / kBT, p = lane % kBT;
-            const int P = (is_y ? ty0 : tx0) + p, n = is_y ? g.gh : g.gw, size = is_y ? H : W;
-            const float start = is_y ? g.start_h : g.start_w, bin = is_y ? g.bin_h : g.bin_w;
-            float w = 0.f;
-            for (int i = 0; i < n; i++) {
-                const AxisSampleN sm = axis_sample_n(start, bin, o * bin_stride, i, n, size);
-                w += (sm.lo == P ? sm.wh : 0.f) + (sm.hi == P ? sm.wl : 0.f);
-            }
-            if (is_y)
-                wy[buf][o][p] = w;
-            else
-                reinterpret_cast<float *>(&wx[buf][p & 1][o])[p >> 1] = w;
-            const unsigned long long m = __ballot(w != 0.f);
-            if (lane == 0) mask[buf][is_y ? 0 : 1] = m;
-        };
-        if (n_list > 0) build(0, 0);
-        __syncthreads();
+        // Every WAVE builds the tables it uses (lanes 0-55: the rows, then the columns of its parity) in its own corner of LDS: the
+        // four waves of the workgroup never wait for each other inside the list.  my / mx: bit 8 o + p set when bin row / column o has
+        // a weight on tile row / column p (ballots: they stay in scalar registers).
+        float (*wyw)[kBT] = wy[wave];
+        float4 *wxw = wx[wave];
         for (int li = 0; li < n_list; li++) {
-            const int buf = li & 1;
             const int r = base + (int)list[li];
             const Geo g = geometry(rois + (int64_t)r * 5);
-            const unsigned long long my = mask[buf][0], mx = mask[buf][1];
-            // ---- the gradient rows of the bins that reach the tile: all requested before any is used (and before the next tables)
+            unsigned long long my, mx;
+            {
+                const int o = lane / kBT, p = lane % kBT;
+                float w = 0.f;
+                if (lane < OB * kBT)
+                    for (int i = 0; i < g.gh; i++) {
+                        const AxisSampleN sm = axis_sample_n(g.start_h, g.bin_h, o * bin_stride, i, g.gh, H);
+                        w += (sm.lo == ty0 + p ? sm.wh : 0.f) + (sm.hi == ty0 + p ? sm.wl : 0.f);
+                    }
+                my = __ballot(w != 0.f);
+                if (lane < OB * kBT) wyw[o][p] = w;
+                w = 0.f;
+                if (lane < OB * kBT)
+                    for (int i = 0; i < g.gw; i++) {
+                        const AxisSampleN sm = axis_sample_n(g.start_w, g.bin_w, o * bin_stride, i, g.gw, W);
+                        w += (sm.lo == tx0 + p ? sm.wh : 0.f) + (sm.hi == tx0 + p ? sm.wl : 0.f);
+                    }
+                mx = __ballot(w != 0.f);
+                if (lane < OB * kBT && (p & 1) == half) reinterpret_cast<float *>(&wxw[o])[p >> 1] = w;
+            }
+            // (the tables are read by OTHER lanes of this wave: order the LDS writes above and the reads below for the wave)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (my == 0 || mx == 0) continue;                      // (the conservative box reached the tile, no sample did)
+            // ---- the gradient rows of the bins that reach the tile: all requested before any is used
             const int prod = g.gh * g.gw;
             const float inv_count = 1.f / (float)(prod > 1 ? prod : 1);
             const float *grow = grad_rows + (int64_t)r * (OB * OB) * grad_ld + c0 + c;
@@ -1120,7 +1122,6 @@ __global__ __launch_bounds__(256, 3) void roi_align_even_bwd_tiles_kernel(const 
 #pragma unroll
                 for (int ow = 0; ow < OB; ow++)
                     gv[oh * OB + ow] = ((my >> (8 * oh)) & 0xffull) != 0 && ((mx >> (8 * ow)) & 0xffull) != 0 ? grow[(int64_t)(oh * OB + ow) * grad_ld] : 0.f;
-            if (li + 1 < n_list) build(li + 1, buf ^ 1);
             // ---- in registers:  acc[py][px] += sum_oh wy[oh][py] * (sum_ow wx[ow][px] * g[oh][ow])   for this thread's 8 x 4 pixels
 #pragma unroll
             for (int oh = 0; oh < OB; oh++) {
@@ -1128,7 +1129,7 @@ __global__ __launch_bounds__(256, 3) void roi_align_even_bwd_tiles_kernel(const 
                 float tq[kBT / 2] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ow = 0; ow < OB; ow++) {
-                    const float4 w4 = wx[buf][half][ow];              // this thread's four columns (its parity) of the column weights
+                    const float4 w4 = wxw[ow];                        // this wave's four columns (its parity) of the column weights
                     const float gq = gv[oh * OB + ow];
                     tq[0] = fmaf(w4.x, gq, tq[0]);
                     tq[1] = fmaf(w4.y, gq, tq[1]);
@@ -1139,13 +1140,15 @@ __global__ __launch_bounds__(256, 3) void roi_align_even_bwd_tiles_kernel(const 
                 for (int q = 0; q < kBT / 2; q++) tq[q] *= inv_count;
 #pragma unroll
                 for (int py = 0; py < kBT; py++) {
-                    const float w = wy[buf][oh][py];
+                    const float w = wyw[oh][py];
 #pragma unroll
                     for (int q = 0; q < kBT / 2; q++) acc_r[py][q] = fmaf(w, tq[q], acc_r[py][q]);
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next proposal's tables overwrite these)
+            __builtin_amdgcn_wave_barrier();
         }
+        __syncthreads();                                            // (the list is rebuilt by the next pass)
     }
     __syncthreads();
     // ---- the tile, added to what the map gradient holds (a wave writes 256 contiguous bytes per pixel)
