@@ -997,8 +997,8 @@ int launch_roi_align_tiles(const float *feat_nhwc, int N, int H, int W, int C, c
 // still 0.64 / 1.15 ms of the LSM / STT step for 0.16 / 0.3 GB of gradient rows.  Here the map is cut into tiles and a workgroup
 // COLLECTS: it lists (in proposal order) the proposals of its image whose footprint reaches its tile, and for each of them every wave
 // builds the separable per-pixel weights of the seven bin rows / columns on ITS eight pixel rows / four pixel columns (the sums of the
-// samples' bilinear weights, as in the forward's separable form; no barrier between the waves inside the list), reads the gradient rows of the bins that reach the tile (its 128 channels: 512
-// contiguous bytes per bin) and adds  sum_oh w_y[oh][py] (sum_ow w_x[ow][px] g[oh][ow])  to REGISTER accumulators: a thread owns one
+// samples' bilinear weights, as in the forward's separable form; no barrier between the waves inside the list), reads the gradient
+// rows of the bins that reach the tile (its 128 channels: 512 contiguous bytes per bin) and adds  sum_oh w_y[oh][py] (sum_ow w_x[ow][px] g[oh][ow])  to REGISTER accumulators: a thread owns one
 // channel and the 8 x 4 pixels of its column parity (two small dense products per proposal, at most 420 FMAs, instead of sparse updates).
 // The tile is written (added to what the map gradient already holds) once: no atomics, and a sum whose order is the proposals'
 // order -- the result is reproducible bit for bit.
