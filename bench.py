@@ -83,6 +83,9 @@ def parse(argv=None):
     p.add_argument("--skip-s1", action="store_true",
                    help="only the S2 scope (profiling runs: the kernel mix then equals the timed region's)")
     p.add_argument("--skip-variants", action="store_true", help="do not time the 1024-d bank variants (profile runs)")
+    p.add_argument("--skip-eval", action="store_true", help="no scopes.eval_1img (the reference's evaluation call incl. post-processing)")
+    p.add_argument("--only-eval", action="store_true",
+                   help="profile runs: ONLY the scopes.eval_1img loop (the kernel mix of the process is then the evaluation call's)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
     # developer/test knobs: rehearse the multi-process flow on a box with fewer GPUs than ranks
     p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl")
@@ -90,6 +93,13 @@ def parse(argv=None):
     p.add_argument("--force-dist", action="store_true",
                    help="initialise the process group and wrap the training step in DistributedDataParallel even with ONE rank: the RCCL "
                         "rehearsal a 1-GPU box allows (communicator, DDP's bucketed all-reduce hooks, the timing collectives)")
+    p.add_argument("--ddp-bucket-mb", type=int, default=17,
+                   help="DistributedDataParallel's bucket_cap_mb for the training steps: 17 MiB = exactly one identity bottleneck of Res5 "
+                        "(2 x 4 MiB + 9 MiB), so that a bucket closes with every block's autograd node (torch's default is 25)")
+    p.add_argument("--multiscale-batches", type=int, default=16,
+                   help="training: batches of the multi-scale pool behind train.*.ms_per_step_multiscale (0: skip)")
+    p.add_argument("--skip-exchange-probe", action="store_true",
+                   help="no train.gradient_exchange.schedule (the traced DDP steps that place the buckets on the Res5 backward's timeline)")
     args = p.parse_args(argv)
     if args.share_gpu and args.dist_backend == "nccl":
         # RCCL cannot place two ranks on one device (the attempt hangs for minutes before it fails): single-GPU test boxes use gloo
@@ -136,6 +146,85 @@ def synth_boxes(gen, n: int):
     w, h = side * aspect.sqrt(), side / aspect.sqrt()
     return torch.stack([(cx - w / 2).clamp(0, 1333), (cy - h / 2).clamp(0, 800),
                         (cx + w / 2).clamp(0, 1333), (cy + h / 2).clamp(0, 800)], dim=1).to(torch.float32)
+
+
+MIN_SIZE_TRAIN = (640, 672, 704, 736, 768, 800)      # configs/coco_stt.yaml:54 (coco_lsm.yaml inherits the same Detectron2 default)
+MAX_SIZE_TRAIN = 1333
+
+
+def synth_image_size(gen):
+    """(H, W) of one training image behind Detectron2's ResizeShortestEdge(MIN_SIZE_TRAIN, MAX_SIZE_TRAIN, "choice") [D2-upstream]: the
+    short side drawn from MIN_SIZE_TRAIN, the long side from COCO-like aspect ratios (4:3 and 3:2 dominate; a quarter of the images
+    are portrait), both scaled down when the long side would pass MAX_SIZE_TRAIN."""
+    import torch
+    short = MIN_SIZE_TRAIN[int(torch.randint(0, len(MIN_SIZE_TRAIN), (1,), generator=gen))]
+    ar = (4 / 3, 4 / 3, 4 / 3, 3 / 2, 3 / 2, 16 / 9, 1.0, 5 / 4)[int(torch.randint(0, 8, (1,), generator=gen))]
+    long = short * ar
+    if long > MAX_SIZE_TRAIN:
+        short, long = short * MAX_SIZE_TRAIN / long, MAX_SIZE_TRAIN
+    h, w = int(short + 0.5), int(long + 0.5)
+    if float(torch.rand(1, generator=gen)) < 0.25:
+        h, w = w, h
+    return h, w
+
+
+def synth_boxes_in(gen, n: int, h: int, w: int):
+    """synth_boxes for an image of h x w pixels (side up to the image's short side)."""
+    import torch
+    cx = torch.rand(n, generator=gen) * w
+    cy = torch.rand(n, generator=gen) * h
+    side = 2.0 ** (4.0 + torch.rand(n, generator=gen) * (np.log2(float(min(h, w))) - 4.0))
+    aspect = 0.5 + 1.5 * torch.rand(n, generator=gen)
+    bw, bh = side * aspect.sqrt(), side / aspect.sqrt()
+    return torch.stack([(cx - bw / 2).clamp(0, w), (cy - bh / 2).clamp(0, h),
+                        (cx + bw / 2).clamp(0, w), (cy + bh / 2).clamp(0, h)], dim=1).to(torch.float32)
+
+
+def synth_train_batch(gen, device, n_images, n_props, n_classes, dim, *, multiscale=False, max_gt=7, fixed_gt=True, short_image=None,
+                      crowded_image=None):
+    """One rank's synthetic training batch: res4 maps, RPN-style proposals (a few of them near the ground truth), targets, captions.
+    multiscale: every image its own size (synth_image_size), the batch padded to its largest image as Detectron2's ImageList does
+    [D2-upstream] -> res4 map [B, 1024, ceil(Hmax / 16), ceil(Wmax / 16)]; else the fixed 1333 x 800 batch.
+    fixed_gt: max_gt boxes on every image; else 0..max_gt (images WITHOUT ground truth included).
+    short_image: (index, n) -- that image gets only n proposals (fewer candidates than the sampling budget: the labelling cannot
+    speculate, the forward waits for the true counts).
+    crowded_image: index -- every proposal of that image sits on a ground-truth box (all foreground): with POSITIVE_FRACTION < 1
+    (configs/coco_stt.yaml: Detectron2's 0.25 of 512) the background candidates do not fill the rest of the budget and the
+    speculated sample MISSES."""
+    import torch
+    from locov_amd.structures import Boxes, Instances
+    sizes = [synth_image_size(gen) if multiscale else (800, 1333) for _ in range(n_images)]
+    Hm, Wm = max(h for h, _ in sizes), max(w for _, w in sizes)
+    mh, mw = -(-Hm // 16), -(-Wm // 16)
+    features = torch.randn(n_images, 1024, mh, mw, generator=gen).to(device)
+    proposals, targets = [], []
+    for i, (h, w) in enumerate(sizes):
+        n_gt = max_gt if fixed_gt else int(torch.randint(0, max_gt + 1, (1,), generator=gen))
+        if crowded_image == i:
+            n_gt = max(n_gt, 1)
+        R = n_props if short_image is None or short_image[0] != i else short_image[1]
+        gt = synth_boxes_in(gen, n_gt, h, w) if multiscale else synth_boxes(gen, n_gt)
+        b = synth_boxes_in(gen, R, h, w) if multiscale else synth_boxes(gen, R)
+        k = min(n_gt, R)
+        if crowded_image == i:
+            b = gt[torch.arange(R) % n_gt] + torch.rand(R, 4, generator=gen) * 2 - 1
+            b = b.clamp(min=0)
+        elif k:
+            b[:k] = (gt[:k] + torch.rand(k, 4, generator=gen) * 8 - 4).clamp(min=0)
+        b[:, 2:] = torch.maximum(b[:, 2:], b[:, :2] + 1.0)
+        p = Instances((h, w))
+        p.proposal_boxes = Boxes(b.to(device))
+        p.objectness_logits = torch.zeros(R, device=device)
+        t = Instances((h, w))
+        t.gt_boxes = Boxes(gt.to(device))
+        t.gt_classes = torch.randint(0, n_classes, (n_gt,), generator=gen).to(device)
+        proposals.append(p)
+        targets.append(t)
+    caption = {"input_embeddings": torch.randn(n_images, 70, dim, generator=gen).to(device),
+               "attention_mask": torch.ones(n_images, 70, device=device),
+               "special_tokens_mask": torch.zeros(n_images, 70, device=device)}
+    caption["special_tokens_mask"][:, 0] = 1
+    return {"features": features, "proposals": proposals, "targets": targets, "caption": caption, "sizes": sizes, "map": (mh, mw)}
 
 
 def build_heads(args, device, *, dim=None, sim_dtype=None, res5=None, res5_dtype=None, train=False, seed=1992, stt=False):
@@ -218,6 +307,40 @@ class Workload:
                 box_features = heads._shared_roi_transform(feats, self.boxes, pooled=True)      # :355-356
             return heads.box_predictor(box_features)                                             # :357 (scores, deltas)
 
+    def eval_heads(self, sigma: float = 3.0):
+        """The heads of the evaluation scope: the SAME Res5 / predictor weights with a bank scaled so that the class logits have
+        standard deviation `sigma` over the workload's proposals.  Random-init logits are ~1e-2, their softmax is uniform and NOTHING
+        passes SCORE_THRESH_TEST 0.05 -- the post-processing would be timed on zero candidates.  sigma = 3 over 1203 classes puts
+        ~2-3 (proposal, class) pairs per proposal above the threshold, i.e. a few thousand NMS candidates per image (what a trained
+        open-vocabulary head yields); swapping the bank is what trainer.py:187-191 does per test set."""
+        import torch
+        hit = self.__dict__.get("_eval_heads")
+        if hit is not None:
+            return hit
+        h, _ = build_heads(self.args, self.device)
+        h.res5 = self.heads.res5
+        h.box_predictor.load_state_dict(self.heads.box_predictor.state_dict())
+        with torch.no_grad():
+            feats = [self.features["res4"][:1]]
+            scores, _ = h.box_predictor(h._shared_roi_transform(feats, self.boxes[:1], pooled=True))
+            std = float(scores[:, :-1].std())
+            bank = self.heads.box_predictor.cls_score.weight.detach().clone() * (sigma / max(std, 1e-30))
+            h.box_predictor.set_class_embeddings(bank)
+        self._eval_heads = h
+        self.eval_logit_sigma = sigma
+        return h
+
+    def step_eval(self, n_images: int = 1):
+        """The reference's EVALUATION call (configs/coco_stt.yaml:50, coco_lsm.yaml:121: TEST.IMS_PER_BATCH 1 -> one image x
+        POST_NMS_TOPK_TEST 1000 proposals per call): roi_heads(images, features, proposals, None) -> inference_detection
+        (roi_emb_heads.py:351-360): ROIAlign + Res5 + mean, the box predictor AND box_predictor.inference (softmax, box
+        decoding, score threshold, class-wise NMS, top-100)."""
+        import torch
+        h = self.eval_heads()
+        with torch.no_grad():
+            feats = {"res4": self.features["res4"][:n_images]}
+            return h(None, feats, self.proposals[:n_images], None)
+
     def step_s1(self):
         import torch
         with torch.no_grad():
@@ -228,7 +351,7 @@ class Workload:
 class TrainWorkload:
     """One LSM training step of the path (see the module docstring)."""
 
-    def __init__(self, args, device, backend, world, data_seed=1992, config=None):
+    def __init__(self, args, device, backend, world, data_seed=1992, config=None, ddp=None):
         import torch
         import locov_amd
         from locov_amd.grounding_head import GroundingHead
@@ -236,6 +359,7 @@ class TrainWorkload:
         self.stt = (config or args.train_config) == "stt"
         self.n_images = 3 if self.stt else args.train_images                 # IMS_PER_BATCH 24 / 8 GPUs (coco_stt.yaml:41)
         self.n_classes = 48 if self.stt else args.classes
+        ddp = (world > 1 or args.force_dist) if ddp is None else bool(ddp)
         self.set_data(data_seed)
         self.heads, cfg = build_heads(args, device, res5=backend, train=True, stt=self.stt)
         if self.stt:
@@ -254,9 +378,10 @@ class TrainWorkload:
 
             self.module = STTStep()
             self.run = self.module
-            if world > 1 or args.force_dist:
+            if ddp:
                 from torch.nn.parallel import DistributedDataParallel as DDP
-                self.run = DDP(self.module, device_ids=None if args.share_gpu else [device.index], broadcast_buffers=False)
+                self.run = DDP(self.module, device_ids=None if args.share_gpu else [device.index], broadcast_buffers=False,
+                               bucket_cap_mb=args.ddp_bucket_mb)
             params = [p for p in self.module.parameters() if p.requires_grad]
             self.opt = torch.optim.SGD(params, lr=0.005, momentum=0.9, weight_decay=1e-4)   # coco_stt.yaml:42
             return
@@ -289,38 +414,47 @@ class TrainWorkload:
 
         self.module = LSMStep()
         self.run = self.module
-        if world > 1 or args.force_dist:       # the gradient exchange of the path: DDP's bucketed all-reduce (RCCL over xGMI), overlapped with backward
+        if ddp:       # the gradient exchange of the path: DDP's bucketed all-reduce (RCCL over xGMI), overlapped with backward
             from torch.nn.parallel import DistributedDataParallel as DDP
-            self.run = DDP(self.module, device_ids=None if args.share_gpu else [device.index], broadcast_buffers=False)
+            self.run = DDP(self.module, device_ids=None if args.share_gpu else [device.index], broadcast_buffers=False,
+                           bucket_cap_mb=args.ddp_bucket_mb)
         params = [p for p in self.module.parameters() if p.requires_grad]
         self.opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=1e-4)   # coco_lsm.yaml:104-105
 
     def set_data(self, seed):
-        """Synthetic batch of one rank: res4 maps, proposals (a few of them near the ground truth), targets, captions."""
+        """The FIXED synthetic batch of one rank (1333 x 800 images, args.proposals proposals, seven GT boxes per image)."""
         import torch
-        from locov_amd.structures import Boxes, Instances
-        args, device = self.args, self.device
         gen = torch.Generator().manual_seed(seed)
-        B, R = self.n_images, args.proposals
-        self.features = torch.randn(B, 1024, 50, 84, generator=gen).to(device)
-        self.proposals, self.targets = [], []
-        for _ in range(B):
-            gt = synth_boxes(gen, 7)
-            b = synth_boxes(gen, R)
-            b[:7] = (gt + torch.rand(7, 4, generator=gen) * 8 - 4).clamp(min=0)
-            b[:, 2:] = torch.maximum(b[:, 2:], b[:, :2] + 1.0)
-            p = Instances((800, 1333))
-            p.proposal_boxes = Boxes(b.to(device))
-            p.objectness_logits = torch.zeros(R, device=device)
-            t = Instances((800, 1333))
-            t.gt_boxes = Boxes(gt.to(device))
-            t.gt_classes = torch.randint(0, self.n_classes, (7,), generator=gen).to(device)
-            self.proposals.append(p)
-            self.targets.append(t)
-        self.caption = {"input_embeddings": torch.randn(B, 70, args.dim, generator=gen).to(device),
-                        "attention_mask": torch.ones(B, 70, device=device),
-                        "special_tokens_mask": torch.zeros(B, 70, device=device)}
-        self.caption["special_tokens_mask"][:, 0] = 1
+        self.use_batch(synth_train_batch(gen, self.device, self.n_images, self.args.proposals, self.n_classes, self.args.dim))
+
+    def use_batch(self, batch):
+        self.features, self.proposals, self.targets, self.caption = batch["features"], batch["proposals"], batch["targets"], batch["caption"]
+
+    def make_pool(self, n_batches: int, seed: int, n_props: int = 2000, underfill_every: int = 0):
+        """`n_batches` batches of the reference's REAL training shapes, resident in HBM: 2 000 RPN proposals per
+        image into the labelling (Detectron2's POST_NMS_TOPK_TRAIN default), every image its own size out of
+        configs/coco_stt.yaml:54's MIN_SIZE_TRAIN (the batch padded to its largest image), 0-15 GT boxes per image incl. none, and
+        every `underfill_every`-th batch with one image that cannot fill the sampling budget -- LSM (POSITIVE_FRACTION 1.0: any 200
+        candidates fill it): an image with fewer proposals than the budget, the forward waits for the true counts; STT (0.25 of
+        512): an image whose proposals all sit on ground-truth boxes, the speculated sample misses and the forward is repeated."""
+        import torch
+        gen = torch.Generator().manual_seed(seed)
+        budget = self.heads.batch_size_per_image
+        self.pool = []
+        for i in range(n_batches):
+            under = bool(underfill_every) and i % underfill_every == underfill_every - 1
+            short = (i % self.n_images, max(budget // 2, 8)) if under and not self.stt else None
+            crowded = i % self.n_images if under and self.stt else None
+            self.pool.append(synth_train_batch(gen, self.device, self.n_images, n_props, self.n_classes, self.args.dim,
+                                               multiscale=True, max_gt=15, fixed_gt=False, short_image=short, crowded_image=crowded))
+        self.pool_at = 0
+        return self.pool
+
+    def step_pool(self):
+        """One training step on the NEXT batch of the pool (a different map size, proposal set and ground truth every step)."""
+        self.use_batch(self.pool[self.pool_at % len(self.pool)])
+        self.pool_at += 1
+        return self.step()
 
     def forward_backward(self, scale: float = 1.0):
         """Forward + backward of one step (gradients ACCUMULATE into .grad; under DDP they are averaged over the ranks)."""
@@ -335,34 +469,76 @@ class TrainWorkload:
         self.opt.step()
         return n_sampled
 
+    def trace_exchange(self, steps: int = 3):
+        """Where DDP's buckets become ready inside the Res5 backward (locov_amd.sharding.GradientExchangeTrace), from the LAST of
+        `steps` traced training steps of this (DDP-wrapped) workload."""
+        from locov_amd.sharding import GradientExchangeTrace
+        if self.run is self.module:
+            raise RuntimeError("trace_exchange: the workload is not wrapped in DistributedDataParallel")
+        trace = self.__dict__.get("_trace")
+        if trace is None:
+            trace = self._trace = GradientExchangeTrace(self.run, self.module.named_parameters(), self.device)
+        rep = None
+        for _ in range(steps):
+            self.opt.zero_grad(set_to_none=True)
+            trace.start()
+            self.forward_backward()
+            rep = trace.stop()
+            self.opt.step()
+        return rep
 
-TRAFFIC_FILE = "r05_pmc_traffic.json"
+
+TRAFFIC_FILE = "r06_pmc_traffic.json"
+
+
+def traffic_record(args):
+    """(record, reason): the committed PMC passes (profiles/<TRAFFIC_FILE>: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
+    this same command on ANOTHER box, corrected as MI355X_MICROARCH.md prescribes) when they describe THIS run -- the same workload
+    and a library built from the same kernel sources -- else (None, why not).  Counters cannot be collected from inside the timed
+    run; a record that does not match is refused loudly (roofline.traffic null + roofline.traffic_source says why), never used
+    silently."""
+    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        wl = rec["workload"]
+    except (OSError, KeyError, ValueError) as e:
+        return None, f"profiles/{TRAFFIC_FILE} unreadable ({type(e).__name__})"
+    diff = [k for k in ("images", "proposals", "classes", "dim", "res5", "conv3x3", "block0", "res5_dtype") if wl.get(k) != getattr(args, k)]
+    if diff:
+        return None, f"profiles/{TRAFFIC_FILE} was taken on another workload (differs in {', '.join(diff)})"
+    # staleness: the PMC pass names the kernel sources it was taken on (locov_amd.build.source_fingerprint at collection
+    # time); a library built from other sources moves different bytes, so the recorded figure is refused
+    from locov_amd import build as _build
+    have, want = rec.get("source_fingerprint"), _build.source_fingerprint()
+    if have != want:
+        return None, (f"profiles/{TRAFFIC_FILE} is STALE: taken on kernel sources {have}, this library is built from {want} "
+                      "(re-run tools/profile_round.sh)")
+    return rec, None
 
 
 def recorded_traffic(args, kernel_key: str):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/<TRAFFIC_FILE>; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
-    same command, corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be collected from
-    inside the timed run, so this is null unless the workload is the one that was profiled."""
+    """HBM bytes per launch of the kernel(s) whose profiler name contains kernel_key, from traffic_record(); None without one."""
+    rec, _ = traffic_record(args)
+    if rec is None:
+        return None
     try:
-        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
-            rec = json.load(f)
-        wl = rec["workload"]
-        if any(wl[k] != getattr(args, k) for k in ("images", "proposals", "classes", "dim", "res5", "conv3x3", "block0", "res5_dtype")):
-            return None
-        # staleness: the PMC pass names the kernel sources it was taken on (locov_amd.build.source_fingerprint at collection
-        # time); a library built from other sources moves different bytes, so the recorded figure is refused
-        from locov_amd import build as _build
-        if rec.get("source_fingerprint") != _build.source_fingerprint():
-            return None
         keys = (kernel_key,) if isinstance(kernel_key, str) else tuple(kernel_key)
         hits = [v for name, v in rec["kernels"].items() if any(k in name for k in keys)]      # every matching template instance
         n = sum(v["launches_sampled"] for v in hits)
         if n:
             return sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in hits) / n
-    except (OSError, KeyError, ValueError):
+    except (KeyError, ValueError, TypeError):
         pass
     return None
+
+
+def traffic_source(args) -> str:
+    rec, why = traffic_record(args)
+    if rec is None:
+        return f"none -- {why}"
+    return (f"profiles/{TRAFFIC_FILE}: rocprofv3 --pmc passes of this command on the same kernel sources (fingerprint "
+            f"{rec.get('source_fingerprint')}), collected by the builder on ANOTHER box, not in this run")
 
 
 def usable_cores() -> int:
@@ -528,6 +704,31 @@ def main():
         # the slowest rank defines the job's time
         return max_over_ranks(dt, device if args.dist_backend == "nccl" else None)
 
+    def eval_scope():
+        """scopes.eval_1img: the reference's evaluation call (TEST.IMS_PER_BATCH 1) incl. the post-processing, per image."""
+        wl.eval_heads()
+        steps_e = max(args.steps, 10)
+        dte = timed(wl.step_eval, steps_e, 5, key="eval1")
+        inst = wl.step_eval()[0][0]
+        n_b = max(args.steps // 2, 3)
+        dte8 = timed(lambda: wl.step_eval(args.images), n_b, 2)
+        ms1 = dte / steps_e * 1e3
+        return {"what": "roi_heads(images, features, proposals, None) -> inference_detection (roi_emb_heads.py:351-360) on ONE image x "
+                        f"{args.proposals} proposals x {args.classes} classes: ROIAlign + Res5 + mean + predictor + softmax / box decoding / "
+                        "score threshold 0.05 / class-wise NMS 0.5 / top-100 (configs/coco_stt.yaml:50 TEST.IMS_PER_BATCH 1)",
+                "ms_per_image": ms1, "proposals_per_s": args.proposals * world / (ms1 * 1e-3),
+                "single_calls_ms": step_stats["eval1"], "wall_ms_per_image": wall["eval1"] / steps_e * 1e3,
+                "detections_per_image": len(inst), "logit_sigma": wl.eval_logit_sigma,
+                f"batched_{args.images}img_ms_per_image": dte8 / n_b / args.images * 1e3,
+                "bank": "the bench's bank scaled to logit sigma 3 over the proposals (random-init logits pass no score threshold)"}
+
+    if args.only_eval:
+        if rank == 0:
+            print(json.dumps({"eval_1img": eval_scope()}))
+        if dist_on:
+            dist.destroy_process_group()
+        return
+
     props_per_step = args.images * args.proposals * world
     # dominant kernel: the library brackets each of its GEMM-kernel launches with HIP events on the
     # launch stream while this is enabled (include/locov_hip.h, locov_gemm_timing_*)
@@ -587,6 +788,12 @@ def main():
             variants[key + "_proposals_per_s"] = props_per_step * max(args.steps // 2, 3) / dtv
             del h2
 
+    eval_1img = None
+    if not args.skip_eval and args.res5 == "hip":
+        eval_1img = eval_scope()
+        eval_1img["vs_batched_S2_rate"] = eval_1img["proposals_per_s"] / (props_per_step * args.steps / dt2)
+        wl.__dict__.pop("_eval_heads", None)
+
     def time_train(config, backend):
         tw = TrainWorkload(args, device, backend, world, data_seed=1992 + rank, config=config)
         n_sampled = tw.step()
@@ -605,9 +812,70 @@ def main():
             dtu = timed(tw.step, steps_u, 0, freeze=False)
             out.update(ms_per_step_unfrozen_heap=dtu / steps_u * 1e3, unfrozen_heap_steps=steps_u,
                        unfrozen_heap_full_collections=gc.get_stats()[2]["collections"] - full0)
+        if args.multiscale_batches > 0:
+            # the same step on the reference's REAL training shapes (TrainWorkload.make_pool): a different map size, 2 000
+            # proposals per image, 0-15 GT boxes and, every 8th batch, an image that cannot fill the sampling budget
+            pool = tw.make_pool(args.multiscale_batches, seed=7 + rank, n_props=2000, underfill_every=8)
+            tw.heads.stats.clear()
+            steps_m = 2 * len(pool)
+            dtm = timed(tw.step_pool, steps_m, len(pool), key="train_ms_" + config)       # (warm-up: every shape once)
+            out.update(ms_per_step_multiscale=dtm / steps_m * 1e3,
+                       multiscale={"steps": steps_m, "batches": len(pool), "proposals_per_image": 2000,
+                                   "res4_maps": sorted({f"{b['map'][0]}x{b['map'][1]}" for b in pool}),
+                                   "gt_boxes_per_image": "0-15", "underfilled_batches": sum(1 for i in range(len(pool)) if i % 8 == 7),
+                                   "single_steps_ms": step_stats["train_ms_" + config],
+                                   "what": "configs/coco_stt.yaml:54 MIN_SIZE_TRAIN (640 ... 800) x COCO-like aspect ratios, batch padded to "
+                                           "its largest image, a different batch every step (pool resident in HBM)"},
+                       speculation_misses=tw.heads.stats.get("speculation_misses", 0),
+                       retry_stats=dict(tw.heads.stats))
+            del pool
+            tw.pool = []
+        if dist_on and not args.skip_exchange_probe:
+            # behind the timed brackets (they ran DDP's stock all-reduce): three traced steps of the same DDP module
+            tw.set_data(1992 + rank)
+            out["exchange_schedule"] = tw.trace_exchange(3)
         del tw
         torch.cuda.empty_cache()
         return out
+
+    def exchange_probe():
+        """The N = 1 run has no process group: place DDP's buckets on the Res5 backward's timeline with a ONE-rank gloo group
+        (the module, the autograd nodes and DDP's bucket logic are the N-rank ones; only the collective's transport differs),
+        behind every timed bracket.  Any failure is reported, never raised: this is a diagnostic beside the figures."""
+        import datetime
+        try:
+            dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
+                                    timeout=datetime.timedelta(seconds=60))
+        except Exception as e:            # noqa: BLE001
+            return {"error": f"one-rank gloo group: {type(e).__name__}: {e}"[:300]}
+        try:
+            tw = TrainWorkload(args, device, "hip", 1, data_seed=1992, config="lsm", ddp=True)
+            for _ in range(3):
+                tw.step()
+            rep = tw.trace_exchange(3)
+            rep["from"] = "one-rank gloo DistributedDataParallel of the LSM step, three traced steps behind the timed brackets"
+            del tw
+            return rep
+        except Exception as e:            # noqa: BLE001
+            return {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            dist.destroy_process_group()
+            torch.cuda.empty_cache()
+
+    def gradient_exchange(tr):
+        ge = {"how": (f"DistributedDataParallel over {world} ranks ({args.dist_backend}), bucket_cap_mb {args.ddp_bucket_mb}" if dist_on
+                      else f"none (1 rank); under N ranks: DistributedDataParallel, bucket_cap_mb {args.ddp_bucket_mb}"),
+              "autograd_nodes": "Res5HeadFn + one Res5BlockFn per bottleneck (locov_amd/res5_train.py): block b's weight gradients reach DDP's "
+                                "hooks when block b's backward kernels are enqueued; 17 MiB buckets close with [bbox_pred + res5.2], [res5.1], "
+                                "[res5.0] (emb_pred / v2l_projection first, 1 MiB first-bucket cap)",
+              "bytes": "res5 59.8 MB + emb_pred 6.3 MB + bbox_pred 33 kB fp32 (SURVEY 8e)"}
+        if args.skip_exchange_probe:
+            return ge
+        if dist_on:
+            ge["schedule"] = {k: tr[k].pop("exchange_schedule", None) for k in ("lsm", "stt") if isinstance(tr.get(k), dict)}
+        else:
+            ge["schedule"] = {"lsm": exchange_probe()}
+        return ge
 
     train = None
     if args.mode == "infer" and not args.skip_train and args.res5 == "hip" and args.res5_dtype in ("f16x2", "fp32"):
@@ -621,8 +889,8 @@ def main():
                  "stt": dict(time_train("stt", "hip"), config="configs/coco_stt.yaml",
                              what=f"3 img/GPU x {args.proposals} proposals -> 512 sampled/img, 48-class bank, emb_pred frozen; "
                                   "EmbeddingRes5ROIHeads.forward(targets) + backward + SGD step"),
-                 "backend": "hip", "res5_dtype": args.res5_dtype,
-                 "gradient_exchange": (f"DistributedDataParallel over {world} ranks ({args.dist_backend})" if dist_on else "none (1 rank)")}
+                 "backend": "hip", "res5_dtype": args.res5_dtype}
+        train["gradient_exchange"] = gradient_exchange(train)
     if args.mode == "train":
         train = {}
         for backend in args.train_backends.split(","):
@@ -657,6 +925,7 @@ def main():
                     "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / MFMA_F32_PEAK_TFLOPS if achieved else None,
                     "traffic": recorded_traffic(args, "gemm_nt_kernel<float, float, 128, 128, 2, 2, 2, 0, false, 8"),
+                    "traffic_source": traffic_source(args),
                     "traffic_unit": f"HBM-side bytes per launch, averaged over the launches of all instances of this kernel (PMC, profiles/{TRAFFIC_FILE})",
                     "launches_per_step": n0 / args.steps, "avg_launch_ms": ms0 / max(n0, 1),
                     "share_of_step_time": ms0 * 1e-3 / dt2,
@@ -699,6 +968,7 @@ def main():
                         "bound": "mfma", "achieved": ach, "peak": MFMA_16BIT_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / MFMA_16BIT_PEAK_TFLOPS,
                         "traffic": recorded_traffic(args, "gemm_split_big_kernel"),
+                        "traffic_source": traffic_source(args),
                         "algorithmic_bytes": bys / max(ns, 1),
                         "traffic_unit": f"HBM-side bytes per launch (memory side of L2: FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes; "
                                         f"separate rocprofv3 --pmc passes, profiles/{TRAFFIC_FILE}), averaged over this kernel's launches; "
@@ -764,7 +1034,7 @@ def main():
             "dtype": ("bf16 operands / f32 accumulate in Res5 (opt-in reduced precision, not the parity configuration)"
                       if args.res5_dtype == "bf16" else
                       ("f32 (Res5 GEMM products formed from f16x2 split operands on the f16 matrix pipe, f32 accumulate; error "
-                       "vs f64 <= the f32-MFMA path's, tests/test_gpu_split_gemm.py)" if args.res5_dtype == "f16x2" and args.res5 == "hip"
+                       "vs f64 <= 1.5 x the f32-MFMA kernel's + 6e-7 and <= 3e-6 on every tested shape, tests/test_gpu_split_gemm.py)" if args.res5_dtype == "f16x2" and args.res5 == "hip"
                        else "f32") + ("" if args.sim_dtype == "fp32" else " (bf16 similarity operands)")),
             "data": "synthetic",
             "config": {"workload": f"{args.images} img/GPU x {args.proposals} proposals, res4 [B,1024,50,84] fp32, "
@@ -781,7 +1051,8 @@ def main():
             "process_group": f"{args.dist_backend} x{world}" if dist_on else None,
             "scopes": {"S2_full_head_proposals_per_s": props_per_step * args.steps / dt2,
                        "S1_handwritten_kernels_proposals_per_s": None if args.skip_s1 else props_per_step * args.steps / dt1,
-                       "S1_ms_per_step": None if args.skip_s1 else dt1 / args.steps * 1e3, "S1_roi_align_roofline": s1_roi, **variants},
+                       "S1_ms_per_step": None if args.skip_s1 else dt1 / args.steps * 1e3, "S1_roi_align_roofline": s1_roi, **variants,
+                       "eval_1img": eval_1img},
             "roofline": roof,
         }
         if dt2_f32 is not None:

@@ -1321,10 +1321,17 @@ int locov_roi_align_nhwc_bwd(const float *grad_rows, int64_t grad_ld, int N, int
     // developer A/B: LOCOV_POOL_BWD_WINDOW=<bytes>, 0 -> every proposal scatters straight to memory
     const char *we = getenv("LOCOV_POOL_BWD_WINDOW");          // (read per launch: tests flip it)
     const int win_bytes = we ? atoi(we) : 20480;
-    static const bool attr_ok = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(&roi_align_nhwc_kernel<float, float, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess;
-    }();
+    // (the attribute belongs to the kernel's code object on ONE device: set once per device a launch is made on -- a process that
+    // drives several GPUs, or whose first call failed on one of them, must not decide for the others)
+    static int attr_state[64] = {};                            // per device: 0 = not tried, 1 = set, -1 = refused
+    int dev = 0;
+    bool attr_ok = false;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (attr_state[dev] == 0)
+            attr_state[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(&roi_align_nhwc_kernel<float, float, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess ? 1 : -1;
+        attr_ok = attr_state[dev] == 1;
+    }
     const int wb = attr_ok && win_bytes > 0 ? (win_bytes < 65536 ? win_bytes : 65536) : 0;
     hipLaunchKernelGGL((roi_align_nhwc_kernel<float, float, true>), grid, dim3(kNhwcThreads), (size_t)wb, as_stream(stream),
                        (const float *)grad_feat, N, H, W, C, rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, bin_stride,

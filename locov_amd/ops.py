@@ -539,7 +539,7 @@ class RangeGuard:
         self.event = None
         # deferred: nobody reads this word before the results are used -- whoever holds the guard zero-fills what the guarded
         # launches produced ON THE DEVICE when it is set (zero_if_raised) and reads the word whenever it next talks to the host
-        # (the training forward: res5_train.Res5RowsFn / EmbeddingProposalsRes5ROIHeads.forward)
+        # (the training forward: res5_train.Res5BlockFn / EmbeddingProposalsRes5ROIHeads.forward)
         self.deferred = deferred
 
     def reset(self) -> None:

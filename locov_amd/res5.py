@@ -131,7 +131,7 @@ class Res5Stage(nn.Sequential):
 
     def range_guard(self, kind: str, device):
         """This stage's range-guard word of the split arithmetic for `kind` ("fwd": owned by whoever runs a guarded forward;
-        "bwd": raised by Res5RowsFn.backward, never reset there) on `device` and the current stream."""
+        "bwd": raised by the backward of res5_train.Res5BlockFn, never reset there) on `device` and the current stream."""
         from . import ops
         key = (kind, torch.device(device), torch.cuda.current_stream(device).cuda_stream)
         g = self._guards.get(key)
@@ -139,7 +139,7 @@ class Res5Stage(nn.Sequential):
             g = self._guards[key] = ops.RangeGuard(device, deferred=kind in self.DEFERRED_KINDS)
         return g
 
-    # guards nobody reads where they are raised: "bwd" (Res5RowsFn.backward) and "fwd_train" (the training forward of the ROI
+    # guards nobody reads where they are raised: "bwd" (res5_train.Res5BlockFn.backward) and "fwd_train" (the training forward of the ROI
     # heads) -- the pass zero-fills its results on the device when the word is set, the word is read with the NEXT host read
     DEFERRED_KINDS = ("bwd", "fwd_train")
 
@@ -152,11 +152,18 @@ class Res5Stage(nn.Sequential):
         """Device words of every "bwd" guard of `device` (to be read together with another host read)."""
         return [g.word for kind, g in self.deferred_guards(device) if kind == "bwd"]
 
+    def forget_scales(self) -> None:
+        """Drop every remembered split-operand scale and everything packed with one (a range guard tripped: what no longer fits
+        may be a remembered scale): the scales are chosen afresh at the next packing, also at unchanged weight versions."""
+        self._scales.clear()
+        self._cache.clear()
+        self.__dict__.pop("_train_ops_by", None)
+        self.__dict__.pop("_train_ops", None)
+
     def backward_guard_tripped(self) -> None:
         """A remembered weight scale stopped covering its weight during a backward: forget the scales (they are chosen
         afresh at the next packing) and clear the words."""
-        self._scales.clear()
-        self._cache.clear()
+        self.forget_scales()
         for (kind, _, _), g in self._guards.items():
             if kind == "bwd":
                 g.reset()
@@ -232,15 +239,25 @@ class Res5Stage(nn.Sequential):
 
     def train_operands(self, split: bool, grid: bool = True, rois: bool = True) -> "TrainOperands":
         """The GEMM operands of one training step (forward and backward of every convolution), valid for the current weight
-        versions: built once per step, by the first Res5 call that asks (see TrainOperands)."""
-        key = (bool(split), bool(grid), bool(rois)) + tuple(
-            (c.weight.data_ptr(), c.weight._version, c.norm.weight._version, c.norm.running_var._version)
-            for blk in self for c in (blk.conv1, blk.conv2, blk.conv3, blk.shortcut) if c is not None)
-        hit = self.__dict__.get("_train_ops")
-        if hit is not None and hit[0] == key:
+        versions: built once per step and FLAVOUR (arithmetic, which 3x3 forms are needed), by the first Res5 call that asks
+        (see TrainOperands).  A step that calls the stage through different flavours (res5_grid and res5_rois separately instead
+        of one Res5Step) gets one operand set per flavour, each in its own buffers: a later set never re-packs, in place, the
+        buffers an earlier set's SplitWeight objects still point at for their backward."""
+        versions = tuple((c.weight.data_ptr(), c.weight._version, c.norm.weight._version, c.norm.running_var._version)
+                         for blk in self for c in (blk.conv1, blk.conv2, blk.conv3, blk.shortcut) if c is not None)
+        flavour = (bool(split), bool(grid), bool(rois))
+        by = self.__dict__.setdefault("_train_ops_by", {})
+        hit = by.get(flavour)
+        if hit is not None and hit[0] == versions:
+            self.__dict__["_train_ops"] = (flavour + versions, hit[1])
             return hit[1]
-        val = TrainOperands(self, split, grid, rois)
-        self.__dict__["_train_ops"] = (key, val)
+        # a NEW step (the weights moved since the last operand set of any flavour): steps are counted and scale refreshes adopted
+        # once per weight version, not once per construction
+        new_step = self.__dict__.get("_train_ops_versions") != versions
+        self.__dict__["_train_ops_versions"] = versions
+        val = TrainOperands(self, split, grid, rois, new_step=new_step)
+        by[flavour] = (versions, val)
+        self.__dict__["_train_ops"] = (flavour + versions, val)      # (the latest set: tests read its `ready`)
         return val
 
     def _packed_block0_tail(self):
@@ -577,7 +594,7 @@ class TrainOperands:
     REFRESH = 64
     WINO_GAIN = 2.25          # max_f (sum_a |G[f][a]|)^2 of csrc/winograd_tables.h: |((G (x) G) w)[f]| <= 2.25 max |w|
 
-    def __init__(self, stage: "Res5Stage", split: bool, grid: bool, rois: bool):
+    def __init__(self, stage: "Res5Stage", split: bool, grid: bool, rois: bool, new_step: bool = True):
         from . import ops
         self.stage, self.split = stage, bool(split)
         self.ready = {}
@@ -593,7 +610,7 @@ class TrainOperands:
                 wanted += [(c2, "wino"), (c2, "uflip")]
             if grid:
                 wanted += [(c2, "col"), (c2, "flip9")]
-        if _ASYNC_REFRESH:
+        if _ASYNC_REFRESH and new_step:
             self._adopt_refresh()
         recs = [stage._scales.get(self.scale_key(conv, tag)) for conv, tag in wanted]
         # (async refresh: a remembered scale stays usable past REFRESH -- the new one is on its way; sync: it sends the step to the chain)
@@ -622,12 +639,14 @@ class TrainOperands:
             w = conv.weight.detach()
             shape = ops.prep_shape(tag, w)
             bk = (id(conv), tag)
-            buf = bufs.get(bk)
+            fk = (bool(grid), bool(rois)) + bk                # (per flavour: see Res5Stage.train_operands)
+            buf = bufs.get(fk)
             if buf is None or tuple(buf.shape) != shape or buf.device != w.device:
-                buf = bufs[bk] = torch.empty(shape, dtype=torch.float32, device=w.device)
+                buf = bufs[fk] = torch.empty(shape, dtype=torch.float32, device=w.device)
             rs = stage._fold(conv)[0] if tag in ("t", "uflip", "flip9") else None
             jobs.append((tag, w, rs, buf, rec[0]))
-            stage._scales[self.scale_key(conv, tag)] = (rec[0], rec[1] + 1)
+            if new_step:
+                stage._scales[self.scale_key(conv, tag)] = (rec[0], rec[1] + 1)
             self.ready[bk] = ops.SplitWeight(buf, rec[0])
         ops.res5_weight_prep(jobs)
 

@@ -34,7 +34,8 @@ import torch
 
 from . import ops
 
-__all__ = ["res5_rows", "res5_grid", "res5_rois", "roi_align_even_rows", "to_nhwc", "Res5RowsFn", "Res5Step", "Segment"]
+__all__ = ["res5_rows", "res5_grid", "res5_rois", "roi_align_even_rows", "to_nhwc", "Res5BlockFn", "Res5HeadFn", "Res5Step", "Segment",
+           "saved_activations"]
 
 _BWD_STREAMS = bool(int(os.environ.get("LOCOV_RES5_BWD_STREAMS", "1")))    # the grid segment's 3x3 gradients on a side stream (0: one stream)
 _SIDE_STREAMS = {}
@@ -175,8 +176,14 @@ class Res5Step:
                              and isinstance(u2, ops.SplitWeight) and isinstance(w3, ops.SplitWeight))
                     keep = None
                     if _KEEP_V and isinstance(u2, ops.SplitWeight) and c2.in_channels % 8 == 0 and seg.n > 0:
-                        keep = self.wino_ws[(bi, si)] = torch.empty(
-                            ops.winograd_workspace_bytes(seg.n, c2.in_channels, c2.out_channels), dtype=torch.uint8, device=self.device)
+                        # (the whole workspace of this convolution -- V and M, 121 * n * (Cin + N) * 4 bytes: 0.4 GB per block at 800
+                        # proposals -- stays alive until the backward although only V is read again: the kernels take ONE
+                        # pointer; trivial against 288 GB.  Only when the forward runs in ONE pass: with the developer knob
+                        # LOCOV_WINO_CHUNK the workspace holds V per chunk as [121][chunk][Cin], which the weight gradient's
+                        # TN GEMMs would misread as [121][R][Cin] -- then the activation is transformed again in the backward)
+                        ws_bytes = ops.winograd_workspace_bytes(seg.n, c2.in_channels, c2.out_channels)
+                        if ws_bytes == 121 * seg.n * (c2.in_channels + c2.out_channels) * 4 + 16:
+                            keep = self.wino_ws[(bi, si)] = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
                     ops.winograd_conv3x3(Y1[sl], u2, scale=s2, shift=b2, relu=True, roi_major=True, in_roi_major=True, out=Y2[sl],
                                          range_check_scale=16.0 if early else None, workspace=keep)
                     if early:
@@ -199,10 +206,86 @@ class Res5Step:
 
     def outputs(self, inputs: Sequence[torch.Tensor], pooled: Sequence[bool]) -> List[torch.Tensor]:
         """The segments' stage outputs as differentiable tensors ([rows, Cout] pixel rows, or with pooled[i] the per-tile mean
-        [n, Cout]) of `inputs` (the tensors the producers wrote into input_rows, carrying the graph) and the stage's weights."""
+        [n, Cout]) of `inputs` (the tensors the producers wrote into input_rows, carrying the graph) and the stage's weights.
+        The graph is ONE autograd node per bottleneck (Res5BlockFn) behind a head node (Res5HeadFn): block b's weight
+        gradients reach their AccumulateGrad nodes -- and DistributedDataParallel's bucket hooks -- as soon as block b's backward
+        kernels are enqueued, while the blocks in front of it are still to come (ovr/engine/trainer.py:61-66: the reference
+        gets the same overlap from Detectron2's per-convolution autograd nodes)."""
         assert len(inputs) == len(pooled) == len(self.segments) and not self._pending
-        outs = Res5RowsFn.apply(self, tuple(bool(p) for p in pooled), len(inputs), *inputs, *_stage_weights(self.stage))
+        # a DEFERRED guard held by the caller (the ROI heads' training forward): nothing reads it before the backward runs, so
+        # the backward must not turn the inf / NaN activations of an out-of-range forward into gradients -- every node zero-fills
+        # what it produced on the device when that word is set (the caller does the same with this forward's outputs)
+        # (its per-forward copy `step_word`, which the caller fills at the end of ITS forward: a later forward's labelling read
+        # may clear the guard's own word before this backward runs)
+        active = ops.active_guard(self.device) if self.split else None
+        self.skip_words = [getattr(active, "step_word", active.word)] if active is not None and getattr(active, "deferred", False) else []
+        self.bwd_split = self.split and not _BWD_F32
+        self._carry = None                            # (gradient of a block's output, its operand-scale slot) on its way to that block's node
+        self._prefetched = False
+        self.need_x0 = any(t.requires_grad for t in inputs)
+        ws = _block_weights(self.stage)
+        h = Res5BlockFn.apply(self, 0, len(inputs), *inputs, *ws[0])
+        for bi in range(1, len(ws)):
+            h = Res5BlockFn.apply(self, bi, 1, h, *ws[bi])
+        outs = Res5HeadFn.apply(self, tuple(bool(p) for p in pooled), h)
         return list(outs) if isinstance(outs, tuple) else [outs]
+
+    # -- pieces of the backward shared by the nodes ---------------------------------------------------------------------------
+    def _bwd_operands(self):
+        # (LOCOV_RES5_BWD_F32: a split forward with the backward on the f32 MFMA takes the fp32 operand set)
+        sp = self.bwd_split
+        return self.operands if self.operands.split == bool(sp) else self.stage.train_operands(bool(sp))
+
+    def _bwd_guarded(self, fn):
+        """Run one node's backward.  Split arithmetic: what can leave fp16's range here is not data -- the activations passed the
+        forward's guard (the weight-gradient GEMMs and the Winograd transforms see the same tensors at the same scales) and every
+        gradient's operand scale is chosen on the device from its own max |g|.  Only a REMEMBERED weight scale (Res5Stage._split:
+        chosen again every 64 steps, 8x headroom) that stopped covering a weight could trip the guard -- the pack kernel raises
+        it.  That is recorded in the stage's "bwd" guard and nothing is read inside autograd (a host read here would stall DDP's
+        overlapped all-reduce).  Instead every node ends with a GradScaler-style skip decided ON THE DEVICE: when the word is set
+        every gradient the node produced is zero-filled (locov_zero_if_raised: one launch that exits after a scalar load when
+        the word is clear), so no inf / NaN can reach the optimizer or the all-reduce whether or not another step follows.  The
+        operands of ALL blocks are packed by the first node that runs (_prefetch_bwd_operands), so a stale scale of any block is
+        known before the first weight gradient is handed to autograd: a skipped pass leaves zeros everywhere, never the
+        gradients of some blocks.  The ROI heads look at the word together with the ONE host read of the next step's labelling
+        (SampleAllROIHeads.label_and_sample_proposals), warn, and drop the remembered scales; `stage.backward_guard_raised()`
+        reads it on demand (e.g. next to a trainer's loss logging)."""
+        if not self.bwd_split:
+            grads = fn()
+            for w in self.skip_words:
+                ops.zero_if_raised(grads, w)
+            return grads
+        guard = self.stage.range_guard("bwd", self.device)
+        with ops.range_guard(guard):
+            self._prefetch_bwd_operands()
+            grads = fn()
+        ops.zero_if_raised(grads, guard.word)          # (every gradient here is a freshly written contiguous tensor or a row slice of one)
+        for w in self.skip_words:
+            ops.zero_if_raised(grads, w)
+        return grads
+
+    def _prefetch_bwd_operands(self) -> None:
+        """Split arithmetic, operands not out of the step's one preparation launch (the steps that choose scales): pack every
+        operand the backward of ANY block will ask for now, under the guard, in front of the first gradient."""
+        if self._prefetched:
+            return
+        self._prefetched = True
+        T = self._bwd_operands()
+        if not T.split:
+            return
+        live = [seg for seg in self.segments if seg.rows > 0]
+        for bi, blk in enumerate(self.stage):
+            c2 = blk.conv2
+            want = [(blk.conv3, "t")]
+            if bi > 0 or self.need_x0:                # (block 0's input gradient only when the stage input asks for one)
+                want.append((blk.conv1, "t"))
+                if blk.shortcut is not None:
+                    want.append((blk.shortcut, "t"))
+            for seg in live:
+                want.append((c2, "uflip" if _wino_ok(seg.H, seg.W, c2.out_channels, c2.in_channels) and not _NO_WINO_BWD else "flip9"))
+            for conv, tag in want:
+                if (id(conv), tag) not in T.ready:
+                    T.get(conv, tag)
 
 
 def _linear(x, W, bias=None, **kw):
@@ -212,45 +295,29 @@ def _linear(x, W, bias=None, **kw):
     return ops.linear(x, W, bias, **kw)
 
 
-class Res5RowsFn(torch.autograd.Function):
-    """The autograd node of a Res5Step: forward hands out what the step already computed; backward is the joint pass
+# test / measurement hook: called as _BACKWARD_MARK(kind, block) with kind "head", "block_begin", "block_end" from inside the
+# backward (host side, kernels of everything before it are enqueued) -- tests/test_gpu_multirank.py and bench.py record HIP events
+# here to place DDP's bucket-ready points on the Res5 backward's timeline
+_BACKWARD_MARK = None
 
-        with g the gradient of a block's output already masked by (output > 0), over the rows of ALL segments:
-          dW3 = s3 * g^T y2                      TN GEMM over the pixel rows (gemm_tn.hip)
-          g2  = (g . s3 W3) * [y2 > 0]           NT GEMM, mask fused into the epilogue
-          dW2 = s2 * wgrad3x3(y1, g2)            per segment: Winograd domain (121 TN GEMMs) or im2col + TN GEMM
-          g1  = conv3x3(g2, flip(s2 W2)) * [y1 > 0]         per segment
-          dW1 = s1 * g1^T x ;  dWs = ss * g^T x
-          gx  = (g1 . s1 W1 + g [. ss Ws]) * [x > 0]      = the masked gradient of the previous block's output
 
-    Inputs: (step, pooled flags, n_segments, x0 of every segment ..., the convolution weights in module order -- block 0:
-    conv1, conv2, conv3, shortcut; then conv1..conv3 of the following blocks -- passed as inputs so that autograd routes their
-    gradients).  saved_tensors: per block (x, y1, y2, out) over the joint rows (tests read the active sets from them)."""
+def _mark(kind: str, bi: int = -1) -> None:
+    if _BACKWARD_MARK is not None:
+        _BACKWARD_MARK(kind, bi)
+
+
+class Res5HeadFn(torch.autograd.Function):
+    """The tail of a Res5Step's graph: hands out the segments' outputs (rows, or their per-tile mean) of the last block's joint
+    rows; backward gathers the segments' output gradients into ONE matrix, masked by the last block's ReLU, and chooses its
+    operand scale (split arithmetic) from the small tensors it was derived from."""
 
     @staticmethod
-    def forward(ctx, step, pooled, nseg, *args):
-        stage = step.stage
-        x_in = args[:nseg]
-        rows = step.filled
-        ctx.step, ctx.pooled, ctx.nseg = step, pooled, nseg
-        ctx.split = step.split and not _BWD_F32
-        # a DEFERRED guard held by the caller (the ROI heads' training forward): nothing reads it before the backward runs, so
-        # the backward must not turn the inf / NaN activations of an out-of-range forward into gradients -- it zero-fills them
-        # on the device when that word is set (the caller does the same with this forward's outputs)
-        # (its per-forward copy `step_word`, which the caller fills at the end of ITS forward: a later forward's labelling read
-        # may clear the guard's own word before this backward runs)
-        active = ops.active_guard(step.device) if step.split else None
-        ctx.skip_words = [getattr(active, "step_word", active.word)] if active is not None and getattr(active, "deferred", False) else []
-        ctx.nw = len(args) - nseg
-        saved = []
-        x = step.x0[:rows]
-        for (y1, y2, out) in step.act:
-            saved += [x, y1[:rows], y2[:rows], out[:rows]]
-            x = out[:rows]
-        ctx.save_for_backward(*saved)
-        outs = []
+    def forward(ctx, step, pooled, h):
+        ctx.step, ctx.pooled = step, pooled
         last = step.act[-1][2]
-        for seg, pool, xi in zip(step.segments, pooled, x_in):
+        ctx.save_for_backward(last[:step.filled])
+        outs = []
+        for seg, pool in zip(step.segments, pooled):
             o = last[seg.row0:seg.row0 + seg.rows]
             if pool:
                 o = ops.spatial_mean(o.view(seg.n, seg.H, seg.W, o.shape[1]), channels_last=1) if seg.rows else o.new_zeros((0, o.shape[1]))
@@ -259,55 +326,26 @@ class Res5RowsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grad_outs):
-        if not ctx.split:
-            grads = Res5RowsFn._backward(ctx, grad_outs, False)
-            for w in ctx.skip_words:
-                ops.zero_if_raised(grads, w)
-            return grads
-        # Split arithmetic.  What can leave fp16's range here is not data: the activations passed the forward's guard (the
-        # weight-gradient GEMMs and the Winograd transforms see the same tensors at the same scales) and every gradient's
-        # operand scale is chosen on the device from its own max |g|.  Only a REMEMBERED weight scale (Res5Stage._split: chosen
-        # again every 64 steps, 8x headroom) that stopped covering a weight could trip the guard -- the pack kernel
-        # raises it.  That is recorded in the stage's "bwd" guard and nothing is read inside autograd (a host read here would
-        # stall DDP's overlapped all-reduce).  Instead the pass ends with a GradScaler-style skip decided ON THE DEVICE: when the
-        # word is set every gradient this pass produced (stage input and all convolution weights) is zero-filled
-        # (locov_zero_if_raised: one launch that exits after a scalar load when the word is clear), so no inf / NaN can reach
-        # the optimizer or the all-reduce whether or not another step follows.  The ROI heads look at the word together with
-        # the ONE host read of the next step's labelling (SampleAllROIHeads.label_and_sample_proposals), warn, and drop the
-        # remembered scales; `stage.backward_guard_raised()` reads it on demand (e.g. next to a trainer's loss logging).
-        guard = ctx.step.stage.range_guard("bwd", ctx.step.device)
-        with ops.range_guard(guard):
-            grads = Res5RowsFn._backward(ctx, grad_outs, True)
-        ops.zero_if_raised(grads, guard.word)          # (every gradient here is a freshly written contiguous tensor or a row slice of one)
-        for w in ctx.skip_words:
-            ops.zero_if_raised(grads, w)
-        return grads
-
-    @staticmethod
-    def _backward(ctx, grad_outs, sp):
         step = ctx.step
-        stage, segs, nseg = step.stage, step.segments, ctx.nseg
+        _mark("head")
+        (out_last,) = ctx.saved_tensors
         rows = step.filled
-        saved = ctx.saved_tensors
-        need_x = any(ctx.needs_input_grad[3:3 + nseg])
-        need_w = ctx.needs_input_grad[3 + nseg:]
-        gw: List[Optional[torch.Tensor]] = [None] * ctx.nw
-        nb = len(stage)
-        out_last = saved[4 * nb - 1]
-        new = lambda c: torch.empty((rows, c), dtype=torch.float32, device=step.device)
-        # Operand scales of the gradients (split arithmetic): every kernel that WRITES a gradient folds max |.| into a zeroed
-        # 16-byte slot (ops.scale_slot) on its way out, and the GEMMs that read the gradient derive its power-of-two scale from
-        # the slot -- no separate pass over the tensor, no host read.
-        slot = (lambda ref: ops.scale_slot(ref)) if sp else (lambda ref: None)
+        sp = step.bwd_split
+        g = torch.empty((rows, out_last.shape[1]), dtype=torch.float32, device=step.device)
+        if rows == 0:
+            step._carry = (g, None)
+            return None, None, g
         # gradient of the last block's output, masked by its ReLU, every segment into its rows of ONE matrix
         # (the element-wise kernels at the head of the chain keep the separate reduction: their waves all finish together,
         # so every one of them would issue its atomic -- measured +110 us on the grid's relu_mask against a 10 us reduction)
-        g = new(out_last.shape[1])
         bound_of, bound_mul = [], []
-        for seg, pool, go in zip(segs, ctx.pooled, grad_outs):
+        for seg, pool, go in zip(step.segments, ctx.pooled, grad_outs):
             if seg.rows == 0:
                 continue
             sl = slice(seg.row0, seg.row0 + seg.rows)
+            if go is None:
+                g[sl].zero_()
+                continue
             go = ops._dev(go, "grad_out")
             if pool:
                 ops.spatial_mean_bwd(go, out_last[sl], seg.H * seg.W, out=g[sl])
@@ -315,20 +353,86 @@ class Res5RowsFn(torch.autograd.Function):
                 ops.relu_mask(go, out_last[sl], out=g[sl])
             bound_of.append(go)
             bound_mul.append(1.0 / (seg.H * seg.W) if pool else 1.0)
-        if rows == 0:
-            return (None, None, None) + tuple(None for _ in range(nseg)) + tuple(
-                torch.zeros_like(w) if need else None for w, need in zip(_stage_weights(stage), need_w))
         # the operand scale of g: its range is bounded by the SMALL tensors it was just derived from (a broadcast of the pooled
         # gradient / 49, a masked copy of the grid's) -- one launch over those instead of a pass over g's 43 400 x 2 048 values
         if not sp:
             sg = None
-        elif len(bound_of) <= ops.AMAX_BOUND_MAX and all(t.numel() % 4 == 0 for t in bound_of):
+        elif bound_of and len(bound_of) <= ops.AMAX_BOUND_MAX and all(t.numel() % 4 == 0 for t in bound_of):
             sg = ops.amax_bound(bound_of, bound_mul)
         else:
             sg = ops.split_scale_from_amax(g)
+        for w in step.skip_words:
+            ops.zero_if_raised([g], w)
+        step._carry = (g, sg)
+        return None, None, g
 
-        # (LOCOV_RES5_BWD_F32: a split forward with the backward on the f32 MFMA takes the fp32 operand set)
-        T = step.operands if step.operands.split == bool(sp) else stage.train_operands(bool(sp))
+
+class Res5BlockFn(torch.autograd.Function):
+    """One bottleneck of a Res5Step under autograd: forward hands out what the step already computed (the block's joint output
+    rows); backward is the block's part of the joint pass
+
+        with g the gradient of the block's output already masked by (output > 0), over the rows of ALL segments:
+          dW3 = s3 * g^T y2                      TN GEMM over the pixel rows (gemm_tn.hip)
+          g2  = (g . s3 W3) * [y2 > 0]           NT GEMM, mask fused into the epilogue
+          dW2 = s2 * wgrad3x3(y1, g2)            per segment: Winograd domain (121 TN GEMMs) or im2col + TN GEMM
+          g1  = conv3x3(g2, flip(s2 W2)) * [y1 > 0]         per segment
+          dW1 = s1 * g1^T x ;  dWs = ss * g^T x
+          gx  = (g1 . s1 W1 + g [. ss Ws]) * [x > 0]      = the masked gradient of the previous block's output
+
+    Inputs: (step, block index, number of data inputs, the data inputs -- block 0: x0 of every segment; every other block: the
+    previous block's joint output rows --, the block's convolution weights in module order: conv1, conv2, conv3[, shortcut],
+    passed as inputs so that autograd routes their gradients).  The tensors between two block nodes are INTERNAL to
+    Res5Step.outputs: the gradient one node returns for its input is the next node's `g` -- already masked by the ReLU in front
+    of it -- and its operand-scale slot travels beside it in step._carry.
+    saved_tensors: (x, y1, y2, out) of the block over the joint rows (tests read the active sets from them: saved_activations)."""
+
+    @staticmethod
+    def forward(ctx, step, bi, n_in, *args):
+        rows = step.filled
+        ctx.step, ctx.bi, ctx.n_in = step, bi, n_in
+        ctx.nw = len(args) - n_in
+        y1, y2, out = step.act[bi]
+        x = step.x0 if bi == 0 else step.act[bi - 1][2]
+        ctx.save_for_backward(x[:rows], y1[:rows], y2[:rows], out[:rows])
+        return out[:rows]
+
+    @staticmethod
+    def backward(ctx, g):
+        step = ctx.step
+        _mark("block_begin", ctx.bi)
+        grads = step._bwd_guarded(lambda: Res5BlockFn._backward(ctx, g))
+        _mark("block_end", ctx.bi)
+        return (None, None, None) + tuple(grads)
+
+    @staticmethod
+    def _backward(ctx, g):
+        step, bi, n_in = ctx.step, ctx.bi, ctx.n_in
+        stage, segs = step.stage, step.segments
+        sp = step.bwd_split
+        rows = step.filled
+        blk = stage[bi]
+        has_sc = blk.shortcut is not None
+        first = bi == 0
+        need_x = any(ctx.needs_input_grad[3:3 + n_in])
+        need_w = ctx.needs_input_grad[3 + n_in:]
+        gw: List[Optional[torch.Tensor]] = [None] * ctx.nw
+        weights = _block_weights(stage)[bi]
+        if rows == 0:
+            return tuple(None for _ in range(n_in)) + tuple(
+                torch.zeros_like(w) if need else None for w, need in zip(weights, need_w))
+        carry, step._carry = step._carry, None
+        if carry is not None and carry[0].data_ptr() == g.data_ptr() and carry[0].shape == g.shape:
+            g, sg = carry
+        else:
+            raise RuntimeError("Res5BlockFn.backward: the gradient of a block's output must come from the node behind it "
+                               "(the tensors between two block nodes are internal to Res5Step.outputs)")
+        x, y1, y2, _ = ctx.saved_tensors
+        new = lambda c: torch.empty((rows, c), dtype=torch.float32, device=step.device)
+        # Operand scales of the gradients (split arithmetic): every kernel that WRITES a gradient folds max |.| into a zeroed
+        # 16-byte slot (ops.scale_slot) on its way out, and the GEMMs that read the gradient derive its power-of-two scale from
+        # the slot -- no separate pass over the tensor, no host read.
+        slot = (lambda ref: ops.scale_slot(ref)) if sp else (lambda ref: None)
+        T = step._bwd_operands()
 
         def wgrad_1x1(g_, sg_, x_, s_):                # dW = s * g^T x
             if sp and g_.shape[1] % 4 == 0 and x_.shape[1] % 4 == 0 and g_.shape[0] > 0:
@@ -342,42 +446,34 @@ class Res5RowsFn(torch.autograd.Function):
             y_ = ops.linear_ex(g_, wt, **kw)
             return y_, (ops.split_scale_from_amax(y_) if sp and amax_out is not None else None)
 
-        wi_of, wi = [], 0
-        for blk in stage:
-            wi_of.append(wi)
-            wi += 4 if blk.shortcut is not None else 3
-        for bi in range(nb - 1, -1, -1):
-            blk = stage[bi]
-            has_sc, wi = blk.shortcut is not None, wi_of[bi]
-            x, y1, y2, _ = saved[4 * bi: 4 * bi + 4]
-            s1, s2, s3 = stage._fold(blk.conv1)[0], stage._fold(blk.conv2)[0], stage._fold(blk.conv3)[0]
-            c2 = blk.conv2
-            # conv3: dW3 = s3 * g^T y2 ; g2 = (g . s3 W3) [y2 > 0]         -- all segments, one launch each
-            if need_w[wi + 2]:
-                gw[wi + 2] = wgrad_1x1(g, sg, y2, s3).view_as(blk.conv3.weight)
-            g2, sg2 = dgrad_1x1(g, sg, blk.conv3, amax_out=slot(g), mask=y2)
-            # conv2 (3x3), per segment: dW2 = s2 * wgrad(y1, g2) ; g1 = conv3x3(g2, flip(s2 W2)) [y1 > 0]
-            g1 = new(y1.shape[1])
-            sg1 = slot(g2)
-            # (on the f32 MFMA nothing fills sg1; in split arithmetic every segment's kernel folds its max into the ONE slot)
-            # The segments' 3x3 gradients are independent of each other: with two of them (whole grid + proposals) the general-grid
-            # segment's chain -- im2col GEMMs of 4 200 rows that fill half the chip -- runs on a SIDE stream next to the proposals'
-            # Winograd-domain chain (between two joins with the main stream per block)
-            live = [(si, seg) for si, seg in enumerate(segs) if seg.rows > 0]
-            side = _side_stream(step.device) if _BWD_STREAMS and len(live) == 2 and sum(step.seg_wino(sg_, c2) for _, sg_ in live) == 1 else None
-            main = torch.cuda.current_stream(step.device)
-            parts = []
-            for si, seg in live:
-                sl = slice(seg.row0, seg.row0 + seg.rows)
-                wino = step.seg_wino(seg, c2)
-                on_side = side is not None and not wino
-                if on_side:
-                    side.wait_stream(main)
-                    for t_ in (g1, g2, y1):
-                        t_.record_stream(side)
-                with torch.cuda.stream(side if on_side else main):
-                  part = None
-                  if need_w[wi + 1]:
+        s1, s2, s3 = stage._fold(blk.conv1)[0], stage._fold(blk.conv2)[0], stage._fold(blk.conv3)[0]
+        c2 = blk.conv2
+        # conv3: dW3 = s3 * g^T y2 ; g2 = (g . s3 W3) [y2 > 0]         -- all segments, one launch each
+        if need_w[2]:
+            gw[2] = wgrad_1x1(g, sg, y2, s3).view_as(blk.conv3.weight)
+        g2, sg2 = dgrad_1x1(g, sg, blk.conv3, amax_out=slot(g), mask=y2)
+        # conv2 (3x3), per segment: dW2 = s2 * wgrad(y1, g2) ; g1 = conv3x3(g2, flip(s2 W2)) [y1 > 0]
+        g1 = new(y1.shape[1])
+        sg1 = slot(g2)
+        # (on the f32 MFMA nothing fills sg1; in split arithmetic every segment's kernel folds its max into the ONE slot)
+        # The segments' 3x3 gradients are independent of each other: with two of them (whole grid + proposals) the general-grid
+        # segment's chain -- im2col GEMMs of 4 200 rows that fill half the chip -- runs on a SIDE stream next to the proposals'
+        # Winograd-domain chain (between two joins with the main stream per block)
+        live = [(si, seg) for si, seg in enumerate(segs) if seg.rows > 0]
+        side = _side_stream(step.device) if _BWD_STREAMS and len(live) == 2 and sum(step.seg_wino(sg_, c2) for _, sg_ in live) == 1 else None
+        main = torch.cuda.current_stream(step.device)
+        parts = []
+        for si, seg in live:
+            sl = slice(seg.row0, seg.row0 + seg.rows)
+            wino = step.seg_wino(seg, c2)
+            on_side = side is not None and not wino
+            if on_side:
+                side.wait_stream(main)
+                for t_ in (g1, g2, y1):
+                    t_.record_stream(side)
+            with torch.cuda.stream(side if on_side else main):
+                part = None
+                if need_w[1]:
                     if wino and c2.out_channels % 4 == 0 and not _NO_WINO_BWD:
                         part = ops.winograd_wgrad(y1[sl], g2[sl], s2, roi_major=True, split=sp, v_split=step.wino_ws.get((bi, si)) if sp else None)
                     else:
@@ -393,7 +489,7 @@ class Res5RowsFn(torch.autograd.Function):
                     if on_side:
                         part.record_stream(main)
                     parts.append(part)
-                  if _wino_ok(seg.H, seg.W, c2.out_channels, c2.in_channels) and not _NO_WINO_BWD:
+                if _wino_ok(seg.H, seg.W, c2.out_channels, c2.in_channels) and not _NO_WINO_BWD:
                     uflip = T.get(c2, "uflip")
                     if isinstance(uflip, ops.SplitWeight):
                         ops.winograd_conv3x3_split_ex(g2[sl], uflip, mask=y1[sl], roi_major=True, amax_out=sg1, out=g1[sl])
@@ -401,56 +497,74 @@ class Res5RowsFn(torch.autograd.Function):
                         ops.winograd_conv3x3_ex(g2[sl], uflip, mask=y1[sl], roi_major=True, out=g1[sl])
                         if sp and g1[sl].numel() % 4 == 0:
                             ops.amax_bound([g1[sl]], [1.0], slot=sg1)
-                  else:
+                else:
                     # data gradient on the general grid: the same im2col GEMM with the flipped filter (im2col only copies and
                     # zero-pads: the patches have g2's range)
                     _, got = dgrad_1x1(ops.im2col3x3(g2[sl], seg.H, seg.W), sg2, c2, "flip9", amax_out=sg1, mask=y1[sl], out=g1[sl])
                     if sp and got is not sg1 and g1[sl].numel() % 4 == 0:
                         ops.amax_bound([g1[sl]], [1.0], slot=sg1)      # (an operand the split GEMM cannot take: its f32 result's range by a pass)
-            if side is not None:
-                main.wait_stream(side)
-            if need_w[wi + 1]:
-                dw2 = parts[0]
-                for part in parts[1:]:
-                    dw2 = dw2.add_(part)
-                gw[wi + 1] = dw2
-            del g2
-            # conv1 (+ shortcut): dW1 = s1 * g1^T x ; gx = (g1 . s1 W1 + shortcut path) [x > 0]
-            if need_w[wi]:
-                gw[wi] = wgrad_1x1(g1, sg1, x, s1).view_as(blk.conv1.weight)
-            if has_sc:
-                ss = stage._fold(blk.shortcut)[0]
-                if need_w[wi + 3]:
-                    gw[wi + 3] = wgrad_1x1(g, sg, x, ss).view_as(blk.shortcut.weight)
-            first = bi == 0
-            if first and not need_x:
-                g = None
-                break
-            # the input of block 0 is the stage input (no ReLU in front of it); every other block's input is the
-            # post-ReLU output of its predecessor, whose mask turns gx into that block's masked output gradient
-            mask = None if first else x
-            # (the slot of gx is only needed when a block below reads it: not for the stage input's gradient)
-            gx, sgx = dgrad_1x1(g1, sg1, blk.conv1, amax_out=None if (first or has_sc) else slot(g1),
-                                residual=None if has_sc else g, mask=None if has_sc else mask)
-            if has_sc:
-                gx, sgx = dgrad_1x1(g, sg, blk.shortcut, amax_out=None if first else slot(g), residual=gx, mask=mask)
-            del g1
-            g, sg = gx, sgx
-        gxs = [None] * nseg
-        if g is not None:
-            for i, seg in enumerate(segs):
-                if ctx.needs_input_grad[3 + i]:
-                    gxs[i] = g[seg.row0:seg.row0 + seg.rows]
-        return (None, None, None, *gxs, *gw)
+        if side is not None:
+            main.wait_stream(side)
+        if need_w[1]:
+            dw2 = parts[0]
+            for part in parts[1:]:
+                dw2 = dw2.add_(part)
+            gw[1] = dw2
+        del g2
+        # conv1 (+ shortcut): dW1 = s1 * g1^T x ; gx = (g1 . s1 W1 + shortcut path) [x > 0]
+        if need_w[0]:
+            gw[0] = wgrad_1x1(g1, sg1, x, s1).view_as(blk.conv1.weight)
+        if has_sc:
+            ss = stage._fold(blk.shortcut)[0]
+            if need_w[3]:
+                gw[3] = wgrad_1x1(g, sg, x, ss).view_as(blk.shortcut.weight)
+        if not need_x:
+            return tuple(None for _ in range(n_in)) + tuple(gw)
+        # the input of block 0 is the stage input (no ReLU in front of it); every other block's input is the
+        # post-ReLU output of its predecessor, whose mask turns gx into that block's masked output gradient
+        mask = None if first else x
+        # (the slot of gx is only needed when a block below reads it: not for the stage input's gradient)
+        gx, sgx = dgrad_1x1(g1, sg1, blk.conv1, amax_out=None if (first or has_sc) else slot(g1),
+                            residual=None if has_sc else g, mask=None if has_sc else mask)
+        if has_sc:
+            gx, sgx = dgrad_1x1(g, sg, blk.shortcut, amax_out=None if first else slot(g), residual=gx, mask=mask)
+        del g1
+        if not first:
+            step._carry = (gx, sgx)
+            return (gx,) + tuple(gw)
+        gxs = [None] * n_in
+        for i, seg in enumerate(segs):
+            if ctx.needs_input_grad[3 + i]:
+                gxs[i] = gx[seg.row0:seg.row0 + seg.rows]
+        return tuple(gxs) + tuple(gw)
 
 
-def _stage_weights(stage) -> Tuple[torch.Tensor, ...]:
-    ws = []
+def saved_activations(out: torch.Tensor) -> List[torch.Tensor]:
+    """The activations the Res5 nodes behind `out` (an output of Res5Step.outputs, possibly behind view / layout nodes) saved
+    for their backward, per block (x, y1, y2, out) over the joint rows, block 0 first -- the device's own active sets."""
+    found, stack, seen = {}, [out.grad_fn], set()
+    while stack:
+        n = stack.pop()
+        if n is None or id(n) in seen:
+            continue
+        seen.add(id(n))
+        if "Res5BlockFn" in type(n).__name__:
+            found[n.bi] = n
+        stack += [f for f, _ in n.next_functions]
+    saved = []
+    for bi in sorted(found):
+        saved += list(found[bi].saved_tensors)
+    return saved
+
+
+def _block_weights(stage) -> List[Tuple[torch.Tensor, ...]]:
+    out = []
     for blk in stage:
-        ws += [blk.conv1.weight, blk.conv2.weight, blk.conv3.weight]
+        ws = [blk.conv1.weight, blk.conv2.weight, blk.conv3.weight]
         if blk.shortcut is not None:
             ws.append(blk.shortcut.weight)
-    return tuple(ws)
+        out.append(tuple(ws))
+    return out
 
 
 def _guarded(stage, split, guard, device, build):
@@ -467,8 +581,7 @@ def _guarded(stage, split, guard, device, build):
     if own is not None and own.raised():
         # (what left the range may be a remembered operand scale that stopped covering its weight -- the step's operands are
         # packed under this guard: the scales are chosen afresh at the next packing)
-        stage._scales.clear()
-        stage._cache.clear()
+        stage.forget_scales()
         if guard[0] is not None:
             guard[0]()
         del step

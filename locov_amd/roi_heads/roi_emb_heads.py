@@ -229,6 +229,20 @@ class SampleAllROIHeads(ROIHeads):
         out.set("fg_proposal", (~is_bg).to(classes.dtype))
         return out, num_neg, num_pos + num_neg
 
+    @property
+    def stats(self) -> Dict[str, int]:
+        """Counters of the training forward's retry machine since construction (or `stats.clear()`): `forwards`; `speculated`
+        (sample formed on the device without a host wait); `speculation_misses` (a speculated forward repeated from the true counts);
+        `unspeculated` (the forward waited for the labelling: a batch the lean path does not take, e.g. an image with fewer
+        candidates than the budget); `guard_trips` (a forward left the split arithmetic's range) and `fp32_repeats` (RES5_TRAIN_GUARD
+        "sync": that forward repeated on the f32 MFMA); `deferred_trips` ("deferred": a skipped step found at the next labelling read);
+        `bwd_guard_trips` (a stale backward weight scale: that backward's Res5 gradients were zeroed)."""
+        return self.__dict__.setdefault("_stats", {})
+
+    def _count(self, key: str, n: int = 1) -> None:
+        st = self.stats
+        st[key] = st.get(key, 0) + n
+
     def _backward_guard_words(self, device):
         """Device words to read with the labelling sync (none in the base class)."""
         return []
@@ -249,7 +263,7 @@ class SampleAllROIHeads(ROIHeads):
         sampled, bg_counts, totals = [], [], []
         matched = [self._match_one_image(props, tgt) for props, tgt in zip(proposals, targets)]     # no host value needed
         # ONE host read for the whole batch: population sizes, the reference's two validity asserts, and -- it costs nothing
-        # here -- the range-guard words the previous step's Res5 backward may have raised (res5_train.Res5RowsFn.backward)
+        # here -- the range-guard words the previous step's Res5 backward may have raised (res5_train.Res5BlockFn.backward)
         avail = []
         if matched:
             rows = torch.stack([m[-1] for m in matched])
@@ -549,7 +563,13 @@ class SampleAllROIHeads(ROIHeads):
             out.set("fg_proposal", flag)
         return sampled
 
-    def _label_log(self, counts) -> None:
+    def _label_log(self, counts, st=None) -> None:
+        """roi_head/num_{fg,bg}_samples (:114-116), ONCE per labelling: a forward that is repeated (the read flipped RES5_DTYPE, a
+        speculation miss) must not enter the event storage's smoothed history twice."""
+        if st is not None:
+            if st.get("logged"):
+                return
+            st["logged"] = True
         bg = np.asarray([n for _, n in counts], dtype=np.float64)
         fg = np.asarray([p for p, _ in counts], dtype=np.float64)
         storage = get_event_storage()
@@ -569,7 +589,7 @@ class SampleAllROIHeads(ROIHeads):
             pieces += [pos_order[off_r[i]:off_r[i] + num_pos], neg_order[off_r[i]:off_r[i] + num_neg]]
         picked = torch.cat(pieces, dim=0)                                       # rows of the concatenated proposals
         sampled = self._label_build(st, picked, [p + n for p, n in counts])
-        self._label_log(counts)
+        self._label_log(counts, st)
         st["done"] = sampled                              # (a forward that is repeated on the f32 MFMA keeps its draw)
         return sampled
 
@@ -640,7 +660,7 @@ class SampleAllROIHeads(ROIHeads):
         counts = self._sample_counts(self._label_host(st))
         ok = all(p + n == int(self.batch_size_per_image) for p, n in counts)
         if ok:
-            self._label_log(counts)
+            self._label_log(counts, st)
         return ok
 
 
@@ -844,15 +864,17 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
 
     def _deferred_guards_tripped(self, kinds) -> None:
         if "bwd" in kinds:
+            self._count("bwd_guard_trips")
             self._backward_guard_tripped()
         if "fwd_train" in kinds:
+            self._count("guard_trips")
+            self._count("deferred_trips")
             import warnings
             for kind, g in self.res5.deferred_guards(next(self.res5.parameters()).device):
                 if kind == "fwd_train":
                     g.reset()
-            if hasattr(self.res5, "_scales"):
-                self.res5._scales.clear()
-                self.res5._cache.clear()
+            if hasattr(self.res5, "forget_scales"):
+                self.res5.forget_scales()
             self.res5_dtype = "fp32"
             warnings.warn("Res5 activations left the range of the f16x2 split arithmetic (|x| >= 4094) during the previous training "
                           "step: that step's Res5 outputs and gradients were ZEROED on the device (no inf / NaN reached the losses "
@@ -861,7 +883,8 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
                           "repeats an out-of-range forward instead", RuntimeWarning, stacklevel=4)
 
     def _train_guard(self, feats: List[torch.Tensor]):
-        """The DEFERRED range guard of a training forward (RES5_TRAIN_GUARD "deferred", the default): never read inside the
+        """The DEFERRED range guard of a training forward (RES5_TRAIN_GUARD "deferred"; opt-in, the default is "sync":
+        config.py, _deferred_guard): never read inside the
         step -- a host read behind the Res5 forward drains the GPU in front of the step's ~200 small launches (predictor,
         losses, grounding head) -- but acted on ON THE DEVICE: the forward's outputs and the backward's gradients are
         zero-filled when the word is set (ops.zero_if_raised), and the word travels with the next step's labelling read."""
@@ -895,9 +918,8 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
                       "are chosen afresh from here on", RuntimeWarning, stacklevel=3)
 
     def _warn_overflow(self):
-        if hasattr(self.res5, "_scales"):
-            self.res5._scales.clear()            # remembered operand scales may be what no longer fits
-            self.res5._cache.clear()
+        if hasattr(self.res5, "forget_scales"):
+            self.res5.forget_scales()            # remembered operand scales may be what no longer fits
         if not self._overflow_warned:
             import warnings
             warnings.warn("Res5 activations left the range of the f16x2 split arithmetic (|x| >= 4094): this call was repeated "
@@ -994,12 +1016,20 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
 
         dtype_was = self.res5_dtype
         sampled = self._label_speculate(pending)
+        self._count("forwards")
+        self._count("speculated" if sampled is not None else "unspeculated")
         proposals, losses, guard = attempt(sampled)
-        if sampled is not None and not (self._label_validate(pending) and self.res5_dtype == dtype_was):
-            del losses
-            proposals, losses, guard = attempt(None)
+        if sampled is not None:
+            filled = self._label_validate(pending)
+            if not (filled and self.res5_dtype == dtype_was):
+                if not filled:
+                    self._count("speculation_misses")
+                del losses
+                proposals, losses, guard = attempt(None)
         if guard is not None and guard.raised():             # RES5_TRAIN_GUARD "sync": waits for the event only -- the predictor's
             self._warn_overflow()                            # and the losses' launches stay queued behind it
+            self._count("guard_trips")
+            self._count("fp32_repeats")
             del losses
             proposals, losses, _ = self._with_res5_dtype("fp32", attempt, proposals)
         return [], losses
@@ -1109,17 +1139,25 @@ class EmbeddingProposalsRes5ROIHeads(EmbeddingRes5ROIHeads):
 
         dtype_was = self.res5_dtype
         sampled = self._label_speculate(pending)
+        self._count("forwards")
+        self._count("speculated" if sampled is not None else "unspeculated")
         visual_grid_features, box_features, proposals, losses, guard = attempt(sampled)
-        if sampled is not None and not (self._label_validate(pending) and self.res5_dtype == dtype_was):
-            # the budget was not filled (the true counts are known now), or the read found the PREVIOUS step's deferred guard set
-            # (RES5_DTYPE is "fp32" from here on): the forward enqueued above is dropped and repeated
-            del visual_grid_features, box_features, proposals, losses
-            visual_grid_features, box_features, proposals, losses, guard = attempt(None)
+        if sampled is not None:
+            filled = self._label_validate(pending)
+            if not (filled and self.res5_dtype == dtype_was):
+                # the budget was not filled (the true counts are known now), or the read found the PREVIOUS step's deferred guard
+                # set (RES5_DTYPE is "fp32" from here on): the forward enqueued above is dropped and repeated
+                if not filled:
+                    self._count("speculation_misses")
+                del visual_grid_features, box_features, proposals, losses
+                visual_grid_features, box_features, proposals, losses, guard = attempt(None)
         if guard is not None and guard.raised():
             # RES5_TRAIN_GUARD "sync": the wait is for the event in front of the stage's last convolution -- the launches behind
             # it (that convolution, the predictor, the losses) are still queued when the host returns to the caller, so the GPU
             # does not drain.  A step that left the split arithmetic's range is repeated on the f32 MFMA (the first graph is dropped)
             self._warn_overflow()
+            self._count("guard_trips")
+            self._count("fp32_repeats")
             del visual_grid_features, box_features, losses
             visual_grid_features, box_features, proposals, losses, _ = self._with_res5_dtype("fp32", attempt, proposals)
         box_features = list(box_features.split([len(x) for x in proposals], dim=0))      # :346

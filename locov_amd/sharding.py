@@ -75,3 +75,81 @@ def gather_per_image(local_results: List[Any], n_images: int) -> List[Any]:
         out.extend(part)
     assert len(out) == n_images
     return out
+
+
+class GradientExchangeTrace:
+    """Where DistributedDataParallel's buckets become ready on the timeline of the path's backward (the one
+    exchange step of a training step is the all-reduce of the gradients of the parameters the path touches, overlapped with the
+    backward -- ovr/engine/trainer.py:61-66).
+
+    Res5's backward is one autograd node per bottleneck (res5_train.Res5BlockFn), so block b's weight gradients reach DDP's hooks
+    when block b's kernels are enqueued.  This registers a DDP communication hook that records a HIP event on the launch stream
+    at the moment a bucket is handed to the all-reduce (the point its collective waits for on the communication stream) and
+    then runs the stock all-reduce, plus marks at the head / begin / end of every block's backward; report() places every
+    bucket on [0, 1] of the Res5 backward's device time and lists the host-side order of marks and buckets.
+
+        trace = GradientExchangeTrace(ddp_module, module.named_parameters(), device)
+        trace.start(); loss.backward(); rep = trace.stop()
+    """
+
+    def __init__(self, ddp, named_parameters, device):
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        self.device = torch.device(device)
+        self.names = {}
+        for n, p in named_parameters:
+            self.names.setdefault(id(p), n)
+        self.seq: List[Tuple[str, Any, Any]] = []
+        self.on = False
+        self._allreduce = default_hooks.allreduce_hook
+        ddp.register_comm_hook(None, self._hook)
+
+    def _event(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def _hook(self, state, bucket):
+        if self.on:
+            buf = bucket.buffer()
+            info = {"index": int(bucket.index()), "bytes": int(buf.numel() * buf.element_size()),
+                    "params": [self.names.get(id(p), "?") for p in bucket.parameters()]}
+            self.seq.append(("bucket", info, self._event()))
+        return self._allreduce(None, bucket)
+
+    def _mark(self, kind: str, bi: int) -> None:
+        self.seq.append((kind, int(bi), self._event()))
+
+    def start(self) -> None:
+        from . import res5_train
+        self.seq = []
+        self.on = True
+        self.t0 = self._event()               # (every time is taken from here: elapsed_time wants its events in order)
+        res5_train._BACKWARD_MARK = self._mark
+
+    def stop(self) -> dict:
+        from . import res5_train
+        res5_train._BACKWARD_MARK = None
+        self.on = False
+        torch.cuda.synchronize(self.device)
+        seq = self.seq
+        head = next((e for k, _, e in seq if k == "head"), None)
+        ends = [e for k, b, e in seq if k == "block_end" and b == 0]
+        out = {"host_order": [k if k == "head" else (f"{k}:{b}" if k != "bucket" else f"bucket:{b['index']}") for k, b, _ in seq]}
+        if head is None or not ends:
+            out["error"] = "no Res5 backward inside the traced region"
+            return out
+        at = lambda e: self.t0.elapsed_time(e)
+        t_head = at(head)
+        total = at(ends[-1]) - t_head
+        out["res5_backward_ms"] = total
+        out["blocks_end_at"] = {f"block{b}": (at(e) - t_head) / total for k, b, e in seq if k == "block_end"}
+        buckets = []
+        for k, info, e in seq:
+            if k != "bucket":
+                continue
+            t = (at(e) - t_head) / total
+            res5 = sorted({n.split("res5.")[1].split(".")[0] for n in info["params"] if "res5." in n})
+            buckets.append({"index": info["index"], "MB": round(info["bytes"] / 1e6, 2), "ready_at": t,
+                            "res5_blocks": res5, "params": info["params"]})
+        out["buckets"] = buckets
+        return out

@@ -35,9 +35,12 @@ def test_ddp_training_step_matches_single_process(tmp_path):
         pytest.fail("GPU tests need a ROCm device")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), os.path.join(ROOT, "tests", "ddp_worker.py"), str(tmp_path)]
-    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    env = _env()
+    env["LOCOV_DDP_WORKER_TRACE"] = "1"
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     ranks = [torch.load(os.path.join(tmp_path, f"rank{i}.pt")) for i in range(2)]
+    _check_bucket_schedule(ranks[0]["exchange"])
     ddp_grads = ranks[0]["grads"]
     # (emb_pred IS the grounding head's v2l_projection -- distill_prop_mmss_gcnn.py:117-125 -- and is listed once, under its first name)
     assert any(k.startswith("heads.res5.") for k in ddp_grads) and "heads.box_predictor.emb_pred.weight" in ddp_grads
@@ -65,11 +68,75 @@ def test_ddp_training_step_matches_single_process(tmp_path):
         assert err <= 1e-5, (k, err)
 
 
+def test_ddp_ranks_on_different_legs_of_the_retry_machine(tmp_path):
+    """inside ONE DistributedDataParallel step rank 0's speculated sample misses (an ignore-band sampler that
+    cannot fill its budget: the forward is repeated from the true counts) while rank 1's forward leaves the split arithmetic's
+    range (RES5_TRAIN_GUARD "sync": repeated on the f32 MFMA).  Both repeats happen inside the forward, so both ranks enter the
+    same collectives in the backward: the step completes and DDP's gradients equal the single-process average of the two shards."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "tests", "ddp_worker.py"), str(tmp_path)]
+    env = _env()
+    env["LOCOV_DDP_WORKER_CASE"] = "legs"
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ranks = [torch.load(os.path.join(tmp_path, f"rank{i}.pt")) for i in range(2)]
+    s0, s1 = ranks[0]["stats"], ranks[1]["stats"]
+    assert s0.get("speculation_misses") == 1 and not s0.get("fp32_repeats"), s0
+    assert s1.get("fp32_repeats") == 1 and s1.get("guard_trips") == 1 and not s1.get("speculation_misses"), s1
+    ddp_grads = ranks[0]["grads"]
+    sys.path.insert(0, ROOT)
+    import warnings
+    import bench
+    from tests import ddp_worker
+    args = bench.parse(ddp_worker.ARGS)
+    tw = bench.TrainWorkload(args, torch.device("cuda", 0), "hip", world=1, data_seed=100)
+    for shard in range(2):
+        ddp_worker.set_case(tw, "legs", shard)
+        torch.manual_seed(500 + shard)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            loss, n = tw.forward_backward(scale=0.5)
+        assert n == ranks[shard]["n_sampled"]
+        assert abs(float(loss) - ranks[shard]["loss"]) <= 1e-5 * max(1.0, abs(float(loss)))
+    assert tw.heads.stats.get("speculation_misses") == 1 and tw.heads.stats.get("fp32_repeats") == 1
+    single = {k: p.grad.detach().cpu() for k, p in tw.module.named_parameters() if p.grad is not None}
+    assert set(single) == set(ddp_grads)
+    for k in single:
+        assert bool(torch.isfinite(ddp_grads[k]).all()), k
+        scale = float(single[k].abs().max().clamp_min(1e-30))
+        assert float((single[k] - ddp_grads[k]).abs().max()) / scale <= 1e-5, k
+
+
+def _check_bucket_schedule(ex):
+    """Res5's backward is one autograd node per bottleneck, so DistributedDataParallel sees block 2's weight
+    gradients -- and can start their all-reduce -- while blocks 1 and 0 are still to run.  `ex`: GradientExchangeTrace.stop() of a
+    traced step (a communication hook recorded a HIP event per ready bucket on the launch stream, then ran the stock all-reduce)."""
+    assert "error" not in ex, ex
+    order, buckets = ex["host_order"], ex["buckets"]
+    assert [o for o in order if not o.startswith("bucket")] == [
+        "head", "block_begin:2", "block_end:2", "block_begin:1", "block_end:1", "block_begin:0", "block_end:0"], order
+    with_res5 = [b for b in buckets if b["res5_blocks"]]
+    assert len(with_res5) >= 3, buckets                                   # (bucket_cap_mb 17: one bucket per bottleneck)
+    first = min(with_res5, key=lambda b: b["ready_at"])
+    assert first["res5_blocks"] == ["2"], first
+    # ready while >= 60 % of the Res5 backward (device time between its first and its last kernel) is still to come ...
+    assert first["ready_at"] <= 0.40, (first["ready_at"], ex["blocks_end_at"])
+    # ... and, on the host, before block 1's backward has been entered: its kernels are not even enqueued yet
+    assert order.index(f"bucket:{first['index']}") < order.index("block_begin:1"), order
+    b1 = [b for b in with_res5 if b["res5_blocks"] == ["1"]]
+    assert b1 and order.index(f"bucket:{b1[0]['index']}") < order.index("block_begin:0"), order
+    assert b1[0]["ready_at"] <= ex["blocks_end_at"]["block1"] + 0.02
+    every = sorted(n for b in buckets for n in b["params"])
+    assert len(every) == len(set(every)) and sum("res5." in n for n in every) == 10, every
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher (it used to run ONE rank and report n_gpus 1)."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--steps", "2",
            "--warmup", "1", "--images", "1", "--proposals", "200", "--classes", "80", "--no-cpu-baseline", "--skip-s1",
-           "--skip-f32-reference", "--skip-variants"]
+           "--skip-f32-reference", "--skip-variants", "--skip-eval", "--multiscale-batches", "2"]
     env = _env()
     env.pop("WORLD_SIZE", None)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -86,7 +153,7 @@ def test_bench_rehearses_eight_ranks():
     training step under DistributedDataParallel on its own images, and the line names all eight."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--dist-backend", "gloo", "--steps", "2",
            "--warmup", "1", "--images", "1", "--proposals", "200", "--classes", "80", "--train-images", "1", "--train-samples", "32",
-           "--unfrozen-steps", "0", "--no-cpu-baseline", "--skip-s1", "--skip-f32-reference", "--skip-variants"]
+           "--unfrozen-steps", "0", "--no-cpu-baseline", "--skip-s1", "--skip-f32-reference", "--skip-variants", "--skip-eval", "--multiscale-batches", "2"]
     env = _env()
     env.pop("WORLD_SIZE", None)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
@@ -99,7 +166,9 @@ def test_bench_rehearses_eight_ranks():
     assert len(out["per_rank_ms_per_step"]) == 8 and all(0 < t < 1e5 for t in out["per_rank_ms_per_step"])
     assert abs(max(out["per_rank_ms_per_step"]) - out["ms_per_step"]) <= 1e-6 * out["ms_per_step"]
     train = out["train"]
-    assert "8 ranks" in train["gradient_exchange"]
+    assert "8 ranks" in train["gradient_exchange"]["how"]
+    sched = train["gradient_exchange"]["schedule"]["lsm"]
+    assert "error" not in sched and any(b["res5_blocks"] == ["2"] for b in sched["buckets"]), sched
     for cfg in ("lsm", "stt"):
         assert len(train[cfg]["per_rank_ms_per_step"]) == 8 and train[cfg]["ms_per_step"] > 0
 
@@ -110,7 +179,7 @@ def test_rccl_one_rank_rehearsal():
     inside the joint Res5 backward with its side stream, on the RCCL stream -- and takes the timing collectives on device tensors."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--steps", "2",
            "--warmup", "1", "--images", "1", "--proposals", "200", "--classes", "80", "--train-images", "1", "--train-samples", "32",
-           "--unfrozen-steps", "0", "--no-cpu-baseline", "--skip-s1", "--skip-f32-reference", "--skip-variants"]
+           "--unfrozen-steps", "0", "--no-cpu-baseline", "--skip-s1", "--skip-f32-reference", "--skip-variants", "--skip-eval", "--multiscale-batches", "2"]
     env = _env()
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -118,7 +187,9 @@ def test_rccl_one_rank_rehearsal():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["process_group"] == "nccl x1" and out["value"] > 0
-    assert "DistributedDataParallel over 1 ranks (nccl)" in out["train"]["gradient_exchange"]
+    assert "DistributedDataParallel over 1 ranks (nccl)" in out["train"]["gradient_exchange"]["how"]
+    sched = out["train"]["gradient_exchange"]["schedule"]["lsm"]              # RCCL's own all-reduce behind the traced hook
+    assert "error" not in sched and any(b["res5_blocks"] == ["2"] for b in sched["buckets"]), sched
     for cfg in ("lsm", "stt"):
         assert out["train"][cfg]["ms_per_step"] > 0
 

@@ -314,17 +314,10 @@ def _float64_stage(oracle, params, x, masks=None, p=None):
 
 def _device_masks(fn_out, R, H, W):
     """The active sets of the device forward: (y1 > 0, y2 > 0, out > 0) per block as NCHW bool tensors on the CPU, read from
-    the activations Res5RowsFn saved for its backward."""
-    node, stack = None, [fn_out.grad_fn]
-    while stack:                                        # the Res5RowsFn node may sit behind view / layout nodes
-        n = stack.pop()
-        if n is None:
-            continue
-        if "Res5RowsFn" in type(n).__name__:
-            node = n
-            break
-        stack += [f for f, _ in n.next_functions]
-    saved = node.saved_tensors
+    the activations the per-block Res5 nodes saved for their backward (res5_train.saved_activations)."""
+    from locov_amd import res5_train
+    saved = res5_train.saved_activations(fn_out)
+    assert saved and len(saved) % 4 == 0
     nchw = lambda t: (t.detach().view(R, H, W, -1).permute(0, 3, 1, 2) > 0).cpu()
     return [tuple(nchw(saved[4 * b + j]) for j in (1, 2, 3)) for b in range(len(saved) // 4)]
 
@@ -545,17 +538,9 @@ def test_joint_step_equals_the_two_calls_and_float64(pkg, oracle, split, togethe
             x0 = res5_train.roi_segment(step, nhwc, rois, 14, 1.0 / 16, 0, True)
         grid_rows, box = step.outputs([rows, x0], [False, True])
         grid = res5_train.to_nchw(grid_rows, N, OH, OW)
-        # the joint node's own active sets (grid rows first, then the proposals' 7x7 tiles), read before the backward frees them
-        stack, fn = [grid.grad_fn], None
-        while stack:
-            n = stack.pop()
-            if n is None:
-                continue
-            if "Res5RowsFn" in type(n).__name__:
-                fn = n
-                break
-            stack += [f_ for f_, _ in n.next_functions]
-        saved = fn.saved_tensors
+        # the block nodes' own active sets (grid rows first, then the proposals' 7x7 tiles), read before the backward frees them
+        saved = res5_train.saved_activations(grid)
+        assert len(saved) == 12
         ng = N * OH * OW
         assert saved[0].shape[0] == ng + 49 * R                                  # the rows in use, not the capacity
         gm = [tuple((saved[4 * b + j][:ng].view(N, OH, OW, -1).permute(0, 3, 1, 2) > 0).cpu() for j in (1, 2, 3)) for b in range(3)]
@@ -794,6 +779,75 @@ def test_training_forward_backward_matches_the_stock_library_path(pkg, oracle, d
     assert worst[0] < 5e-3, worst
 
 
+def _train_batch_sized(pkg, oracle, sizes, r, n_gts, seed):
+    """_train_batch with every image its own (h, w), its own number of proposals (r: int or list) and ground-truth count."""
+    from locov_amd.structures import Boxes, Instances
+    rng = np.random.default_rng(seed)
+    props, targets = [], []
+    rs = r if isinstance(r, (list, tuple)) else [r] * len(sizes)
+    for (h, w), ri, n_gt in zip(sizes, rs, n_gts):
+        scale = np.array([w / 1333.0, h / 800.0, w / 1333.0, h / 800.0], dtype=np.float32)
+        gt = oracle.synth_boxes(rng, n_gt) * scale
+        b = oracle.synth_boxes(rng, ri) * scale
+        if n_gt:
+            b[:n_gt] = gt + rng.uniform(-4, 4, gt.shape).astype(np.float32)
+        b = np.maximum(b, 0)
+        b[:, 2:] = np.maximum(b[:, 2:], b[:, :2] + 1.0)
+        p = Instances((h, w))
+        p.proposal_boxes = Boxes(torch.from_numpy(b.astype(np.float32)).cuda())
+        p.objectness_logits = torch.zeros(ri, device="cuda")
+        t = Instances((h, w))
+        t.gt_boxes = Boxes(torch.from_numpy(gt.astype(np.float32).reshape(-1, 4)).cuda())
+        t.gt_classes = torch.from_numpy(rng.integers(0, 80, n_gt)).cuda()
+        props.append(p)
+        targets.append(t)
+    return props, targets
+
+
+def test_changing_map_sizes_in_one_process_match_the_stock_library_path(pkg, oracle):
+    """the reference trains multi-scale (configs/coco_stt.yaml:54 MIN_SIZE_TRAIN (640 ... 800), batches padded to
+    their largest image), so consecutive steps see DIFFERENT res4 maps, proposal counts and ground-truth counts.  Three steps
+    with three map sizes through ONE pair of modules (hand-written path / torch conv2d autograd), each followed by an SGD step:
+    every step's outputs and gradients agree -- the packed operands, workspaces, cached index tensors and the Res5Step matrices
+    must follow the shape, not remember the previous one.  The second batch holds an image WITHOUT ground truth, the third an
+    image with fewer proposals than the sampling budget (the forward cannot speculate and waits for the true counts)."""
+    heads = {b: _train_heads(pkg, oracle, b, "f16x2")[0] for b in ("miopen", "hip")}
+    c_in = 128
+    opts = {b: torch.optim.SGD([p for p in h.parameters() if p.requires_grad], lr=1e-3) for b, h in heads.items()}
+    cases = [  # (map H, W), per-image sizes, proposals per image, GT per image
+        ((50, 84), [(800, 1333), (800, 1200)], 60, [5, 3]),
+        ((40, 60), [(640, 960), (640, 853)], [48, 70], [0, 9]),
+        ((67, 67), [(1067, 800), (800, 1067)], [90, 16], [15, 2]),
+        ((50, 84), [(800, 1333), (800, 1200)], 60, [5, 3]),          # ... and back to the first shape
+    ]
+    rel_l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    for it, ((mh, mw), sizes, r, n_gts) in enumerate(cases):
+        outs = {}
+        for backend, h in heads.items():
+            feat = torch.randn(2, c_in, mh, mw, generator=torch.Generator().manual_seed(50 + it)).cuda().requires_grad_(True)
+            props, targets = _train_batch_sized(pkg, oracle, sizes, r, n_gts, seed=60 + it)
+            opts[backend].zero_grad(set_to_none=True)
+            torch.manual_seed(90 + it)
+            grid, box_feats, sampled, losses = h(None, {"res4": feat}, props, targets)
+            loss = losses["loss_box_reg"] + losses["loss_cls"] + 1e-3 * grid.square().mean() + 1e-2 * torch.cat(box_feats).square().mean()
+            loss.backward()
+            outs[backend] = (grid.detach(), torch.cat(box_feats).detach(), float(losses["loss_box_reg"]), feat.grad.clone(),
+                             {k: p.grad.clone() for k, p in h.named_parameters() if p.grad is not None}, [len(x) for x in sampled])
+            opts[backend].step()
+        gm, bm, lm, fm, pm, nm = outs["miopen"]
+        gh, bh, lh, fh, ph, nh = outs["hip"]
+        assert tuple(gh.shape) == tuple(gm.shape) == (2, 256, (mh + 1) // 2, (mw + 1) // 2), (it, gh.shape)
+        assert nh == nm, (it, nh, nm)
+        tol = 3e-4            # two fp32 evaluations against each other, on weights that took the previous steps' (slightly different) updates
+        assert rel_err(gh, gm) < tol and rel_err(bh, bm) < tol and abs(lh - lm) <= tol * max(abs(lm), 1e-3), (it, rel_err(gh, gm), rel_err(bh, bm), lh, lm)
+        assert rel_l2(fh, fm) < 5e-3, (it, rel_l2(fh, fm))
+        assert set(ph) == set(pm)
+        worst = max((rel_l2(ph[k], pm[k]), k) for k in ph)
+        assert worst[0] < 5e-3, (it, worst)
+    st = heads["hip"].stats
+    assert st["forwards"] == 4 and st.get("unspeculated", 0) == 1 and st.get("speculated", 0) == 3, st      # (16 proposals < the budget of 24)
+
+
 def test_operand_scales_are_refreshed_without_a_host_wait(pkg, oracle, monkeypatch):
     """Every REFRESH steps the remembered operand scales are chosen again from max |w| / max |s| sent to pinned memory behind an event
     (TrainOperands._start_refresh / _adopt_refresh): the one-launch preparation is never left (the synchronous form sends every
@@ -943,6 +997,141 @@ def test_training_forward_out_of_range_never_reaches_the_losses_or_the_parameter
     for k in want[4]:
         if k.startswith("res5."):
             assert rel_err(got[4][k], want[4][k]) < 1e-5, k
+
+
+def _ignore_band_heads(pkg, oracle, dtype):
+    """_train_heads with a sampler that has an IGNORE band (Matcher [0.3, 0.7] -> [0, -1, 1]): the one configuration in which a
+    speculated sample can miss -- an image with enough proposals whose CANDIDATES (labels != -1) do not fill the budget."""
+    from locov_amd.roi_heads.roi_emb_heads import Matcher
+    heads, c_in = _train_heads(pkg, oracle, "hip", dtype)
+    heads.proposal_matcher = Matcher([0.3, 0.7], [0, -1, 1], allow_low_quality_matches=False)
+    return heads, c_in
+
+
+def _miss_batch(n_img, r, budget, seed):
+    from locov_amd.structures import Boxes, Instances
+    from tests import ddp_worker
+    props, targets = [], []
+    for i in range(n_img):
+        b, gt = ddp_worker.ignore_band_boxes(r, budget, seed * 10 + i)
+        p = Instances((800, 1333))
+        p.proposal_boxes = Boxes(torch.from_numpy(b).cuda())
+        p.objectness_logits = torch.zeros(len(b), device="cuda")
+        t = Instances((800, 1333))
+        t.gt_boxes = Boxes(torch.from_numpy(gt).cuda())
+        t.gt_classes = torch.tensor([3, 17, 42], device="cuda")
+        props.append(p)
+        targets.append(t)
+    return props, targets
+
+
+def test_speculation_miss_and_range_trip_in_one_step(pkg, oracle, monkeypatch):
+    """VERDICT r5 item 4 -- the training forward's retry machine through TWO legs in one step: the speculated sample misses
+    (repeat from the true counts) AND that repeated forward leaves the split arithmetic's range (RES5_TRAIN_GUARD "sync": repeat on
+    the f32 MFMA): attempt() runs three times, the step's outputs, losses and gradients are those of the fp32 module on the same
+    draw, the counters say what happened, and roi_head/num_{fg,bg}_samples is logged ONCE."""
+    import warnings
+    from locov_amd.roi_heads import roi_emb_heads as mod
+    heads, c_in = _ignore_band_heads(pkg, oracle, "f16x2")
+    ref, _ = _ignore_band_heads(pkg, oracle, "fp32")
+    assert heads.res5_train_guard == "sync"
+    base = torch.randn(2, c_in, 50, 84, generator=torch.Generator().manual_seed(6)).cuda()
+    props, targets = _miss_batch(2, 60, heads.batch_size_per_image, seed=3)
+    puts = []
+    monkeypatch.setattr(mod._EVENTS, "put_scalar", lambda name, value: puts.append(name))
+
+    def step(h, scale, seed):
+        h.zero_grad()
+        feat = (base * scale).requires_grad_(True)
+        torch.manual_seed(seed)
+        grid, box_feats, sampled, losses = h(None, {"res4": feat}, props, targets)
+        (sum(losses.values()) + grid.mean() + sum(b.sum() for b in box_feats) * 1e-3).backward()
+        torch.cuda.synchronize()
+        return grid, torch.cat(box_feats), losses, feat.grad, {k: p.grad for k, p in h.named_parameters() if p.grad is not None}, [len(x) for x in sampled]
+
+    big = 3.0e4
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        want = step(ref, big, 2)
+    assert ref.stats == {"forwards": 1, "speculated": 1, "speculation_misses": 1}, ref.stats
+    assert all(n == heads.batch_size_per_image // 3 + 3 for n in want[5]), want[5]        # the under-filled sample: bg candidates + the GT
+    del puts[:]
+    with pytest.warns(RuntimeWarning, match="repeated"):
+        got = step(heads, big, 2)
+    assert heads.stats == {"forwards": 1, "speculated": 1, "speculation_misses": 1, "guard_trips": 1, "fp32_repeats": 1}, heads.stats
+    assert sorted(puts) == ["roi_head/num_bg_samples", "roi_head/num_fg_samples"], puts
+    assert got[5] == want[5]
+    assert rel_err(got[0], want[0]) < 1e-6 and rel_err(got[1], want[1]) < 1e-6 and rel_err(got[3], want[3]) < 1e-5
+    for k in want[2]:
+        assert abs(float(got[2][k]) - float(want[2][k])) <= 1e-6 * max(1.0, abs(float(want[2][k]))), k
+    assert set(got[4]) == set(want[4])
+    for k in want[4]:
+        assert rel_err(got[4][k], want[4][k]) < 1e-5, k
+    # the next (in-range, budget-filling) step is back on the split arithmetic and on the speculated path, silently
+    props2, targets2 = _train_batch(pkg, oracle, 2, 60, 5, seed=32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        heads.zero_grad()
+        torch.manual_seed(5)
+        heads(None, {"res4": base.clone().requires_grad_(True)}, props2, targets2)
+    assert heads.res5_dtype == "f16x2" and heads.stats["speculated"] == 2 and heads.stats["speculation_misses"] == 1
+
+
+@pytest.mark.parametrize("order", ["miss_then_trip", "trip_then_miss"])
+def test_retry_legs_under_gradient_accumulation(pkg, oracle, order):
+    """Two forwards, then two backwards (gradient accumulation): one forward's speculated sample misses, the other leaves the split
+    arithmetic's range and is repeated on the f32 MFMA (which drops the remembered operand scales while the FIRST forward's graph,
+    with its own operand set, still waits for its backward).  The accumulated gradients equal those of the same two steps run one
+    after the other (forward, backward, forward, backward)."""
+    import warnings
+    heads, c_in = _ignore_band_heads(pkg, oracle, "f16x2")
+    base = torch.randn(2, c_in, 50, 84, generator=torch.Generator().manual_seed(8)).cuda()
+    miss = _miss_batch(2, 60, heads.batch_size_per_image, seed=4)
+    plain = _train_batch(pkg, oracle, 2, 60, 5, seed=33)
+    legs = [(miss, 1.0, 11), (plain, 3.0e4, 12)]
+    if order == "trip_then_miss":
+        legs = legs[::-1]
+    opt = torch.optim.SGD([p for p in heads.parameters() if p.requires_grad], lr=1e-4)
+    for it in range(2):                                  # (two plain steps first: the operand scales are remembered, the one-launch
+        opt.zero_grad(set_to_none=True)                  #  preparation is what the steps under test run on)
+        torch.manual_seed(20 + it)
+        g, bf, _, ls = heads(None, {"res4": base.clone().requires_grad_(True)}, *plain)
+        (sum(ls.values()) + g.mean()).backward()
+        opt.step()
+
+    def forward(leg):
+        (props, targets), scale, seed = leg
+        feat = (base * scale).requires_grad_(True)
+        torch.manual_seed(seed)
+        grid, box_feats, sampled, losses = heads(None, {"res4": feat}, props, targets)
+        return feat, sum(losses.values()) + grid.mean() * 1e-3 + sum(b.sum() for b in box_feats) * 1e-6
+
+    def grads(feats):
+        return [f.grad.clone() for f in feats], {k: p.grad.clone() for k, p in heads.named_parameters() if p.grad is not None}
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        heads.zero_grad()
+        feats = []
+        for leg in legs:                                 # one after the other
+            f, loss = forward(leg)
+            loss.backward()
+            feats.append(f)
+        torch.cuda.synchronize()
+        want_f, want_p = grads(feats)
+        heads.stats.clear()
+        heads.zero_grad()
+        pend = [forward(leg) for leg in legs]            # both forwards ...
+        for _, loss in pend:                             # ... then both backwards
+            loss.backward()
+        torch.cuda.synchronize()
+        got_f, got_p = grads([f for f, _ in pend])
+    assert heads.stats.get("speculation_misses") == 1 and heads.stats.get("fp32_repeats") == 1 and heads.stats["forwards"] == 2, heads.stats
+    for a, b in zip(got_f, want_f):
+        assert bool(torch.isfinite(a).all()) and rel_err(a, b) < 1e-5
+    assert set(got_p) == set(want_p) and any(k.startswith("res5.") for k in got_p)
+    for k in want_p:
+        assert bool(torch.isfinite(got_p[k]).all()) and rel_err(got_p[k], want_p[k]) < 1e-5, k
 
 
 def test_training_step_at_config_sizes_runs_on_the_hip_kernels(pkg, oracle):

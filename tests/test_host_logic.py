@@ -376,17 +376,28 @@ def test_bench_refuses_a_pmc_traffic_record_taken_on_other_sources(monkeypatch):
     sys.path.insert(0, root)
     bench = importlib.import_module("bench")
     from locov_amd import build
-    rec = json.load(open(os.path.join(root, "profiles", bench.TRAFFIC_FILE)))
+    path = os.path.join(root, "profiles", bench.TRAFFIC_FILE)
+    if not os.path.exists(path):                      # (no PMC pass committed for this round yet: said so, loudly, in the line)
+        args = bench.parse([])
+        assert bench.traffic_record(args)[0] is None and "unreadable" in bench.traffic_source(args)
+        assert bench.recorded_traffic(args, "gemm_split") is None
+        return
+    rec = json.load(open(path))
     wl = rec["workload"]
     args = types.SimpleNamespace(**{k: wl[k] for k in ("images", "proposals", "classes", "dim", "res5", "conv3x3", "block0", "res5_dtype")})
     if rec.get("source_fingerprint") == build.source_fingerprint():       # (a tree whose kernels changed after the last PMC pass: already None)
         got = bench.recorded_traffic(args, "gemm_split")
         assert got is not None and 1e9 < got < 2e10
+        assert "ANOTHER box" in bench.traffic_source(args)
+    else:
+        assert "STALE" in bench.traffic_source(args) and bench.recorded_traffic(args, "gemm_split") is None
     monkeypatch.setattr(build, "source_fingerprint", lambda: "some other tree")
     assert bench.recorded_traffic(args, "gemm_split") is None
+    assert bench.traffic_source(args).startswith("none -- ") and "STALE" in bench.traffic_source(args)
     monkeypatch.undo()
     args.proposals = wl["proposals"] + 1
     assert bench.recorded_traffic(args, "gemm_split") is None
+    assert "another workload (differs in proposals)" in bench.traffic_source(args)
 
 
 def test_stock_library_fallback_is_announced_once_with_the_failed_condition(lsm_cfg):
