@@ -188,8 +188,8 @@ def synth_train_batch(gen, device, n_images, n_props, n_classes, dim, *, multisc
     fixed_gt: max_gt boxes on every image; else 0..max_gt (images WITHOUT ground truth included).
     short_image: (index, n) -- that image gets only n proposals (fewer candidates than the sampling budget: the labelling cannot
     speculate, the forward waits for the true counts).
-    crowded_image: index -- every proposal of that image sits on a ground-truth box (all foreground): with POSITIVE_FRACTION < 1
-    (configs/coco_stt.yaml: Detectron2's 0.25 of 512) the background candidates do not fill the rest of the budget and the
+    crowded_image: index -- every proposal of that image sits on a ground-truth box (all foreground): with a POSITIVE_FRACTION < 1
+    (not the reference's: both configurations use 1.0) the background candidates do not fill the rest of the budget and the
     speculated sample MISSES."""
     import torch
     from locov_amd.structures import Boxes, Instances
@@ -434,19 +434,19 @@ class TrainWorkload:
         """`n_batches` batches of the reference's REAL training shapes, resident in HBM: 2 000 RPN proposals per
         image into the labelling (Detectron2's POST_NMS_TOPK_TRAIN default), every image its own size out of
         configs/coco_stt.yaml:54's MIN_SIZE_TRAIN (the batch padded to its largest image), 0-15 GT boxes per image incl. none, and
-        every `underfill_every`-th batch with one image that cannot fill the sampling budget -- LSM (POSITIVE_FRACTION 1.0: any 200
-        candidates fill it): an image with fewer proposals than the budget, the forward waits for the true counts; STT (0.25 of
-        512): an image whose proposals all sit on ground-truth boxes, the speculated sample misses and the forward is repeated."""
+        every `underfill_every`-th batch with one image of fewer proposals than the sampling budget: the labelling cannot speculate
+        and the forward waits for the true counts.  (Both reference configurations sample with POSITIVE_FRACTION 1.0 --
+        coco_lsm.yaml:30, coco_stt.yaml:25 -- under which ANY `budget` candidates fill the budget: with no ignore band in the
+        matcher a speculated sample cannot miss; the miss leg is driven by tests with an ignore-band matcher.)"""
         import torch
         gen = torch.Generator().manual_seed(seed)
         budget = self.heads.batch_size_per_image
         self.pool = []
         for i in range(n_batches):
             under = bool(underfill_every) and i % underfill_every == underfill_every - 1
-            short = (i % self.n_images, max(budget // 2, 8)) if under and not self.stt else None
-            crowded = i % self.n_images if under and self.stt else None
+            short = (i % self.n_images, max(budget // 2, 8)) if under else None
             self.pool.append(synth_train_batch(gen, self.device, self.n_images, n_props, self.n_classes, self.args.dim,
-                                               multiscale=True, max_gt=15, fixed_gt=False, short_image=short, crowded_image=crowded))
+                                               multiscale=True, max_gt=15, fixed_gt=False, short_image=short))
         self.pool_at = 0
         return self.pool
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LOCOV_ABI_VERSION 7
+#define LOCOV_ABI_VERSION 8
 
 #define LOCOV_OK 0
 #define LOCOV_ERR_INVALID_ARG (-1)
@@ -71,6 +71,12 @@ typedef void *locov_stream_t;
 
 int locov_abi_version(void);
 const char *locov_last_error(void);
+
+/* Kernel launches this library has enqueued in this process so far (every entry point checks its launches through one helper,
+ * which counts them; an entry point that enqueues several kernels behind one check counts once per check).  A monotonic host-side
+ * counter for diagnostics: locov_amd/sharding.GradientExchangeTrace places DistributedDataParallel's bucket-ready points on the
+ * Res5 backward by it (ovr/engine/trainer.py:61-66), independent of what else shares the GPU. */
+int64_t locov_launch_count(void);
 
 /* Number of compute units / XCDs of the current device (for grid sizing in callers/bench). */
 int locov_device_info(int *cu_count, int *wave_size, int *lds_bytes_per_cu);
@@ -465,6 +471,34 @@ int64_t locov_nms_workspace_bytes(int64_t K);
 
 int locov_nms_sorted(const float *boxes_sorted, int64_t K, float iou_threshold, void *workspace,
                      unsigned char *keep, int *num_keep, locov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a-10  the detection post-processing of the evaluation call, on the device, without a host read.  Replaces the torch-op chain
+ * of [D2-upstream] FastRCNNOutputLayers.inference as the reference reaches it (ovr/modeling/roi_heads/roi_emb_heads.py:280,357;
+ * evaluation runs it once per image: configs/coco_stt.yaml:50 TEST.IMS_PER_BATCH 1): Box2BoxTransform.apply_deltas with
+ * class-agnostic deltas (ovr/modeling/roi_heads/box_emb_head.py:160-161 CLS_AGNOSTIC_BBOX_REG), Boxes.clip, `probs[:, :K] >
+ * score_thresh`, class-wise NMS (batched_nms's coordinate shift, greedy in descending score order, IoU > nms_thresh dropped) and the
+ * top `topk` detections per image in descending score order, ties in candidate (row, class) order.
+ *   probs [R, ld_probs] fp32 = softmax of the logits (K foreground columns + background), deltas / proposal_boxes [R, 4] fp32
+ *   (16-byte aligned), rows of image i = [row_offsets[i], row_offsets[i + 1]) (n_images + 1 HOST ints), image_hw: n_images HOST
+ *   (height, width) pairs; wx..wh: Box2BoxTransform weights, scale_clamp its clamp of dw / dh.
+ *   out_boxes [n_images, topk, 4], out_scores / out_classes / out_rows [n_images, topk] (rows: proposal index inside its image);
+ *   counts_and_flags [n_images + 1] int32: detections per image, then LOCOV_DETECT_FLAG_* bits -- when one is set the outputs are
+ *   not to be used (the caller runs the torch chain): NONFINITE = a decoded box or a probability is inf / NaN (the reference drops
+ *   such proposals with a warning), OVERFLOW = an image has more than LOCOV_DETECT_MAX_CANDIDATES candidates.
+ *   workspace: locov_detect_postprocess_workspace_bytes(R, n_images) bytes.  At most LOCOV_LABEL_MAX_IMAGES images, 16 383
+ *   proposals per image, 32 767 classes.  Bit-identical to the torch chain (tests/test_gpu_postprocess.py).
+ * ------------------------------------------------------------------------------------- */
+#define LOCOV_DETECT_MAX_CANDIDATES 8192
+#define LOCOV_DETECT_FLAG_NONFINITE 1
+#define LOCOV_DETECT_FLAG_OVERFLOW 2
+int64_t locov_detect_postprocess_workspace_bytes(int64_t R, int n_images);
+
+int locov_detect_postprocess(const float *probs, int64_t ld_probs, int num_classes, const float *deltas, const float *proposal_boxes,
+                             const int *row_offsets, const float *image_hw, int n_images, float wx, float wy, float ww, float wh,
+                             float scale_clamp, float score_thresh, float nms_thresh, int topk, void *workspace, int64_t workspace_bytes,
+                             float *out_boxes, float *out_scores, int64_t *out_classes, int64_t *out_rows, int *counts_and_flags,
+                             locov_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * a-12  LSM grounding: word<->region alignment -> [caption, image] cost matrices.

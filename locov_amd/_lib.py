@@ -26,7 +26,8 @@ EPI_RES_SPLIT = 0x4000
 MAX_LEVELS = 8
 ZERO_LIST_MAX = 24
 LABEL_MAX_IMAGES, LABEL_MAX_THRESHOLDS, SAMPLE_MAX_PROPOSALS = 64, 6, 4096
-ABI_VERSION = 7
+ABI_VERSION = 8
+DETECT_MAX_CANDIDATES, DETECT_FLAG_NONFINITE, DETECT_FLAG_OVERFLOW = 8192, 1, 2
 
 _p = c_void_p  # device pointer
 
@@ -44,6 +45,7 @@ class WeightPrepJob(ctypes.Structure):
 SIGNATURES = {
     "locov_abi_version": (c_int, []),
     "locov_last_error": (c_char_p, []),
+    "locov_launch_count": (c_int64, []),
     "locov_device_info": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "locov_level_assign": (c_int, [_p, c_int64, c_int, c_int, c_int, c_int, _p, _p]),
     "locov_roi_align_fwd": (c_int, [_p, c_int, c_int, c_int, c_int, _p, c_int64, c_int, c_int, c_float,
@@ -90,6 +92,9 @@ SIGNATURES = {
     "locov_grounding_ce_bwd": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, _p, _p, _p, _p, _p, _p, _p]),
     "locov_nms_workspace_bytes": (c_int64, [c_int64]),
     "locov_nms_sorted": (c_int, [_p, c_int64, c_float, _p, _p, _p, _p]),
+    "locov_detect_postprocess_workspace_bytes": (c_int64, [c_int64, c_int]),
+    "locov_detect_postprocess": (c_int, [_p, c_int64, c_int, _p, _p, POINTER(c_int), POINTER(c_float), c_int, c_float, c_float, c_float,
+                                         c_float, c_float, c_float, c_float, c_int, _p, c_int64, _p, _p, _p, _p, _p, _p]),
     "locov_grounding_fwd": (c_int, [_p, c_int, c_int, c_int, _p, _p, c_float, _p, _p, _p]),
     "locov_grounding_bwd": (c_int, [_p, c_int, c_int, c_int, _p, _p, c_float, _p, _p, _p, _p]),
     "locov_token_attention_fwd": (c_int, [_p, c_int64, c_int, _p, _p, c_int, c_int, c_float, c_int, c_int, _p, _p, _p, _p]),

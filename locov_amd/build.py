@@ -32,6 +32,7 @@ FILE_FLAGS = {
     "roi_align_tiles.hip": ["-ffp-contract=off"],
     "label.hip": ["-ffp-contract=off"],          # (IoU values must be the torch ops', rounded step by step)
     "losses.hip": ["-ffp-contract=off"],         # (box deltas / log-softmax pieces as the torch ops form them)
+    "detect.hip": ["-ffp-contract=off"],         # (box decoding / shifted IoU as the torch ops round them)
 }
 
 

@@ -1,9 +1,12 @@
 // Error handling, device info, and small element-wise kernels.
 #include "common.h"
 
+#include <atomic>
 #include <cstring>
 
 namespace locov {
+
+static std::atomic<long long> g_launch_checks{0};
 
 static thread_local char g_err[512] = "";
 
@@ -20,6 +23,7 @@ int set_error(int code, const char *fmt, ...)
 
 int check_launch(const char *what)
 {
+    g_launch_checks.fetch_add(1, std::memory_order_relaxed);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return set_error(LOCOV_ERR_LAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
@@ -52,6 +56,8 @@ extern "C" {
 int locov_abi_version(void) { return LOCOV_ABI_VERSION; }
 
 const char *locov_last_error(void) { return locov::err_buf(); }
+
+int64_t locov_launch_count(void) { return (int64_t)locov::g_launch_checks.load(std::memory_order_relaxed); }
 
 int locov_device_info(int *cu_count, int *wave_size, int *lds_bytes_per_cu)
 {

@@ -135,17 +135,20 @@ __global__ __launch_bounds__(kSampleThreads) void sample_proposals_kernel(
             __syncthreads();
         }
     const unsigned long long avail = rows[4 * img];
+    const unsigned long long population = part == 0 ? avail : rows[4 * img + 1];      // candidates of THIS part's kind
     const int num_pos = avail < (unsigned long long)g.max_pos ? (int)avail : g.max_pos;
     const int j_lo = part == 0 ? 0 : num_pos, j_hi = part == 0 ? num_pos : g.budget;
     const bool has_gt = g.goff[img + 1] > g.goff[img];
     for (int j = j_lo + tid; j < j_hi && j < g.budget; j += kSampleThreads) {
-        // (an image that does not fill its budget reads past its population: the caller throws such a batch's sample away; the
-        //  index only has to stay inside the image)
+        // (an image that does not fill its budget reads past its population: the caller throws such a batch's sample away, but
+        //  it has already enqueued the losses on it -- the index has to stay inside the image, and the class has to be one a
+        //  loss can take: a row past the population may carry the IGNORE label -1 of a matcher with an ignore band, which
+        //  torch's cross-entropy answers with a device-side assert; such a slot counts as background)
         const int rank = j - j_lo;
         const int row = r0 + (int)idx[rank < n ? rank : n - 1];
         const int64_t slot = (int64_t)img * g.budget + j;
         const float4 b = boxes[row];
-        const int64_t cls = labels[row];
+        const int64_t cls = (unsigned long long)rank < population ? labels[row] : num_classes;
         picked[slot] = row;
         out_boxes[slot] = b;
         out_classes[slot] = cls;

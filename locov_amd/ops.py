@@ -786,6 +786,60 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torc
     return order[keep.bool()]
 
 
+DETECT_MAX_IMAGES = _lib.LABEL_MAX_IMAGES
+DETECT_MAX_ROWS_PER_IMAGE, DETECT_MAX_CLASSES, DETECT_MAX_TOPK = (1 << 14) - 1, (1 << 15) - 1, _lib.DETECT_MAX_CANDIDATES
+_DETECT_PINNED = {}
+
+
+def detect_postprocess(probs: torch.Tensor, deltas: torch.Tensor, proposal_boxes: torch.Tensor, sizes, image_shapes, weights,
+                       scale_clamp: float, score_thresh: float, nms_thresh: float, topk: int):
+    """The detection post-processing of a batch on the device (csrc/detect.hip): box decoding, clipping, score threshold,
+    class-wise NMS, top-k -- five launches and ONE host read (the detections per image + the flag word) instead of the torch
+    chain's ~100 launches and four reads.
+    probs [R, K + 1] = softmax of the logits, deltas / proposal_boxes [R, 4] (class-agnostic regression), sizes: rows per image,
+    image_shapes: (height, width) per image, weights: Box2BoxTransform's.
+    Returns (boxes [B, topk, 4], scores [B, topk], classes [B, topk] int64, rows [B, topk] int64, counts: list of B ints), or None
+    when the kernels flagged a case they do not take (non-finite values, more than DETECT_MAX_CANDIDATES candidates in an image):
+    the caller then runs the torch chain."""
+    probs, deltas, proposal_boxes = _dev(probs, "probs"), _dev(deltas, "deltas"), _dev(proposal_boxes, "proposal_boxes")
+    B, R, K = len(sizes), probs.shape[0], probs.shape[1] - 1
+    if not (tuple(deltas.shape) == (R, 4) and tuple(proposal_boxes.shape) == (R, 4) and sum(sizes) == R and len(image_shapes) == B):
+        raise ValueError("detect_postprocess: inconsistent shapes")
+    if not (0 < B <= DETECT_MAX_IMAGES and 1 <= K <= DETECT_MAX_CLASSES and 1 <= topk <= DETECT_MAX_TOPK
+            and max(sizes, default=0) <= DETECT_MAX_ROWS_PER_IMAGE):
+        raise ValueError("detect_postprocess: outside the kernels' limits (images, classes, rows per image or top-k)")
+    lib = _lib.load()
+    dev = probs.device
+    offs = (ctypes.c_int * (B + 1))(0, *itertools.accumulate(int(n) for n in sizes))
+    hw = (ctypes.c_float * (2 * B))(*[float(v) for shape in image_shapes for v in shape[:2]])
+    nbytes = int(lib.locov_detect_postprocess_workspace_bytes(max(R, 1), B))
+    ws = _workspace("detect", probs, nbytes)
+    out_boxes = torch.empty((B, topk, 4), dtype=torch.float32, device=dev)
+    out_scores = torch.empty((B, topk), dtype=torch.float32, device=dev)
+    out_classes = torch.empty((B, topk), dtype=torch.int64, device=dev)
+    out_rows = torch.empty((B, topk), dtype=torch.int64, device=dev)
+    counts = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+    wx, wy, ww, wh = (float(w) for w in weights)
+    with torch.cuda.device(dev):
+        check(lib.locov_detect_postprocess(_ptr(probs), probs.stride(0), K, _ptr(deltas), _ptr(proposal_boxes), offs, hw, B, wx, wy, ww, wh,
+                                           float(scale_clamp), float(score_thresh), float(nms_thresh), int(topk), _ptr(ws), ws.numel(),
+                                           _ptr(out_boxes), _ptr(out_scores), _ptr(out_classes), _ptr(out_rows), _ptr(counts),
+                                           _stream(probs)), "locov_detect_postprocess")
+    # the ONE host read: B + 1 ints to pinned memory behind an event (the stream's later work stays queued)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    host = _DETECT_PINNED.get(key)
+    if host is None or host.numel() < B + 1:
+        host = _DETECT_PINNED[key] = torch.empty(max(B + 1, DETECT_MAX_IMAGES + 1), dtype=torch.int32).pin_memory()
+    host[:B + 1].copy_(counts, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    ev.synchronize()
+    vals = host[:B + 1].tolist()
+    if vals[B]:
+        return None
+    return out_boxes, out_scores, out_classes, out_rows, vals[:B]
+
+
 # --------------------------------------------------------------------------------------
 # Backward-pass building blocks of the Res5 stage (csrc/gemm_tn.hip, res5_bwd.hip, the mask epilogue of gemm_nt.hip and
 # the gradient transforms of winograd.hip); composed by locov_amd/res5_train.py.

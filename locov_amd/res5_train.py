@@ -439,8 +439,9 @@ class Res5BlockFn(torch.autograd.Function):
                 return ops.gemm_tn_split(g_, x_, s_, sg_, 16.0)
             return ops.gemm_tn(g_, x_, s_)
 
-        def dgrad_1x1(g_, sg_, conv, tag="t", amax_out=None, **kw):   # (g . wt^T [+ residual]) [mask]; amax_out: slot of the result
-            wt = T.get(conv, tag)
+        def dgrad_1x1(g_, sg_, conv, tag="t", amax_out=None, wt=None, **kw):   # (g . wt^T [+ residual]) [mask]; amax_out: slot of the result
+            if wt is None:
+                wt = T.get(conv, tag)
             if isinstance(wt, ops.SplitWeight):
                 return ops.linear_split_ex(g_, wt, x_scale_dev=sg_, amax_out=amax_out, **kw), amax_out
             y_ = ops.linear_ex(g_, wt, **kw)
@@ -462,6 +463,15 @@ class Res5BlockFn(torch.autograd.Function):
         live = [(si, seg) for si, seg in enumerate(segs) if seg.rows > 0]
         side = _side_stream(step.device) if _BWD_STREAMS and len(live) == 2 and sum(step.seg_wino(sg_, c2) for _, sg_ in live) == 1 else None
         main = torch.cuda.current_stream(step.device)
+        # the flipped 3x3 filters of BOTH forms, taken here on the main stream, in front of the fork: on the on-demand chain (first
+        # step, the f32 MFMA, a step behind forget_scales) the Winograd-domain form is derived from the flipped weight the im2col
+        # form derives too -- built inside the side stream's block it would be read by the main stream's segment without an order
+        # between the two (found by tests/test_gpu_multirank.py: garbage gradients from block 2's conv1 on under DDP's timing)
+        flipped = {}
+        for _, seg in live:
+            tag = "uflip" if _wino_ok(seg.H, seg.W, c2.out_channels, c2.in_channels) and not _NO_WINO_BWD else "flip9"
+            if tag not in flipped:
+                flipped[tag] = T.get(c2, tag)
         parts = []
         for si, seg in live:
             sl = slice(seg.row0, seg.row0 + seg.rows)
@@ -490,7 +500,7 @@ class Res5BlockFn(torch.autograd.Function):
                         part.record_stream(main)
                     parts.append(part)
                 if _wino_ok(seg.H, seg.W, c2.out_channels, c2.in_channels) and not _NO_WINO_BWD:
-                    uflip = T.get(c2, "uflip")
+                    uflip = flipped["uflip"]
                     if isinstance(uflip, ops.SplitWeight):
                         ops.winograd_conv3x3_split_ex(g2[sl], uflip, mask=y1[sl], roi_major=True, amax_out=sg1, out=g1[sl])
                     else:
@@ -500,7 +510,8 @@ class Res5BlockFn(torch.autograd.Function):
                 else:
                     # data gradient on the general grid: the same im2col GEMM with the flipped filter (im2col only copies and
                     # zero-pads: the patches have g2's range)
-                    _, got = dgrad_1x1(ops.im2col3x3(g2[sl], seg.H, seg.W), sg2, c2, "flip9", amax_out=sg1, mask=y1[sl], out=g1[sl])
+                    _, got = dgrad_1x1(ops.im2col3x3(g2[sl], seg.H, seg.W), sg2, c2, "flip9", amax_out=sg1, wt=flipped["flip9"],
+                                       mask=y1[sl], out=g1[sl])
                     if sp and got is not sg1 and g1[sl].numel() % 4 == 0:
                         ops.amax_bound([g1[sl]], [1.0], slot=sg1)      # (an operand the split GEMM cannot take: its f32 result's range by a pass)
         if side is not None:

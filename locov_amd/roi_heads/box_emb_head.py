@@ -32,6 +32,7 @@ __all__ = ["Box2BoxTransform", "FastRCNNOutputLayers", "EmbeddingFastRCNNOutputL
 
 _DEFAULT_SCALE_CLAMP = math.log(1000.0 / 16)
 _FUSED_BOX_LOSS = os.environ.get("LOCOV_FUSED_LOSSES", "1") != "0"          # (developer A/B switch: tools/ab_fused_losses.py)
+_FUSED_POSTPROCESS = os.environ.get("LOCOV_FUSED_POSTPROCESS", "1") != "0"  # (developer A/B / tests: 0 = the torch-op post-processing chain)
 
 
 class Box2BoxTransform:
@@ -398,12 +399,51 @@ class FastRCNNOutputLayers(nn.Module):
         return loss_box_reg / max(gt_classes.numel(), 1.0)
 
     def inference(self, predictions, proposals):
+        fused = self._inference_fused(predictions, proposals)
+        if fused is not None:
+            return fused
         boxes = self.predict_boxes(predictions, proposals)
         scores = self.predict_probs(predictions, proposals)
         image_shapes = [x.image_size for x in proposals]
         instances_cls, boxes_cls = boxes_class_of(proposals)
         return fast_rcnn_inference(boxes, scores, image_shapes, self.test_score_thresh, self.test_nms_thresh,
                                    self.test_topk_per_image, instances_cls, boxes_cls)
+
+    def _inference_fused(self, predictions, proposals):
+        """predict_boxes + predict_probs + fast_rcnn_inference as ONE device pipeline (ops.detect_postprocess: csrc/detect.hip)
+        for the case both reference configurations evaluate: class-agnostic box regression on device fp32 tensors, a top-k.
+        Returns None for anything else -- and when the kernels flag non-finite values or too many candidates -- so that the
+        caller runs the torch chain; the detections are bit-identical to that chain's (tests/test_gpu_postprocess.py)."""
+        if not _FUSED_POSTPROCESS or not len(proposals):
+            return None
+        scores, deltas = predictions
+        sizes = [len(p) for p in proposals]
+        K = scores.shape[1] - 1
+        if not (scores.is_cuda and scores.dtype == torch.float32 and deltas.dtype == torch.float32 and deltas.dim() == 2 and deltas.shape[1] == 4
+                and scores.shape[0] == sum(sizes) > 0 and len(sizes) <= ops.DETECT_MAX_IMAGES and 1 <= K <= ops.DETECT_MAX_CLASSES
+                and 1 <= self.test_topk_per_image <= ops.DETECT_MAX_TOPK and max(sizes) <= ops.DETECT_MAX_ROWS_PER_IMAGE):
+            return None
+        pieces = [p.proposal_boxes.tensor for p in proposals]
+        if any(t.dtype != torch.float32 or not t.is_cuda for t in pieces):
+            return None
+        image_shapes = [x.image_size for x in proposals]
+        probs = F.softmax(scores, dim=-1)                                  # (torch's own softmax: predict_probs' values)
+        out = ops.detect_postprocess(probs, deltas, cat_rows(pieces), sizes, image_shapes, self.box2box_transform.weights,
+                                     self.box2box_transform.scale_clamp, self.test_score_thresh, self.test_nms_thresh,
+                                     self.test_topk_per_image)
+        if out is None:
+            return None
+        boxes, det_scores, classes, rows, counts = out
+        instances_cls, boxes_cls = boxes_class_of(proposals)
+        results, kept = [], []
+        for i, n in enumerate(counts):
+            res = instances_cls(image_shapes[i])
+            res.pred_boxes = boxes_cls(boxes[i, :n])
+            res.scores = det_scores[i, :n]
+            res.pred_classes = classes[i, :n]
+            results.append(res)
+            kept.append(rows[i, :n])
+        return results, kept
 
     def predict_boxes(self, predictions, proposals):
         if not len(proposals):

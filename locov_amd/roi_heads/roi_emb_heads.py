@@ -526,7 +526,7 @@ class SampleAllROIHeads(ROIHeads):
         return out
 
     @torch.no_grad()
-    def _label_build(self, st, picked: torch.Tensor, sizes: List[int]) -> List[Instances]:
+    def _label_build(self, st, picked: torch.Tensor, sizes: List[int], speculated: bool = False) -> List[Instances]:
         """The sampled Instances of a batch from `picked` (rows of the concatenated candidates, image-major) and the per-image
         sample counts: ONE gather per field for the batch (the sampled rows of image i are a slice of the two image-major orders:
         its foreground draws sit at the head of its segment of pos_order, likewise neg_order)."""
@@ -535,6 +535,11 @@ class SampleAllROIHeads(ROIHeads):
         n_g = [len(t) for t in targets]
         off_g = np.concatenate([[0], np.cumsum(n_g)]).tolist()
         picked_labels = labels[picked]
+        if speculated:
+            # (a speculated sample of a batch that does NOT fill its budget reads past the populations: such rows may carry the
+            # ignore label -1, which the cross-entropy enqueued on this sample answers with a device-side assert before the
+            # validation can throw the sample away -- they count as background)
+            picked_labels = torch.where(picked_labels < 0, torch.full_like(picked_labels, self.num_classes), picked_labels)
         classes = torch.split(picked_labels, sizes)
         fg_flags = torch.split((picked_labels != self.num_classes).to(picked_labels.dtype), sizes)     # (one launch pair for the batch)
         src_global = gt_index[picked]
@@ -644,7 +649,7 @@ class SampleAllROIHeads(ROIHeads):
         last = pos_order.numel() - 1
         picked = torch.where(j < num_pos, pos_order[(off + j).clamp(max=last)], neg_order[(off + (j - num_pos).clamp(min=0)).clamp(max=last)])
         st["speculated"] = True
-        return self._label_build(st, picked.reshape(-1), [B] * len(n_r))
+        return self._label_build(st, picked.reshape(-1), [B] * len(n_r), speculated=True)
 
     @staticmethod
     def _sampled_rois(st, sampled: List[Instances]) -> torch.Tensor:

@@ -85,8 +85,10 @@ class GradientExchangeTrace:
     Res5's backward is one autograd node per bottleneck (res5_train.Res5BlockFn), so block b's weight gradients reach DDP's hooks
     when block b's kernels are enqueued.  This registers a DDP communication hook that records a HIP event on the launch stream
     at the moment a bucket is handed to the all-reduce (the point its collective waits for on the communication stream) and
-    then runs the stock all-reduce, plus marks at the head / begin / end of every block's backward; report() places every
-    bucket on [0, 1] of the Res5 backward's device time and lists the host-side order of marks and buckets.
+    then runs the stock all-reduce, plus marks at the head / begin / end of every block's backward; stop() places every
+    bucket on [0, 1] of the Res5 backward -- in device time (`ready_at`) and in kernel launches of this library issued so far
+    (`ready_at_launch`: the share of the Res5 backward's kernels that were NOT yet enqueued is 1 - that) -- and lists the host-side
+    order of marks and buckets.
 
         trace = GradientExchangeTrace(ddp_module, module.named_parameters(), device)
         trace.start(); loss.backward(); rep = trace.stop()
@@ -104,9 +106,11 @@ class GradientExchangeTrace:
         ddp.register_comm_hook(None, self._hook)
 
     def _event(self):
+        """(HIP event on the launch stream, the library's launch counter) at this point of the host's enqueueing."""
+        from . import _lib
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream(self.device))
-        return ev
+        return ev, int(_lib.load().locov_launch_count())
 
     def _hook(self, state, bucket):
         if self.on:
@@ -138,11 +142,16 @@ class GradientExchangeTrace:
         if head is None or not ends:
             out["error"] = "no Res5 backward inside the traced region"
             return out
-        at = lambda e: self.t0.elapsed_time(e)
+        at = lambda e: self.t0[0].elapsed_time(e[0])
         t_head = at(head)
         total = at(ends[-1]) - t_head
+        # the same points counted in the library's kernel launches (host side, exact; the device times above are this process's
+        # view of a GPU it may share with other ranks)
+        l_head, l_total = head[1], max(ends[-1][1] - head[1], 1)
         out["res5_backward_ms"] = total
+        out["res5_backward_launches"] = l_total
         out["blocks_end_at"] = {f"block{b}": (at(e) - t_head) / total for k, b, e in seq if k == "block_end"}
+        out["blocks_end_at_launch"] = {f"block{b}": (e[1] - l_head) / l_total for k, b, e in seq if k == "block_end"}
         buckets = []
         for k, info, e in seq:
             if k != "bucket":
@@ -150,6 +159,6 @@ class GradientExchangeTrace:
             t = (at(e) - t_head) / total
             res5 = sorted({n.split("res5.")[1].split(".")[0] for n in info["params"] if "res5." in n})
             buckets.append({"index": info["index"], "MB": round(info["bytes"] / 1e6, 2), "ready_at": t,
-                            "res5_blocks": res5, "params": info["params"]})
+                            "ready_at_launch": (e[1] - l_head) / l_total, "res5_blocks": res5, "params": info["params"]})
         out["buckets"] = buckets
         return out

@@ -97,9 +97,27 @@ def main():
     torch.cuda.synchronize()
     grads = {k: p.grad.detach().cpu() for k, p in tw.module.named_parameters() if p.grad is not None}
     rec = {"loss": float(loss), "n_sampled": n, "grads": grads if rank == 0 else None, "stats": dict(tw.heads.stats)}
+    if case:
+        # this rank's OWN gradients of the same step without DistributedDataParallel (a second, identically seeded workload): what
+        # the all-reduce should have averaged
+        tw2 = bench.TrainWorkload(args, device, "hip", 1, data_seed=100 + rank, ddp=False)
+        set_case(tw2, case, rank)
+        torch.manual_seed(500 + rank)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            loss2, n2 = tw2.forward_backward()
+        torch.cuda.synchronize()
+        rec["local"] = {"loss": float(loss2), "n_sampled": n2,
+                        "grads": {k: p.grad.detach().cpu() for k, p in tw2.module.named_parameters() if p.grad is not None}}
+        del tw2
     if os.environ.get("LOCOV_DDP_WORKER_TRACE"):
         # (behind the stock step whose gradients are compared: a communication hook that records an event per ready bucket and
         # runs the stock all-reduce; the last of three traced steps -- DDP has rebuilt its buckets in arrival order by then)
+        # (on a batch of the LSM step's order of size -- 2 x 200 sampled proposals: the few thousand rows of the gradient test's batch
+        # spend their backward on weight-sized work, which block 0's projection shortcut has most of)
+        tw.heads.batch_size_per_image = 200
+        tw.args.proposals = 600
+        tw.set_data(300 + rank)
         rec["exchange"] = tw.trace_exchange(3)
         rec["bucket_cap_mb"] = args.ddp_bucket_mb
     torch.save(rec, os.path.join(out_dir, f"rank{rank}.pt"))

@@ -32,7 +32,7 @@ def test_every_symbol_is_exported(lib):
     for name in _declared():
         assert hasattr(lib, name), name
     from locov_amd import _lib
-    assert lib.locov_abi_version() == _lib.ABI_VERSION == 7        # 2: range-guard word on the split entry points; 3: amax_out slots; 4: locov_zero_if_raised, exact fused workspaces, timing_read_ex; 5: locov_box_reg_loss, locov_grounding_ce_fwd / _bwd; 6: locov_res5_weight_prep, locov_gemm_segmean_supported; 7: locov_sample_proposals, locov_gemm_tn_f32_split_b, locov_winograd_wgrad_f32_split_v
+    assert lib.locov_abi_version() == _lib.ABI_VERSION == 8        # 2: range-guard word on the split entry points; 3: amax_out slots; 4: locov_zero_if_raised, exact fused workspaces, timing_read_ex; 5: locov_box_reg_loss, locov_grounding_ce_fwd / _bwd; 6: locov_res5_weight_prep, locov_gemm_segmean_supported; 7: locov_sample_proposals, locov_gemm_tn_f32_split_b, locov_winograd_wgrad_f32_split_v; 8: locov_detect_postprocess
 
 
 def test_argument_errors_are_reported_without_a_gpu(lib):
@@ -90,6 +90,23 @@ def test_sample_proposals_validates_its_arguments(lib):
     big = (ctypes.c_int * 2)(0, _lib.SAMPLE_MAX_PROPOSALS + 1)
     assert lib.locov_sample_proposals(*none, big, off, 1, 16, 4, 80, *outs, None) == -1 and b"proposals per image" in lib.locov_last_error()
     assert lib.locov_sample_proposals(*none, off, off, 1, 16, 4, 80, *outs, None) == -1 and b"null pointer" in lib.locov_last_error()
+
+
+def test_detect_postprocess_validates_its_arguments(lib):
+    """locov_detect_postprocess: argument errors before any HIP call."""
+    import ctypes
+    from locov_amd import _lib
+    off, hw = (ctypes.c_int * 2)(0, 100), (ctypes.c_float * 2)(800, 1333)
+    tail = [None, 0] + [None] * 6
+    call = lambda n_img, k, topk, offsets=off: lib.locov_detect_postprocess(None, 1204, k, None, None, offsets, hw, n_img, 10, 10, 5, 5, 4.1, 0.05, 0.5, topk, *tail)
+    assert call(0, 1203, 100) == 0                                                                     # no images: a no-op
+    assert call(_lib.LABEL_MAX_IMAGES + 1, 1203, 100) == -1
+    assert call(1, 1 << 15, 100) == -1 and b"classes" in lib.locov_last_error()
+    assert call(1, 1203, 0) == -1 and b"topk" in lib.locov_last_error()
+    assert call(1, 1203, _lib.DETECT_MAX_CANDIDATES + 1) == -1
+    assert call(1, 1203, 100, (ctypes.c_int * 2)(0, 1 << 14)) == -1 and b"proposals per image" in lib.locov_last_error()
+    assert call(1, 1203, 100) == -1 and b"null pointer" in lib.locov_last_error()
+    assert lib.locov_detect_postprocess_workspace_bytes(0, 1) == 0 and lib.locov_detect_postprocess_workspace_bytes(1000, 1) >= 1000 * 24 + 8192 * 8
 
 
 def test_presplit_weight_gradient_entry_points_validate_their_arguments(lib):

@@ -103,10 +103,14 @@ def test_ddp_ranks_on_different_legs_of_the_retry_machine(tmp_path):
     assert tw.heads.stats.get("speculation_misses") == 1 and tw.heads.stats.get("fp32_repeats") == 1
     single = {k: p.grad.detach().cpu() for k, p in tw.module.named_parameters() if p.grad is not None}
     assert set(single) == set(ddp_grads)
-    for k in single:
-        assert bool(torch.isfinite(ddp_grads[k]).all()), k
-        scale = float(single[k].abs().max().clamp_min(1e-30))
-        assert float((single[k] - ddp_grads[k]).abs().max()) / scale <= 1e-5, k
+    rel = lambda a, b: float((a - b).abs().max()) / float(b.abs().max().clamp_min(1e-30))
+    # the ranks' own (un-reduced) gradients of the same step, averaged: what DDP's all-reduce has to produce
+    local = {k: 0.5 * (ranks[0]["local"]["grads"][k] + ranks[1]["local"]["grads"][k]) for k in ddp_grads}
+    errs_ddp = {k: rel(ddp_grads[k], local[k]) for k in ddp_grads}
+    errs_single = {k: rel(single[k], local[k]) for k in single}
+    assert all(bool(torch.isfinite(v).all()) for v in ddp_grads.values())
+    assert max(errs_ddp.values()) <= 1e-5, ("DDP vs the average of the ranks' own gradients", errs_ddp)
+    assert max(errs_single.values()) <= 1e-5, ("one process running both shards vs the average of the ranks' own gradients", errs_single)
 
 
 def _check_bucket_schedule(ex):
@@ -119,15 +123,18 @@ def _check_bucket_schedule(ex):
         "head", "block_begin:2", "block_end:2", "block_begin:1", "block_end:1", "block_begin:0", "block_end:0"], order
     with_res5 = [b for b in buckets if b["res5_blocks"]]
     assert len(with_res5) >= 3, buckets                                   # (bucket_cap_mb 17: one bucket per bottleneck)
-    first = min(with_res5, key=lambda b: b["ready_at"])
+    first = min(with_res5, key=lambda b: b["ready_at_launch"])
     assert first["res5_blocks"] == ["2"], first
-    # ready while >= 60 % of the Res5 backward (device time between its first and its last kernel) is still to come ...
-    assert first["ready_at"] <= 0.40, (first["ready_at"], ex["blocks_end_at"])
-    # ... and, on the host, before block 1's backward has been entered: its kernels are not even enqueued yet
+    # ready while >= 60 % of the Res5 backward's kernels are still to be enqueued (counted in the library's launches: exact on the
+    # host; the two ranks of this test share ONE GPU, whose time slices make device-time fractions of a single rank noisy) ...
+    assert first["ready_at_launch"] <= 0.40, (first["ready_at_launch"], ex["blocks_end_at_launch"])
+    assert ex["res5_backward_launches"] >= 30
+    # ... and, on the host, before block 1's backward has been entered
     assert order.index(f"bucket:{first['index']}") < order.index("block_begin:1"), order
-    b1 = [b for b in with_res5 if b["res5_blocks"] == ["1"]]
+    # the bucket that closes with block 1's gradients is handed over before block 0's backward is entered
+    b1 = [b for b in with_res5 if any(".res5.1.conv2." in n for n in b["params"])]
     assert b1 and order.index(f"bucket:{b1[0]['index']}") < order.index("block_begin:0"), order
-    assert b1[0]["ready_at"] <= ex["blocks_end_at"]["block1"] + 0.02
+    assert b1[0]["ready_at_launch"] <= ex["blocks_end_at_launch"]["block1"] + 1e-9
     every = sorted(n for b in buckets for n in b["params"])
     assert len(every) == len(set(every)) and sum("res5." in n for n in every) == 10, every
 
