@@ -704,27 +704,39 @@ def main():
         # the slowest rank defines the job's time
         return max_over_ranks(dt, device if args.dist_backend == "nccl" else None)
 
-    def eval_scope():
-        """scopes.eval_1img: the reference's evaluation call (TEST.IMS_PER_BATCH 1) incl. the post-processing, per image."""
+    def eval_scope(batched=True):
+        """scopes.eval_1img: the reference's evaluation call (TEST.IMS_PER_BATCH 1) incl. the post-processing, per image.
+        batched: also the same call on the bench's whole batch (per image); False for profile runs (--only-eval: the process's kernel
+        mix is then the one-image call's)."""
         wl.eval_heads()
         steps_e = max(args.steps, 10)
         dte = timed(wl.step_eval, steps_e, 5, key="eval1")
         inst = wl.step_eval()[0][0]
         n_b = max(args.steps // 2, 3)
-        dte8 = timed(lambda: wl.step_eval(args.images), n_b, 2)
+        dte8 = timed(lambda: wl.step_eval(args.images), n_b, 2) if batched else float("nan")
         ms1 = dte / steps_e * 1e3
+        lib_launches = None
+        try:
+            c0 = int(lib.locov_launch_count())
+            wl.step_eval()
+            lib_launches = int(lib.locov_launch_count()) - c0
+        except Exception:                 # noqa: BLE001
+            pass
         return {"what": "roi_heads(images, features, proposals, None) -> inference_detection (roi_emb_heads.py:351-360) on ONE image x "
                         f"{args.proposals} proposals x {args.classes} classes: ROIAlign + Res5 + mean + predictor + softmax / box decoding / "
                         "score threshold 0.05 / class-wise NMS 0.5 / top-100 (configs/coco_stt.yaml:50 TEST.IMS_PER_BATCH 1)",
                 "ms_per_image": ms1, "proposals_per_s": args.proposals * world / (ms1 * 1e-3),
                 "single_calls_ms": step_stats["eval1"], "wall_ms_per_image": wall["eval1"] / steps_e * 1e3,
                 "detections_per_image": len(inst), "logit_sigma": wl.eval_logit_sigma,
+                "library_launches_per_image": lib_launches,
+                "launches": "library_launches_per_image counts this library's launch checks in one call (live); every kernel of the call "
+                            "incl. torch's: profiles/r06_eval_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --only-eval`)",
                 f"batched_{args.images}img_ms_per_image": dte8 / n_b / args.images * 1e3,
                 "bank": "the bench's bank scaled to logit sigma 3 over the proposals (random-init logits pass no score threshold)"}
 
     if args.only_eval:
         if rank == 0:
-            print(json.dumps({"eval_1img": eval_scope()}))
+            print(json.dumps({"eval_1img": eval_scope(batched=False)}))
         if dist_on:
             dist.destroy_process_group()
         return

@@ -1,4 +1,4 @@
-// Detection post-processing of the evaluation call in five launches, no host read inside.
+// Detection post-processing of the evaluation call in seven launches, no host read inside.
 //
 // Replaces the torch-op chain of [D2-upstream] FastRCNNOutputLayers.inference as the reference reaches it
 // (ovr/modeling/roi_heads/roi_emb_heads.py:280,357 -> predict_boxes / fast_rcnn_inference): Box2BoxTransform.apply_deltas,
@@ -13,11 +13,12 @@
 //   det_count_kernel         a wave per proposal: how many of its K class probabilities pass the threshold
 //   det_scan_kernel          one workgroup: per image, the exclusive scan of those counts (= where each proposal's candidates go)
 //   det_emit_kernel          a wave per proposal: its candidates as 64-bit keys  class | ~score bits | row  in (row, class) order
-//   det_select_kernel        a workgroup per image: bitonic sort of the keys in LDS (class-major, descending score, ties by row =
-//                            candidate order); every wave sweeps the class segments that start in its part of the list (greedy NMS
-//                            inside a class: classes never suppress each other, which is all the coordinate shift achieves --
-//                            the IoU is still taken on the SHIFTED boxes, so every decision rounds as batched_nms's does);
-//                            second sort of the survivors by (descending score, row, class) = the reference's order; top-k out.
+//   det_sort_kernel          a workgroup per image: bitonic sort of the keys in LDS (class-major, descending score, ties by row =
+//                            candidate order); shifted boxes, class starts
+//   det_pairs_kernel         a thread per candidate: which earlier candidates of its class it overlaps (IoU on the SHIFTED boxes,
+//                            so every decision rounds as batched_nms's does) -- the m^2 / 2 pair tests of a crowded class, chip-wide
+//   det_nms_topk_kernel      a workgroup per image: the greedy sweep as a fix-point over kept / undecided bit sets; second sort of
+//                            the survivors by (descending score, row, class) = the reference's order; top-k out.
 //
 // Candidate order, tie-breaking and every fp32 operation equal the torch chain's (tests/test_gpu_postprocess.py: bit-identical
 // detections).  What the kernels cannot take is flagged on the device and read by the caller with the counts (its ONE host
@@ -187,65 +188,49 @@ __device__ __forceinline__ void det_bitonic_sort(unsigned long long *key, int P,
         }
 }
 
-#ifdef LOCOV_DET_TRACE          // tools/make_variant.py dettrace detect.hip -DLOCOV_DET_TRACE: phase stamps of image 0's workgroup
-__device__ long long det_trace[16];
-#define DET_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) det_trace[i] = (long long)wall_clock64(); } while (0)
-#else
-#define DET_STAMP(i) do { } while (0)
-#endif
+// ---- selection: sort (a workgroup per image) -> pair tests (the whole chip) -> NMS fix-point + top-k (a workgroup per image) -----------
+//
+// Classes never suppress each other (that is all batched_nms's coordinate shift achieves; the IoU is still taken on the SHIFTED
+// boxes so that every decision rounds as the reference's does), so the greedy sweep runs inside the class segments of the sorted
+// candidate list.  A class with m candidates needs m (m - 1) / 2 pair tests -- 500 000 for a class every proposal of an image is
+// a candidate of -- which ONE compute unit takes 0.8 ms over; spread over the chip they take microseconds.  So the tests go to
+// their own launch, which leaves for every candidate the bit set "which earlier candidates of my class overlap me", and the sweep
+// becomes a fix-point over two bit sets (kept / undecided) that ends in exactly the sequential sweep's result.
+constexpr int kDetOvWords = kDetMaxCand / 128 * kDetMaxCand + kDetMaxCand;     // 64-bit words of overlap bit sets per image, worst case
 
-constexpr int kDetLdsRows = 2048;      // P > kDetLdsCand: proposals of one image whose clipped boxes are staged in LDS (more: read through L2)
-constexpr int kDetLdsCand = 4096;      // P <= this: the candidates' SHIFTED boxes in sorted order in LDS (one 16-byte read per pair test)
+struct DetLists {                       // per-image work lists in the workspace (element offsets are per image: * kDetMaxCand etc.)
+    unsigned long long *keys;           // [n_img][kDetMaxCand]        candidates; sorted in place by det_sort_kernel
+    int *cstart;                        // [n_img][kDetMaxCand]        first candidate of candidate i's class
+    int *woff;                          // [n_img][kDetMaxCand + 4]    where candidate i's overlap words start; [n] = their total
+    float4 *cbox;                       // [n_img][kDetMaxCand]        candidate i's shifted box
+    unsigned long long *ov;             // [n_img][kDetOvWords]        bit j of word w of candidate i: candidate cstart + 64 w + j overlaps it
+};
 
-__global__ __launch_bounds__(kDetThreads) void det_select_kernel(const unsigned long long *__restrict__ keys, const int *__restrict__ img_count,
-                                                                 const float4 *__restrict__ boxes, DetGeom g, float nms_thr, int topk,
-                                                                 float4 *__restrict__ out_boxes, float *__restrict__ out_scores,
-                                                                 int64_t *__restrict__ out_classes, int64_t *__restrict__ out_rows,
-                                                                 int *__restrict__ counts, int *__restrict__ flags)
+__global__ __launch_bounds__(kDetThreads) void det_sort_kernel(DetLists L, const int *__restrict__ img_count, const float4 *__restrict__ boxes,
+                                                               DetGeom g, int *__restrict__ counts, int *__restrict__ flags)
 {
-    extern __shared__ unsigned long long key[];                  // P keys, P alive bytes (16-byte aligned), then the image's row boxes
+    extern __shared__ unsigned long long key[];                  // P keys
     __shared__ float red[kDetThreads / 64];
-    __shared__ int n_keep_s;
+    __shared__ int wave_sum[kDetThreads / 64];
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = img_count[img];
     if (n > kDetMaxCand) {
-        if (tid == 0) {
-            atomicOr(flags, LOCOV_DETECT_FLAG_OVERFLOW);
-            counts[img] = 0;
-        }
+        if (tid == 0) atomicOr(flags, LOCOV_DETECT_FLAG_OVERFLOW);
         return;
     }
-    if (n == 0) {
-        if (tid == 0) counts[img] = 0;
-        return;
-    }
+    if (n == 0) return;
     int P = 2;
     while (P < n) P <<= 1;
-    unsigned char *alive = reinterpret_cast<unsigned char *>(key + P);
-    const int r0 = g.roff[img], n_rows = g.roff[img + 1] - r0;
-    const bool direct = P <= kDetLdsCand;                        // cbox[i] = candidate i's shifted box (sorted order)
-    const bool staged = !direct && n_rows <= kDetLdsRows;        // rbox[row] = the image's clipped row boxes
-    float4 *lbox = reinterpret_cast<float4 *>(alive + ((P + 15) & ~15));
-    const float4 *gbox = boxes + r0;
-    const unsigned long long *src = keys + (int64_t)img * kDetMaxCand;
-    for (int i = tid; i < P; i += kDetThreads) key[i] = i < n ? src[i] : ~0ull;
-    if (staged)
-        for (int i = tid; i < n_rows; i += kDetThreads) lbox[i] = gbox[i];
-    if (tid == 0) n_keep_s = 0;
-    DET_STAMP(0);
+    unsigned long long *keys_g = L.keys + (int64_t)img * kDetMaxCand;
+    for (int i = tid; i < P; i += kDetThreads) key[i] = i < n ? keys_g[i] : ~0ull;
     __syncthreads();
-    DET_STAMP(1);
     det_bitonic_sort(key, P, tid);                               // class-major; inside a class: descending score, ties by row
-    DET_STAMP(2);
     constexpr unsigned long long kRowMask = (1ull << kRowBits) - 1ull;
-    auto row_box = [&](int i) {
-        const int row = (int)(key[i] & kRowMask);
-        return staged ? lbox[row] : gbox[row];
-    };
+    const float4 *gbox = boxes + g.roff[img];
     // batched_nms's coordinate offset: class * (max coordinate of the image's candidate boxes + 1)
     float m = -__builtin_inff();
     for (int i = tid; i < n; i += kDetThreads) {
-        const float4 b = row_box(i);
+        const float4 b = gbox[(int)(key[i] & kRowMask)];
         m = fmaxf(m, fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
     }
 #pragma unroll
@@ -255,102 +240,165 @@ __global__ __launch_bounds__(kDetThreads) void det_select_kernel(const unsigned 
     m = red[0];
     for (int w = 1; w < kDetThreads / 64; w++) m = fmaxf(m, red[w]);
     const float shift_unit = m + 1.f;
-    DET_STAMP(3);
-    auto cls_of = [&](int i) { return (int)(key[i] >> (kRowBits + kScoreBits)); };
-    auto shift_box = [&](float4 b, float off) {
-        b.x += off;
-        b.y += off;
-        b.z += off;
-        b.w += off;
-        return b;
-    };
-    if (direct) {
-        for (int i = tid; i < n; i += kDetThreads) lbox[i] = shift_box(row_box(i), (float)cls_of(i) * shift_unit);
-        __syncthreads();
-    }
-    auto shifted = [&](int i, float off) { return direct ? lbox[i] : shift_box(row_box(i), off); };
-    // Greedy NMS inside every class segment (classes never suppress each other: that is all the coordinate shift achieves; the
-    // IoU is still taken on the shifted boxes), as a fix-point over three states -- 2 undecided, 1 kept, 0 suppressed -- that ends in
-    // exactly the sequential sweep's result: a candidate walks its class's earlier candidates in score order; one that is
-    // suppressed is skipped for good, a KEPT one that overlaps suppresses it, an UNDECIDED one that overlaps makes it wait at
-    // that position for the next round, and having passed them all it is kept.  States only ever move from 2 to 0 / 1, so a
-    // stale read merely costs a round, and every pair is examined once (plus once per wait): the sweep's m sequential steps of a
-    // class with m candidates become m parallel walks and as many rounds as its longest wait chain (a handful).
+    int *cstart = L.cstart + (int64_t)img * kDetMaxCand, *woff = L.woff + (int64_t)img * (kDetMaxCand + 4);
+    float4 *cbox = L.cbox + (int64_t)img * kDetMaxCand;
+    // sorted keys, shifted boxes, class starts; and -- a block-wide exclusive scan, candidates in CONSECUTIVE runs of kQ per thread --
+    // where each candidate's overlap words go
     constexpr int kQ = kDetMaxCand / kDetThreads;
-    unsigned short resume[kQ];
+    int words[kQ], run = 0;
 #pragma unroll
     for (int q = 0; q < kQ; q++) {
-        const int i = tid + q * kDetThreads;
-        resume[q] = 0;
+        const int i = tid * kQ + q;
+        words[q] = 0;
         if (i < n) {
-            const unsigned long long first_of_class = (unsigned long long)cls_of(i) << (kRowBits + kScoreBits);
+            const unsigned long long k = key[i];
+            const int cls = (int)(k >> (kRowBits + kScoreBits));
+            const unsigned long long first_of_class = (unsigned long long)cls << (kRowBits + kScoreBits);
             int lo = 0, hi = i;
             while (lo < hi) {                                    // the first candidate of i's class (the keys are sorted)
                 const int mid = (lo + hi) >> 1;
                 if (key[mid] < first_of_class) lo = mid + 1;
                 else hi = mid;
             }
-            resume[q] = (unsigned short)lo;
-            alive[i] = lo == i ? 1 : 2;
+            float4 b = gbox[(int)(k & kRowMask)];
+            const float off = (float)cls * shift_unit;
+            b.x += off;
+            b.y += off;
+            b.z += off;
+            b.w += off;
+            keys_g[i] = k;
+            cbox[i] = b;
+            cstart[i] = lo;
+            words[q] = (i - lo + 63) >> 6;
         }
+        run += words[q];
     }
+    int incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
     __syncthreads();
-    DET_STAMP(4);
+    int before = incl - run;
+    for (int w = 0; w < wave; w++) before += wave_sum[w];
+#pragma unroll
+    for (int q = 0; q < kQ; q++) {
+        const int i = tid * kQ + q;
+        if (i < n) woff[i] = before;
+        before += words[q];
+    }
+    if (tid == kDetThreads - 1) woff[n] = before;                // (thread 1023 holds the tail: every i >= n contributes no word)
+    (void)counts;
+}
+
+// a thread per candidate: which earlier candidates of its class overlap it (IoU > threshold on the shifted boxes)
+__global__ __launch_bounds__(256) void det_pairs_kernel(DetLists L, const int *__restrict__ img_count, float nms_thr)
+{
+    const int img = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
+    const int n = img_count[img];
+    if (n > kDetMaxCand || a >= n) return;
+    const int s = L.cstart[(int64_t)img * kDetMaxCand + a];
+    if (s == a) return;
+    const float4 *cbox = L.cbox + (int64_t)img * kDetMaxCand;
+    unsigned long long *ov = L.ov + (int64_t)img * kDetOvWords + L.woff[(int64_t)img * (kDetMaxCand + 4) + a];
+    const float4 box_a = cbox[a];
+    for (int w = 0, base = s; base < a; w++, base += 64) {
+        unsigned long long bits = 0;
+        const int lim = min(64, a - base);
+        for (int j = 0; j < lim; j++)
+            if (det_iou_gt(cbox[base + j], box_a, nms_thr)) bits |= 1ull << j;
+        ov[w] = bits;
+    }
+}
+
+__device__ __forceinline__ unsigned long long det_window64(const unsigned *bits, int pos)      // 64 bits of a bit set from bit `pos` on
+{
+    const int w = pos >> 5, sh = pos & 31;
+    const unsigned long long lo = (unsigned long long)bits[w] | ((unsigned long long)bits[w + 1] << 32);
+    return sh ? (lo >> sh) | ((unsigned long long)bits[w + 2] << (64 - sh)) : lo;
+}
+
+__global__ __launch_bounds__(kDetThreads) void det_nms_topk_kernel(DetLists L, const int *__restrict__ img_count, const float4 *__restrict__ boxes,
+                                                                   DetGeom g, int topk, float4 *__restrict__ out_boxes, float *__restrict__ out_scores,
+                                                                   int64_t *__restrict__ out_classes, int64_t *__restrict__ out_rows,
+                                                                   int *__restrict__ counts)
+{
+    extern __shared__ unsigned long long key[];                  // P keys (the second sort's)
+    __shared__ unsigned kept[kDetMaxCand / 32 + 4], und[kDetMaxCand / 32 + 4];
+    __shared__ int n_keep_s;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int n = img_count[img];
+    if (n > kDetMaxCand || n == 0) {
+        if (tid == 0) counts[img] = 0;
+        return;
+    }
+    int P = 2;
+    while (P < n) P <<= 1;
+    const unsigned long long *keys_g = L.keys + (int64_t)img * kDetMaxCand;
+    const int *cstart = L.cstart + (int64_t)img * kDetMaxCand, *woff = L.woff + (int64_t)img * (kDetMaxCand + 4);
+    const unsigned long long *ov = L.ov + (int64_t)img * kDetOvWords;
+    for (int w = tid; w < kDetMaxCand / 32 + 4; w += kDetThreads) {
+        kept[w] = 0;
+        const int lo = w * 32;
+        und[w] = lo + 32 <= n ? 0xffffffffu : (lo < n ? (1u << (n - lo)) - 1u : 0u);
+    }
+    if (tid == 0) n_keep_s = 0;
+    __syncthreads();
+    // Greedy NMS as a fix-point over the two bit sets: an undecided candidate with a KEPT overlapping predecessor is suppressed;
+    // with none kept and none undecided it is kept; otherwise it waits.  A candidate is marked kept BEFORE it leaves the undecided
+    // set and readers look at the undecided set FIRST, so a reader never takes a just-decided candidate for a suppressed one;
+    // bits only ever move one way, so a stale read costs a round, never the result (= the sequential sweep's).
+    constexpr int kQ = kDetMaxCand / kDetThreads;
     for (;;) {
         int pending = 0;
 #pragma unroll
         for (int q = 0; q < kQ; q++) {
             const int i = tid + q * kDetThreads;
-            if (i < n && alive[i] == 2) {
-                const float off = (float)cls_of(i) * shift_unit;
-                const float4 box_a = shifted(i, off);
-                int b = resume[q];
-                unsigned char state = 2;
-                while (b < i) {
-                    const unsigned char sb = alive[b];
-                    if (sb != 0 && det_iou_gt(shifted(b, off), box_a, nms_thr)) {
-                        if (sb == 1) state = 0;
-                        break;
-                    }
-                    b++;
+            if (i < n && ((und[i >> 5] >> (i & 31)) & 1u)) {
+                const int s = cstart[i];
+                const unsigned long long *mine = ov + woff[i];
+                bool sup = false, wait = false;
+                for (int w = 0, base = s; base < i && !sup; w++, base += 64) {
+                    const unsigned long long mask = mine[w];
+                    if (!mask) continue;
+                    const unsigned long long u = det_window64(und, base);     // (undecided first, then kept: see above)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const unsigned long long k = det_window64(kept, base);
+                    if (mask & k) sup = true;
+                    else if (mask & u) wait = true;
                 }
-                if (b == i) state = 1;
-                resume[q] = (unsigned short)b;
-                if (state != 2) alive[i] = state;
-                else pending = 1;
+                if (sup) atomicAnd(&und[i >> 5], ~(1u << (i & 31)));
+                else if (!wait) {
+                    atomicOr(&kept[i >> 5], 1u << (i & 31));
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    atomicAnd(&und[i >> 5], ~(1u << (i & 31)));
+                } else
+                    pending = 1;
             }
         }
         if (__syncthreads_or(pending) == 0) break;
     }
-    DET_STAMP(5);
     // the survivors in the reference's order: descending score, ties in candidate (row, class) order
-    int mine = 0;
-    unsigned long long k2[(kDetMaxCand + kDetThreads - 1) / kDetThreads];
-#pragma unroll
-    for (int q = 0; q < (kDetMaxCand + kDetThreads - 1) / kDetThreads; q++) {
-        const int i = tid + q * kDetThreads;
+    constexpr unsigned long long kRowMask = (1ull << kRowBits) - 1ull;
+    int mine_n = 0;
+    for (int i = tid; i < P; i += kDetThreads) {
         unsigned long long v = ~0ull;
-        if (i < n && alive[i]) {
-            const unsigned long long k = key[i];
+        if (i < n && ((kept[i >> 5] >> (i & 31)) & 1u)) {
+            const unsigned long long k = keys_g[i];
             const unsigned long long cls = k >> (kRowBits + kScoreBits), nscore = (k >> kRowBits) & 0xffffffffull, row = k & kRowMask;
             v = (nscore << (kRowBits + kClsBits)) | (row << kClsBits) | cls;
-            mine++;
+            mine_n++;
         }
-        k2[q] = v;
+        key[i] = v;
     }
-    __syncthreads();                                             // (every read of key[] / alive[] above is done)
-#pragma unroll
-    for (int q = 0; q < (kDetMaxCand + kDetThreads - 1) / kDetThreads; q++) {
-        const int i = tid + q * kDetThreads;
-        if (i < P) key[i] = k2[q];
-    }
-    if (mine) atomicAdd(&n_keep_s, mine);
+    if (mine_n) atomicAdd(&n_keep_s, mine_n);
     __syncthreads();
-    DET_STAMP(6);
     det_bitonic_sort(key, P, tid);
-    DET_STAMP(7);
     const int n_keep = n_keep_s;
     const int count = n_keep < topk ? n_keep : topk;
+    const float4 *gbox = boxes + g.roff[img];
     for (int j = tid; j < count; j += kDetThreads) {
         const unsigned long long k = key[j];
         const int cls = (int)(k & ((1ull << kClsBits) - 1ull)), row = (int)((k >> kClsBits) & kRowMask);
@@ -362,15 +410,6 @@ __global__ __launch_bounds__(kDetThreads) void det_select_kernel(const unsigned 
         out_rows[slot] = row;
     }
     if (tid == 0) counts[img] = count;
-    DET_STAMP(8);
-#ifdef LOCOV_DET_TRACE
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        det_trace[9] = n;
-        det_trace[10] = P;
-        det_trace[11] = n_keep;
-        det_trace[12] = 0;
-    }
-#endif
 }
 
 }  // namespace locov
@@ -379,18 +418,16 @@ using namespace locov;
 
 extern "C" {
 
-#ifdef LOCOV_DET_TRACE
-int locov_detect_trace_read(long long *host16)
-{
-    return hipMemcpyFromSymbol(host16, HIP_SYMBOL(det_trace), sizeof(long long) * 16) == hipSuccess ? 0 : -1;
-}
-#endif
+static int64_t det_align16(int64_t v) { return (v + 15) & ~(int64_t)15; }
 
 int64_t locov_detect_postprocess_workspace_bytes(int64_t R, int n_images)
 {
     if (R <= 0 || n_images <= 0) return 0;
-    // clipped boxes [R, 4] fp32, row counts [R], row offsets [R], candidates per image [n_images] (padded), keys [n_images, MAX]
-    return R * 16 + R * 4 + R * 4 + (int64_t)((n_images + 3) & ~3) * 4 + (int64_t)n_images * kDetMaxCand * 8 + 64;
+    // clipped boxes [R, 4] fp32, row counts [R], row offsets [R], candidates per image [n_images]; then per image: keys, class starts,
+    // overlap-word offsets, shifted boxes (kDetMaxCand each) and the overlap bit sets (kDetOvWords 64-bit words: 4.3 MB)
+    const int64_t head = det_align16(R * 24 + (int64_t)((n_images + 3) & ~3) * 4);
+    const int64_t per_image = (int64_t)kDetMaxCand * (8 + 4 + 16) + (int64_t)(kDetMaxCand + 4) * 4 + (int64_t)kDetOvWords * 8;
+    return head + (int64_t)n_images * per_image + 64;
 }
 
 int locov_detect_postprocess(const float *probs, int64_t ld_probs, int num_classes, const float *deltas, const float *proposal_boxes,
@@ -435,7 +472,14 @@ int locov_detect_postprocess(const float *probs, int64_t ld_probs, int num_class
     int *row_count = reinterpret_cast<int *>(ws + R * 16);
     int *row_off = row_count + R;
     int *img_count = row_off + R;
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(ws + ((R * 24 + (int64_t)((n_images + 3) & ~3) * 4 + 15) & ~(int64_t)15));
+    char *lists = ws + det_align16(R * 24 + (int64_t)((n_images + 3) & ~3) * 4);
+    DetLists L;
+    L.keys = reinterpret_cast<unsigned long long *>(lists);
+    L.cbox = reinterpret_cast<float4 *>(lists + (int64_t)n_images * kDetMaxCand * 8);
+    L.ov = reinterpret_cast<unsigned long long *>(lists + (int64_t)n_images * kDetMaxCand * 24);
+    L.cstart = reinterpret_cast<int *>(lists + (int64_t)n_images * kDetMaxCand * 24 + (int64_t)n_images * kDetOvWords * 8);
+    L.woff = L.cstart + (int64_t)n_images * kDetMaxCand;
+    unsigned long long *keys = L.keys;
     int *flags = counts_and_flags + n_images;
     // (torch divides a tensor by a python scalar by multiplying with the reciprocal formed in fp32)
     const float inv_wx = 1.0f / wx, inv_wy = 1.0f / wy, inv_ww = 1.0f / ww, inv_wh = 1.0f / wh;
@@ -446,19 +490,21 @@ int locov_detect_postprocess(const float *probs, int64_t ld_probs, int num_class
     hipLaunchKernelGGL(det_scan_kernel, dim3(1), dim3(kDetThreads), 0, s, row_count, g, row_off, img_count);
     hipLaunchKernelGGL(det_emit_kernel, dim3((unsigned)ceil_div(R, 4)), dim3(256), 0, s, probs, ld_probs, num_classes, (int)R, score_thresh, g,
                        row_off, keys);
-    // (LDS: 9 bytes per candidate slot + either the sorted candidates' shifted boxes or the image's row boxes; the attribute belongs
-    //  to the kernel on ONE device)
-    const size_t lds_direct = (size_t)kDetLdsCand * (9 + 16) + 16, lds_rows = (size_t)kDetMaxCand * 9 + 16 + (size_t)kDetLdsRows * 16;
-    const size_t lds = lds_direct > lds_rows ? lds_direct : lds_rows;
+    // (the sorts' LDS: 8 bytes per candidate slot, 64 KB; the attribute belongs to the kernel on ONE device)
+    const size_t lds = (size_t)kDetMaxCand * 8;
     static int attr_state[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return set_error(LOCOV_ERR_LAUNCH, "locov_detect_postprocess: hipGetDevice");
     if (attr_state[dev] == 0)
-        attr_state[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(det_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)lds) == hipSuccess ? 1 : -1;
+        attr_state[dev] = (hipFuncSetAttribute(reinterpret_cast<const void *>(det_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds) == hipSuccess &&
+                           hipFuncSetAttribute(reinterpret_cast<const void *>(det_nms_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds) == hipSuccess) ? 1 : -1;
     if (attr_state[dev] != 1) return set_error(LOCOV_ERR_LAUNCH, "locov_detect_postprocess: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    hipLaunchKernelGGL(det_select_kernel, dim3((unsigned)n_images), dim3(kDetThreads), lds, s, keys, img_count, boxes, g, nms_thresh, topk,
-                       reinterpret_cast<float4 *>(out_boxes), out_scores, out_classes, out_rows, counts_and_flags, flags);
+    hipLaunchKernelGGL(det_sort_kernel, dim3((unsigned)n_images), dim3(kDetThreads), lds, s, L, img_count, boxes, g, counts_and_flags, flags);
+    hipLaunchKernelGGL(det_pairs_kernel, dim3(kDetMaxCand / 256, (unsigned)n_images), dim3(256), 0, s, L, img_count, nms_thresh);
+    hipLaunchKernelGGL(det_nms_topk_kernel, dim3((unsigned)n_images), dim3(kDetThreads), lds, s, L, img_count, boxes, g, topk,
+                       reinterpret_cast<float4 *>(out_boxes), out_scores, out_classes, out_rows, counts_and_flags);
     return check_launch("locov_detect_postprocess");
 }
 

@@ -91,6 +91,8 @@ def _same(a, b):
     ([300, 0, 1, 517], 80, 2.0, {"image_shapes": [(800, 1333), (640, 960), (480, 640), (1067, 800)]}),   # ragged, an empty image
     ([1000], 48, 1.5, {"crowd": 12}),                                          # few classes: hundreds of candidates per class
     ([400, 400], 65, 2.5, {"dup_rows": 50}),                                   # exact score ties
+    ([1500], 3, 0.2, {"crowd": 40}),                                           # every proposal a candidate of every class: 1 500 per class
+    ([2000, 700], 2, 0.3, {}),                                                 # ... and spread-out boxes (most survive: long wait chains)
     ([64], 5, 0.1, {}),                                                        # nearly uniform scores: everything passes 0.05 at 6 columns
     ([200], 1203, 0.01, {}),                                                   # nothing passes the threshold
 ])

@@ -392,8 +392,18 @@ def test_sampling_kernel_equals_the_two_global_sorts():
             c = oc[i * B:(i + 1) * B].cpu()
             k = min(int(rows[i, 0]), max_pos)
             assert bool(((c[:k] >= 0) & (c[:k] < K)).all()) and bool((c[k:] == K).all())
-    assert torch.equal(ob.cpu(), boxes[want]) and torch.equal(oc.cpu(), labels[want]) and torch.equal(fo.cpu(), field[want])
-    assert torch.equal(fg.cpu(), (labels[want] != K).long())
+    # classes: labels[picked] -- except in the slots of an image that does NOT fill its budget which read past the background
+    # population: the caller throws that sample away but has already enqueued the losses on it, so such a slot counts as
+    # background (never the ignore label -1, which torch's cross-entropy answers with a device-side assert)
+    want_cls = labels[want].clone()
+    for i in range(len(n_r)):
+        k = min(int(rows[i, 0]), max_pos)
+        past = k + int(rows[i, 1])
+        if past < B:
+            want_cls[i * B + past:(i + 1) * B] = K
+    assert bool((oc.cpu() != -1).all())
+    assert torch.equal(ob.cpu(), boxes[want]) and torch.equal(oc.cpu(), want_cls) and torch.equal(fo.cpu(), field[want])
+    assert torch.equal(fg.cpu(), (want_cls != K).long())
     has_gt = torch.tensor([n_g[i] > 0 for i in range(len(n_r))]).repeat_interleave(B)
     assert torch.equal(og.cpu()[has_gt], gtb[gt_index[want]][has_gt]) and not bool(og.cpu()[~has_gt].any())
     assert torch.equal(rois.cpu(), torch.cat([torch.arange(len(n_r)).repeat_interleave(B).float()[:, None], boxes[want]], dim=1))

@@ -73,6 +73,8 @@ json.dump(util, open(dst("pmc_mfma_util.json"), "w"), indent=1)
 extra = []
 for src, name in ((os.path.join(SRC, "find_syncs.txt"), "find_syncs.txt"), (os.path.join(SRC, "train_timeline.txt"), "train_timeline.txt"),
                   (os.path.join(SRC, "power_step.txt"), "power_step.txt"),
+                  (os.path.join(SRC, "eval_stats", "s_kernel_stats.csv"), "eval_kernel_stats.csv"),
+                  (os.path.join(SRC, "eval.json"), "eval.json"),
                   (os.path.join(ROOT, "gpurun_out", "prof_train", "stats", "s_kernel_stats.csv"), "train_kernel_stats.csv")):
     if os.path.exists(src):
         shutil.copy(src, dst(name))
