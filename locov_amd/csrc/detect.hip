@@ -293,24 +293,24 @@ __global__ __launch_bounds__(kDetThreads) void det_sort_kernel(DetLists L, const
     (void)counts;
 }
 
-// a thread per candidate: which earlier candidates of its class overlap it (IoU > threshold on the shifted boxes)
+// a thread per (candidate, 64 predecessors): which earlier candidates of its class overlap it (IoU > threshold on the shifted boxes).
+// grid (candidates / 256, images, word index): the word index runs to the worst case, the workgroups past an image's longest class
+// leave at once
 __global__ __launch_bounds__(256) void det_pairs_kernel(DetLists L, const int *__restrict__ img_count, float nms_thr)
 {
-    const int img = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
+    const int img = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x, w = blockIdx.z;
     const int n = img_count[img];
     if (n > kDetMaxCand || a >= n) return;
     const int s = L.cstart[(int64_t)img * kDetMaxCand + a];
-    if (s == a) return;
+    const int base = s + 64 * w;
+    if (base >= a) return;
     const float4 *cbox = L.cbox + (int64_t)img * kDetMaxCand;
-    unsigned long long *ov = L.ov + (int64_t)img * kDetOvWords + L.woff[(int64_t)img * (kDetMaxCand + 4) + a];
     const float4 box_a = cbox[a];
-    for (int w = 0, base = s; base < a; w++, base += 64) {
-        unsigned long long bits = 0;
-        const int lim = min(64, a - base);
-        for (int j = 0; j < lim; j++)
-            if (det_iou_gt(cbox[base + j], box_a, nms_thr)) bits |= 1ull << j;
-        ov[w] = bits;
-    }
+    const int lim = min(64, a - base);
+    unsigned long long bits = 0;
+#pragma unroll 8
+    for (int j = 0; j < lim; j++) bits |= (unsigned long long)det_iou_gt(cbox[base + j], box_a, nms_thr) << j;
+    L.ov[(int64_t)img * kDetOvWords + L.woff[(int64_t)img * (kDetMaxCand + 4) + a] + w] = bits;
 }
 
 __device__ __forceinline__ unsigned long long det_window64(const unsigned *bits, int pos)      // 64 bits of a bit set from bit `pos` on
@@ -502,7 +502,12 @@ int locov_detect_postprocess(const float *probs, int64_t ld_probs, int num_class
                                                (int)lds) == hipSuccess) ? 1 : -1;
     if (attr_state[dev] != 1) return set_error(LOCOV_ERR_LAUNCH, "locov_detect_postprocess: cannot raise the dynamic LDS limit to %zu bytes", lds);
     hipLaunchKernelGGL(det_sort_kernel, dim3((unsigned)n_images), dim3(kDetThreads), lds, s, L, img_count, boxes, g, counts_and_flags, flags);
-    hipLaunchKernelGGL(det_pairs_kernel, dim3(kDetMaxCand / 256, (unsigned)n_images), dim3(256), 0, s, L, img_count, nms_thresh);
+    // (a class holds at most one candidate per proposal: its predecessors fit ceil(rows of the largest image / 64) words)
+    int max_rows = 0;
+    for (int i = 0; i < n_images; i++) max_rows = g.roff[i + 1] - g.roff[i] > max_rows ? g.roff[i + 1] - g.roff[i] : max_rows;
+    const int pair_words = (int)ceil_div(max_rows < kDetMaxCand ? max_rows : kDetMaxCand, 64);
+    hipLaunchKernelGGL(det_pairs_kernel, dim3(kDetMaxCand / 256, (unsigned)n_images, (unsigned)pair_words), dim3(256), 0, s, L, img_count,
+                       nms_thresh);
     hipLaunchKernelGGL(det_nms_topk_kernel, dim3((unsigned)n_images), dim3(kDetThreads), lds, s, L, img_count, boxes, g, topk,
                        reinterpret_cast<float4 *>(out_boxes), out_scores, out_classes, out_rows, counts_and_flags);
     return check_launch("locov_detect_postprocess");
