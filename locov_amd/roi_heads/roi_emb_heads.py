@@ -243,10 +243,6 @@ class SampleAllROIHeads(ROIHeads):
         st = self.stats
         st[key] = st.get(key, 0) + n
 
-    def _backward_guard_words(self, device):
-        """Device words to read with the labelling sync (none in the base class)."""
-        return []
-
     def _backward_guard_tripped(self) -> None:
         pass
 
@@ -860,9 +856,6 @@ class EmbeddingRes5ROIHeads(SampleAllROIHeads):
         guard = self.res5.range_guard("fwd", dev)
         guard.reset()
         return guard
-
-    def _backward_guard_words(self, device):
-        return self.res5.backward_guard_words(device) if hasattr(self.res5, "backward_guard_words") else []
 
     def _deferred_guards(self, device):
         return self.res5.deferred_guards(device) if hasattr(self.res5, "deferred_guards") else []

@@ -170,7 +170,8 @@ def test_roi_align_even_backward_window_equals_the_direct_scatter(pkg, oracle, m
     assert abs(lhs - rhs) <= 1e-5 * float(y.double().norm() * G.double().norm())
 
 
-@pytest.mark.parametrize("N,C,H,W,per", [(4, 1024, 50, 84, 200), (3, 1024, 50, 84, 512), (2, 128, 13, 9, 40), (1, 256, 64, 64, 2500)])
+@pytest.mark.parametrize("N,C,H,W,per", [(4, 1024, 50, 84, 200), (3, 1024, 50, 84, 512), (2, 128, 13, 9, 40), (1, 256, 64, 64, 2500),
+                                         (2, 128, 50, 84, 6000)])        # (12 000 proposals: six list passes per tile -- ADVICE r5)
 def test_roi_align_even_backward_by_tile_ownership(pkg, oracle, N, C, H, W, per, monkeypatch):
     """The ownership form of the even-grid ROIAlign backward (a workgroup per 8 x 8 map tile and 128-channel slice collects the
     proposals that reach its tile; no atomics) against the scatter form at the LSM / STT steps' shapes, a map smaller than two tiles
