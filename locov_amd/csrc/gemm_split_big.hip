@@ -497,7 +497,10 @@ bool gemm_split_big_applicable(int64_t lda, int64_t ldc, int64_t M, int N, int K
     if (tiles > 0x7fffffffLL) return false;
     if (forced > 0) return true;
     // enough tiles for four rounds over 256 CUs, and N a whole number of 256-wide tiles (a half-empty N tile wastes a quarter of the CU)
-    return tiles >= 1024 && N % GBN == 0 && M >= 4 * GBM;
+#ifndef LOCOV_BIG_BATCHED_MIN_TILES
+#define LOCOV_BIG_BATCHED_MIN_TILES 1024       // (tools/make_variant.py A/B: the batched launches' own threshold, R6.6)
+#endif
+    return tiles >= (count > 1 ? LOCOV_BIG_BATCHED_MIN_TILES : 1024) && N % GBN == 0 && M >= (LOCOV_BIG_BATCHED_MIN_TILES < 1024 && count > 1 ? 3 : 4) * GBM;
 }
 
 int launch_gemm_split_big(const float *A, int64_t lda, const void *Wsplit, float *C, int64_t ldc, int64_t M, int N, int K,
