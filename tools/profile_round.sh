@@ -10,8 +10,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err          # the driver's command (defaults)
-ARGS="--no-cpu-baseline --skip-s1 --skip-f32-reference --skip-variants --skip-train --steps 3 --warmup 1"
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py --no-cpu-baseline --skip-s1 --skip-f32-reference --skip-variants --skip-train --steps 5 --warmup 2 > /dev/null 2>&1
+ARGS="--no-cpu-baseline --skip-s1 --skip-f32-reference --skip-variants --skip-train --skip-eval --steps 3 --warmup 1"      # (only the S2 step: the kernel mix of the process is the timed region's)
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py --no-cpu-baseline --skip-s1 --skip-f32-reference --skip-variants --skip-train --skip-eval --steps 5 --warmup 2 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p --output-format csv -- python3 bench.py $ARGS > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p --output-format csv -- python3 bench.py $ARGS > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT -d $OUT/pmc_mfma -o p --output-format csv -- python3 bench.py $ARGS > /dev/null 2>&1
