@@ -211,6 +211,9 @@ def synth_train_batch(gen, device, n_images, n_props, n_classes, dim, *, multisc
             b = b.clamp(min=0)
         elif k:
             b[:k] = (gt[:k] + torch.rand(k, 4, generator=gen) * 8 - 4).clamp(min=0)
+        if multiscale:                                   # (RPN proposals are clipped to their image; the fixed batch keeps round 5's data)
+            b[:, 0::2] = b[:, 0::2].clamp(max=float(w) - 1.0)
+            b[:, 1::2] = b[:, 1::2].clamp(max=float(h) - 1.0)
         b[:, 2:] = torch.maximum(b[:, 2:], b[:, :2] + 1.0)
         p = Instances((h, w))
         p.proposal_boxes = Boxes(b.to(device))

@@ -455,3 +455,35 @@ def test_cat_rows_is_a_view_of_adjacent_pieces_and_a_copy_otherwise():
     g = torch.ones(4, 2, requires_grad=True) * 1.0
     assert cat_rows([g[0:2], g[2:4]]).requires_grad                                           # autograd tensors: torch.cat
     assert cat_rows([b[1:3]]).data_ptr() == b[1:3].data_ptr()
+
+
+
+def test_bench_training_batches_of_the_references_real_shapes():
+    """bench.synth_train_batch / synth_image_size: image sizes out of configs/coco_stt.yaml:54's MIN_SIZE_TRAIN with
+    the long side capped at 1333, the batch's res4 map = ceil(largest image / 16) per axis, per-image proposal / ground-truth counts,
+    an image that cannot fill the sampling budget, boxes inside their own image."""
+    import importlib, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    gen = torch.Generator().manual_seed(3)
+    sizes = [bench.synth_image_size(gen) for _ in range(500)]
+    assert all(min(h, w) <= 800 and max(h, w) <= 1333 for h, w in sizes)
+    assert {min(h, w) for h, w in sizes if max(h, w) < 1333} <= set(bench.MIN_SIZE_TRAIN)
+    assert any(h > w for h, w in sizes) and any(w > h for h, w in sizes)                         # portrait and landscape
+    b = bench.synth_train_batch(gen, "cpu", 4, 300, 80, 32, multiscale=True, max_gt=15, fixed_gt=False, short_image=(2, 17))
+    hm, wm = max(h for h, _ in b["sizes"]), max(w for _, w in b["sizes"])
+    assert tuple(b["features"].shape) == (4, 1024, -(-hm // 16), -(-wm // 16)) == (4, 1024) + b["map"]
+    assert [len(p) for p in b["proposals"]] == [300, 300, 17, 300]
+    assert all(0 <= len(t) <= 15 for t in b["targets"])
+    for p, t, (h, w) in zip(b["proposals"], b["targets"], b["sizes"]):
+        assert p.image_size == (h, w) == t.image_size
+        box = p.proposal_boxes.tensor
+        assert float(box[:, 0].min()) >= 0 and float(box[:, 2].max()) <= w + 1 and float(box[:, 3].max()) <= h + 1
+        assert bool(((box[:, 2] - box[:, 0]) > 0).all() and ((box[:, 3] - box[:, 1]) > 0).all())
+    fixed = bench.synth_train_batch(torch.Generator().manual_seed(5), "cpu", 2, 50, 80, 32)
+    assert tuple(fixed["features"].shape) == (2, 1024, 50, 84) and [len(t) for t in fixed["targets"]] == [7, 7]
+    crowded = bench.synth_train_batch(torch.Generator().manual_seed(6), "cpu", 2, 64, 80, 32, multiscale=True, crowded_image=1)
+    from locov_amd.structures import pairwise_iou
+    iou = pairwise_iou(crowded["targets"][1].gt_boxes, crowded["proposals"][1].proposal_boxes)
+    assert float(iou.max(dim=0).values.min()) > 0.5                                                 # every proposal sits on a GT box
