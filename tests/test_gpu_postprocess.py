@@ -93,6 +93,8 @@ def _same(a, b):
     ([400, 400], 65, 2.5, {"dup_rows": 50}),                                   # exact score ties
     ([1500], 3, 0.2, {"crowd": 40}),                                           # every proposal a candidate of every class: 1 500 per class
     ([2000, 700], 2, 0.3, {}),                                                 # ... and spread-out boxes (most survive: long wait chains)
+    ([2700], 3, 0.2, {}),                                                      # 8 100 candidates: the 8 192-slot sort, full
+    ([37] * 64, 20, 1.0, {}),                                                  # the most images one call takes
     ([64], 5, 0.1, {}),                                                        # nearly uniform scores: everything passes 0.05 at 6 columns
     ([200], 1203, 0.01, {}),                                                   # nothing passes the threshold
 ])

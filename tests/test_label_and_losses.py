@@ -127,7 +127,7 @@ def test_labelling_raises_the_references_asserts_on_the_host(oracle):
     props[0].proposal_boxes = Boxes(bad)
     heads.label_and_sample_proposals(props, targets)
     # Matcher's assert: a match-quality matrix with a negative (or NaN) entry
-    import locov_amd.roi_heads.roi_emb_heads as reh
+    import locov_amd.roi_heads.labelling as reh
     real_iou = reh.pairwise_iou
     for poison in (-0.25, float("nan")):
         def fake(a, b, poison=poison):
@@ -258,7 +258,7 @@ def test_speculated_sample_equals_the_host_driven_one(oracle, kernel, monkeypatc
     validate afterwards (_label_validate).  On the same draw the speculated Instances equal the host-driven ones field for field,
     in the same field order; a batch that cannot fill its budget (too few background candidates) fails the validation, and the
     forward then returns the reference's counts."""
-    from locov_amd.roi_heads import roi_emb_heads
+    from locov_amd.roi_heads import labelling as roi_emb_heads
     from locov_amd.roi_heads.roi_emb_heads import get_event_storage
     monkeypatch.setattr(roi_emb_heads, "_SAMPLE_KERNEL", kernel)
     heads = _heads(True, 64, 0.25, "cuda")
@@ -418,7 +418,7 @@ def test_sampling_kernel_equals_the_two_global_sorts():
 def test_training_forward_with_the_sampling_kernel_equals_the_torch_op_form(oracle, monkeypatch):
     """One training forward + backward of the LSM heads with the lean labelling + sampling kernel and with the torch-op form, same
     seeds: the same sampled proposals, losses and Res5 weight gradients, bit for bit."""
-    from locov_amd.roi_heads import roi_emb_heads
+    from locov_amd.roi_heads import labelling as roi_emb_heads
     outs = {}
     for kernel in (True, False):
         monkeypatch.setattr(roi_emb_heads, "_SAMPLE_KERNEL", kernel)
