@@ -110,6 +110,36 @@ def test_fused_postprocess_is_bit_identical_to_the_torch_chain(pkg, monkeypatch,
         assert all(len(r) == 0 for r in got[0])
 
 
+@pytest.fixture(scope="module")
+def oracle_mod():
+    from oracle import lsm_oracle
+    lsm_oracle.build()
+    return lsm_oracle
+
+
+def test_fused_postprocess_vs_the_oracle_pipeline(pkg, oracle_mod, monkeypatch):
+    """The device pipeline against the CPU oracle's apply_deltas -> softmax -> fast_rcnn_inference_single_image on the same logits,
+    deltas and proposals (numpy arithmetic: a decoded coordinate may differ in its last bits, so a borderline NMS decision may too):
+    same number of detections, classes and scores agree as the end-to-end gate of tests/test_gpu_stt.py asks."""
+    pred = _predictor(pkg, 80)
+    sizes = [400, 250]
+    predictions, props = _inputs(pkg, sizes, 80, 2.0, seed=19, image_shapes=[(800, 1333), (640, 960)])
+    got, _ = _run(pkg, pred, predictions, props, True, monkeypatch)
+    logits, deltas = predictions[0].cpu().numpy(), predictions[1].cpu().numpy()
+    r0 = 0
+    for n, p, res in zip(sizes, props, got):
+        boxes = oracle_mod.apply_deltas(deltas[r0:r0 + n], p.proposal_boxes.tensor.cpu().numpy())
+        cb, cs, cc = oracle_mod.fast_rcnn_inference_single_image(boxes, oracle_mod.softmax(logits[r0:r0 + n]), p.image_size,
+                                                                 pred.test_score_thresh, pred.test_nms_thresh, pred.test_topk_per_image)
+        db, ds, dc = res.pred_boxes.tensor.cpu().numpy(), res.scores.cpu().numpy(), res.pred_classes.cpu().numpy()
+        assert len(ds) == len(cs) == 100
+        np.testing.assert_allclose(np.sort(ds)[::-1], np.sort(cs)[::-1], atol=1e-6)
+        od, oc = np.lexsort((db[:, 0], dc, -np.round(ds, 4))), np.lexsort((cb[:, 0], cc, -np.round(cs, 4)))
+        assert (dc[od] == cc[oc]).mean() > 0.98
+        np.testing.assert_allclose(db[od][dc[od] == cc[oc]], cb[oc][dc[od] == cc[oc]], atol=2e-3)
+        r0 += n
+
+
 def test_box_decoding_and_clipping_round_as_the_torch_ops(pkg):
     """det_decode_clip_kernel == Box2BoxTransform.apply_deltas + Boxes.clip bit for bit (torch divides by the weights through a
     multiplication with the fp32 reciprocal; the clamp of dw / dh; exp)."""
