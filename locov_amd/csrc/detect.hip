@@ -15,8 +15,9 @@
 //   det_emit_kernel          a wave per proposal: its candidates as 64-bit keys  class | ~score bits | row  in (row, class) order
 //   det_sort_kernel          a workgroup per image: bitonic sort of the keys in LDS (class-major, descending score, ties by row =
 //                            candidate order); shifted boxes, class starts
-//   det_pairs_kernel         a thread per candidate: which earlier candidates of its class it overlaps (IoU on the SHIFTED boxes,
-//                            so every decision rounds as batched_nms's does) -- the m^2 / 2 pair tests of a crowded class, chip-wide
+//   det_pairs_kernel         a thread per (candidate, 64 predecessors): which earlier candidates of its class overlap it (IoU on the
+//                            SHIFTED boxes, so every decision rounds as batched_nms's does) -- the m^2 / 2 pair tests of a
+//                            crowded class, chip-wide, into per-candidate overlap bit sets
 //   det_nms_topk_kernel      a workgroup per image: the greedy sweep as a fix-point over kept / undecided bit sets; second sort of
 //                            the survivors by (descending score, row, class) = the reference's order; top-k out.
 //
@@ -207,7 +208,7 @@ struct DetLists {                       // per-image work lists in the workspace
 };
 
 __global__ __launch_bounds__(kDetThreads) void det_sort_kernel(DetLists L, const int *__restrict__ img_count, const float4 *__restrict__ boxes,
-                                                               DetGeom g, int *__restrict__ counts, int *__restrict__ flags)
+                                                               DetGeom g, int *__restrict__ flags)
 {
     extern __shared__ unsigned long long key[];                  // P keys
     __shared__ float red[kDetThreads / 64];
@@ -290,7 +291,6 @@ __global__ __launch_bounds__(kDetThreads) void det_sort_kernel(DetLists L, const
         before += words[q];
     }
     if (tid == kDetThreads - 1) woff[n] = before;                // (thread 1023 holds the tail: every i >= n contributes no word)
-    (void)counts;
 }
 
 // a thread per (candidate, 64 predecessors): which earlier candidates of its class overlap it (IoU > threshold on the shifted boxes).
@@ -501,7 +501,7 @@ int locov_detect_postprocess(const float *probs, int64_t ld_probs, int num_class
                            hipFuncSetAttribute(reinterpret_cast<const void *>(det_nms_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)lds) == hipSuccess) ? 1 : -1;
     if (attr_state[dev] != 1) return set_error(LOCOV_ERR_LAUNCH, "locov_detect_postprocess: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    hipLaunchKernelGGL(det_sort_kernel, dim3((unsigned)n_images), dim3(kDetThreads), lds, s, L, img_count, boxes, g, counts_and_flags, flags);
+    hipLaunchKernelGGL(det_sort_kernel, dim3((unsigned)n_images), dim3(kDetThreads), lds, s, L, img_count, boxes, g, flags);
     // (a class holds at most one candidate per proposal: its predecessors fit ceil(rows of the largest image / 64) words)
     int max_rows = 0;
     for (int i = 0; i < n_images; i++) max_rows = g.roff[i + 1] - g.roff[i] > max_rows ? g.roff[i + 1] - g.roff[i] : max_rows;
