@@ -880,9 +880,9 @@ def main():
     def gradient_exchange(tr):
         ge = {"how": (f"DistributedDataParallel over {world} ranks ({args.dist_backend}), bucket_cap_mb {args.ddp_bucket_mb}" if dist_on
                       else f"none (1 rank); under N ranks: DistributedDataParallel, bucket_cap_mb {args.ddp_bucket_mb}"),
-              "autograd_nodes": "Res5HeadFn + one Res5BlockFn per bottleneck (locov_amd/res5_train.py): block b's weight gradients reach DDP's "
-                                "hooks when block b's backward kernels are enqueued; 17 MiB buckets close with [bbox_pred + res5.2], [res5.1], "
-                                "[res5.0] (emb_pred / v2l_projection first, 1 MiB first-bucket cap)",
+              "autograd_nodes": "Res5OutputFn + two Res5BlockFn per bottleneck (locov_amd/res5_train.py: tail = conv2 + conv3, head = conv1 + "
+                                "shortcut): a half-block's weight gradients reach DDP's hooks when that half's backward kernels are enqueued; "
+                                "which parameters DDP's (rebuilt) buckets hold and when they are ready: `schedule`",
               "bytes": "res5 59.8 MB + emb_pred 6.3 MB + bbox_pred 33 kB fp32 (SURVEY 8e)"}
         if args.skip_exchange_probe:
             return ge

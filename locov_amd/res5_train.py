@@ -34,7 +34,7 @@ import torch
 
 from . import ops
 
-__all__ = ["res5_rows", "res5_grid", "res5_rois", "roi_align_even_rows", "to_nhwc", "Res5BlockFn", "Res5HeadFn", "Res5Step", "Segment",
+__all__ = ["res5_rows", "res5_grid", "res5_rois", "roi_align_even_rows", "to_nhwc", "Res5BlockFn", "Res5OutputFn", "Res5Step", "Segment",
            "saved_activations"]
 
 _BWD_STREAMS = bool(int(os.environ.get("LOCOV_RES5_BWD_STREAMS", "1")))    # the grid segment's 3x3 gradients on a side stream (0: one stream)
@@ -207,10 +207,10 @@ class Res5Step:
     def outputs(self, inputs: Sequence[torch.Tensor], pooled: Sequence[bool]) -> List[torch.Tensor]:
         """The segments' stage outputs as differentiable tensors ([rows, Cout] pixel rows, or with pooled[i] the per-tile mean
         [n, Cout]) of `inputs` (the tensors the producers wrote into input_rows, carrying the graph) and the stage's weights.
-        The graph is ONE autograd node per bottleneck (Res5BlockFn) behind a head node (Res5HeadFn): block b's weight
-        gradients reach their AccumulateGrad nodes -- and DistributedDataParallel's bucket hooks -- as soon as block b's backward
-        kernels are enqueued, while the blocks in front of it are still to come (ovr/engine/trainer.py:61-66: the reference
-        gets the same overlap from Detectron2's per-convolution autograd nodes)."""
+        The graph is TWO autograd nodes per bottleneck (Res5BlockFn "head": conv1 + shortcut, "tail": conv2 + conv3) behind an output
+        node (Res5OutputFn): a half's weight gradients reach their AccumulateGrad nodes -- and DistributedDataParallel's bucket
+        hooks -- as soon as that half's backward kernels are enqueued, while everything in front of it is still to come
+        (ovr/engine/trainer.py:61-66: the reference gets the same overlap from Detectron2's per-convolution autograd nodes)."""
         assert len(inputs) == len(pooled) == len(self.segments) and not self._pending
         # a DEFERRED guard held by the caller (the ROI heads' training forward): nothing reads it before the backward runs, so
         # the backward must not turn the inf / NaN activations of an out-of-range forward into gradients -- every node zero-fills
@@ -220,14 +220,15 @@ class Res5Step:
         active = ops.active_guard(self.device) if self.split else None
         self.skip_words = [getattr(active, "step_word", active.word)] if active is not None and getattr(active, "deferred", False) else []
         self.bwd_split = self.split and not _BWD_F32
-        self._carry = None                            # (gradient of a block's output, its operand-scale slot) on its way to that block's node
+        self._carry = None                            # ("tail" | "head", gradient, its operand-scale slot[, ...]) on its way to the next node
         self._prefetched = False
         self.need_x0 = any(t.requires_grad for t in inputs)
-        ws = _block_weights(self.stage)
-        h = Res5BlockFn.apply(self, 0, len(inputs), *inputs, *ws[0])
-        for bi in range(1, len(ws)):
-            h = Res5BlockFn.apply(self, bi, 1, h, *ws[bi])
-        outs = Res5HeadFn.apply(self, tuple(bool(p) for p in pooled), h)
+        h = None
+        for bi, blk in enumerate(self.stage):
+            head_w = (blk.conv1.weight,) + ((blk.shortcut.weight,) if blk.shortcut is not None else ())
+            y1 = Res5BlockFn.apply(self, bi, "head", len(inputs), *inputs, *head_w) if bi == 0 else Res5BlockFn.apply(self, bi, "head", 1, h, *head_w)
+            h = Res5BlockFn.apply(self, bi, "tail", 1, y1, blk.conv2.weight, blk.conv3.weight)
+        outs = Res5OutputFn.apply(self, tuple(bool(p) for p in pooled), h)
         return list(outs) if isinstance(outs, tuple) else [outs]
 
     # -- pieces of the backward shared by the nodes ---------------------------------------------------------------------------
@@ -295,7 +296,7 @@ def _linear(x, W, bias=None, **kw):
     return ops.linear(x, W, bias, **kw)
 
 
-# test / measurement hook: called as _BACKWARD_MARK(kind, block) with kind "head", "block_begin", "block_end" from inside the
+# test / measurement hook: called as _BACKWARD_MARK(kind, block) with kind "backward_begin", "block_begin", "block_mid", "block_end" from inside the
 # backward (host side, kernels of everything before it are enqueued) -- tests/test_gpu_multirank.py and bench.py record HIP events
 # here to place DDP's bucket-ready points on the Res5 backward's timeline
 _BACKWARD_MARK = None
@@ -306,7 +307,7 @@ def _mark(kind: str, bi: int = -1) -> None:
         _BACKWARD_MARK(kind, bi)
 
 
-class Res5HeadFn(torch.autograd.Function):
+class Res5OutputFn(torch.autograd.Function):
     """The tail of a Res5Step's graph: hands out the segments' outputs (rows, or their per-tile mean) of the last block's joint
     rows; backward gathers the segments' output gradients into ONE matrix, masked by the last block's ReLU, and chooses its
     operand scale (split arithmetic) from the small tensors it was derived from."""
@@ -327,13 +328,13 @@ class Res5HeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grad_outs):
         step = ctx.step
-        _mark("head")
+        _mark("backward_begin")
         (out_last,) = ctx.saved_tensors
         rows = step.filled
         sp = step.bwd_split
         g = torch.empty((rows, out_last.shape[1]), dtype=torch.float32, device=step.device)
         if rows == 0:
-            step._carry = (g, None)
+            step._carry = ("tail", g, None)
             return None, None, g
         # gradient of the last block's output, masked by its ReLU, every segment into its rows of ONE matrix
         # (the element-wise kernels at the head of the chain keep the separate reduction: their waves all finish together,
@@ -363,76 +364,75 @@ class Res5HeadFn(torch.autograd.Function):
             sg = ops.split_scale_from_amax(g)
         for w in step.skip_words:
             ops.zero_if_raised([g], w)
-        step._carry = (g, sg)
+        step._carry = ("tail", g, sg)
         return None, None, g
 
 
 class Res5BlockFn(torch.autograd.Function):
-    """One bottleneck of a Res5Step under autograd: forward hands out what the step already computed (the block's joint output
-    rows); backward is the block's part of the joint pass
+    """One HALF of a bottleneck of a Res5Step under autograd -- "head": conv1 (+ the projection shortcut), "tail": conv2 + conv3 --
+    forward hands out what the step already computed (the half's output rows: y1 / the block's output); backward is the half's
+    part of the joint pass
 
-        with g the gradient of the block's output already masked by (output > 0), over the rows of ALL segments:
+        tail, with g the gradient of the block's output already masked by (output > 0), over the rows of ALL segments:
           dW3 = s3 * g^T y2                      TN GEMM over the pixel rows (gemm_tn.hip)
           g2  = (g . s3 W3) * [y2 > 0]           NT GEMM, mask fused into the epilogue
           dW2 = s2 * wgrad3x3(y1, g2)            per segment: Winograd domain (121 TN GEMMs) or im2col + TN GEMM
           g1  = conv3x3(g2, flip(s2 W2)) * [y1 > 0]         per segment
+        head:
           dW1 = s1 * g1^T x ;  dWs = ss * g^T x
           gx  = (g1 . s1 W1 + g [. ss Ws]) * [x > 0]      = the masked gradient of the previous block's output
 
-    Inputs: (step, block index, number of data inputs, the data inputs -- block 0: x0 of every segment; every other block: the
-    previous block's joint output rows --, the block's convolution weights in module order: conv1, conv2, conv3[, shortcut],
-    passed as inputs so that autograd routes their gradients).  The tensors between two block nodes are INTERNAL to
-    Res5Step.outputs: the gradient one node returns for its input is the next node's `g` -- already masked by the ReLU in front
-    of it -- and its operand-scale slot travels beside it in step._carry.
-    saved_tensors: (x, y1, y2, out) of the block over the joint rows (tests read the active sets from them: saved_activations)."""
+    Two nodes per block because autograd hands a node's weight gradients on when the node RETURNS: conv3's and conv2's leave half a
+    block earlier than they would with the block as one node (block 0's 13.6 MB: while its conv1 / shortcut gradients are still
+    being formed, instead of behind the stage's last kernel).
+    Inputs: (step, block index, half, number of data inputs, the data inputs -- head of block 0: x0 of every segment; head of any
+    other block: the previous block's joint output rows; tail: the head's y1 --, the half's convolution weights: conv1[, shortcut] /
+    conv2, conv3, passed as inputs so that autograd routes their gradients).  The tensors between two nodes are INTERNAL to
+    Res5Step.outputs: the gradient one node returns for its input is the next node's operand -- already masked by the ReLU in
+    front of it -- and travels with its operand-scale slot (and, from a tail to its head, with the block's output gradient, which
+    the shortcut path needs) in step._carry.
+    saved_tensors: head (x, y1), tail (y1, y2, out) over the joint rows (tests read the active sets through saved_activations)."""
 
     @staticmethod
-    def forward(ctx, step, bi, n_in, *args):
+    def forward(ctx, step, bi, half, n_in, *args):
         rows = step.filled
-        ctx.step, ctx.bi, ctx.n_in = step, bi, n_in
+        ctx.step, ctx.bi, ctx.half, ctx.n_in = step, bi, half, n_in
         ctx.nw = len(args) - n_in
         y1, y2, out = step.act[bi]
-        x = step.x0 if bi == 0 else step.act[bi - 1][2]
-        ctx.save_for_backward(x[:rows], y1[:rows], y2[:rows], out[:rows])
+        if half == "head":
+            x = step.x0 if bi == 0 else step.act[bi - 1][2]
+            ctx.save_for_backward(x[:rows], y1[:rows])
+            return y1[:rows]
+        ctx.save_for_backward(y1[:rows], y2[:rows], out[:rows])
         return out[:rows]
 
     @staticmethod
     def backward(ctx, g):
         step = ctx.step
-        _mark("block_begin", ctx.bi)
-        grads = step._bwd_guarded(lambda: Res5BlockFn._backward(ctx, g))
-        _mark("block_end", ctx.bi)
-        return (None, None, None) + tuple(grads)
+        if ctx.half == "tail":
+            _mark("block_begin", ctx.bi)
+        fn = Res5BlockFn._backward_tail if ctx.half == "tail" else Res5BlockFn._backward_head
+        grads = step._bwd_guarded(lambda: fn(ctx, g))
+        _mark("block_mid" if ctx.half == "tail" else "block_end", ctx.bi)
+        return (None, None, None, None) + tuple(grads)
 
     @staticmethod
-    def _backward(ctx, g):
-        step, bi, n_in = ctx.step, ctx.bi, ctx.n_in
-        stage, segs = step.stage, step.segments
-        sp = step.bwd_split
-        rows = step.filled
-        blk = stage[bi]
-        has_sc = blk.shortcut is not None
-        first = bi == 0
-        need_x = any(ctx.needs_input_grad[3:3 + n_in])
-        need_w = ctx.needs_input_grad[3 + n_in:]
-        gw: List[Optional[torch.Tensor]] = [None] * ctx.nw
-        weights = _block_weights(stage)[bi]
-        if rows == 0:
-            return tuple(None for _ in range(n_in)) + tuple(
-                torch.zeros_like(w) if need else None for w, need in zip(weights, need_w))
+    def _take_carry(step, g, what):
         carry, step._carry = step._carry, None
-        if carry is not None and carry[0].data_ptr() == g.data_ptr() and carry[0].shape == g.shape:
-            g, sg = carry
-        else:
-            raise RuntimeError("Res5BlockFn.backward: the gradient of a block's output must come from the node behind it "
-                               "(the tensors between two block nodes are internal to Res5Step.outputs)")
-        x, y1, y2, _ = ctx.saved_tensors
-        new = lambda c: torch.empty((rows, c), dtype=torch.float32, device=step.device)
+        if carry is None or carry[0] != what or carry[1].data_ptr() != g.data_ptr() or carry[1].shape != g.shape:
+            raise RuntimeError("Res5BlockFn.backward: the gradient of a node's output must come from the node behind it "
+                               "(the tensors between two Res5 nodes are internal to Res5Step.outputs)")
+        return carry[1:]
+
+    @staticmethod
+    def _helpers(ctx):
+        step = ctx.step
+        sp = step.bwd_split
+        T = step._bwd_operands()
         # Operand scales of the gradients (split arithmetic): every kernel that WRITES a gradient folds max |.| into a zeroed
         # 16-byte slot (ops.scale_slot) on its way out, and the GEMMs that read the gradient derive its power-of-two scale from
         # the slot -- no separate pass over the tensor, no host read.
         slot = (lambda ref: ops.scale_slot(ref)) if sp else (lambda ref: None)
-        T = step._bwd_operands()
 
         def wgrad_1x1(g_, sg_, x_, s_):                # dW = s * g^T x
             if sp and g_.shape[1] % 4 == 0 and x_.shape[1] % 4 == 0 and g_.shape[0] > 0:
@@ -447,14 +447,32 @@ class Res5BlockFn(torch.autograd.Function):
             y_ = ops.linear_ex(g_, wt, **kw)
             return y_, (ops.split_scale_from_amax(y_) if sp and amax_out is not None else None)
 
-        s1, s2, s3 = stage._fold(blk.conv1)[0], stage._fold(blk.conv2)[0], stage._fold(blk.conv3)[0]
+        return sp, T, slot, wgrad_1x1, dgrad_1x1
+
+    @staticmethod
+    def _backward_tail(ctx, g):
+        """conv3 and conv2 of block bi: (dW2, dW3) and g1, the masked gradient of y1."""
+        step, bi = ctx.step, ctx.bi
+        stage, segs = step.stage, step.segments
+        rows = step.filled
+        blk = stage[bi]
+        need_w = ctx.needs_input_grad[5:]
+        gw: List[Optional[torch.Tensor]] = [None, None]
+        if rows == 0:
+            g1 = g.new_empty((0, blk.conv1.out_channels))
+            step._carry = ("head", g1, None, g, None)
+            return (g1,) + tuple(torch.zeros_like(w) if need else None for w, need in zip((blk.conv2.weight, blk.conv3.weight), need_w))
+        g, sg = Res5BlockFn._take_carry(step, g, "tail")
+        sp, T, slot, wgrad_1x1, dgrad_1x1 = Res5BlockFn._helpers(ctx)
+        y1, y2, _ = ctx.saved_tensors
+        s2, s3 = stage._fold(blk.conv2)[0], stage._fold(blk.conv3)[0]
         c2 = blk.conv2
         # conv3: dW3 = s3 * g^T y2 ; g2 = (g . s3 W3) [y2 > 0]         -- all segments, one launch each
-        if need_w[2]:
-            gw[2] = wgrad_1x1(g, sg, y2, s3).view_as(blk.conv3.weight)
+        if need_w[1]:
+            gw[1] = wgrad_1x1(g, sg, y2, s3).view_as(blk.conv3.weight)
         g2, sg2 = dgrad_1x1(g, sg, blk.conv3, amax_out=slot(g), mask=y2)
         # conv2 (3x3), per segment: dW2 = s2 * wgrad(y1, g2) ; g1 = conv3x3(g2, flip(s2 W2)) [y1 > 0]
-        g1 = new(y1.shape[1])
+        g1 = torch.empty((rows, y1.shape[1]), dtype=torch.float32, device=step.device)
         sg1 = slot(g2)
         # (on the f32 MFMA nothing fills sg1; in split arithmetic every segment's kernel folds its max into the ONE slot)
         # The segments' 3x3 gradients are independent of each other: with two of them (whole grid + proposals) the general-grid
@@ -483,7 +501,7 @@ class Res5BlockFn(torch.autograd.Function):
                     t_.record_stream(side)
             with torch.cuda.stream(side if on_side else main):
                 part = None
-                if need_w[1]:
+                if need_w[0]:
                     if wino and c2.out_channels % 4 == 0 and not _NO_WINO_BWD:
                         part = ops.winograd_wgrad(y1[sl], g2[sl], s2, roi_major=True, split=sp, v_split=step.wino_ws.get((bi, si)) if sp else None)
                     else:
@@ -516,19 +534,45 @@ class Res5BlockFn(torch.autograd.Function):
                         ops.amax_bound([g1[sl]], [1.0], slot=sg1)      # (an operand the split GEMM cannot take: its f32 result's range by a pass)
         if side is not None:
             main.wait_stream(side)
-        if need_w[1]:
+        if need_w[0]:
             dw2 = parts[0]
             for part in parts[1:]:
                 dw2 = dw2.add_(part)
-            gw[1] = dw2
-        del g2
+            gw[0] = dw2
+        step._carry = ("head", g1, sg1, g, sg)
+        return (g1,) + tuple(gw)
+
+    @staticmethod
+    def _backward_head(ctx, g1):
+        """conv1 (+ shortcut) of block bi: (dW1[, dWs]) and gx, the masked gradient of the previous block's output."""
+        step, bi, n_in = ctx.step, ctx.bi, ctx.n_in
+        stage, segs = step.stage, step.segments
+        rows = step.filled
+        blk = stage[bi]
+        has_sc = blk.shortcut is not None
+        first = bi == 0
+        need_x = any(ctx.needs_input_grad[4:4 + n_in])
+        need_w = ctx.needs_input_grad[4 + n_in:]
+        gw: List[Optional[torch.Tensor]] = [None] * ctx.nw
+        weights = (blk.conv1.weight,) + ((blk.shortcut.weight,) if has_sc else ())
+        if rows == 0:
+            step._carry = None
+            if not first:
+                gx = torch.empty((0, blk.conv1.in_channels), dtype=torch.float32, device=step.device)
+                step._carry = ("tail", gx, None)
+                return (gx,) + tuple(torch.zeros_like(w) if need else None for w, need in zip(weights, need_w))
+            return tuple(None for _ in range(n_in)) + tuple(torch.zeros_like(w) if need else None for w, need in zip(weights, need_w))
+        g1, sg1, g, sg = Res5BlockFn._take_carry(step, g1, "head")
+        sp, T, slot, wgrad_1x1, dgrad_1x1 = Res5BlockFn._helpers(ctx)
+        x, _ = ctx.saved_tensors
+        s1 = stage._fold(blk.conv1)[0]
         # conv1 (+ shortcut): dW1 = s1 * g1^T x ; gx = (g1 . s1 W1 + shortcut path) [x > 0]
         if need_w[0]:
             gw[0] = wgrad_1x1(g1, sg1, x, s1).view_as(blk.conv1.weight)
         if has_sc:
             ss = stage._fold(blk.shortcut)[0]
-            if need_w[3]:
-                gw[3] = wgrad_1x1(g, sg, x, ss).view_as(blk.shortcut.weight)
+            if need_w[1]:
+                gw[1] = wgrad_1x1(g, sg, x, ss).view_as(blk.shortcut.weight)
         if not need_x:
             return tuple(None for _ in range(n_in)) + tuple(gw)
         # the input of block 0 is the stage input (no ReLU in front of it); every other block's input is the
@@ -539,13 +583,12 @@ class Res5BlockFn(torch.autograd.Function):
                             residual=None if has_sc else g, mask=None if has_sc else mask)
         if has_sc:
             gx, sgx = dgrad_1x1(g, sg, blk.shortcut, amax_out=None if first else slot(g), residual=gx, mask=mask)
-        del g1
         if not first:
-            step._carry = (gx, sgx)
+            step._carry = ("tail", gx, sgx)
             return (gx,) + tuple(gw)
         gxs = [None] * n_in
         for i, seg in enumerate(segs):
-            if ctx.needs_input_grad[3 + i]:
+            if ctx.needs_input_grad[4 + i]:
                 gxs[i] = gx[seg.row0:seg.row0 + seg.rows]
         return tuple(gxs) + tuple(gw)
 
@@ -560,22 +603,14 @@ def saved_activations(out: torch.Tensor) -> List[torch.Tensor]:
             continue
         seen.add(id(n))
         if "Res5BlockFn" in type(n).__name__:
-            found[n.bi] = n
+            found[(n.bi, n.half)] = n
         stack += [f for f, _ in n.next_functions]
     saved = []
-    for bi in sorted(found):
-        saved += list(found[bi].saved_tensors)
+    for bi in sorted({k[0] for k in found}):
+        x, y1 = found[(bi, "head")].saved_tensors
+        _, y2, o = found[(bi, "tail")].saved_tensors
+        saved += [x, y1, y2, o]
     return saved
-
-
-def _block_weights(stage) -> List[Tuple[torch.Tensor, ...]]:
-    out = []
-    for blk in stage:
-        ws = [blk.conv1.weight, blk.conv2.weight, blk.conv3.weight]
-        if blk.shortcut is not None:
-            ws.append(blk.shortcut.weight)
-        out.append(tuple(ws))
-    return out
 
 
 def _guarded(stage, split, guard, device, build):

@@ -82,10 +82,10 @@ class GradientExchangeTrace:
     exchange step of a training step is the all-reduce of the gradients of the parameters the path touches, overlapped with the
     backward -- ovr/engine/trainer.py:61-66).
 
-    Res5's backward is one autograd node per bottleneck (res5_train.Res5BlockFn), so block b's weight gradients reach DDP's hooks
-    when block b's kernels are enqueued.  This registers a DDP communication hook that records a HIP event on the launch stream
+    Res5's backward is two autograd nodes per bottleneck (res5_train.Res5BlockFn: "tail" = conv2 + conv3, "head" = conv1 + shortcut),
+    so a half-block's weight gradients reach DDP's hooks when that half's kernels are enqueued.  This registers a DDP communication hook that records a HIP event on the launch stream
     at the moment a bucket is handed to the all-reduce (the point its collective waits for on the communication stream) and
-    then runs the stock all-reduce, plus marks at the head / begin / end of every block's backward; stop() places every
+    then runs the stock all-reduce, plus marks at the begin / middle / end of every block's backward; stop() places every
     bucket on [0, 1] of the Res5 backward -- in device time (`ready_at`) and in kernel launches of this library issued so far
     (`ready_at_launch`: the share of the Res5 backward's kernels that were NOT yet enqueued is 1 - that) -- and lists the host-side
     order of marks and buckets.
@@ -136,9 +136,9 @@ class GradientExchangeTrace:
         self.on = False
         torch.cuda.synchronize(self.device)
         seq = self.seq
-        head = next((e for k, _, e in seq if k == "head"), None)
+        head = next((e for k, _, e in seq if k == "backward_begin"), None)
         ends = [e for k, b, e in seq if k == "block_end" and b == 0]
-        out = {"host_order": [k if k == "head" else (f"{k}:{b}" if k != "bucket" else f"bucket:{b['index']}") for k, b, _ in seq]}
+        out = {"host_order": [k if k == "backward_begin" else (f"{k}:{b}" if k != "bucket" else f"bucket:{b['index']}") for k, b, _ in seq]}
         if head is None or not ends:
             out["error"] = "no Res5 backward inside the traced region"
             return out
@@ -152,6 +152,7 @@ class GradientExchangeTrace:
         out["res5_backward_launches"] = l_total
         out["blocks_end_at"] = {f"block{b}": (at(e) - t_head) / total for k, b, e in seq if k == "block_end"}
         out["blocks_end_at_launch"] = {f"block{b}": (e[1] - l_head) / l_total for k, b, e in seq if k == "block_end"}
+        out["block_tails_end_at"] = {f"block{b}": (at(e) - t_head) / total for k, b, e in seq if k == "block_mid"}
         buckets = []
         for k, info, e in seq:
             if k != "bucket":
