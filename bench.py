@@ -667,7 +667,7 @@ def main():
         kept beside it (wall[key]).  The interpreter's full garbage-collection pass is taken HERE, in front of the warm-up steps and
         the bracket, and the objects alive at that point are frozen (gc.freeze): with a quarter of a million tracked objects a
         generation-2 pass takes ~90 ms, and one landing at a random step inside a 10-step training window moved
-        `train.lsm.ms_per_step` between 14.5 and 24 ms from run to run (tools/ab_fused_losses.py).  Collections of the younger
+        `train.lsm.ms_per_step` between 14.5 and 24 ms from run to run (tools/attic/ab_fused_losses.py).  Collections of the younger
         generations keep running inside the bracket, and the heap is un-frozen behind it (a frozen object is never collected:
         freezing per phase would pin every earlier workload's tensors).  freeze=False: nothing of that -- the interpreter's
         collector runs as it does under an unchanged train_ovnet.py (`train.*.ms_per_step_unfrozen_heap`)."""

@@ -31,7 +31,7 @@ __all__ = ["Box2BoxTransform", "FastRCNNOutputLayers", "EmbeddingFastRCNNOutputL
            "fast_rcnn_inference", "batched_nms"]
 
 _DEFAULT_SCALE_CLAMP = math.log(1000.0 / 16)
-_FUSED_BOX_LOSS = os.environ.get("LOCOV_FUSED_LOSSES", "1") != "0"          # (developer A/B switch: tools/ab_fused_losses.py)
+_FUSED_BOX_LOSS = os.environ.get("LOCOV_FUSED_LOSSES", "1") != "0"          # (developer A/B switch: tools/attic/ab_fused_losses.py)
 _FUSED_POSTPROCESS = os.environ.get("LOCOV_FUSED_POSTPROCESS", "1") != "0"  # (developer A/B / tests: 0 = the torch-op post-processing chain)
 
 

@@ -1,7 +1,7 @@
 """Developer aid (round 4): the 256x256 split GEMM's launch kinds at the bench's sizes, one library per process (LOCOV_HIP_LIB selects a
 tools/liblocov_<tag>.so variant: tile order / cache policy of the operand DMAs).  Prints ms per launch, best of 3 rounds of 6."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops
 g = torch.Generator().manual_seed(0)

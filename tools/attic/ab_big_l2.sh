@@ -4,14 +4,14 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/ab_l2
 for lib in product $VARIANTS; do
   if [ $lib = product ]; then unset LOCOV_HIP_LIB; else export LOCOV_HIP_LIB=tools/liblocov_$lib.so; fi
-  timeout 300 python3 tools/ab_big_l2.py 2>&1 | tail -1
+  timeout 300 python3 tools/attic/ab_big_l2.py 2>&1 | tail -1
 done | tee gpurun_out/ab_l2/times.txt
 for lib in product $VARIANTS; do
   if [ $lib = product ]; then unset LOCOV_HIP_LIB; else export LOCOV_HIP_LIB=tools/liblocov_$lib.so; fi
   for case in conv3_asplit conv1_asplit; do
     export PMC_SPLIT_CASE=$case
     rm -rf gpurun_out/ab_l2/pmc_$lib_$case
-    timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/ab_l2/pmc_${lib}_$case -o p --output-format csv -- python3 tools/pmc_split.py > /dev/null 2>&1
+    timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/ab_l2/pmc_${lib}_$case -o p --output-format csv -- python3 tools/attic/pmc_split.py > /dev/null 2>&1
     python3 - <<PY
 import csv, glob
 v = [float(r["Counter_Value"]) for f in glob.glob("gpurun_out/ab_l2/pmc_${lib}_$case/**/p_counter_collection.csv", recursive=True)

@@ -1,6 +1,6 @@
 """Developer A/B: the LSM / STT training step of bench.py with the one-launch loss tails (ops.box_reg_loss, ops.grounding_ce) on / off."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from locov_amd import ops

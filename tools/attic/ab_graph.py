@@ -1,7 +1,7 @@
 """Developer experiment: the S2 inference step captured in a HIP graph (torch.cuda.CUDAGraph) vs eager launches, at small batches
 where ~25 launches per step are a visible share of the step."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
 for images in (1, 2, 8):
     args = bench.parse(["--images", str(images)])

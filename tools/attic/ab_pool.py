@@ -1,7 +1,7 @@
 """Developer aid (round 4): the even-grid channels-last ROIAlign of block 0's shortcut (2048 of the map GEMM's 2560 output channels,
-8 x 1000 bench proposals) -- ms per launch; LOCOV_HIP_LIB / LOCOV_ROIALIGN_SLICES select the variant (tools/ab_pool.sh)."""
+8 x 1000 bench proposals) -- ms per launch; LOCOV_HIP_LIB / LOCOV_ROIALIGN_SLICES select the variant (tools/attic/ab_pool.sh)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from locov_amd import ops

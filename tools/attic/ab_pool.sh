@@ -5,11 +5,11 @@ for lib in product $VARIANTS; do
   for sl in 0 16; do
     if [ $lib = product ]; then unset LOCOV_HIP_LIB; else export LOCOV_HIP_LIB=tools/liblocov_$lib.so; fi
     if [ $sl = 0 ]; then unset LOCOV_ROIALIGN_SLICES; else export LOCOV_ROIALIGN_SLICES=$sl; fi
-    timeout 200 python3 tools/ab_pool.py 2>&1 | tail -1
+    timeout 200 python3 tools/attic/ab_pool.py 2>&1 | tail -1
     for ctr in FETCH_SIZE WRITE_SIZE; do
       d=gpurun_out/ab_pool/pmc_${lib}_${sl}_$ctr
       rm -rf $d
-      timeout 120 rocprofv3 --kernel-trace --pmc $ctr -d $d -o p --output-format csv -- python3 tools/ab_pool.py > /dev/null 2>&1
+      timeout 120 rocprofv3 --kernel-trace --pmc $ctr -d $d -o p --output-format csv -- python3 tools/attic/ab_pool.py > /dev/null 2>&1
       python3 - <<PY
 import csv, glob
 v = [float(r["Counter_Value"]) for f in glob.glob("$d/**/p_counter_collection.csv", recursive=True)

@@ -5,6 +5,6 @@
 cd $GRAFT_REPO_ROOT
 python3 tools/make_variant.py poolnostore roi_align_nhwc.hip -DLOCOV_POOL_NO_STORE=1 > /dev/null
 for rep in 1 2; do
-  python3 tools/ab_pool.py 2>&1 | tail -1
-  LOCOV_HIP_LIB=tools/liblocov_poolnostore.so python3 tools/ab_pool.py 2>&1 | tail -1
+  python3 tools/attic/ab_pool.py 2>&1 | tail -1
+  LOCOV_HIP_LIB=tools/liblocov_poolnostore.so python3 tools/attic/ab_pool.py 2>&1 | tail -1
 done

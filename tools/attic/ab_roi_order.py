@@ -1,6 +1,6 @@
 """Developer experiment: even-grid ROIAlign (map path shapes) with proposals in random vs spatially sorted order."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
 from locov_amd import ops
 gen = torch.Generator().manual_seed(1992)

@@ -1,7 +1,7 @@
 """Developer aid (round 4): the pooler-contract ROIAlign per box-size class (8 000 proposals of ONE class each, 1024 channels) -- where the
 LDS-window path (proposals whose pixel rectangle fits the transpose tile) pays; LOCOV_HIP_LIB=tools/liblocov_nowin.so is the direct form alone."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from locov_amd import ops
 g = torch.Generator().manual_seed(7)

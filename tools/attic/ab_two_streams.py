@@ -1,7 +1,7 @@
 """Developer experiment: the S2 step on one stream vs split in two half-batches (4 images each) on two HIP streams -- do the
 HBM-bound kernels of one half (ROIAlign, Winograd transforms) run under the MFMA-bound GEMMs of the other?"""
 import sys, os, time, types
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
 args = bench.parse([])
 dev = torch.device("cuda")

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for lib in product ${AB_LIBS}; do
   if [ $lib = product ]; then unset LOCOV_HIP_LIB; else export LOCOV_HIP_LIB=tools/liblocov_$lib.so; fi
-  rm -rf gpurun_out/abwino; timeout 200 rocprofv3 --kernel-trace --stats -d gpurun_out/abwino -o s --output-format csv -- python3 tools/bench_wino_transforms.py > /dev/null 2>&1
+  rm -rf gpurun_out/abwino; timeout 200 rocprofv3 --kernel-trace --stats -d gpurun_out/abwino -o s --output-format csv -- python3 tools/attic/bench_wino_transforms.py > /dev/null 2>&1
   echo "== $lib"
   python3 - <<'PY'
 import csv, glob

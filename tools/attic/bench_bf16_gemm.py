@@ -1,6 +1,6 @@
 """Developer timing of the bf16 NT GEMM (fp32 accumulate / output) at Res5-size shapes, vs torch (hipBLASLt)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from locov_amd import ops
 

@@ -1,6 +1,6 @@
 """Times the hand-written NT GEMM at the Res5 / box-head shapes (developer tool, not the bench contract)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops
 

@@ -1,6 +1,6 @@
 """Developer aid: the pooler-contract ROIAlign (NCHW out, 14x14, 1024 channels) in its exact and fast forms at the bench shape."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from locov_amd import ops
 import bench

@@ -1,7 +1,7 @@
 """Developer aid: one Winograd-domain convolution of the default inference path (split operands, split-layout output) repeated --
-run under rocprofv3 --kernel-trace --stats for the per-kernel times of the two transforms and the batched GEMM (tools/ab_wino.sh)."""
+run under rocprofv3 --kernel-trace --stats for the per-kernel times of the two transforms and the batched GEMM (tools/attic/ab_wino.sh)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops
 R = 8000

@@ -1,7 +1,7 @@
 """developer diagnostic (round 5): where does a 12 000-proposal Res5 call differ from two 6 000-proposal calls?  Wraps the ops the
 stage calls and compares every intermediate of the big call with the concatenation of the halves' (ROI-major rows)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import locov_amd

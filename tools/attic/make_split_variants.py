@@ -1,13 +1,13 @@
 """DIAGNOSTIC builds of gemm_split.hip (tools/liblocov_splitv<N>.so, never the product; results are WRONG on purpose):
 ablations that remove one cost at a time from the K-loop, to see what bounds the kernel.  Run with
-LOCOV_HIP_LIB=tools/liblocov_splitv<N>.so python tools/bench_split.py speed
+LOCOV_HIP_LIB=tools/liblocov_splitv<N>.so python tools/attic/bench_split.py speed
   1: no fp32 -> (hi, lo) conversion (raw bits stored)     2: also no A refill loads in the K-loop
   3: no staging at all (no loads, no LDS writes, no DMA)  4: no fragment reads either (MFMA-only loop)
   7: A taken as ALREADY split and staged by LDS DMA like W (what the kernel would do if the producers wrote the
      activations in split format): timing only
  11: conversion executed but raw bits stored (variant 1's data with variant 0's instruction stream)"""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SRC = open(os.path.join(ROOT, "locov_amd/csrc/gemm_split.hip")).read().replace('#include "gemm_nt.h"', '#include "%s/locov_amd/csrc/gemm_nt.h"' % ROOT)
 def variant(n):
     s = SRC

@@ -1,9 +1,9 @@
 """DIAGNOSTIC build (tools/liblocov_trace.so, never the product): every workgroup of the GEMM records
 (s_memtime at start, after its K-loop, at the end of its epilogue, HW_ID, XCC_ID) so that the overlap of the
-workgroups sharing a CU can be read off (tools/trace_gemm.py).  Enabled per launch by epilogue flag 0x2000 with the
+workgroups sharing a CU can be read off (tools/attic/trace_gemm.py).  Enabled per launch by epilogue flag 0x2000 with the
 record buffer passed in the `scale` slot."""
 import os, subprocess
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 s = open(os.path.join(ROOT, "locov_amd/csrc/gemm_nt.hip")).read().replace('#include "gemm_nt.h"', '#include "%s/locov_amd/csrc/gemm_nt.h"' % ROOT)
 def rep(a, b):
     global s

@@ -1,11 +1,11 @@
-# developer diagnostic: SQ counter passes over one launch set of the hand-written GEMM and hipBLASLt (tools/pmc_gemm.py)
+# developer diagnostic: SQ counter passes over one launch set of the hand-written GEMM and hipBLASLt (tools/attic/pmc_gemm.py)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM_RD SQ_VALU_MFMA_COEXEC_CYCLES" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmccmp$i -o p --output-format csv -- python3 tools/pmc_gemm.py > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmccmp$i -o p --output-format csv -- python3 tools/attic/pmc_gemm.py > /dev/null 2>&1
 done
 python3 - <<'PY'
 import csv, collections, glob

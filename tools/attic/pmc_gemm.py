@@ -1,6 +1,6 @@
 """One launch of each GEMM (hand-written and hipBLASLt) at a Res5 shape, for rocprofv3 --pmc runs."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops
 M, N, K = 196000, 512, 2048

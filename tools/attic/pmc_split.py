@@ -1,8 +1,8 @@
-"""A few launches of the split-operand GEMM at a Res5 shape, for rocprofv3 --pmc runs (tools/pmc_split.sh).
+"""A few launches of the split-operand GEMM at a Res5 shape, for rocprofv3 --pmc runs (tools/attic/pmc_split.sh).
 PMC_SPLIT_CASE: conv1 (default) [196000,2048] x [512,2048]^T, A converted in the kernel; conv3_asplit [196000,512] x [2048,512]^T +
 residual + ReLU with A pre-split; conv1_asplit the first shape with A pre-split."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from locov_amd import ops
 case = os.environ.get("PMC_SPLIT_CASE", "conv1")

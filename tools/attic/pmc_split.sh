@@ -1,4 +1,4 @@
-# developer diagnostic: SQ / L2 counter passes over the split-operand GEMM (tools/pmc_split.py); PMC_SPLIT_CASE selects the shape
+# developer diagnostic: SQ / L2 counter passes over the split-operand GEMM (tools/attic/pmc_split.py); PMC_SPLIT_CASE selects the shape
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export PMC_SPLIT_CASE=${PMC_SPLIT_CASE:-conv1}
 rm -rf gpurun_out/pmcsplit*
@@ -8,7 +8,7 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_AN
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum"; do
   i=$((i+1))
-  timeout 120 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmcsplit$i -o p --output-format csv -- python3 tools/pmc_split.py > /dev/null 2>&1
+  timeout 120 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmcsplit$i -o p --output-format csv -- python3 tools/attic/pmc_split.py > /dev/null 2>&1
 done
 python3 - <<'PY'
 import csv, collections, glob, os

@@ -1,7 +1,7 @@
 """Developer aid: time of the post-processing tail (softmax, box decoding, threshold, class-wise NMS, top-k: fast_rcnn_inference,
 roi_emb_heads.py:280,357) next to the logits path."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
 args = bench.parse(sys.argv[1:])
 dev = torch.device("cuda")

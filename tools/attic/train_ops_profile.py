@@ -1,9 +1,9 @@
 """Developer aid: which Python lines of one LSM / STT training step issue the small torch ops (fills, adds, copies, cats)?  A TorchDispatchMode over one
 step of bench.py's TrainWorkload counts every aten call by (op, innermost frame inside this repository); ops issued by autograd's backward nodes have no
 Python frame and are listed under "(autograd engine)".
-usage: python3 tools/train_ops_profile.py [lsm|stt]"""
+usage: python3 tools/attic/train_ops_profile.py [lsm|stt]"""
 import collections, os, sys, traceback
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 import bench

@@ -1,7 +1,7 @@
 # texture-address / L1 / VALU counters of the pooler-contract ROIAlign (and the even-grid pooler) at the bench workload -> gpurun_out/ra_pmc.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python3 tools/ab_t2.py 2>/dev/null | tail -1 > gpurun_out/ra_pmc.txt
-python3 tools/ab_pool.py 2>/dev/null | tail -1 >> gpurun_out/ra_pmc.txt
+python3 tools/attic/ab_pool.py 2>/dev/null | tail -1 >> gpurun_out/ra_pmc.txt
 for tgt in ab_t2 ab_pool; do
   rm -rf gpurun_out/ra_pmc_$tgt
   timeout 200 rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ TA_TA_BUSY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/ra_pmc_$tgt -o p --output-format csv -- python3 tools/$tgt.py > /dev/null 2>&1

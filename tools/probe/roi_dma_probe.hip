@@ -7,7 +7,7 @@
 // accumulates S samples x 4 taps (ds_read_b128, sequential accumulation as torchvision's order demands) while the next stage's rows
 // are in flight; the 7 results per thread go through the [32][196] transpose tile and leave as one 25 KB run.  LDS per workgroup
 // = tile + ring => ONE workgroup (4 waves) per CU for the 448-800 px class.
-// Reported per size class: ms per 8 000 proposals, to be read against tools/ab_t2_sizes.py's figures of the product on the same box
+// Reported per size class: ms per 8 000 proposals, to be read against tools/attic/ab_t2_sizes.py's figures of the product on the same box
 // (round 4: 224-448 px 2.88 ms, 448-800 px 5.40 ms).  The probe is an UPPER bound on what the real kernel could reach: no sampling
 // validity rules, perfectly regular rows (the sampling tables are the real kernel's: one 16-byte LDS entry per axis sample).
 #include <hip/hip_runtime.h>
