@@ -117,13 +117,15 @@ def oracle_mod():
     return lsm_oracle
 
 
-def test_fused_postprocess_vs_the_oracle_pipeline(pkg, oracle_mod, monkeypatch):
+@pytest.mark.parametrize("sizes,classes,sigma,shapes", [([400, 250], 80, 2.0, [(800, 1333), (640, 960)]),
+                                                        ([1000], 1203, 3.0, [(800, 1333)])],        # BASELINE's evaluation call: full size
+                         ids=["two_images_80_classes", "evaluation_call_1000x1203"])
+def test_fused_postprocess_vs_the_oracle_pipeline(pkg, oracle_mod, monkeypatch, sizes, classes, sigma, shapes):
     """The device pipeline against the CPU oracle's apply_deltas -> softmax -> fast_rcnn_inference_single_image on the same logits,
     deltas and proposals (numpy arithmetic: a decoded coordinate may differ in its last bits, so a borderline NMS decision may too):
     same number of detections, classes and scores agree as the end-to-end gate of tests/test_gpu_stt.py asks."""
-    pred = _predictor(pkg, 80)
-    sizes = [400, 250]
-    predictions, props = _inputs(pkg, sizes, 80, 2.0, seed=19, image_shapes=[(800, 1333), (640, 960)])
+    pred = _predictor(pkg, classes)
+    predictions, props = _inputs(pkg, sizes, classes, sigma, seed=19, image_shapes=shapes)
     got, _ = _run(pkg, pred, predictions, props, True, monkeypatch)
     logits, deltas = predictions[0].cpu().numpy(), predictions[1].cpu().numpy()
     r0 = 0
