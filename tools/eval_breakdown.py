@@ -1,13 +1,14 @@
 """Developer aid: where the evaluation call (scopes.eval_1img of bench.py: one image x 1000 proposals incl. post-processing) spends
 its time -- ROIAlign + Res5 + predictor alone, the post-processing alone on fixed predictions, the whole call; HIP events, medians.
-usage: python3 tools/eval_breakdown.py [n_images]"""
+usage: python3 tools/eval_breakdown.py [n_images [proposals [classes]]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 
 n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-args = bench.parse(["--no-cpu-baseline"])
+extra = (["--proposals", sys.argv[2]] if len(sys.argv) > 2 else []) + (["--classes", sys.argv[3]] if len(sys.argv) > 3 else [])
+args = bench.parse(["--no-cpu-baseline", "--images", str(max(n_img, 1))] + extra)
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 wl = bench.Workload(args, dev)
