@@ -794,7 +794,7 @@ _DETECT_PINNED = {}
 def detect_postprocess(probs: torch.Tensor, deltas: torch.Tensor, proposal_boxes: torch.Tensor, sizes, image_shapes, weights,
                        scale_clamp: float, score_thresh: float, nms_thresh: float, topk: int):
     """The detection post-processing of a batch on the device (csrc/detect.hip): box decoding, clipping, score threshold,
-    class-wise NMS, top-k -- five launches and ONE host read (the detections per image + the flag word) instead of the torch
+    class-wise NMS, top-k -- seven launches and ONE host read (the detections per image + the flag word) instead of the torch
     chain's ~100 launches and four reads.
     probs [R, K + 1] = softmax of the logits, deltas / proposal_boxes [R, 4] (class-agnostic regression), sizes: rows per image,
     image_shapes: (height, width) per image, weights: Box2BoxTransform's.
