@@ -93,9 +93,10 @@ def parse(argv=None):
     p.add_argument("--force-dist", action="store_true",
                    help="initialise the process group and wrap the training step in DistributedDataParallel even with ONE rank: the RCCL "
                         "rehearsal a 1-GPU box allows (communicator, DDP's bucketed all-reduce hooks, the timing collectives)")
-    p.add_argument("--ddp-bucket-mb", type=int, default=17,
-                   help="DistributedDataParallel's bucket_cap_mb for the training steps: 17 MiB = exactly one identity bottleneck of Res5 "
-                        "(2 x 4 MiB + 9 MiB), so that a bucket closes with every block's autograd node (torch's default is 25)")
+    p.add_argument("--ddp-bucket-mb", type=int, default=0,
+                   help="DistributedDataParallel's bucket_cap_mb for the training steps; 0 = chosen per configuration so that a bucket closes "
+                        "with every bottleneck's conv2 + conv3 node: 17 MiB for LSM (emb_pred's 6 MiB arrive first: 6 + 9 + 4 closes the "
+                        "first bucket), 13 MiB = conv2 + conv3 for STT (emb_pred frozen).  torch's default is 25")
     p.add_argument("--multiscale-batches", type=int, default=16,
                    help="training: batches of the multi-scale pool behind train.*.ms_per_step_multiscale (0: skip)")
     p.add_argument("--skip-exchange-probe", action="store_true",
@@ -363,6 +364,7 @@ class TrainWorkload:
         self.n_images = 3 if self.stt else args.train_images                 # IMS_PER_BATCH 24 / 8 GPUs (coco_stt.yaml:41)
         self.n_classes = 48 if self.stt else args.classes
         ddp = (world > 1 or args.force_dist) if ddp is None else bool(ddp)
+        self.bucket_cap_mb = args.ddp_bucket_mb or (13 if self.stt else 17)
         self.set_data(data_seed)
         self.heads, cfg = build_heads(args, device, res5=backend, train=True, stt=self.stt)
         if self.stt:
@@ -384,7 +386,7 @@ class TrainWorkload:
             if ddp:
                 from torch.nn.parallel import DistributedDataParallel as DDP
                 self.run = DDP(self.module, device_ids=None if args.share_gpu else [device.index], broadcast_buffers=False,
-                               bucket_cap_mb=args.ddp_bucket_mb)
+                               bucket_cap_mb=self.bucket_cap_mb)
             params = [p for p in self.module.parameters() if p.requires_grad]
             self.opt = torch.optim.SGD(params, lr=0.005, momentum=0.9, weight_decay=1e-4)   # coco_stt.yaml:42
             return
@@ -420,7 +422,7 @@ class TrainWorkload:
         if ddp:       # the gradient exchange of the path: DDP's bucketed all-reduce (RCCL over xGMI), overlapped with backward
             from torch.nn.parallel import DistributedDataParallel as DDP
             self.run = DDP(self.module, device_ids=None if args.share_gpu else [device.index], broadcast_buffers=False,
-                           bucket_cap_mb=args.ddp_bucket_mb)
+                           bucket_cap_mb=self.bucket_cap_mb)
         params = [p for p in self.module.parameters() if p.requires_grad]
         self.opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=1e-4)   # coco_lsm.yaml:104-105
 
@@ -878,8 +880,9 @@ def main():
             torch.cuda.empty_cache()
 
     def gradient_exchange(tr):
-        ge = {"how": (f"DistributedDataParallel over {world} ranks ({args.dist_backend}), bucket_cap_mb {args.ddp_bucket_mb}" if dist_on
-                      else f"none (1 rank); under N ranks: DistributedDataParallel, bucket_cap_mb {args.ddp_bucket_mb}"),
+        caps = f"bucket_cap_mb {args.ddp_bucket_mb}" if args.ddp_bucket_mb else "bucket_cap_mb 17 (LSM) / 13 (STT)"
+        ge = {"how": (f"DistributedDataParallel over {world} ranks ({args.dist_backend}), {caps}" if dist_on
+                      else f"none (1 rank); under N ranks: DistributedDataParallel, {caps}"),
               "autograd_nodes": "Res5OutputFn + two Res5BlockFn per bottleneck (locov_amd/res5_train.py: tail = conv2 + conv3, head = conv1 + "
                                 "shortcut): a half-block's weight gradients reach DDP's hooks when that half's backward kernels are enqueued; "
                                 "which parameters DDP's (rebuilt) buckets hold and when they are ready: `schedule`",

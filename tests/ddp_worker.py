@@ -119,7 +119,7 @@ def main():
         tw.args.proposals = 600
         tw.set_data(300 + rank)
         rec["exchange"] = tw.trace_exchange(3)
-        rec["bucket_cap_mb"] = args.ddp_bucket_mb
+        rec["bucket_cap_mb"] = tw.bucket_cap_mb
     torch.save(rec, os.path.join(out_dir, f"rank{rank}.pt"))
     ones = torch.ones(1, device=device if backend == "nccl" else "cpu")
     dist.all_reduce(ones)
