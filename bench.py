@@ -17,6 +17,12 @@ Images shard over ranks with no data-path collective (inference needs none, SURV
 `value` is scope S2 = the full head as the reference executes it (Res5 included).  Scope S1 = the north-star kernel list only
 (ROIAlign + mean/FCs/similarity on a stand-in for the Res5 output) and the 1024-d bank variants are reported in "scopes".
 
+`scopes.eval_1img` is the reference's EVALUATION call (TEST.IMS_PER_BATCH 1: one image x 1000 proposals per call through
+roi_heads(images, features, proposals, None) incl. softmax / box decoding / score threshold / class-wise NMS / top-100), per image.
+The default run's `train` object times one LSM and one STT training step of the path (fixed batch, then `ms_per_step_multiscale`:
+a different batch of the reference's real training shapes every step) and, under N ranks or through a one-rank probe, places
+DistributedDataParallel's buckets on the Res5 backward's timeline (`train.gradient_exchange.schedule`).
+
 --mode train adds a `train` object: one LSM training step of the path per iteration (configs/coco_lsm.yaml: 4 images per GPU,
 200 sampled proposals per image) -- EmbeddingProposalsRes5ROIHeads.forward with targets (roi_emb_heads.py:311-349: labelling /
 sampling, whole-grid Res5, ROIAlign + Res5 + mean, box predictor, losses) + GroundingHead on the box branch
