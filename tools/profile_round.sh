@@ -17,7 +17,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p --o
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT -d $OUT/pmc_mfma -o p --output-format csv -- python3 bench.py $ARGS > /dev/null 2>&1
 # the evaluation call alone (scopes.eval_1img: one image x 1000 proposals incl. post-processing)
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/eval_stats -o s --output-format csv -- python3 bench.py --only-eval --no-cpu-baseline --steps 20 > $OUT/eval.json 2> $OUT/eval.err
-for m in infer lsm stt; do python3 tools/find_syncs.py $m 2>/dev/null | grep -v "^/"; done > $OUT/find_syncs.txt
+for m in infer eval eval_torch_chain lsm stt; do python3 tools/find_syncs.py $m 2>/dev/null | grep -v "^/"; done > $OUT/find_syncs.txt
 bash tools/profile_train.sh > $OUT/profile_train.txt 2>&1
 python3 tools/train_timeline.py > $OUT/train_timeline.txt 2>/dev/null
 timeout 300 python3 tools/power_step.py > $OUT/power_step.txt 2>/dev/null      # package power / clock of the step and its launch kinds
